@@ -1,0 +1,94 @@
+"""ctypes binding of libepnn_hip.so (include/epnn.h).  There is no CPU fallback: a missing library or a
+missing MI355X raises, it never silently computes somewhere else."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libepnn_hip.so")
+
+W_MSG, W_UPD, W_PAS = 0, 1, 2
+
+
+class EpnnConfig(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("h_dim", C.c_int32), ("e_dim", C.c_int32), ("T", C.c_int32),
+                ("hidden", C.c_int32), ("cutoff", C.c_float), ("eta", C.c_float), ("near_tol", C.c_float)]
+
+
+class EpnnError(RuntimeError):
+    pass
+
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/epnn.h declares
+SIGNATURES = {
+    "epnn_last_error": (C.c_char_p, []),
+    "epnn_version": (C.c_int, []),
+    "epnn_device_count": (C.c_int, []),
+    "epnn_create": (C.c_int, [C.POINTER(EpnnConfig), C.c_int, C.POINTER(_vp)]),
+    "epnn_destroy": (C.c_int, [_vp]),
+    "epnn_set_weights": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "epnn_get_weights": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "epnn_weight_shape": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "epnn_edges": (C.c_int, [_vp, C.c_int, _fp, _fp]),
+    "epnn_forward_xyz": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp, _fp]),
+    "epnn_forward_xyz_dev": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _vp, _vp, _vp, _vp]),
+    "epnn_model_forward_dense": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "epnn_model_forward_dense_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epnn_gnn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "epnn_epn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "epnn_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "epnn_dev_free": (C.c_int, [_vp, _vp]),
+    "epnn_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "epnn_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "epnn_sync": (C.c_int, [_vp]),
+    "epnn_timer_begin": (C.c_int, [_vp]),
+    "epnn_timer_end": (C.c_int, [_vp, _fp]),
+    "epnn_last_timing": (C.c_int, [_vp, _fp]),
+    "epnn_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "epnn_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libepnn_hip.so (built by __graft_entry__.build()); raises EpnnError if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EpnnError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the EPNN hot path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise EpnnError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise EpnnError(lib.epnn_last_error().decode(errors="replace"))
+
+
+def fptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_fp)
+
+
+def iptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_ip)

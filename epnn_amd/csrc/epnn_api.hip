@@ -1,0 +1,607 @@
+// C ABI of libepnn_hip.so (see include/epnn.h).  gfx950 only.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "epnn_host.h"
+#include "epnn_frontend.hip.h"
+#include "epnn_small.hip.h"
+#include "epnn_large.hip.h"
+#include "epnn_dense.hip.h"
+
+thread_local std::string g_epnn_err;
+
+extern "C" const char *epnn_last_error(void) { return g_epnn_err.c_str(); }
+extern "C" int epnn_version(void) { return 1; }
+extern "C" int epnn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ create
+static void shape_layers(epnn_handle *h) {
+    const int F = h->cfg.nx + h->cfg.h_dim + 1, H = h->cfg.hidden, E = h->cfg.e_dim;
+    auto set = [](HostDense &d, int i, int o) {
+        d.n_in = i;
+        d.n_out = o;
+        d.W.assign((size_t)i * o, 0.f);
+        d.b.assign(o, 0.f);
+    };
+    for (int t = 0; t < h->cfg.T; ++t) {
+        set(h->msg[t][0], 2 * F + E, H);
+        set(h->msg[t][1], H, H);
+        set(h->msg[t][2], H, H);                 // message width is hard-coded 32 (charge_gn.py:52)
+        set(h->pas[t][0], 2 * F + E, H);
+        set(h->pas[t][1], H, H);
+        set(h->pas[t][2], H, 1);
+    }
+    set(h->upd[0], h->cfg.h_dim + H, H);
+    set(h->upd[1], H, H);
+    set(h->upd[2], H, h->cfg.h_dim);
+}
+
+extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out) {
+    if (!cfg || !out) EPNN_FAIL("epnn_create: null argument");
+    if (cfg->h_dim != EPNN_EDIM || cfg->e_dim != EPNN_EDIM)
+        EPNN_FAIL("epnn_create: h_dim and e_dim must both be %d (charge_gn.py:377 requires e_dim == h_dim)", EPNN_EDIM);
+    if (cfg->hidden != EPNN_HID) EPNN_FAIL("epnn_create: hidden must be %d", EPNN_HID);
+    if (cfg->T < 1 || cfg->T > EPNN_MAXT) EPNN_FAIL("epnn_create: T must be in 1..%d", EPNN_MAXT);
+    if (cfg->nx < 1 || cfg->nx + EPNN_EDIM + 1 > 2 * EPNN_KA) EPNN_FAIL("epnn_create: nx must be in 1..%d", 2 * EPNN_KA - EPNN_EDIM - 1);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        EPNN_FAIL("epnn_create: no HIP device visible; the EPNN hot path has no CPU fallback");
+    if (device < 0 || device >= ndev) EPNN_FAIL("epnn_create: device %d out of range (0..%d)", device, ndev - 1);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        EPNN_FAIL("epnn_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    epnn_handle *h = new epnn_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&h->ev_t0));
+    HIPCHK(hipEventCreate(&h->ev_t1));
+    for (auto &e : h->ev_stage) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_status), 4 * sizeof(int), hipHostMallocDefault));
+    memset(h->h_status, 0, 4 * sizeof(int));
+    if (h->d_status.ensure(4 * sizeof(int))) return 1;
+    HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    // mu = np.linspace(0.1, cutoff, e_dim): arange(num)*step + start, last element forced to stop
+    std::vector<double> mu(cfg->e_dim);
+    const double start = 0.1, stop = (double)cfg->cutoff;
+    const double step = (stop - start) / (double)(cfg->e_dim - 1);
+    for (int k = 0; k < cfg->e_dim; ++k) mu[k] = (double)k * step + start;
+    mu[cfg->e_dim - 1] = stop;
+    if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
+    HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
+    shape_layers(h);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    *out = h;
+    return 0;
+}
+
+extern "C" int epnn_destroy(epnn_handle *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
+                      &h->d_status, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
+                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
+                      &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm};
+    for (DevBuf *b : bufs) b->release();
+    if (h->h_status) (void)hipHostFree(h->h_status);
+    (void)hipEventDestroy(h->ev_t0);
+    (void)hipEventDestroy(h->ev_t1);
+    for (auto &e : h->ev_stage) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+static HostDense *find_layer(epnn_handle *h, int which, int t, int layer) {
+    if (!h || layer < 0 || layer > 2) return nullptr;
+    if (which == EPNN_W_UPD) return &h->upd[layer];
+    if (t < 0 || t >= h->cfg.T) return nullptr;
+    if (which == EPNN_W_MSG) return &h->msg[t][layer];
+    if (which == EPNN_W_PAS) return &h->pas[t][layer];
+    return nullptr;
+}
+
+extern "C" int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, int32_t *n_in, int32_t *n_out) {
+    HostDense *d = find_layer(h, which, t, layer);
+    if (!d) EPNN_FAIL("epnn_weight_shape: bad (which=%d, t=%d, layer=%d)", which, t, layer);
+    if (n_in) *n_in = d->n_in;
+    if (n_out) *n_out = d->n_out;
+    return 0;
+}
+
+extern "C" int epnn_set_weights(epnn_handle *h, int which, int t, int layer, const float *kernel, const float *bias) {
+    HostDense *d = find_layer(h, which, t, layer);
+    if (!d || !kernel || !bias) EPNN_FAIL("epnn_set_weights: bad (which=%d, t=%d, layer=%d) or null pointer", which, t, layer);
+    memcpy(d->W.data(), kernel, d->W.size() * sizeof(float));
+    memcpy(d->b.data(), bias, d->b.size() * sizeof(float));
+    h->weights_dirty = true;
+    return 0;
+}
+
+extern "C" int epnn_get_weights(epnn_handle *h, int which, int t, int layer, float *kernel, float *bias) {
+    HostDense *d = find_layer(h, which, t, layer);
+    if (!d) EPNN_FAIL("epnn_get_weights: bad (which=%d, t=%d, layer=%d)", which, t, layer);
+    if (kernel) memcpy(kernel, d->W.data(), d->W.size() * sizeof(float));
+    if (bias) memcpy(bias, d->b.data(), d->b.size() * sizeof(float));
+    return 0;
+}
+
+// Re-lay the Keras kernels into MFMA fragment order (see epnn_common.h) and upload.
+static int pack_weights(epnn_handle *h) {
+    if (!h->weights_dirty) return 0;
+    const int nx = h->cfg.nx, F = nx + EPNN_EDIM + 1, T = h->cfg.T;
+    std::vector<float> buf;
+    auto alloc = [&](size_t n) {
+        size_t off = (buf.size() + 63) & ~size_t(63);      // 256-byte aligned sections
+        buf.resize(off + n, 0.f);
+        return (int)off;
+    };
+    auto pack_pair = [&](HostDense (&m)[3], PairMlpPack &pk, bool is_pass) {
+        const float *W1 = m[0].W.data(), *b1 = m[0].b.data(), *W2 = m[1].W.data(), *b2 = m[1].b.data();
+        pk.wiF = alloc(EPNN_KA * 64);
+        pk.wjF = alloc(EPNN_KA * 64);
+        for (int s = 0; s < EPNN_KA; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int c = l & 31, hh = l >> 5, f = 2 * s + hh;
+                buf[pk.wiF + s * 64 + l] = f < F ? W1[(size_t)f * 32 + c] : 0.f;
+                buf[pk.wjF + s * 64 + l] = f < F ? W1[(size_t)(F + f) * 32 + c] : 0.f;
+            }
+        pk.b1p = alloc(32);
+        pk.b2p = alloc(32);
+        pk.b2 = alloc(32);
+        pk.w3p = alloc(32);
+        for (int hh = 0; hh < 2; ++hh)
+            for (int r = 0; r < 16; ++r) {
+                buf[pk.b1p + hh * 16 + r] = b1[epnn_kappa(hh, r)];
+                buf[pk.b2p + hh * 16 + r] = b2[epnn_kappa(hh, r)];
+                buf[pk.w3p + hh * 16 + r] = is_pass ? m[2].W[epnn_kappa(hh, r)] : 0.f;
+            }
+        for (int c = 0; c < 32; ++c) buf[pk.b2 + c] = b2[c];
+        pk.weF = alloc(24 * 64);
+        for (int s = 0; s < 24; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int c = l & 31, hh = l >> 5;
+                buf[pk.weF + s * 64 + l] = W1[(size_t)(2 * F + 24 * hh + s) * 32 + c];
+            }
+        pk.w2F = alloc(16 * 64);
+        for (int s = 0; s < 16; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int c = l & 31, hh = l >> 5;
+                buf[pk.w2F + s * 64 + l] = W2[(size_t)epnn_kappa(hh, s) * 32 + c];
+            }
+    };
+    for (int t = 0; t < T; ++t) {
+        pack_pair(h->msg[t], h->widx.msg[t], false);
+        pack_pair(h->pas[t], h->widx.pas[t], true);
+    }
+    const float *Wu1 = h->upd[0].W.data(), *Wu2 = h->upd[1].W.data(), *Wu3 = h->upd[2].W.data();
+    for (int t = 0; t < T; ++t) {
+        UpdPack &U = h->widx.upd[t];
+        const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
+        // fold the last message Dense into the first update Dense:  Wu1_M^T (W3^T S + N b3)
+        std::vector<double> fold(32 * 32), cb3(32);
+        for (int o = 0; o < 32; ++o)
+            for (int k = 0; k < 32; ++k) {
+                double a = 0;
+                for (int m = 0; m < 32; ++m) a += (double)W3[o * 32 + m] * (double)Wu1[(size_t)(EPNN_EDIM + m) * 32 + k];
+                fold[o * 32 + k] = a;
+            }
+        for (int k = 0; k < 32; ++k) {
+            double a = 0;
+            for (int m = 0; m < 32; ++m) a += (double)b3[m] * (double)Wu1[(size_t)(EPNN_EDIM + m) * 32 + k];
+            cb3[k] = a;
+        }
+        U.u1F = alloc(40 * 64);
+        for (int s = 0; s < 40; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int c = l & 31, hh = l >> 5;
+                float v;
+                if (s < 24) {
+                    const int u0 = (nx - hh + 1) >> 1;
+                    const int fp = 2 * (u0 + s) + hh - nx;          // h feature read at a_eo[hh*32 + u0 + s]
+                    v = Wu1[(size_t)fp * 32 + c];
+                } else {
+                    v = (float)fold[(2 * (s - 24) + hh) * 32 + c];
+                }
+                buf[U.u1F + s * 64 + l] = v;
+            }
+        U.cb3p = alloc(32);
+        U.bu1p = alloc(32);
+        U.bu2p = alloc(32);
+        U.bu3p = alloc(64);
+        for (int hh = 0; hh < 2; ++hh)
+            for (int r = 0; r < 16; ++r) {
+                const int k = epnn_kappa(hh, r);
+                buf[U.cb3p + hh * 16 + r] = (float)cb3[k];
+                buf[U.bu1p + hh * 16 + r] = h->upd[0].b[k];
+                buf[U.bu2p + hh * 16 + r] = h->upd[1].b[k];
+                buf[U.bu3p + hh * 16 + r] = h->upd[2].b[k];
+                buf[U.bu3p + 32 + hh * 16 + r] = 32 + k < EPNN_EDIM ? h->upd[2].b[32 + k] : 0.f;
+            }
+        U.u2F = alloc(16 * 64);
+        U.u3F = alloc(2 * 16 * 64);
+        for (int s = 0; s < 16; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int c = l & 31, hh = l >> 5, k = epnn_kappa(hh, s);
+                buf[U.u2F + s * 64 + l] = Wu2[(size_t)k * 32 + c];
+                buf[U.u3F + s * 64 + l] = Wu3[(size_t)k * EPNN_EDIM + c];
+                buf[U.u3F + (16 + s) * 64 + l] = 32 + c < EPNN_EDIM ? Wu3[(size_t)k * EPNN_EDIM + 32 + c] : 0.f;
+            }
+    }
+    if (h->d_wpack.ensure(buf.size() * sizeof(float))) return 1;
+    HIPCHK(hipMemcpyAsync(h->d_wpack.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));     // buf is a local
+    h->weights_dirty = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ plan
+static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
+    Plan &P = h->plan;
+    if (P.valid && P.B == B && P.N == N && (int)P.offsets.size() == B + 1 &&
+        memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0)
+        return 0;
+    if (B < 1) EPNN_FAIL("forward: batch must have at least one molecule");
+    if (offsets[0] != 0) EPNN_FAIL("forward: offsets[0] must be 0");
+    P.valid = false;
+    P.B = B;
+    P.N = N;
+    P.A = offsets[B];
+    P.offsets.assign(offsets, offsets + B + 1);
+    P.small_order.clear();
+    P.large_list.clear();
+    P.small_nmax = 0;
+    std::vector<int> molof(P.A);
+    for (int b = 0; b < B; ++b) {
+        const int n = offsets[b + 1] - offsets[b];
+        if (n < 1) EPNN_FAIL("forward: molecule %d has %d atoms", b, n);
+        if (n > N) EPNN_FAIL("forward: molecule %d has %d atoms but the padded size N is %d", b, n, N);
+        for (int a = offsets[b]; a < offsets[b + 1]; ++a) molof[a] = b;
+        const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX);
+        if (small && n > EPNN_SMALL_NMAX) EPNN_FAIL("forward: force_path=1 but molecule %d has %d > %d atoms", b, n, EPNN_SMALL_NMAX);
+        if (small) {
+            P.small_order.push_back(b);
+            P.small_nmax = std::max(P.small_nmax, n);
+        } else {
+            P.large_list.push_back(b);
+        }
+    }
+    std::stable_sort(P.small_order.begin(), P.small_order.end(), [&](int a, int b) {
+        return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
+    });
+    if (h->d_moff.ensure((B + 1) * sizeof(int)) || h->d_molof.ensure(std::max(1, P.A) * sizeof(int)) ||
+        h->d_order.ensure(std::max<size_t>(1, P.small_order.size()) * sizeof(int)) ||
+        h->d_rowcnt.ensure((P.A + 1) * sizeof(int)) || h->d_rowoff.ensure((P.A + 1) * sizeof(int)))
+        return 1;
+    HIPCHK(hipMemcpyAsync(h->d_moff.p, offsets, (B + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_molof.p, molof.data(), P.A * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!P.small_order.empty())
+        HIPCHK(hipMemcpyAsync(h->d_order.p, P.small_order.data(), P.small_order.size() * sizeof(int),
+                              hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));     // molof is a local
+    if (large_plan(h)) return 1;
+    P.valid = true;
+    return 0;
+}
+
+static int ensure_pairs(epnn_handle *h, int pcap) {
+    if (pcap <= h->pcap) return 0;
+    if (h->d_pi.ensure((size_t)pcap * sizeof(int)) || h->d_pj.ensure((size_t)pcap * sizeof(int)) ||
+        h->d_psym.ensure((size_t)pcap * sizeof(int)) || h->d_pwi.ensure((size_t)pcap * sizeof(float)) ||
+        h->d_pwj.ensure((size_t)pcap * sizeof(float)) || h->d_pe.ensure((size_t)pcap * EPNN_EDIM * sizeof(float)))
+        return 1;
+    h->pcap = pcap;
+    return 0;
+}
+
+static SmallLds small_layout(int gcap) {
+    SmallLds L;
+    int o = 0;
+    auto take = [&](int words) {
+        int r = o;
+        o += (words + 3) & ~3;
+        return r;
+    };
+    L.a_eo = take(32 * EPNN_AST);
+    L.P = take(32 * EPNN_PST);
+    L.R = take(40 * EPNN_PST);
+    L.Sw = take(4 * 32 * EPNN_SST);
+    L.zp = take(32 * EPNN_SST);
+    L.G = take(gcap * EPNN_PST);
+    L.dl = take(gcap);
+    L.pij = take(gcap);
+    L.pwi = take(gcap);
+    L.pwj = take(gcap);
+    L.pm = take((32 * 36) / 2);
+    L.glut = take(288 / 4);
+    L.nm = take(32);
+    L.total = o;
+    return L;
+}
+
+struct PairSource {     // where the fused / tiled kernels read atoms and pairs from
+    const float *d_x = nullptr, *d_Q = nullptr, *d_hin = nullptr, *d_qin = nullptr;
+    float *d_q = nullptr, *d_hout = nullptr;
+    int run_gnn = 1, run_epn = 1;
+};
+
+static int launch_small(epnn_handle *h, const PairSource &S) {
+    const Plan &P = h->plan;
+    if (P.small_order.empty()) return 0;
+    const int nmax = P.small_nmax;
+    const int full = nmax * (nmax - 1) / 2 + nmax;   // every unordered pair + diagonal entries (dense front-end)
+    int gcap = h->small_gcap > 0 ? h->small_gcap : std::min(full, std::max(32, 8 * nmax));
+    gcap = std::min(std::max(gcap, 1), full > 0 ? std::max(full, 1) : 1);
+    SmallArgs A{};
+    A.wpack = h->d_wpack.as<float>();
+    A.wi = h->widx;
+    A.xin = S.d_x;
+    A.Q = S.d_Q;
+    A.moff = h->d_moff.as<int>();
+    A.order = h->d_order.as<int>();
+    A.row_off = h->d_rowoff.as<int>();
+    A.pi = h->d_pi.as<int>();
+    A.pj = h->d_pj.as<int>();
+    A.psym = h->d_psym.as<int>();
+    A.pe = h->d_pe.as<float>();
+    A.pwi = h->d_pwi.as<float>();
+    A.pwj = h->d_pwj.as<float>();
+    A.q_out = S.d_q;
+    A.h_out = S.d_hout;
+    A.h_in = S.d_hin;
+    A.q_in = S.d_qin;
+    A.status = h->d_status.as<int>();
+    A.N = P.N;
+    A.T = h->cfg.T;
+    A.nx = h->cfg.nx;
+    A.gcap = gcap;
+    A.pcap = h->pcap;
+    A.A = P.A;
+    A.run_gnn = S.run_gnn;
+    A.run_epn = S.run_epn;
+    A.L = small_layout(gcap);
+    const size_t lds = (size_t)A.L.total * 4;
+    if (lds > 160 * 1024) EPNN_FAIL("fused kernel: LDS budget exceeded (%zu bytes)", lds);
+    hipLaunchKernelGGL(k_small_forward, dim3((unsigned)P.small_order.size()), dim3(256), lds, h->stream, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int run_frontend_xyz(epnn_handle *h, const float *d_xyz) {
+    const Plan &P = h->plan;
+    FrontArgs F{};
+    F.xyz = d_xyz;
+    F.mol_of = h->d_molof.as<int>();
+    F.moff = h->d_moff.as<int>();
+    F.A = P.A;
+    F.cutoff = (double)h->cfg.cutoff;
+    F.eta = (double)h->cfg.eta;
+    F.tol = h->cfg.near_tol;
+    F.e_dim = h->cfg.e_dim;
+    F.mu = h->d_mu.as<double>();
+    F.row_cnt = h->d_rowcnt.as<int>();
+    F.row_off = h->d_rowoff.as<int>();
+    F.pcap = h->pcap;
+    F.pi = h->d_pi.as<int>();
+    F.pj = h->d_pj.as<int>();
+    F.psym = h->d_psym.as<int>();
+    F.pe = h->d_pe.as<float>();
+    F.pwi = h->d_pwi.as<float>();
+    F.pwj = h->d_pwj.as<float>();
+    F.status = h->d_status.as<int>();
+    const unsigned rows = (unsigned)((P.A + 3) / 4);
+    hipLaunchKernelGGL(k_front_count, dim3(rows), dim3(256), 0, h->stream, F);
+    hipLaunchKernelGGL(k_front_scan, dim3(1), dim3(1024), 0, h->stream, F);
+    hipLaunchKernelGGL(k_front_fill, dim3(rows), dim3(256), 0, h->stream, F);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *d_xyz,
+                               const float *d_x, const float *d_Q, float *d_q) {
+    HIPCHK(hipSetDevice(h->device));
+    if (pack_weights(h)) return 1;
+    if (build_plan(h, B, N, offsets)) return 1;
+    const Plan &P = h->plan;
+    if (ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
+    HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[0], h->stream));
+    if (run_frontend_xyz(h, d_xyz)) return 1;
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[1], h->stream));
+    PairSource S;
+    S.d_x = d_x;
+    S.d_Q = d_Q;
+    S.d_q = d_q;
+    if (launch_small(h, S)) return 1;
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[2], h->stream));
+    if (launch_large(h, S)) return 1;
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[3], h->stream));
+    // status + pair count come back with the results
+    HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    h->stats[1] = (int64_t)P.small_order.size();
+    h->stats[2] = (int64_t)P.large_list.size();
+    return 0;
+}
+
+// wait for the stream; if the last forward overflowed a capacity, grow it and run again
+static int finish_forward(epnn_handle *h) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!h->pending.active) return 0;
+        const int st = h->h_status[0];
+        h->stats[0] = h->h_status[1];
+        if (h->opt_profile) {
+            float ms = 0;
+            for (int k = 0; k < 3; ++k) {
+                HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[k], h->ev_stage[k + 1]));
+                h->timing[k] = ms;
+            }
+            HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[0], h->ev_stage[3]));
+            h->timing[3] = ms;
+        }
+        if (st == 0) {
+            h->pending.active = false;
+            return 0;
+        }
+        h->stats[3] += 1;
+        if (st & EPNN_ST_PAIR_OVERFLOW) {
+            if (ensure_pairs(h, h->h_status[1] + h->h_status[1] / 8 + 1024)) return 1;
+        }
+        if (st & EPNN_ST_SMALL_OVERFLOW) {
+            const int nmax = h->plan.small_nmax;
+            h->small_gcap = nmax * (nmax - 1) / 2 + nmax;     // worst case; fits LDS for n <= 32
+        }
+        auto &pd = h->pending;
+        if (enqueue_forward_xyz(h, pd.B, pd.N, pd.offsets.data(), pd.d_xyz, pd.d_x, pd.d_Q, pd.d_q)) return 1;
+    }
+    EPNN_FAIL("forward: capacity regrow did not converge");
+}
+
+extern "C" int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t *offsets, const float *d_xyz,
+                                    const float *d_x, const float *d_Q, float *d_q_out) {
+    if (!h || !offsets || !d_xyz || !d_x || !d_Q || !d_q_out) EPNN_FAIL("epnn_forward_xyz_dev: null argument");
+    if (h->pending.active && finish_forward(h)) return 1;     // previous call may still need a regrow
+    if (enqueue_forward_xyz(h, B, N, offsets, d_xyz, d_x, d_Q, d_q_out)) return 1;
+    auto &pd = h->pending;
+    pd.active = true;
+    pd.B = B;
+    pd.N = N;
+    pd.offsets.assign(offsets, offsets + B + 1);
+    pd.d_xyz = d_xyz;
+    pd.d_x = d_x;
+    pd.d_Q = d_Q;
+    pd.d_q = d_q_out;
+    return 0;
+}
+
+extern "C" int epnn_sync(epnn_handle *h) {
+    if (!h) EPNN_FAIL("epnn_sync: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    return finish_forward(h);
+}
+
+extern "C" int epnn_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz,
+                                const float *x, const float *Q, float *q_out) {
+    if (!h || !offsets || !xyz || !x || !Q || !q_out) EPNN_FAIL("epnn_forward_xyz: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (B < 1) EPNN_FAIL("epnn_forward_xyz: empty batch");
+    const int A = offsets[B];
+    if (A < 1) EPNN_FAIL("epnn_forward_xyz: no atoms");
+    const int nx = h->cfg.nx;
+    if (h->s_xyz.ensure((size_t)A * 3 * 4) || h->s_x.ensure((size_t)A * nx * 4) || h->s_Q.ensure((size_t)B * 4) ||
+        h->s_q.ensure((size_t)A * 4))
+        return 1;
+    HIPCHK(hipMemcpyAsync(h->s_xyz.p, xyz, (size_t)A * 3 * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_x.p, x, (size_t)A * nx * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_Q.p, Q, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    if (epnn_forward_xyz_dev(h, B, N, offsets, h->s_xyz.as<float>(), h->s_x.as<float>(), h->s_Q.as<float>(),
+                             h->s_q.as<float>()))
+        return 1;
+    if (finish_forward(h)) return 1;
+    HIPCHK(hipMemcpyAsync(q_out, h->s_q.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ edges
+extern "C" int epnn_edges(epnn_handle *h, int n, const float *xyz, float *e_out) {
+    if (!h || !xyz || !e_out || n < 1) EPNN_FAIL("epnn_edges: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t total = (size_t)n * n * h->cfg.e_dim;
+    if (h->s_xyz.ensure((size_t)n * 3 * 4) || h->s_misc.ensure(total * 4)) return 1;
+    HIPCHK(hipMemcpyAsync(h->s_xyz.p, xyz, (size_t)n * 3 * 4, hipMemcpyHostToDevice, h->stream));
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_edges_dense, dim3(grid), dim3(256), 0, h->stream, h->s_xyz.as<float>(), n, h->cfg.e_dim,
+                       (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->s_misc.as<float>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e_out, h->s_misc.p, total * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ plumbing
+extern "C" int epnn_dev_alloc(epnn_handle *h, size_t bytes, void **out) {
+    if (!h || !out) EPNN_FAIL("epnn_dev_alloc: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+    return 0;
+}
+extern "C" int epnn_dev_free(epnn_handle *h, void *p) {
+    if (!h) EPNN_FAIL("epnn_dev_free: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (p) HIPCHK(hipFree(p));
+    return 0;
+}
+extern "C" int epnn_memcpy_h2d(epnn_handle *h, void *dst, const void *src, size_t bytes) {
+    if (!h) EPNN_FAIL("epnn_memcpy_h2d: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int epnn_memcpy_d2h(epnn_handle *h, void *dst, const void *src, size_t bytes) {
+    if (!h) EPNN_FAIL("epnn_memcpy_d2h: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (finish_forward(h)) return 1;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int epnn_timer_begin(epnn_handle *h) {
+    if (!h) EPNN_FAIL("epnn_timer_begin: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev_t0, h->stream));
+    return 0;
+}
+extern "C" int epnn_timer_end(epnn_handle *h, float *elapsed_ms) {
+    if (!h || !elapsed_ms) EPNN_FAIL("epnn_timer_end: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev_t1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev_t1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev_t0, h->ev_t1));
+    return 0;
+}
+extern "C" int epnn_last_timing(epnn_handle *h, float *out4) {
+    if (!h || !out4) EPNN_FAIL("epnn_last_timing: null argument");
+    memcpy(out4, h->timing, sizeof(h->timing));
+    return 0;
+}
+extern "C" int epnn_last_stats(epnn_handle *h, int64_t *out4) {
+    if (!h || !out4) EPNN_FAIL("epnn_last_stats: null argument");
+    memcpy(out4, h->stats, sizeof(h->stats));
+    return 0;
+}
+extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
+    if (!h || !name) EPNN_FAIL("epnn_set_option: null argument");
+    if (!strcmp(name, "profile")) h->opt_profile = value;
+    else if (!strcmp(name, "force_path")) { h->opt_force_path = value; h->plan.valid = false; }
+    else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
+    else if (!strcmp(name, "small_gcap")) { h->small_gcap = value; }
+    else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
+    return 0;
+}
+
+static int launch_large(epnn_handle *h, const PairSource &S) {
+    (void)S;
+    if (!h->plan.large_list.empty()) EPNN_FAIL("tiled large-system path not built yet");
+    return 0;
+}
+
+// ---- dense entry points: filled in by epnn_dense.hip.h once built
+#ifndef EPNN_HAVE_DENSE
+extern "C" int epnn_model_forward_dense(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_model_forward_dense: not built yet"); }
+extern "C" int epnn_model_forward_dense_dev(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_model_forward_dense_dev: not built yet"); }
+extern "C" int epnn_gnn_forward(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_gnn_forward: not built yet"); }
+extern "C" int epnn_epn_forward(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_epn_forward: not built yet"); }
+#endif

@@ -1,0 +1,94 @@
+// Shared definitions of the EPNN HIP library (gfx950 / MI355X only).
+//
+// Arithmetic model (exact re-association of reference charge_gn.py:56-119):
+//   first Dense of every pair MLP is split by input block  W1^T[a_i|a_j|e_ij] = Wi^T a_i + Wj^T a_j + We^T e_ij,
+//   so   P_i = Wi^T a_i + b1,  R_j = Wj^T a_j  (per atom)   and   G_ij = We^T e_ij  (per near pair only),
+//   z1_ij = relu(P_i + R_j + G_ij),  z2_ij = relu(W2^T z1_ij + b2).
+//   GNN:  sum_j m_ij = W3^T (sum_j z2_ij) + N b3 ;  EPN:  f_ij = w3 . z2_ij (+ b3, cancels in f_ij - f_ji).
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  Lane l = 32*hh + c.  Accumulator register r of lane
+// (c,hh) is element (row kappa(hh,r), col c) with kappa(hh,r) = 4*hh + (r&3) + 8*(r>>2).  All 32-wide feature
+// vectors that feed an MFMA as the K dimension are kept "kappa-permuted": element r of half hh is feature
+// kappa(hh,r), so that an accumulator can be fed straight back as the next A/B operand (no LDS round trip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EPNN_HID 32          // hidden width of every MLP
+#define EPNN_EDIM 48         // edge channels == h_dim
+#define EPNN_KA 30           // K-steps of the per-atom projection: features f = 2*s + hh, f < 60
+#define EPNN_AST 68          // LDS/HBM row stride (floats) of the even/odd atom-feature image a_eo
+#define EPNN_PST 36          // LDS row stride (floats) of kappa-permuted 32-vectors (P, R, G)
+#define EPNN_SST 33          // LDS row stride (floats) of out-major 32-vectors (S partial sums)
+#define EPNN_MAXT 8
+#define EPNN_SMALL_NMAX 32   // fused kernel handles molecules with n <= 32 real atoms
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Offsets (in floats) into the packed weight buffer.
+struct PairMlpPack {      // one message_fns[t] / pass_fns[t]
+    int wiF;              // [KA][64]  Wi[2s+hh][c]      (A operand of P^T = Wi^T a^T)
+    int wjF;              // [KA][64]  Wj[2s+hh][c]
+    int b1p;              // [2][16]   b1[kappa(hh,r)]
+    int weF;              // [24][64]  We[24hh+s][c]     (A operand of G^T = We^T e^T)
+    int w2F;              // [16][64]  W2[kappa(hh,s)][c]
+    int b2;               // [32]      b2[c]
+    int b2p;              // [2][16]   b2[kappa(hh,r)]
+    int w3p;              // [2][16]   w3[kappa(hh,r)]   (pass MLP only)
+};
+struct UpdPack {          // update_fn with message_fns[t]'s last Dense folded in
+    int u1F;              // [40][64]  s<24: Wu1[h feature][c]; s>=24: (W3_t Wu1_M)[2(s-24)+hh][c]
+    int cb3p;             // [2][16]   (Wu1_M^T b3_t)[kappa(hh,r)]   (times N at run time)
+    int bu1p;             // [2][16]
+    int u2F;              // [16][64]  Wu2[kappa(hh,s)][c]
+    int bu2p;             // [2][16]
+    int u3F;              // [2][16][64] Wu3[kappa(hh,s)][32*tile+c]
+    int bu3p;             // [2][2][16]
+};
+struct WeightIndex {
+    PairMlpPack msg[EPNN_MAXT];
+    PairMlpPack pas[EPNN_MAXT];
+    UpdPack upd[EPNN_MAXT];
+};
+
+__host__ __device__ static inline int epnn_kappa(int hh, int r) { return 4 * hh + (r & 3) + 8 * (r >> 2); }
+
+// position of atom feature f inside the even/odd image row: half (f&1), slot f>>1
+__host__ __device__ static inline int epnn_aeo(int f) { return (f & 1) * 32 + (f >> 1); }
+
+// status bits written by kernels
+#define EPNN_ST_PAIR_OVERFLOW 1   // near-pair list capacity exceeded
+#define EPNN_ST_SMALL_OVERFLOW 2  // a molecule on the fused path has more near pairs than its LDS budget
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ f32x16 epnn_mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 epnn_splat16(float v) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = v;
+    return o;
+}
+// 16 contiguous floats (16-byte aligned) -> registers
+__device__ __forceinline__ void epnn_ld16(const float *p, float (&o)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+        o[4 * q + 0] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
+    }
+}
+__device__ __forceinline__ void epnn_st16(float *p, const f32x16 &v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 o;
+        o[0] = v[4 * q + 0]; o[1] = v[4 * q + 1]; o[2] = v[4 * q + 2]; o[3] = v[4 * q + 3];
+        *reinterpret_cast<f32x4 *>(p + 4 * q) = o;
+    }
+}
+// value held by the other half-wave's lane with the same c (lane ^ 32)
+__device__ __forceinline__ float epnn_swap32(float v) {
+    return __shfl_xor(v, 32, 64);
+}
+#endif

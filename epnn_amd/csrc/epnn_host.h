@@ -1,0 +1,101 @@
+// Host-side state of one epnn_handle (one per device).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/epnn.h"
+#include "epnn_common.h"
+
+extern thread_local std::string g_epnn_err;
+
+#define EPNN_FAIL(...)                                        \
+    do {                                                      \
+        char _buf[512];                                       \
+        snprintf(_buf, sizeof(_buf), __VA_ARGS__);            \
+        g_epnn_err = _buf;                                    \
+        return 1;                                             \
+    } while (0)
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) EPNN_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        HIPCHK(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct HostDense {            // one Keras Dense: kernel [in][out], bias [out]
+    int n_in = 0, n_out = 0;
+    std::vector<float> W, b;
+};
+
+struct Plan {                 // what the host derives from `offsets`
+    int B = 0, A = 0, N = 0;
+    std::vector<int> offsets;
+    std::vector<int> small_order;   // molecules on the fused path, largest first
+    std::vector<int> large_list;    // molecules on the tiled path
+    int small_nmax = 0;
+    bool valid = false;
+};
+
+struct epnn_handle {
+    epnn_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // weights
+    HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
+    bool weights_dirty = true;
+    WeightIndex widx{};
+    DevBuf d_wpack;
+    DevBuf d_mu;
+    // plan + workspace
+    Plan plan;
+    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status;
+    DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
+    int pcap = 0;
+    int pair_cap_per_atom = 16;
+    int small_gcap = 0;           // 0 = heuristic
+    int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
+    // staging for the host-pointer entry points
+    DevBuf s_xyz, s_x, s_Q, s_q, s_misc;
+    // large path workspace (epnn_large.hip.h)
+    DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
+    // options / stats
+    int opt_profile = 0, opt_force_path = 0;
+    float timing[4] = {0, 0, 0, 0};
+    int64_t stats[4] = {0, 0, 0, 0};
+    // deferred overflow handling for the asynchronous entry point
+    struct Pending {
+        bool active = false;
+        int B = 0, N = 0;
+        std::vector<int> offsets;
+        const float *d_xyz = nullptr, *d_x = nullptr, *d_Q = nullptr;
+        float *d_q = nullptr;
+    } pending;
+};

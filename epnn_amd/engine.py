@@ -1,0 +1,196 @@
+"""Thin object wrapper over the C ABI: one Engine == one epnn_handle == one GPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import W_MSG, W_PAS, W_UPD, EpnnConfig, EpnnError, check, fptr, iptr
+
+_WHICH = {"msg": W_MSG, "upd": W_UPD, "pas": W_PAS}
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class DeviceArray:
+    """A device allocation owned by an Engine (used by bench.py to keep inputs resident in HBM)."""
+
+    def __init__(self, eng, nbytes):
+        self.eng = eng
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(eng.lib.epnn_dev_alloc(eng.h, self.nbytes, C.byref(p)), eng.lib)
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(self.eng.lib.epnn_memcpy_h2d(self.eng.h, self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes), self.eng.lib)
+        return self
+
+    def download(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.eng.lib.epnn_memcpy_d2h(self.eng.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes), self.eng.lib)
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.eng.h:
+            self.eng.lib.epnn_dev_free(self.eng.h, self.ptr)
+        self.ptr = None
+
+
+class Engine:
+    def __init__(self, nx=9, h_dim=48, e_dim=48, T=5, hidden=32, cutoff=3.0, eta=2.0, near_tol=1e-5, device=0):
+        self.lib = _lib.load()
+        self.cfg = EpnnConfig(nx, h_dim, e_dim, T, hidden, cutoff, eta, near_tol)
+        self.nx, self.h_dim, self.e_dim, self.T = nx, h_dim, e_dim, T
+        self.device = device
+        h = C.c_void_p()
+        check(self.lib.epnn_create(C.byref(self.cfg), device, C.byref(h)), self.lib)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.epnn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def weight_shape(self, group, t, layer):
+        a, b = C.c_int32(), C.c_int32()
+        check(self.lib.epnn_weight_shape(self.h, _WHICH[group], t, layer, C.byref(a), C.byref(b)), self.lib)
+        return a.value, b.value
+
+    def set_layer(self, group, t, layer, kernel, bias):
+        shp = self.weight_shape(group, t, layer)
+        kernel, bias = _f32(kernel), _f32(bias)
+        if kernel.shape != shp or bias.shape != (shp[1],):
+            raise EpnnError(f"{group}[{t}] layer {layer}: expected kernel {shp} / bias ({shp[1]},), "
+                            f"got {kernel.shape} / {bias.shape}")
+        check(self.lib.epnn_set_weights(self.h, _WHICH[group], t, layer, fptr(kernel), fptr(bias)), self.lib)
+
+    def get_layer(self, group, t, layer):
+        shp = self.weight_shape(group, t, layer)
+        k = np.empty(shp, dtype=np.float32)
+        b = np.empty((shp[1],), dtype=np.float32)
+        check(self.lib.epnn_get_weights(self.h, _WHICH[group], t, layer, fptr(k), fptr(b)), self.lib)
+        return k, b
+
+    def set_weights(self, weights):
+        """weights = {"msg": [T][3](W,b), "upd": [3](W,b), "pas": [T][3](W,b)} (checkpoint.load_epnn_weights)."""
+        if len(weights["msg"]) != self.T or len(weights["pas"]) != self.T:
+            raise EpnnError(f"checkpoint has T={len(weights['msg'])}, engine was built with T={self.T}")
+        for t in range(self.T):
+            for l in range(3):
+                self.set_layer("msg", t, l, *weights["msg"][t][l])
+                self.set_layer("pas", t, l, *weights["pas"][t][l])
+        for l in range(3):
+            self.set_layer("upd", 0, l, *weights["upd"][l])
+
+    def get_weights(self):
+        return {"msg": [[self.get_layer("msg", t, l) for l in range(3)] for t in range(self.T)],
+                "upd": [self.get_layer("upd", 0, l) for l in range(3)],
+                "pas": [[self.get_layer("pas", t, l) for l in range(3)] for t in range(self.T)]}
+
+    # ------------------------------------------------------------------ compute
+    def edges(self, xyz):
+        xyz = _f32(xyz)
+        n = xyz.shape[0]
+        out = np.empty((n, n, self.e_dim), dtype=np.float32)
+        check(self.lib.epnn_edges(self.h, n, fptr(xyz), fptr(out)), self.lib)
+        return out
+
+    def forward_xyz(self, offsets, xyz, x, Q, N):
+        """Flat batch: offsets (B+1,), xyz (A,3), x (A,nx), Q (B,) -> q (A,) float32."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        xyz, x, Q = _f32(xyz), _f32(x), _f32(Q)
+        B = len(offsets) - 1
+        A = int(offsets[-1])
+        if xyz.shape != (A, 3) or x.shape != (A, self.nx) or Q.shape != (B,):
+            raise EpnnError(f"forward_xyz: shapes xyz {xyz.shape} x {x.shape} Q {Q.shape} do not match offsets (A={A}, B={B}, nx={self.nx})")
+        out = np.empty((A,), dtype=np.float32)
+        check(self.lib.epnn_forward_xyz(self.h, B, int(N), iptr(offsets), fptr(xyz), fptr(x), fptr(Q), fptr(out)), self.lib)
+        return out
+
+    def _dense_args(self, B, N, tensors, chans):
+        out = []
+        for t, ch in zip(tensors, chans):
+            t = _f32(t)
+            if t.ndim == len(ch) + 1 - 1 and ch[-1] == 1 and t.shape == (B,) + ch[:-1]:
+                t = t.reshape((B,) + ch)          # rank-3 mask -> rank 4 like Keras does
+            if t.shape != (B,) + ch:
+                raise EpnnError(f"expected shape {(B,) + ch}, got {t.shape}")
+            out.append(t)
+        return out
+
+    def model_forward_dense(self, h_inp, e_inp, x_inp, q_inp, mask_inp):
+        e_inp = _f32(e_inp)
+        B, N = e_inp.shape[0], e_inp.shape[1]
+        h_inp, e_inp, x_inp, q_inp, mask_inp = self._dense_args(
+            B, N, (h_inp, e_inp, x_inp, q_inp, mask_inp),
+            ((N, N, self.h_dim), (N, N, self.e_dim), (N, N, self.nx), (N, N, 1), (N, N, 1)))
+        out = np.empty((B, N, 1), dtype=np.float32)
+        check(self.lib.epnn_model_forward_dense(self.h, B, N, fptr(h_inp), fptr(e_inp), fptr(x_inp), fptr(q_inp),
+                                                fptr(mask_inp), fptr(out)), self.lib)
+        return out
+
+    def _layer(self, fn, h, e, x, q, mask, out_ch):
+        e = _f32(e)
+        B, N = e.shape[0], e.shape[1]
+        h, e, x, q, mask = self._dense_args(
+            B, N, (h, e, x, q, mask), ((N, self.h_dim), (N, N, self.e_dim), (N, self.nx), (N, 1), (N, N, 1)))
+        out = np.empty((B, N, out_ch), dtype=np.float32)
+        check(fn(self.h, B, N, fptr(h), fptr(e), fptr(x), fptr(q), fptr(mask), fptr(out)), self.lib)
+        return out
+
+    def gnn_forward(self, h, e, x, q, mask):
+        return self._layer(self.lib.epnn_gnn_forward, h, e, x, q, mask, self.h_dim)
+
+    def epn_forward(self, h, e, x, q, mask):
+        return self._layer(self.lib.epnn_epn_forward, h, e, x, q, mask, 1)
+
+    # ------------------------------------------------------------------ device-resident plumbing
+    def alloc(self, nbytes):
+        return DeviceArray(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceArray(self, arr.nbytes).upload(arr)
+
+    def forward_xyz_dev(self, offsets, d_xyz, d_x, d_Q, d_q, N):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        check(self.lib.epnn_forward_xyz_dev(self.h, len(offsets) - 1, int(N), iptr(offsets), d_xyz.ptr, d_x.ptr,
+                                            d_Q.ptr, d_q.ptr), self.lib)
+
+    def sync(self):
+        check(self.lib.epnn_sync(self.h), self.lib)
+
+    def timer_begin(self):
+        check(self.lib.epnn_timer_begin(self.h), self.lib)
+
+    def timer_end(self):
+        ms = C.c_float()
+        check(self.lib.epnn_timer_end(self.h, C.byref(ms)), self.lib)
+        return ms.value
+
+    def set_option(self, name, value):
+        check(self.lib.epnn_set_option(self.h, name.encode(), int(value)), self.lib)
+
+    def last_timing(self):
+        out = np.zeros(4, dtype=np.float32)
+        check(self.lib.epnn_last_timing(self.h, fptr(out)), self.lib)
+        return out
+
+    def last_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        check(self.lib.epnn_last_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_int64))), self.lib)
+        return out

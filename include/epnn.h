@@ -1,0 +1,117 @@
+/*
+ * epnn.h -- C ABI of libepnn_hip.so, the MI355X (gfx950) implementation of the EPNN hot path.
+ *
+ * The reference (derekmetcalf/epnn) has no FFI: its "operator API" for this path is the Python/Keras layer
+ * interface of charge_gn.py.  Each entry point below names the reference interface it stands in for; the
+ * Python mirror of that interface (epnn_amd/charge_gn.py) binds these symbols with ctypes and nothing else.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; epnn_last_error() gives the message of the
+ *     last failing call on the calling thread.
+ *   - all tensors are float32, row-major, caller-owned.  "host" entry points take host pointers and copy;
+ *     "_dev" entry points take pointers obtained from epnn_dev_alloc() on the same handle and run
+ *     asynchronously on the handle's stream (epnn_sync() waits).
+ *   - one handle per device; calls on one handle must be serialised by the caller.
+ *   - flat ("ragged") molecule batches: B molecules, molecule b owns atoms [offsets[b], offsets[b+1]) of the
+ *     flat atom arrays; N is the padded atom count the reference would have used (gen_padded_init_state pads
+ *     every molecule to the directory maximum, charge_gn.py:340-364).  N enters the arithmetic: the reference
+ *     sums messages over all N partners including the padded ones (charge_gn.py:70).
+ */
+#ifndef EPNN_H
+#define EPNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct epnn_handle epnn_handle;
+
+/* Hyper-parameters fixed at make_model time (charge_gn.py:369-374, 413-418) and the featuriser constants of
+ * get_init_edges (charge_gn.py:122: cutoff=3.0, eta=2.0, mu=linspace(0.1,cutoff,e_dim)); near_tol is the
+ * 1e-5 of EPN_layer.call (charge_gn.py:90). */
+typedef struct epnn_config {
+    int32_t nx;       /* atom feature columns: 9 (infer.py table) or 10 (charge_gn.py table)          */
+    int32_t h_dim;    /* 48 (must equal e_dim, charge_gn.py:377)                                       */
+    int32_t e_dim;    /* 48                                                                            */
+    int32_t T;        /* message / electron passing steps, 1..8                                        */
+    int32_t hidden;   /* 32: hidden width of every MLP and the message width (charge_gn.py:52,84,415)  */
+    float cutoff;     /* 3.0                                                                           */
+    float eta;        /* 2.0                                                                           */
+    float near_tol;   /* 1e-5                                                                          */
+} epnn_config;
+
+enum { EPNN_W_MSG = 0, EPNN_W_UPD = 1, EPNN_W_PAS = 2 };
+
+const char *epnn_last_error(void);
+int epnn_version(void);
+/* number of HIP devices visible (0 when there is none; never initialises a context beyond the count). */
+int epnn_device_count(void);
+
+/* make_model (charge_gn.py:369-391): creates the layer stack on `device`.  Weights start at zero. */
+int epnn_create(const epnn_config *cfg, int device, epnn_handle **out);
+int epnn_destroy(epnn_handle *h);
+
+/* model.load_weights / layer.set_weights (infer.py:57): one Dense layer of one MLP.
+ * which = EPNN_W_MSG (message_fns[t], charge_gn.py:52), EPNN_W_UPD (update_fn, t ignored, charge_gn.py:371),
+ * EPNN_W_PAS (pass_fns[t], charge_gn.py:84); layer = 0..2; kernel is Keras layout [in][out]. */
+int epnn_set_weights(epnn_handle *h, int which, int t, int layer, const float *kernel, const float *bias);
+/* model.trainable_variables / save_weights (charge_gn.py:462). */
+int epnn_get_weights(epnn_handle *h, int which, int t, int layer, float *kernel, float *bias);
+int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, int32_t *n_in, int32_t *n_out);
+
+/* get_init_edges (charge_gn.py:122-163): xyz[n][3] float32 -> e[n][n][e_dim] float32, host pointers. */
+int epnn_edges(epnn_handle *h, int n, const float *xyz, float *e_out);
+
+/* Compact entry == gen_padded_init_state featurisation (charge_gn.py:292-366) + model([h,e,x,q,mask])
+ * (charge_gn.py:369-391, infer.py:32-35) without materialising the dense (N,N,.) tensors:
+ * xyz[A][3], x[A][nx] (Z + one-hot), Q[B] total charges -> q_out[A] predicted charges of the real atoms
+ * (padded atoms are 0 in the reference output and are not stored).  Host pointers. */
+int epnn_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz, const float *x,
+                     const float *Q, float *q_out);
+/* Same with device-resident xyz/x/Q/q_out (offsets stay on the host); asynchronous. */
+int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t *offsets, const float *d_xyz,
+                         const float *d_x, const float *d_Q, float *d_q_out);
+
+/* Literal make_model call (charge_gn.py:376-389): h_inp/e_inp [B][N][N][h_dim], x_inp [B][N][N][nx],
+ * q_inp/mask_inp [B][N][N][1] -> q_out [B][N][1].  Host pointers. */
+int epnn_model_forward_dense(epnn_handle *h, int B, int N, const float *h_inp, const float *e_inp,
+                             const float *x_inp, const float *q_inp, const float *mask_inp, float *q_out);
+int epnn_model_forward_dense_dev(epnn_handle *h, int B, int N, const float *d_h_inp, const float *d_e_inp,
+                                 const float *d_x_inp, const float *d_q_inp, const float *d_mask_inp,
+                                 float *d_q_out);
+/* GNN_layer.call (charge_gn.py:57-75): h[B][N][h_dim], e[B][N][N][e_dim], x[B][N][nx], q[B][N][1],
+ * mask[B][N][N][1] -> h_out[B][N][h_dim].  Host pointers. */
+int epnn_gnn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,
+                     const float *q, const float *mask, float *h_out);
+/* EPN_layer.call (charge_gn.py:88-119): same inputs -> q_out[B][N][1].  Host pointers. */
+int epnn_epn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,
+                     const float *q, const float *mask, float *q_out);
+
+/* Device memory and stream plumbing for callers that keep inputs resident (bench.py). */
+int epnn_dev_alloc(epnn_handle *h, size_t bytes, void **out);
+int epnn_dev_free(epnn_handle *h, void *p);
+int epnn_memcpy_h2d(epnn_handle *h, void *dst, const void *src, size_t bytes);
+int epnn_memcpy_d2h(epnn_handle *h, void *dst, const void *src, size_t bytes);
+int epnn_sync(epnn_handle *h);
+
+/* hipEvent timing on the handle's stream: begin/end bracket any number of calls; elapsed in ms.
+ * epnn_last_timing: per-stage device times of the most recent forward when profiling is enabled with
+ * epnn_set_option("profile", 1): out[0]=front-end, out[1]=fused small-molecule kernel, out[2]=tiled
+ * large-system kernels, out[3]=total. (infer.py:70-79 prints wall-clock; this is the device-side view.) */
+int epnn_timer_begin(epnn_handle *h);
+int epnn_timer_end(epnn_handle *h, float *elapsed_ms);
+int epnn_last_timing(epnn_handle *h, float *out4);
+/* options: "profile" (0/1), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
+ * "pair_cap_per_atom" (initial capacity of the near-pair list). */
+int epnn_set_option(epnn_handle *h, const char *name, int value);
+/* counters of the most recent forward: out[0]=near pairs, out[1]=molecules on the fused path,
+ * out[2]=molecules on the tiled path, out[3]=pair-list regrows. */
+int epnn_last_stats(epnn_handle *h, int64_t *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPNN_H */
