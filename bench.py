@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""EPNN inference throughput on MI355X: atoms/sec on a QM9-sized batch (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward of the whole hot path (near-pair construction + T GNN steps + T EPN steps) over one
+batch of 1024 synthetic QM9-like molecules padded to N=29, inputs (coordinates, atom features, total charges)
+already resident in HBM, charges left in HBM.  With N > 1 ranks (torch.distributed.run, one rank per GPU) every
+rank runs its own batch of 1024 molecules (weak scaling, molecules are independent: no data-path collective);
+the only communication is the barrier and the MAX over ranks of the timed interval.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=20.0):
+    """The oracle (literal dense float32 restatement of charge_gn.py, one molecule per call like infer.py:62-76)
+    timed on this host on a bounded sample of the same workload."""
+    from oracle import epnn_oracle as orc
+    B = len(offsets) - 1
+    threads = os.cpu_count() or 1
+    done_atoms = 0
+    done_mols = 0
+    t0 = time.perf_counter()
+    for b in range(B):
+        lo, hi = offsets[b], offsets[b + 1]
+        orc.forward_xyz(xyz[lo:hi], x[lo:hi], Q[b], weights, N=N, dtype=np.float32)
+        done_atoms += hi - lo
+        done_mols += 1
+        if time.perf_counter() - t0 > budget_s and done_mols >= 32:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done_atoms / dt, "unit": "atoms/s", "cores": threads, "kind": "port",
+            "sample": f"first {done_mols} molecules ({done_atoms} atoms) of the same batch, padded to N={N}, "
+                      f"one molecule per call, NumPy float32 + multithreaded BLAS, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--molecules", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        try:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # RCCL on ROCm
+            sync_dev = torch.device("cuda", local_rank)
+        except Exception:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            sync_dev = torch.device("cpu")
+
+    from epnn_amd import checkpoint, synth
+    from epnn_amd.engine import Engine
+
+    weights = checkpoint.load_epnn_weights(os.path.join(ROOT, "models", "decay_model_weights"))
+    eng = Engine(nx=9, T=5, device=local_rank)
+    eng.set_weights(weights)
+
+    B = args.molecules
+    offsets, xyz, x, Q, N = synth.qm9_like_batch(B=B, seed=rank, N=29)
+    A = int(offsets[-1])
+    d_xyz, d_x, d_Q = eng.to_device(xyz), eng.to_device(x), eng.to_device(Q)
+    d_q = eng.alloc(A * 4)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.forward_xyz_dev(offsets, d_xyz, d_x, d_Q, d_q, N)
+    eng.sync()
+    eng.set_option("profile", args.steps)      # stage events of every timed step, read after the final sync
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward_xyz_dev(offsets, d_xyz, d_x, d_Q, d_q, N)
+    barrier()
+    dt = time.perf_counter() - t0
+    stage = np.array([eng.timing_at(k) for k in range(args.steps)])     # ms: front-end, fused kernel, tiled, total
+    eng.set_option("profile", 0)
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=sync_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_max = float(tt.item())
+        at = torch.tensor([float(A)], dtype=torch.float64, device=sync_dev)
+        dist.all_reduce(at, op=dist.ReduceOp.SUM)
+        atoms_total = float(at.item())
+    else:
+        dt_max, atoms_total = dt, float(A)
+
+    q = d_q.download((A,))
+    stats = eng.last_stats()
+    # sanity inside the bench: charges finite and every molecule's total charge conserved
+    assert np.isfinite(q).all()
+    sums = np.add.reduceat(q.astype(np.float64), offsets[:-1])
+    assert np.abs(sums - Q).max() < 1e-4, np.abs(sums - Q).max()
+
+    if rank == 0:
+        ns = np.diff(offsets)
+        flops = synth.algorithmic_flops(ns, int(stats[0]))
+        k_ms = float(stage[:, 1].mean())
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "atoms/sec (inference), QM9-sized batch",
+            "value": atoms_total * args.steps / dt_max,
+            "unit": "atoms/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"qm9_like_b{B}_N{N}", "molecules_per_gpu": B, "atoms_per_gpu": A, "N": N,
+                       "near_pairs_per_gpu": int(stats[0]), "entry": "epnn_forward_xyz_dev (coordinates in HBM)",
+                       "weights": "decay_model_weights", "parallelism": f"molecule-sharded x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "k_small_forward", "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "algorithmic_gflop_per_launch": flops / 1e9,
+                         "kernel_ms_avg": k_ms, "frontend_ms_avg": float(stage[:, 0].mean()),
+                         "device_ms_per_step_avg": float(stage[:, 3].mean())},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(offsets, xyz, x, Q, N, weights)
+        print(json.dumps(out), flush=True)
+
+    for d in (d_xyz, d_x, d_Q, d_q):
+        d.free()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

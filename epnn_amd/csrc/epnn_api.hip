@@ -63,7 +63,6 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev_t0));
     HIPCHK(hipEventCreate(&h->ev_t1));
-    for (auto &e : h->ev_stage) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_status), 4 * sizeof(int), hipHostMallocDefault));
     memset(h->h_status, 0, 4 * sizeof(int));
     if (h->d_status.ensure(4 * sizeof(int))) return 1;
@@ -95,7 +94,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (h->h_status) (void)hipHostFree(h->h_status);
     (void)hipEventDestroy(h->ev_t0);
     (void)hipEventDestroy(h->ev_t1);
-    for (auto &e : h->ev_stage) (void)hipEventDestroy(e);
+    for (auto &e : h->evpool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -415,17 +414,22 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     const Plan &P = h->plan;
     if (ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
-    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[0], h->stream));
+    hipEvent_t *ev = nullptr;
+    if (h->opt_profile > 0) {
+        ev = h->evpool.data() + 4 * (h->ev_next % h->opt_profile);
+        h->ev_next += 1;
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
     if (run_frontend_xyz(h, d_xyz)) return 1;
-    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[1], h->stream));
+    if (ev) HIPCHK(hipEventRecord(ev[1], h->stream));
     PairSource S;
     S.d_x = d_x;
     S.d_Q = d_Q;
     S.d_q = d_q;
     if (launch_small(h, S)) return 1;
-    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[2], h->stream));
+    if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
     if (launch_large(h, S)) return 1;
-    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_stage[3], h->stream));
+    if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
     // status + pair count come back with the results
     HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -441,15 +445,6 @@ static int finish_forward(epnn_handle *h) {
         if (!h->pending.active) return 0;
         const int st = h->h_status[0];
         h->stats[0] = h->h_status[1];
-        if (h->opt_profile) {
-            float ms = 0;
-            for (int k = 0; k < 3; ++k) {
-                HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[k], h->ev_stage[k + 1]));
-                h->timing[k] = ms;
-            }
-            HIPCHK(hipEventElapsedTime(&ms, h->ev_stage[0], h->ev_stage[3]));
-            h->timing[3] = ms;
-        }
         if (st == 0) {
             h->pending.active = false;
             return 0;
@@ -572,10 +567,21 @@ extern "C" int epnn_timer_end(epnn_handle *h, float *elapsed_ms) {
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev_t0, h->ev_t1));
     return 0;
 }
+extern "C" int epnn_timing_at(epnn_handle *h, int idx, float *out4) {
+    if (!h || !out4) EPNN_FAIL("epnn_timing_at: null argument");
+    if (h->opt_profile <= 0) EPNN_FAIL("epnn_timing_at: profiling is off (epnn_set_option(\"profile\", pool_size))");
+    if (idx < 0 || idx >= h->ev_next || idx < h->ev_next - h->opt_profile)
+        EPNN_FAIL("epnn_timing_at: forward %d is not in the event pool (recorded %d, pool %d)", idx, h->ev_next, h->opt_profile);
+    HIPCHK(hipSetDevice(h->device));
+    if (finish_forward(h)) return 1;
+    hipEvent_t *ev = h->evpool.data() + 4 * (idx % h->opt_profile);
+    for (int k = 0; k < 3; ++k) HIPCHK(hipEventElapsedTime(&out4[k], ev[k], ev[k + 1]));
+    HIPCHK(hipEventElapsedTime(&out4[3], ev[0], ev[3]));
+    return 0;
+}
 extern "C" int epnn_last_timing(epnn_handle *h, float *out4) {
     if (!h || !out4) EPNN_FAIL("epnn_last_timing: null argument");
-    memcpy(out4, h->timing, sizeof(h->timing));
-    return 0;
+    return epnn_timing_at(h, h->ev_next - 1, out4);
 }
 extern "C" int epnn_last_stats(epnn_handle *h, int64_t *out4) {
     if (!h || !out4) EPNN_FAIL("epnn_last_stats: null argument");
@@ -584,7 +590,18 @@ extern "C" int epnn_last_stats(epnn_handle *h, int64_t *out4) {
 }
 extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     if (!h || !name) EPNN_FAIL("epnn_set_option: null argument");
-    if (!strcmp(name, "profile")) h->opt_profile = value;
+    if (!strcmp(name, "profile")) {
+        HIPCHK(hipSetDevice(h->device));
+        if (finish_forward(h)) return 1;
+        value = std::max(0, std::min(value, 4096));
+        while ((int)h->evpool.size() < 4 * value) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            h->evpool.push_back(e);
+        }
+        h->opt_profile = value;
+        h->ev_next = 0;
+    }
     else if (!strcmp(name, "force_path")) { h->opt_force_path = value; h->plan.valid = false; }
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
     else if (!strcmp(name, "small_gcap")) { h->small_gcap = value; }

@@ -67,7 +67,8 @@ struct epnn_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    hipEvent_t ev_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)
+    int ev_next = 0;                  // forwards recorded since the option was set
     // weights
     HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
     bool weights_dirty = true;

@@ -190,6 +190,11 @@ class Engine:
         check(self.lib.epnn_last_timing(self.h, fptr(out)), self.lib)
         return out
 
+    def timing_at(self, idx):
+        out = np.zeros(4, dtype=np.float32)
+        check(self.lib.epnn_timing_at(self.h, int(idx), fptr(out)), self.lib)
+        return out
+
     def last_stats(self):
         out = np.zeros(4, dtype=np.int64)
         check(self.lib.epnn_last_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_int64))), self.lib)

@@ -99,12 +99,14 @@ int epnn_sync(epnn_handle *h);
 
 /* hipEvent timing on the handle's stream: begin/end bracket any number of calls; elapsed in ms.
  * epnn_last_timing: per-stage device times of the most recent forward when profiling is enabled with
- * epnn_set_option("profile", 1): out[0]=front-end, out[1]=fused small-molecule kernel, out[2]=tiled
+ * epnn_set_option("profile", k): out[0]=front-end, out[1]=fused small-molecule kernel, out[2]=tiled
  * large-system kernels, out[3]=total. (infer.py:70-79 prints wall-clock; this is the device-side view.) */
 int epnn_timer_begin(epnn_handle *h);
 int epnn_timer_end(epnn_handle *h, float *elapsed_ms);
 int epnn_last_timing(epnn_handle *h, float *out4);
-/* options: "profile" (0/1), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
+/* same for the idx-th forward issued since "profile" was set (pool of that many event sets; no sync in between). */
+int epnn_timing_at(epnn_handle *h, int idx, float *out4);
+/* options: "profile" (0 = off, k > 0 = keep stage events of the last k forwards), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
  * "pair_cap_per_atom" (initial capacity of the near-pair list). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* counters of the most recent forward: out[0]=near pairs, out[1]=molecules on the fused path,
