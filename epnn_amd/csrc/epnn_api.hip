@@ -89,7 +89,8 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
-                      &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm};
+                      &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
+                      &h->l_mflag, &h->l_stasks, &h->l_schunk};
     for (DevBuf *b : bufs) b->release();
     if (h->h_status) (void)hipHostFree(h->h_status);
     (void)hipEventDestroy(h->ev_t0);
@@ -333,6 +334,10 @@ struct PairSource {     // where the fused / tiled kernels read atoms and pairs 
     float *d_q = nullptr, *d_hout = nullptr;
     int run_gnn = 1, run_epn = 1;
 };
+
+static int launch_large(epnn_handle *h, const PairSource &S) {
+    return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_q, S.d_hout, S.run_gnn, S.run_epn);
+}
 
 static int launch_small(epnn_handle *h, const PairSource &S) {
     const Plan &P = h->plan;
@@ -609,11 +614,6 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     return 0;
 }
 
-static int launch_large(epnn_handle *h, const PairSource &S) {
-    (void)S;
-    if (!h->plan.large_list.empty()) EPNN_FAIL("tiled large-system path not built yet");
-    return 0;
-}
 
 // ---- dense entry points: filled in by epnn_dense.hip.h once built
 #ifndef EPNN_HAVE_DENSE

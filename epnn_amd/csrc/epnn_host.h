@@ -87,6 +87,8 @@ struct epnn_handle {
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc;
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
+    DevBuf l_mflag, l_stasks, l_schunk;
+    int l_natiles = 0, l_nstasks = 0, l_maxchunk = 0;
     // options / stats
     int opt_profile = 0, opt_force_path = 0;
     float timing[4] = {0, 0, 0, 0};

@@ -1,6 +1,536 @@
-// Tiled large-system path (placeholder until implemented)
+// Tiled path for molecules the fused kernel cannot hold (n > 32: the 2220-atom protein, the 100k-atom box).
+// Same arithmetic as epnn_small.hip.h, split into per-step kernels with the per-atom state in HBM:
+//
+//   GNN step (charge_gn.py:60-74)
+//     k_lg_proj   P_i = Wi^T a_i + b1, R_j = Wj^T a_j, zp_i = relu(W2^T relu(P_i) + b2)       per 32-atom tile
+//     k_lg_sweep  S0[chunk][i] = sum_{j in chunk} relu(W2^T relu(P_i + R_j) + b2)              ALL pairs, G ignored
+//     k_lg_corr   for every listed pair: relu(W2^T relu(P_i+R_j+G)+b2) - relu(W2^T relu(P_i+R_j)+b2)   (both sides)
+//     k_lg_update S_i = sum_chunk S0 + sum corr + (N-n) zp_i ; h_i = node_mask * update MLP([h_i | M_i])
+//   EPN step (charge_gn.py:98-118)
+//     k_lg_proj, k_lg_epn (pair tiles: 0.5*(f_ij - f_ji)), k_lg_apply (q_i += sum over the atom's pairs)
+//
+// The all-pairs sweep is the reference's semantics (charge_gn.py:70 sums over every j, near or not); the near
+// pairs are <1% of the pairs of a large system, so adding their G-term as a correction costs ~1%.
+// Both z2 evaluations of a correction use bit-identical inputs to the sweep's, so "without G" cancels exactly
+// against the sweep's term up to the summation order.  All sums are order-fixed (no float atomics).
 #pragma once
 #include "epnn_host.h"
+#include "epnn_small.hip.h"
+
+struct LargeArgs {
+    const float *wpack;
+    WeightIndex wi;
+    int nx, T, N, A, B;
+    const int *moff, *mol_of, *mflag;       // mflag[b] != 0: molecule runs on this path
+    const float *xin, *Q, *h_in, *q_in;
+    float *a_eo;                            // [A][AST]
+    float *P, *R;                           // [A][32] kappa-permuted
+    float *zp;                              // [A][32]
+    float *S0;                              // [maxchunk][A][32]
+    float *corr;                            // [pcap][2][32]
+    float *dl;                              // [pcap]
+    const int *row_off, *pi, *pj, *psym;
+    const float *pe, *pwi, *pwj;
+    const int *dn_off, *dn_ent;             // per atom: pairs in which it is the second index
+    const int4 *atiles;                     // (first atom, count, molecule, first chunk-independent S0 row) per 32-atom tile
+    int natiles;
+    const int4 *stasks;                     // sweep tasks: (first atile, natiles<=4, j_lo, j_hi | chunk<<... ) see host
+    const int *stask_chunk;                 // chunk index of each sweep task
+    int nstasks;
+    int pcap;
+    float *q_out, *h_out;
+    int *status;
+    int *dn_cnt;
+};
+
+// ------------------------------------------------------------------------------------------------ init
+__global__ __launch_bounds__(256) void k_lg_init(LargeArgs L) {
+    const int fq = L.nx + EPNN_EDIM;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < L.A * EPNN_AST; idx += gridDim.x * 256) {
+        const int at = idx / EPNN_AST, slot = idx - at * EPNN_AST;
+        const int b = L.mol_of[at];
+        if (!L.mflag[b]) continue;
+        float v = 0.f;
+        if (slot < 64) {
+            const int f = (slot & 31) * 2 + (slot >> 5);
+            if (f < L.nx) v = L.xin[(size_t)at * L.nx + f];
+            else if (f < fq) v = L.h_in ? L.h_in[(size_t)at * EPNN_EDIM + (f - L.nx)] : 0.f;
+            else if (f == fq) v = L.q_in ? L.q_in[at] : L.Q[b] / (float)(L.moff[b + 1] - L.moff[b]);
+        }
+        L.a_eo[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ "down" lists
+__global__ __launch_bounds__(256) void k_lg_dn_count(LargeArgs L) {
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256)
+        if (L.psym[p] || L.pwj[p] != 0.f) atomicAdd(&L.dn_cnt[L.pj[p]], 1);
+}
+// exclusive scan dn_cnt[0..A) -> dn_off[0..A]; dn_cnt is reused as the fill cursor (reset to 0)
+__global__ __launch_bounds__(1024) void k_lg_dn_scan(LargeArgs L, int *dn_off_w) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < L.A; base += 1024) {
+        const int idx = base + tid;
+        const int v = idx < L.A ? L.dn_cnt[idx] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int c0 = carry;
+        if (idx < L.A) {
+            dn_off_w[idx] = c0 + woff + incl - v;
+            L.dn_cnt[idx] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = c0 + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) dn_off_w[L.A] = carry;
+}
+__global__ __launch_bounds__(256) void k_lg_dn_fill(LargeArgs L, int *dn_ent_w) {
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256)
+        if (L.psym[p] || L.pwj[p] != 0.f) {
+            const int j = L.pj[p];
+            const int pos = atomicAdd(&L.dn_cnt[j], 1);
+            dn_ent_w[L.dn_off[j] + pos] = p;
+        }
+}
+// order every atom's list by pair slot so that sums over it have a fixed order
+__global__ __launch_bounds__(256) void k_lg_dn_sort(LargeArgs L, int *dn_ent_w) {
+    if (L.row_off[L.A] > L.pcap) return;
+    for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
+        const int lo = L.dn_off[at], hi = L.dn_off[at + 1];
+        for (int a = lo + 1; a < hi; ++a) {
+            const int v = dn_ent_w[a];
+            int b = a - 1;
+            while (b >= lo && dn_ent_w[b] > v) {
+                dn_ent_w[b + 1] = dn_ent_w[b];
+                --b;
+            }
+            dn_ent_w[b + 1] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ projection
+// one wave per 32-atom tile
+__global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int with_zp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    if (it >= L.natiles) return;
+    const int4 tl = L.atiles[it];
+    const int at = tl.x + (c < tl.y ? c : 0);
+    const float *wp = L.wpack;
+    const float *arow = L.a_eo + (size_t)at * EPNN_AST + hh * 32;
+    float bv[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
+        bv[4 * q] = v[0]; bv[4 * q + 1] = v[1]; bv[4 * q + 2] = v[2]; bv[4 * q + 3] = v[3];
+    }
+    float ci[16];
+    epnn_ld16(wp + M.b1p + hh * 16, ci);
+    f32x16 accP, accR = epnn_splat16(0.f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accP[r] = ci[r];
+#pragma unroll
+    for (int s = 0; s < EPNN_KA; ++s) {
+        accP = epnn_mfma(wp[M.wiF + s * 64 + lane], bv[s], accP);
+        accR = epnn_mfma(wp[M.wjF + s * 64 + lane], bv[s], accR);
+    }
+    if (c < tl.y) {
+        epnn_st16(L.P + (size_t)at * 32 + hh * 16, accP);
+        epnn_st16(L.R + (size_t)at * 32 + hh * 16, accR);
+    }
+    if (with_zp) {
+        // padded partner: R = 0, G = 0  ->  zp_i = relu(W2^T relu(P_i) + b2); rows = atoms, cols = out
+        f32x16 acc = epnn_splat16(wp[M.b2 + c]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = epnn_mfma(fmaxf(accP[s], 0.f), wp[M.w2F + s * 64 + lane], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = epnn_kappa(hh, r);
+            if (row < tl.y) L.zp[(size_t)(tl.x + row) * 32 + c] = fmaxf(acc[r], 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ all-pairs sweep
+// workgroup = up to 4 atom tiles (one per wave) x one j-chunk of the same molecule; R_j staged in LDS
+#define EPNN_LG_JC 64
+__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, PairMlpPack M) {
+    __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int4 tk = L.stasks[blockIdx.x];            // first atile, #atiles, j_lo, j_hi (global atom indices)
+    const int chunk = L.stask_chunk[blockIdx.x];
+    const bool active = wave < tk.y;
+    const int4 tl = L.atiles[tk.x + (active ? wave : 0)];
+    const float *wp = L.wpack;
+    float pr[16], w2[16];
+    epnn_ld16(L.P + (size_t)(tl.x + (c < tl.y ? c : 0)) * 32 + hh * 16, pr);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
+    const f32x16 cb2 = epnn_splat16(wp[M.b2 + c]);
+    f32x16 sum = epnn_splat16(0.f);
+    for (int j0 = tk.z; j0 < tk.w; j0 += EPNN_LG_JC) {
+        const int nj = min(EPNN_LG_JC, tk.w - j0);
+        __syncthreads();
+        for (int i = tid; i < nj * 32; i += 256) Rs[i] = L.R[(size_t)j0 * 32 + i];
+        __syncthreads();
+        if (active)
+            for (int j = 0; j < nj; ++j) {
+                float rj[16];
+                epnn_ld16(Rs + j * 32 + hh * 16, rj);
+                f32x16 acc = cb2;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = epnn_mfma(fmaxf(pr[s] + rj[s], 0.f), w2[s], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[r] += fmaxf(acc[r], 0.f);
+            }
+    }
+    if (!active) return;
+    float *dst = L.S0 + ((size_t)chunk * L.A) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = epnn_kappa(hh, r);
+        if (row < tl.y) dst[(size_t)(tl.x + row) * 32 + c] = sum[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pair tiles
+// one wave per 32 listed pairs.  mode 0: GNN correction -> corr[p][side][32]; mode 1: EPN -> dl[p]
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    const int slot = (blockIdx.x * 4 + wave) * 32 + c;
+    bool valid = slot < np;
+    int gi = 0, gj = 0, sym = 0;
+    if (valid) {
+        gi = L.pi[slot];
+        gj = L.pj[slot];
+        sym = L.psym[slot];
+        valid = L.mflag[L.mol_of[gi]] != 0;
+    }
+    if (__ballot(valid) == 0ull) return;
+    const float *wp = L.wpack;
+    const f32x16 g = small_gtile(wp + M.weF, L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24, valid, lane);
+    float pi_[16], rj_[16], pj_[16], ri_[16], w2[16];
+    epnn_ld16(L.P + (size_t)gi * 32 + hh * 16, pi_);
+    epnn_ld16(L.R + (size_t)gj * 32 + hh * 16, rj_);
+    epnn_ld16(L.P + (size_t)gj * 32 + hh * 16, pj_);
+    epnn_ld16(L.R + (size_t)gi * 32 + hh * 16, ri_);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
+    if (MODE == 0) {
+        // rows = pairs kappa(hh,r), cols = out c
+        const f32x16 cb2 = epnn_splat16(wp[M.b2 + c]);
+        f32x16 aG = cb2, a0 = cb2, bG = cb2, b0 = cb2;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float u0 = pi_[s] + rj_[s], v0 = pj_[s] + ri_[s];
+            a0 = epnn_mfma(fmaxf(u0, 0.f), w2[s], a0);
+            aG = epnn_mfma(fmaxf(u0 + g[s], 0.f), w2[s], aG);
+            b0 = epnn_mfma(fmaxf(v0, 0.f), w2[s], b0);
+            bG = epnn_mfma(fmaxf(v0 + g[s], 0.f), w2[s], bG);
+        }
+        const int base = (blockIdx.x * 4 + wave) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = base + epnn_kappa(hh, r);
+            if (p < np) {
+                L.corr[((size_t)p * 2 + 0) * 32 + c] = fmaxf(aG[r], 0.f) - fmaxf(a0[r], 0.f);
+                L.corr[((size_t)p * 2 + 1) * 32 + c] = fmaxf(bG[r], 0.f) - fmaxf(b0[r], 0.f);
+            }
+        }
+    } else {
+        float b2v[16], w3[16];
+        epnn_ld16(wp + M.b2p + hh * 16, b2v);
+        epnn_ld16(wp + M.w3p + hh * 16, w3);
+        f32x16 au, av;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            au = epnn_mfma(w2[s], fmaxf((g[s] + pi_[s]) + rj_[s], 0.f), au);
+            av = epnn_mfma(w2[s], fmaxf((g[s] + pj_[s]) + ri_[s], 0.f), av);
+        }
+        float fu = 0.f, fv = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
+            fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
+        }
+        fu += epnn_swap32(fu);
+        fv += epnn_swap32(fv);
+        if (hh == 0 && valid) L.dl[slot] = 0.5f * (fu - fv);
+    }
+    (void)sym;
+}
+
+// ------------------------------------------------------------------------------------------------ update
+// workgroup = up to 4 atom tiles; all threads reduce S, then one wave per tile runs the update MLP
+__global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int maxchunk) {
+    __shared__ float Ss[4 * 32 * EPNN_SST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int t0 = blockIdx.x * 4;
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    for (int idx = tid; idx < 4 * 32 * 32; idx += 256) {
+        const int o = idx & 31, a = (idx >> 5) & 31, w = idx >> 10;
+        float s = 0.f;
+        if (t0 + w < L.natiles) {
+            const int4 tl = L.atiles[t0 + w];
+            if (a < tl.y) {
+                const int at = tl.x + a;
+                const int b = tl.z;
+                const int n = L.moff[b + 1] - L.moff[b];
+                const int nchunk = tl.w;
+                for (int ch = 0; ch < nchunk; ++ch) s += L.S0[((size_t)ch * L.A + at) * 32 + o];
+                for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) s += L.corr[((size_t)p * 2 + 0) * 32 + o];
+                for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
+                    const int p = L.dn_ent[e];
+                    if (L.psym[p]) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
+                }
+                s += (float)(L.N - n) * L.zp[(size_t)at * 32 + o];
+            }
+        }
+        Ss[(w * 32 + a) * EPNN_SST + o] = s;
+    }
+    (void)maxchunk;
+    __syncthreads();
+    if (t0 + wave >= L.natiles) return;
+    const int4 tl = L.atiles[t0 + wave];
+    const bool live = c < tl.y;
+    const int at = tl.x + (live ? c : 0);
+    const float *wp = L.wpack;
+    const int nx = L.nx;
+    const int u0 = (nx - hh + 1) >> 1;
+    const float *arow = L.a_eo + (size_t)at * EPNN_AST + hh * 32 + u0;
+    float hv[24], sv[16];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) hv[s] = arow[s];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sv[s] = Ss[(wave * 32 + c) * EPNN_SST + 2 * s + hh];
+    float cb[16], b1[16];
+    epnn_ld16(wp + U.cb3p + hh * 16, cb);
+    epnn_ld16(wp + U.bu1p + hh * 16, b1);
+    const float Nf = (float)L.N;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = Nf * cb[r];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) acc = epnn_mfma(wp[U.u1F + s * 64 + lane], hv[s], acc);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = epnn_mfma(wp[U.u1F + (24 + s) * 64 + lane], sv[s], acc);
+    float u1[16], b2v[16];
+    // every atom on this path is a real atom: node_mask = 1 (charge_gn.py:59)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u1[r] = fmaxf(acc[r] + b1[r], 0.f);
+    epnn_ld16(wp + U.bu2p + hh * 16, b2v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b2v[r];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = epnn_mfma(wp[U.u2F + s * 64 + lane], u1[s], acc);
+    float u2[16], b3a[16], b3b[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u2[r] = fmaxf(acc[r], 0.f);
+    epnn_ld16(wp + U.bu3p + hh * 16, b3a);
+    epnn_ld16(wp + U.bu3p + 32 + hh * 16, b3b);
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = b3a[r]; o1[r] = b3b[r]; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        o0 = epnn_mfma(wp[U.u3F + s * 64 + lane], u2[s], o0);
+        o1 = epnn_mfma(wp[U.u3F + (16 + s) * 64 + lane], u2[s], o1);
+    }
+    if (live) {
+        float *dst = L.a_eo + (size_t)at * EPNN_AST;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = epnn_kappa(hh, r);
+            dst[epnn_aeo(nx + f)] = o0[r];
+            if (r < 8) dst[epnn_aeo(nx + 32 + f)] = o1[r];
+        }
+    }
+}
+
+// q_i += sum_j antisym_ij (charge_gn.py:118); thread per atom, fixed order (own row first, then the down list)
+__global__ __launch_bounds__(256) void k_lg_apply(LargeArgs L, int last) {
+    if (L.row_off[L.A] > L.pcap) return;
+    const int fq = L.nx + EPNN_EDIM;
+    for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
+        if (!L.mflag[L.mol_of[at]]) continue;
+        float acc = 0.f;
+        for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
+            const int p = L.dn_ent[e];
+            acc -= L.pwj[p] * L.dl[p];
+        }
+        for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) acc += L.pwi[p] * L.dl[p];
+        float *qp = L.a_eo + (size_t)at * EPNN_AST + epnn_aeo(fq);
+        const float q = *qp + acc;
+        *qp = q;
+        if (last && L.q_out) L.q_out[at] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lg_export_h(LargeArgs L) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < L.A * EPNN_EDIM; idx += gridDim.x * 256) {
+        const int at = idx / EPNN_EDIM, f = idx - at * EPNN_EDIM;
+        if (!L.mflag[L.mol_of[at]]) continue;
+        L.h_out[idx] = L.a_eo[(size_t)at * EPNN_AST + epnn_aeo(L.nx + f)];
+    }
+}
+__global__ __launch_bounds__(256) void k_lg_export_q(LargeArgs L) {
+    const int fq = L.nx + EPNN_EDIM;
+    for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
+        if (!L.mflag[L.mol_of[at]]) continue;
+        L.q_out[at] = L.a_eo[(size_t)at * EPNN_AST + epnn_aeo(fq)];
+    }
+}
+
+// ================================================================================================ host side
+struct LargePlanHost {
+    std::vector<int4> atiles, stasks;
+    std::vector<int> stask_chunk, mflag;
+    int maxchunk = 0;
+};
+
+static int large_plan(epnn_handle *h) {
+    Plan &P = h->plan;
+    LargePlanHost lp;
+    lp.mflag.assign(P.B, 0);
+    for (int b : P.large_list) {
+        lp.mflag[b] = 1;
+        const int a0 = P.offsets[b], n = P.offsets[b + 1] - a0;
+        const int first_tile = (int)lp.atiles.size();
+        const int ntile = (n + 31) / 32, ngroup = (ntile + 3) / 4;
+        // split the j range so that the sweep has a few thousand workgroups, in pieces of EPNN_LG_JC atoms
+        const int want = std::max(1, (4096 + ngroup - 1) / ngroup);
+        int nchunk = std::min(want, (n + EPNN_LG_JC - 1) / EPNN_LG_JC);
+        int clen = ((n + nchunk - 1) / nchunk + EPNN_LG_JC - 1) / EPNN_LG_JC * EPNN_LG_JC;
+        nchunk = (n + clen - 1) / clen;
+        for (int i0 = 0; i0 < n; i0 += 32) lp.atiles.push_back(make_int4(a0 + i0, std::min(32, n - i0), b, nchunk));
+        lp.maxchunk = std::max(lp.maxchunk, nchunk);
+        for (int tg = 0; tg < ntile; tg += 4)
+            for (int ch = 0; ch < nchunk; ++ch) {
+                lp.stasks.push_back(make_int4(first_tile + tg, std::min(4, ntile - tg), a0 + ch * clen,
+                                              a0 + std::min(n, (ch + 1) * clen)));
+                lp.stask_chunk.push_back(ch);
+            }
+    }
+    h->l_natiles = (int)lp.atiles.size();
+    h->l_nstasks = (int)lp.stasks.size();
+    h->l_maxchunk = lp.maxchunk;
+    if (h->l_mflag.ensure(std::max(1, P.B) * sizeof(int))) return 1;
+    HIPCHK(hipMemcpyAsync(h->l_mflag.p, lp.mflag.data(), P.B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (P.large_list.empty()) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    const size_t A = (size_t)P.A;
+    if (h->l_tiles.ensure(lp.atiles.size() * sizeof(int4)) || h->l_stasks.ensure(lp.stasks.size() * sizeof(int4)) ||
+        h->l_schunk.ensure(lp.stask_chunk.size() * sizeof(int)) || h->l_a.ensure(A * EPNN_AST * 4) ||
+        h->l_P.ensure(A * 32 * 4) || h->l_R.ensure(A * 32 * 4) || h->l_zp.ensure(A * 32 * 4) ||
+        h->l_S0.ensure((size_t)lp.maxchunk * A * 32 * 4) || h->l_csr_off.ensure((A + 1) * sizeof(int)) ||
+        h->l_cnt.ensure((A + 1) * sizeof(int)))
+        return 1;
+    HIPCHK(hipMemcpyAsync(h->l_tiles.p, lp.atiles.data(), lp.atiles.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->l_stasks.p, lp.stasks.data(), lp.stasks.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->l_schunk.p, lp.stask_chunk.data(), lp.stask_chunk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 struct PairSource;
-static int large_plan(epnn_handle *h) { (void)h; return 0; }
-static int launch_large(epnn_handle *h, const PairSource &S);
+static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
+                             float *d_q, float *d_hout, int run_gnn, int run_epn) {
+    const Plan &P = h->plan;
+    if (P.large_list.empty()) return 0;
+    const size_t pc = (size_t)h->pcap;
+    if (h->l_corr.ensure(pc * 2 * 32 * 4) || h->l_dl.ensure(pc * 4) || h->l_csr_ent.ensure(pc * sizeof(int))) return 1;
+    LargeArgs L{};
+    L.wpack = h->d_wpack.as<float>();
+    L.wi = h->widx;
+    L.nx = h->cfg.nx;
+    L.T = h->cfg.T;
+    L.N = P.N;
+    L.A = P.A;
+    L.B = P.B;
+    L.moff = h->d_moff.as<int>();
+    L.mol_of = h->d_molof.as<int>();
+    L.mflag = h->l_mflag.as<int>();
+    L.xin = d_x;
+    L.Q = d_Q;
+    L.h_in = d_hin;
+    L.q_in = d_qin;
+    L.a_eo = h->l_a.as<float>();
+    L.P = h->l_P.as<float>();
+    L.R = h->l_R.as<float>();
+    L.zp = h->l_zp.as<float>();
+    L.S0 = h->l_S0.as<float>();
+    L.corr = h->l_corr.as<float>();
+    L.dl = h->l_dl.as<float>();
+    L.row_off = h->d_rowoff.as<int>();
+    L.pi = h->d_pi.as<int>();
+    L.pj = h->d_pj.as<int>();
+    L.psym = h->d_psym.as<int>();
+    L.pe = h->d_pe.as<float>();
+    L.pwi = h->d_pwi.as<float>();
+    L.pwj = h->d_pwj.as<float>();
+    L.dn_off = h->l_csr_off.as<int>();
+    L.dn_ent = h->l_csr_ent.as<int>();
+    L.dn_cnt = h->l_cnt.as<int>();
+    L.atiles = h->l_tiles.as<int4>();
+    L.natiles = h->l_natiles;
+    L.stasks = h->l_stasks.as<int4>();
+    L.stask_chunk = h->l_schunk.as<int>();
+    L.nstasks = h->l_nstasks;
+    L.pcap = h->pcap;
+    L.q_out = d_q;
+    L.h_out = d_hout;
+    L.status = h->d_status.as<int>();
+    hipStream_t st = h->stream;
+    const unsigned gA = (unsigned)std::min<size_t>(((size_t)P.A * EPNN_AST + 255) / 256, 4096);
+    const unsigned gP = (unsigned)std::min<size_t>((pc + 255) / 256, 4096);
+    const unsigned gAt = (unsigned)std::min<size_t>(((size_t)P.A + 255) / 256, 4096);
+    const unsigned gT = (unsigned)((L.natiles + 3) / 4);
+    const unsigned gPT = (unsigned)((pc + 127) / 128);
+    hipLaunchKernelGGL(k_lg_init, dim3(gA), dim3(256), 0, st, L);
+    HIPCHK(hipMemsetAsync(L.dn_cnt, 0, ((size_t)P.A + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(k_lg_dn_count, dim3(gP), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(k_lg_dn_scan, dim3(1), dim3(1024), 0, st, L, h->l_csr_off.as<int>());
+    hipLaunchKernelGGL(k_lg_dn_fill, dim3(gP), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
+    hipLaunchKernelGGL(k_lg_dn_sort, dim3(gAt), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
+    for (int t = 0; t < (run_gnn ? L.T : 0); ++t) {
+        hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[t], 1);
+        hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->widx.msg[t]);
+        hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
+        hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk);
+    }
+    if (d_hout) hipLaunchKernelGGL(k_lg_export_h, dim3(gA), dim3(256), 0, st, L);
+    for (int t = 0; t < (run_epn ? L.T : 0); ++t) {
+        hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.pas[t], 0);
+        hipLaunchKernelGGL(k_lg_pairs<1>, dim3(gPT), dim3(256), 0, st, L, h->widx.pas[t]);
+        hipLaunchKernelGGL(k_lg_apply, dim3(gAt), dim3(256), 0, st, L, 0);
+    }
+    if (d_q) hipLaunchKernelGGL(k_lg_export_q, dim3(gAt), dim3(256), 0, st, L);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

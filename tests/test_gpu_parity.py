@@ -61,3 +61,75 @@ def test_small_random_weights_vs_oracle(gpu_engine_factory, val_dir, val_names, 
     print(f"nx={nx} T={T} N={N}: worst |dq| {worst:.3e}; float32 oracle noise {noise:.3e}; |q| up to {scale:.3f}")
     # 1e-5 absolute, or the float32 noise of the reference algorithm itself where that is larger
     assert worst <= max(TOL, 3 * noise), (worst, noise)
+
+
+def _batch(mols):
+    off = np.zeros(len(mols) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([m[1].shape[0] for m in mols])
+    return (off, np.concatenate([m[0] for m in mols]), np.concatenate([m[1] for m in mols]),
+            np.array([m[2] for m in mols], dtype=np.float32))
+
+
+def test_val_golden_all(gpu_engine_factory, weights_decay, val_dir, val_names, val_gold):
+    """All 871 validation systems in ONE mixed batch (n <= 32 on the fused kernel, larger ones on the tiled
+    kernels) vs the stored TensorFlow predictions."""
+    eng = gpu_engine_factory(nx=9, T=5)
+    eng.set_weights(weights_decay)
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, val_names)
+    q = eng.forward_xyz(offsets, xyz, x, Q, N=41)
+    st = eng.last_stats()
+    assert st[1] > 0 and st[2] > 0, st          # both paths were exercised
+    worst = 0.0
+    for i, m in enumerate(mols):
+        n = m[1].shape[0]
+        qi = q[offsets[i]:offsets[i + 1]]
+        worst = max(worst, np.abs(qi - val_gold[i, :n]).max())
+        assert abs(float(qi.sum(dtype=np.float64)) - float(m[2])) < 5e-6
+        assert np.all(val_gold[i, n:] == 0)      # the reference's padded atoms stay exactly 0
+    print(f"871 systems: worst |dq| vs TF golden {worst:.3e}; paths fused/tiled = {st[1]}/{st[2]}")
+    assert worst <= TOL, worst
+
+
+def test_protein_golden(gpu_engine_factory, weights_decay, golden_dir):
+    """2220-atom Galectin-3C, Q=+2 (BASELINE.json configs[3]) vs the stored TensorFlow prediction."""
+    from oracle import epnn_oracle as orc
+    eng = gpu_engine_factory(nx=9, T=5)
+    eng.set_weights(weights_decay)
+    xyz, x, Q = orc.parse_xyz(os.path.join(golden_dir, "protein", "6qlp_capped.xyz"), 9)
+    gold = np.load(os.path.join(golden_dir, "protein", "preds.npy")).ravel()
+    n = x.shape[0]
+    assert n == 2220 and float(Q) == 2.0
+    q = eng.forward_xyz(np.array([0, n], dtype=np.int32), xyz, x, np.array([Q], dtype=np.float32), N=n)
+    err = np.abs(q - gold).max()
+    drift = abs(float(q.sum(dtype=np.float64)) - 2.0)
+    print(f"protein: max |dq| {err:.3e}; |sum q - Q| {drift:.3e} (reference's own drift 1.5e-5); pairs {eng.last_stats()[0]}")
+    assert err <= TOL, err
+    assert drift < 5e-5
+
+
+@pytest.mark.parametrize("nx,T,N", [(9, 3, 41), (10, 2, 50)])
+def test_tiled_random_weights_vs_oracle(gpu_engine_factory, val_dir, val_names, nx, T, N):
+    """Tiled kernels in the non-degenerate regime, on molecules of every size (force_path=2), incl. N > n."""
+    w = random_weights(nx, T, seed=7 * nx + T, scale=0.35)
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+    eng.set_option("force_path", 2)
+    names = [nm for nm in val_names if nm.startswith("SSI")][:10] + [nm for nm in val_names if nm.startswith("dsgdb9nsd")][:6]
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, names, nx)
+    q = eng.forward_xyz(offsets, xyz, x, Q, N=N)
+    assert eng.last_stats()[1] == 0
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    worst = max(np.abs(q[offsets[k]:offsets[k + 1]] - ref[k][:m[1].shape[0]]).max() for k, m in enumerate(mols))
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    print(f"tiled nx={nx} T={T} N={N}: worst |dq| {worst:.3e}; float32 oracle noise {noise:.3e}")
+    assert worst <= max(TOL, 3 * noise), (worst, noise)
+    # fused and tiled paths agree on the molecules both can run
+    eng2 = gpu_engine_factory(nx=nx, T=T)
+    eng2.set_weights(w)
+    small = [m for m in mols if m[1].shape[0] <= 32]
+    off, xyz_s, x_s, Q_s = _batch(small)
+    qa = eng2.forward_xyz(off, xyz_s, x_s, Q_s, N=N)
+    eng2.set_option("force_path", 2)
+    qb = eng2.forward_xyz(off, xyz_s, x_s, Q_s, N=N)
+    assert np.abs(qa - qb).max() <= 2e-6
