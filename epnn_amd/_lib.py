@@ -43,6 +43,7 @@ SIGNATURES = {
     "epnn_model_forward_dense_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "epnn_gnn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_epn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "epnn_mlp_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "epnn_dev_free": (C.c_int, [_vp, _vp]),
     "epnn_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -8,6 +8,7 @@
 #include "epnn_small.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
+#include "epnn_mlp.hip.h"
 
 thread_local std::string g_epnn_err;
 
@@ -90,7 +91,9 @@ extern "C" int epnn_destroy(epnn_handle *h) {
                       &h->d_status, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
-                      &h->l_mflag, &h->l_stasks, &h->l_schunk};
+                      &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
+                      &h->dn_flag, &h->dn_neff, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
+                      &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
     for (DevBuf *b : bufs) b->release();
     if (h->h_status) (void)hipHostFree(h->h_status);
     (void)hipEventDestroy(h->ev_t0);
@@ -330,13 +333,13 @@ static SmallLds small_layout(int gcap) {
 }
 
 struct PairSource {     // where the fused / tiled kernels read atoms and pairs from
-    const float *d_x = nullptr, *d_Q = nullptr, *d_hin = nullptr, *d_qin = nullptr;
+    const float *d_x = nullptr, *d_Q = nullptr, *d_hin = nullptr, *d_qin = nullptr, *d_nm = nullptr;
     float *d_q = nullptr, *d_hout = nullptr;
     int run_gnn = 1, run_epn = 1;
 };
 
 static int launch_large(epnn_handle *h, const PairSource &S) {
-    return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_q, S.d_hout, S.run_gnn, S.run_epn);
+    return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_nm, S.d_q, S.d_hout, S.run_gnn, S.run_epn);
 }
 
 static int launch_small(epnn_handle *h, const PairSource &S) {
@@ -364,6 +367,7 @@ static int launch_small(epnn_handle *h, const PairSource &S) {
     A.h_out = S.d_hout;
     A.h_in = S.d_hin;
     A.q_in = S.d_qin;
+    A.nm_in = S.d_nm;
     A.status = h->d_status.as<int>();
     A.N = P.N;
     A.T = h->cfg.T;
@@ -452,6 +456,11 @@ static int finish_forward(epnn_handle *h) {
         h->stats[0] = h->h_status[1];
         if (st == 0) {
             h->pending.active = false;
+            if (h->force_tmp) {
+                h->opt_force_path = h->force_saved;
+                h->force_tmp = false;
+                h->plan.valid = false;
+            }
             return 0;
         }
         h->stats[3] += 1;
@@ -460,10 +469,16 @@ static int finish_forward(epnn_handle *h) {
         }
         if (st & EPNN_ST_SMALL_OVERFLOW) {
             const int nmax = h->plan.small_nmax;
-            h->small_gcap = nmax * (nmax - 1) / 2 + nmax;     // worst case; fits LDS for n <= 32
+            const int full = nmax * (nmax - 1) / 2 + nmax;
+            if (h->small_gcap >= full) {          // one-sided entries beyond the LDS budget: use the tiled kernels
+                if (!h->force_tmp) h->force_saved = h->opt_force_path;
+                h->force_tmp = true;
+                h->opt_force_path = 2;
+                h->plan.valid = false;
+            }
+            h->small_gcap = full;
         }
-        auto &pd = h->pending;
-        if (enqueue_forward_xyz(h, pd.B, pd.N, pd.offsets.data(), pd.d_xyz, pd.d_x, pd.d_Q, pd.d_q)) return 1;
+        if (h->pending.redo()) return 1;
     }
     EPNN_FAIL("forward: capacity regrow did not converge");
 }
@@ -475,13 +490,10 @@ extern "C" int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t 
     if (enqueue_forward_xyz(h, B, N, offsets, d_xyz, d_x, d_Q, d_q_out)) return 1;
     auto &pd = h->pending;
     pd.active = true;
-    pd.B = B;
-    pd.N = N;
-    pd.offsets.assign(offsets, offsets + B + 1);
-    pd.d_xyz = d_xyz;
-    pd.d_x = d_x;
-    pd.d_Q = d_Q;
-    pd.d_q = d_q_out;
+    std::vector<int> offs(offsets, offsets + B + 1);
+    pd.redo = [h, B, N, offs, d_xyz, d_x, d_Q, d_q_out]() {
+        return enqueue_forward_xyz(h, B, N, offs.data(), d_xyz, d_x, d_Q, d_q_out);
+    };
     return 0;
 }
 
@@ -615,10 +627,198 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
 }
 
 
-// ---- dense entry points: filled in by epnn_dense.hip.h once built
-#ifndef EPNN_HAVE_DENSE
-extern "C" int epnn_model_forward_dense(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_model_forward_dense: not built yet"); }
-extern "C" int epnn_model_forward_dense_dev(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_model_forward_dense_dev: not built yet"); }
-extern "C" int epnn_gnn_forward(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_gnn_forward: not built yet"); }
-extern "C" int epnn_epn_forward(epnn_handle *, int, int, const float *, const float *, const float *, const float *, const float *, float *) { EPNN_FAIL("epnn_epn_forward: not built yet"); }
-#endif
+// ------------------------------------------------------------------------------------------------ dense entries
+// mode 0: make_model (model-level inputs, both stacks); 1: GNN_layer.call; 2: EPN_layer.call.  Device pointers.
+static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_h, const float *d_e, const float *d_x,
+                         const float *d_q, const float *d_mask, float *d_out) {
+    HIPCHK(hipSetDevice(h->device));
+    if (B < 1 || N < 1) EPNN_FAIL("dense forward: B and N must be positive");
+    if (pack_weights(h)) return 1;
+    const int nx = h->cfg.nx;
+    const size_t slots = (size_t)B * N;
+    if (h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) || h->dn_qs.ensure(slots * 4) ||
+        h->dn_nms.ensure(slots * 4) || h->dn_flag.ensure(slots * 4) || h->dn_neff.ensure((size_t)B * 4))
+        return 1;
+    DenseArgs D{};
+    D.B = B;
+    D.N = N;
+    D.nx = nx;
+    D.model_level = mode == 0;
+    D.h_in = d_h;
+    D.e_in = d_e;
+    D.x_in = d_x;
+    D.q_in = d_q;
+    D.mask_in = d_mask;
+    D.xs = h->dn_xs.as<float>();
+    D.hs = h->dn_hs.as<float>();
+    D.qs = h->dn_qs.as<float>();
+    D.nms = h->dn_nms.as<float>();
+    D.flag = h->dn_flag.as<int>();
+    D.neff = h->dn_neff.as<int>();
+    D.tol = h->cfg.near_tol;
+    hipLaunchKernelGGL(k_dn_atoms, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, h->stream, D);
+    hipLaunchKernelGGL(k_dn_neff, dim3((unsigned)B), dim3(64), 0, h->stream, D);
+    HIPCHK(hipGetLastError());
+    h->dn_neff_host.resize(B);
+    HIPCHK(hipMemcpyAsync(h->dn_neff_host.data(), D.neff, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));       // the host plans tiles from the effective atom counts
+    std::vector<int> offsets(B + 1, 0);
+    for (int b = 0; b < B; ++b) offsets[b + 1] = offsets[b] + h->dn_neff_host[b];
+    if (build_plan(h, B, N, offsets.data())) return 1;
+    const Plan &P = h->plan;
+    const size_t A = (size_t)P.A;
+    const int C = mode == 1 ? EPNN_EDIM : 1;
+    if (h->dn_xf.ensure(A * nx * 4) || h->dn_hf.ensure(A * EPNN_EDIM * 4) || h->dn_qf.ensure(A * 4) ||
+        h->dn_nmf.ensure(A * 4) || h->dn_out.ensure(A * EPNN_EDIM * 4))
+        return 1;
+    if (ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
+    D.A = P.A;
+    D.moff = h->d_moff.as<int>();
+    D.mol_of = h->d_molof.as<int>();
+    D.xf = h->dn_xf.as<float>();
+    D.hf = h->dn_hf.as<float>();
+    D.qf = h->dn_qf.as<float>();
+    D.nmf = h->dn_nmf.as<float>();
+    D.row_cnt = h->d_rowcnt.as<int>();
+    D.row_off = h->d_rowoff.as<int>();
+    D.pcap = h->pcap;
+    D.pi = h->d_pi.as<int>();
+    D.pj = h->d_pj.as<int>();
+    D.psym = h->d_psym.as<int>();
+    D.pe = h->d_pe.as<float>();
+    D.pwi = h->d_pwi.as<float>();
+    D.pwj = h->d_pwj.as<float>();
+    D.status = h->d_status.as<int>();
+    HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    const unsigned gA = (unsigned)std::min<size_t>((A * (nx + EPNN_EDIM + 2) + 255) / 256, 4096);
+    const unsigned rows = (unsigned)((P.A + 3) / 4);
+    hipLaunchKernelGGL(k_dn_compact, dim3(gA), dim3(256), 0, h->stream, D);
+    hipLaunchKernelGGL(k_dn_pairs<0>, dim3(rows), dim3(256), 0, h->stream, D);
+    FrontArgs F{};
+    F.A = P.A;
+    F.row_cnt = h->d_rowcnt.as<int>();
+    F.row_off = h->d_rowoff.as<int>();
+    F.pcap = h->pcap;
+    F.status = h->d_status.as<int>();
+    hipLaunchKernelGGL(k_front_scan, dim3(1), dim3(1024), 0, h->stream, F);
+    hipLaunchKernelGGL(k_dn_pairs<1>, dim3(rows), dim3(256), 0, h->stream, D);
+    HIPCHK(hipGetLastError());
+    PairSource S;
+    S.d_x = D.xf;
+    S.d_hin = D.hf;
+    S.d_qin = D.qf;
+    S.d_nm = D.nmf;
+    S.run_gnn = mode != 2;
+    S.run_epn = mode != 1;
+    float *flat = h->dn_out.as<float>();
+    S.d_q = mode == 1 ? nullptr : flat;
+    S.d_hout = mode == 1 ? flat : nullptr;
+    if (mode == 1) S.d_q = h->dn_qf.as<float>();      // the fused kernel always stores q; keep it off the h buffer
+    if (launch_small(h, S)) return 1;
+    if (launch_large(h, S)) return 1;
+    D.out = d_out;
+    D.src = flat;
+    D.C = C;
+    const unsigned gO = (unsigned)std::min<size_t>((slots * C + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_dn_scatter, dim3(gO), dim3(256), 0, h->stream, D);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    h->stats[1] = (int64_t)P.small_order.size();
+    h->stats[2] = (int64_t)P.large_list.size();
+    return 0;
+}
+
+static int dense_dev(epnn_handle *h, int B, int N, int mode, const float *d_h, const float *d_e, const float *d_x,
+                     const float *d_q, const float *d_mask, float *d_out) {
+    if (!h || !d_h || !d_e || !d_x || !d_q || !d_mask || !d_out) EPNN_FAIL("dense forward: null argument");
+    if (h->pending.active && finish_forward(h)) return 1;
+    const int saved_force = h->opt_force_path;
+    if (enqueue_dense(h, B, N, mode, d_h, d_e, d_x, d_q, d_mask, d_out)) return 1;
+    h->pending.active = true;
+    h->pending.redo = [=]() { return enqueue_dense(h, B, N, mode, d_h, d_e, d_x, d_q, d_mask, d_out); };
+    (void)saved_force;
+    return 0;
+}
+
+static int dense_host(epnn_handle *h, int B, int N, int mode, const float *hh, const float *e, const float *x,
+                      const float *q, const float *mask, float *out) {
+    if (!h || !hh || !e || !x || !q || !mask || !out) EPNN_FAIL("dense forward: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const int nx = h->cfg.nx;
+    const size_t pairs = (size_t)B * N * N, atoms = (size_t)B * N;
+    const size_t nh = (mode == 0 ? pairs : atoms) * EPNN_EDIM, nxx = (mode == 0 ? pairs : atoms) * nx,
+                 nq = mode == 0 ? pairs : atoms, ne = pairs * EPNN_EDIM, nm = pairs;
+    const size_t nout = atoms * (mode == 1 ? EPNN_EDIM : 1);
+    if (h->sd_h.ensure(nh * 4) || h->sd_e.ensure(ne * 4) || h->sd_x.ensure(nxx * 4) || h->sd_q.ensure(nq * 4) ||
+        h->sd_mask.ensure(nm * 4) || h->sd_out.ensure(nout * 4))
+        return 1;
+    HIPCHK(hipMemcpyAsync(h->sd_h.p, hh, nh * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_e.p, e, ne * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_x.p, x, nxx * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_q.p, q, nq * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_mask.p, mask, nm * 4, hipMemcpyHostToDevice, h->stream));
+    if (dense_dev(h, B, N, mode, h->sd_h.as<float>(), h->sd_e.as<float>(), h->sd_x.as<float>(), h->sd_q.as<float>(),
+                  h->sd_mask.as<float>(), h->sd_out.as<float>()))
+        return 1;
+    if (finish_forward(h)) return 1;
+    HIPCHK(hipMemcpyAsync(out, h->sd_out.p, nout * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int epnn_model_forward_dense(epnn_handle *h, int B, int N, const float *h_inp, const float *e_inp,
+                                        const float *x_inp, const float *q_inp, const float *mask_inp, float *q_out) {
+    return dense_host(h, B, N, 0, h_inp, e_inp, x_inp, q_inp, mask_inp, q_out);
+}
+extern "C" int epnn_model_forward_dense_dev(epnn_handle *h, int B, int N, const float *d_h_inp, const float *d_e_inp,
+                                            const float *d_x_inp, const float *d_q_inp, const float *d_mask_inp,
+                                            float *d_q_out) {
+    return dense_dev(h, B, N, 0, d_h_inp, d_e_inp, d_x_inp, d_q_inp, d_mask_inp, d_q_out);
+}
+extern "C" int epnn_gnn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,
+                                const float *q, const float *mask, float *h_out) {
+    return dense_host(h, B, N, 1, hin, e, x, q, mask, h_out);
+}
+extern "C" int epnn_epn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,
+                                const float *q, const float *mask, float *q_out) {
+    return dense_host(h, B, N, 2, hin, e, x, q, mask, q_out);
+}
+
+// ------------------------------------------------------------------------------------------------ MLP_layer.call
+extern "C" int epnn_mlp_forward(epnn_handle *h, int rows, int n_in, int n_out, const float *W1, const float *b1,
+                                const float *W2, const float *b2, const float *W3, const float *b3, const float *x,
+                                float *out) {
+    if (!h || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !x || !out) EPNN_FAIL("epnn_mlp_forward: null argument");
+    if (rows < 1 || n_in < 1 || n_out < 1) EPNN_FAIL("epnn_mlp_forward: rows, n_in and n_out must be positive");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    const size_t nw = (size_t)n_in * 32 + 32 + 32 * 32 + 32 + (size_t)32 * n_out + n_out;
+    const size_t nxs = (size_t)rows * n_in, no = (size_t)rows * n_out;
+    if (h->s_misc.ensure((nw + nxs + no) * 4)) return 1;
+    float *d = h->s_misc.as<float>();
+    MlpArgs M{};
+    size_t off = 0;
+    auto up = [&](const float *src, size_t n) -> const float * {
+        float *dst = d + off;
+        (void)hipMemcpyAsync(dst, src, n * 4, hipMemcpyHostToDevice, h->stream);
+        off += n;
+        return dst;
+    };
+    M.W1 = up(W1, (size_t)n_in * 32);
+    M.b1 = up(b1, 32);
+    M.W2 = up(W2, 32 * 32);
+    M.b2 = up(b2, 32);
+    M.W3 = up(W3, (size_t)32 * n_out);
+    M.b3 = up(b3, n_out);
+    M.x = up(x, nxs);
+    M.out = d + off;
+    M.rows = rows;
+    M.n_in = n_in;
+    M.n_out = n_out;
+    hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, h->stream, M);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, M.out, no * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -96,9 +97,12 @@ struct epnn_handle {
     // deferred overflow handling for the asynchronous entry point
     struct Pending {
         bool active = false;
-        int B = 0, N = 0;
-        std::vector<int> offsets;
-        const float *d_xyz = nullptr, *d_x = nullptr, *d_Q = nullptr;
-        float *d_q = nullptr;
+        std::function<int()> redo;    // re-enqueues the same forward after a capacity regrow
     } pending;
+    // dense front-end workspace (epnn_dense.hip.h)
+    DevBuf dn_xs, dn_hs, dn_qs, dn_nms, dn_flag, dn_neff, dn_xf, dn_hf, dn_qf, dn_nmf, dn_out;
+    DevBuf sd_h, sd_e, sd_x, sd_q, sd_mask, sd_out;
+    std::vector<int> dn_neff_host;
+    bool force_tmp = false;           // force_path was switched to the tiled kernels for one call only
+    int force_saved = 0;
 };

@@ -22,7 +22,7 @@ struct LargeArgs {
     WeightIndex wi;
     int nx, T, N, A, B;
     const int *moff, *mol_of, *mflag;       // mflag[b] != 0: molecule runs on this path
-    const float *xin, *Q, *h_in, *q_in;
+    const float *xin, *Q, *h_in, *q_in, *nm_in;
     float *a_eo;                            // [A][AST]
     float *P, *R;                           // [A][32] kappa-permuted
     float *zp;                              // [A][32]
@@ -339,9 +339,10 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = epnn_mfma(wp[U.u1F + (24 + s) * 64 + lane], sv[s], acc);
     float u1[16], b2v[16];
-    // every atom on this path is a real atom: node_mask = 1 (charge_gn.py:59)
+    // node_mask (charge_gn.py:59,72,74): 1 for every real atom unless the dense front-end supplies one
+    const float nmc = L.nm_in ? L.nm_in[at] : 1.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) u1[r] = fmaxf(acc[r] + b1[r], 0.f);
+    for (int r = 0; r < 16; ++r) u1[r] = fmaxf(nmc * acc[r] + b1[r], 0.f);
     epnn_ld16(wp + U.bu2p + hh * 16, b2v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b2v[r];
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = epnn_kappa(hh, r);
-            dst[epnn_aeo(nx + f)] = o0[r];
-            if (r < 8) dst[epnn_aeo(nx + 32 + f)] = o1[r];
+            dst[epnn_aeo(nx + f)] = nmc * o0[r];
+            if (r < 8) dst[epnn_aeo(nx + 32 + f)] = nmc * o1[r];
         }
     }
 }
@@ -460,7 +461,7 @@ static int large_plan(epnn_handle *h) {
 
 struct PairSource;
 static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
-                             float *d_q, float *d_hout, int run_gnn, int run_epn) {
+                             const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn) {
     const Plan &P = h->plan;
     if (P.large_list.empty()) return 0;
     const size_t pc = (size_t)h->pcap;
@@ -480,6 +481,7 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.Q = d_Q;
     L.h_in = d_hin;
     L.q_in = d_qin;
+    L.nm_in = d_nm;
     L.a_eo = h->l_a.as<float>();
     L.P = h->l_P.as<float>();
     L.R = h->l_R.as<float>();

@@ -35,6 +35,7 @@ struct SmallArgs {
     int run_gnn, run_epn;  // layer-level entry points run only one of the two stacks
     const float *h_in;     // optional [A][48] initial h (layer-level API), null -> zeros
     const float *q_in;     // optional [A] initial q (layer-level API), null -> Q/n
+    const float *nm_in;    // optional [A] node mask (dense front-end), null -> 1 for every real atom
     SmallLds L;
 };
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_small_forward(SmallArgs A) {
             a_eo[at * EPNN_AST + epnn_aeo(nx + f)] = A.h_in[(size_t)(a0 + at) * EPNN_EDIM + f];
         }
     if (tid < 32) {
-        nm[tid] = tid < n ? 1.f : 0.f;
+        nm[tid] = tid < n ? (A.nm_in ? A.nm_in[a0 + tid] : 1.f) : 0.f;
         if (tid < n)   // charge_gn.py:337-338: q0 = float32(Q) / n
             a_eo[tid * EPNN_AST + epnn_aeo(fq)] = A.q_in ? A.q_in[a0 + tid] : A.Q[b] / (float)n;
     }

@@ -158,6 +158,17 @@ class Engine:
     def epn_forward(self, h, e, x, q, mask):
         return self._layer(self.lib.epnn_epn_forward, h, e, x, q, mask, 1)
 
+    def mlp_forward(self, rows, layers):
+        """MLP_layer.call: rows (R, n_in) through [(W1,b1),(W2,b2),(W3,b3)] with hidden width 32."""
+        rows = _f32(rows)
+        (W1, b1), (W2, b2), (W3, b3) = [(_f32(k), _f32(b)) for k, b in layers]
+        if W1.shape != (rows.shape[1], 32) or W2.shape != (32, 32) or W3.shape[0] != 32:
+            raise EpnnError(f"mlp_forward: unsupported layer shapes {W1.shape} {W2.shape} {W3.shape}")
+        out = np.empty((rows.shape[0], W3.shape[1]), dtype=np.float32)
+        check(self.lib.epnn_mlp_forward(self.h, rows.shape[0], rows.shape[1], W3.shape[1], fptr(W1), fptr(b1), fptr(W2),
+                                        fptr(b2), fptr(W3), fptr(b3), fptr(rows), fptr(out)), self.lib)
+        return out
+
     # ------------------------------------------------------------------ device-resident plumbing
     def alloc(self, nbytes):
         return DeviceArray(self, nbytes)

@@ -90,6 +90,11 @@ int epnn_gnn_forward(epnn_handle *h, int B, int N, const float *hin, const float
 int epnn_epn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,
                      const float *q, const float *mask, float *q_out);
 
+/* MLP_layer.call (charge_gn.py:41-45) as a stand-alone operator: x[rows][n_in] -> relu 32 -> relu 32 -> out[rows][n_out];
+ * kernels in Keras layout [in][out].  Host pointers. */
+int epnn_mlp_forward(epnn_handle *h, int rows, int n_in, int n_out, const float *W1, const float *b1,
+                     const float *W2, const float *b2, const float *W3, const float *b3, const float *x, float *out);
+
 /* Device memory and stream plumbing for callers that keep inputs resident (bench.py). */
 int epnn_dev_alloc(epnn_handle *h, size_t bytes, void **out);
 int epnn_dev_free(epnn_handle *h, void *p);

@@ -1,0 +1,181 @@
+"""The reference's layer/model API (epnn_amd.charge_gn) on the GPU vs the CPU oracle. GPU only."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, random_weights
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _small_state(golden_dir, nx):
+    from epnn_amd import charge_gn
+    path = os.path.join(golden_dir, "qm9_small") + "/"
+    return charge_gn.gen_padded_init_state(path, 48, 48, n_elems=nx)
+
+
+def _set(model_or_layers, w):
+    model_or_layers.set_weights_dict(w)
+
+
+@pytest.mark.parametrize("nx,T", [(9, 5), (10, 2)])
+def test_make_model_dense_vs_oracle(golden_dir, nx, T):
+    """model([h,e,x,q,mask]) with the literal (B,N,N,.) tensors: random non-degenerate weights vs float64 oracle."""
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, nx)
+    w = random_weights(nx, T, seed=11, scale=0.35)
+    model = charge_gn.make_model([32, 32], 48, T, nx, x.shape[1])
+    model.set_weights_dict(w)
+    pred = model([h, e, x, q, mask])
+    assert pred.shape == (x.shape[0], x.shape[1], 1) and pred.dtype == np.float32
+    ref = orc.model_forward(h, e, x, q, mask, w, dtype=np.float64)
+    ref32 = orc.model_forward(h, e, x, q, mask, w, dtype=np.float32)
+    err, noise = np.abs(pred - ref).max(), np.abs(ref32 - ref).max()
+    print(f"dense model nx={nx} T={T}: |dq| {err:.3e}, float32 oracle noise {noise:.3e}")
+    assert err <= max(TOL, 3 * noise)
+    # padded atoms stay exactly zero, like in the reference
+    for b in range(x.shape[0]):
+        n = int(mask[b].sum(axis=0).max())
+        assert np.all(pred[b, n:] == 0)
+
+
+def test_make_model_golden_row(golden_dir, weights_decay, val_gold, val_names):
+    """BASELINE.json configs[0]: QM9 single molecule through the infer.py plumbing vs the stored TF prediction."""
+    from epnn_amd import charge_gn
+    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, 9)
+    model = charge_gn.make_model([32, 32], 48, 5, 9, x.shape[1])
+    model.load_weights(os.path.join(ROOT, "models", "decay_model_weights"))
+    names = [str(n) for n in names]
+    for nm in names:
+        if nm not in val_names:
+            continue
+        k, g = names.index(nm), val_names.index(nm)
+        pred = model([h[k:k + 1], e[k:k + 1], x[k:k + 1], q[k:k + 1], mask[k:k + 1]])
+        n = int(mask[k].sum(axis=0).max())
+        assert np.abs(pred[0, :n, 0] - val_gold[g, :n]).max() <= TOL
+
+
+def test_layer_calls_vs_oracle(golden_dir):
+    """GNN_layer.call and EPN_layer.call stand-alone (charge_gn.py:57,88) with non-trivial h and q inputs."""
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    nx, T = 9, 3
+    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, nx)
+    w = random_weights(nx, T, seed=5, scale=0.35)
+    rng = np.random.default_rng(1)
+    hx, xx, qx, m4 = orc.model_reduce(h, x, q, mask)
+    hx = (rng.normal(size=hx.shape) * 0.2 * (xx[..., :1] != 0)).astype(np.float32)     # h only on real atoms
+    qx = (qx + 0.05 * rng.normal(size=qx.shape) * (xx[..., :1] != 0)).astype(np.float32)
+    gnn = charge_gn.GNN_layer(charge_gn.MLP_layer, charge_gn.MLP_layer([32, 32], out_dim=48), T)
+    for t in range(T):
+        gnn.message_fns[t].set_weights(w["msg"][t])
+    gnn.update_fn.set_weights(w["upd"])
+    h_gpu = gnn.call(hx, e, xx, qx, m4)
+    h_ref = orc.gnn_layer(hx, e, xx, qx, m4, w["msg"], w["upd"], dtype=np.float64)
+    h_r32 = orc.gnn_layer(hx, e, xx, qx, m4, w["msg"], w["upd"], dtype=np.float32)
+    err, noise = np.abs(h_gpu - h_ref).max(), np.abs(h_r32 - h_ref).max()
+    print(f"GNN_layer.call: |dh| {err:.3e} (noise {noise:.3e}, |h| up to {np.abs(h_ref).max():.2f})")
+    assert err <= max(TOL, 3 * noise)
+    epn = charge_gn.EPN_layer(charge_gn.MLP_layer, T=T)
+    for t in range(T):
+        epn.pass_fns[t].set_weights(w["pas"][t])
+    q_gpu = epn.call(h_ref.astype(np.float32), e, xx, qx, m4)
+    q_ref = orc.epn_layer(h_ref.astype(np.float32), e, xx, qx, m4, w["pas"], dtype=np.float64)
+    q_r32 = orc.epn_layer(h_ref.astype(np.float32), e, xx, qx, m4, w["pas"], dtype=np.float32)
+    err, noise = np.abs(q_gpu - q_ref).max(), np.abs(q_r32 - q_ref).max()
+    print(f"EPN_layer.call: |dq| {err:.3e} (noise {noise:.3e})")
+    assert err <= max(TOL, 3 * noise)
+    # total charge is conserved by the layer (antisymmetric transfer)
+    assert np.abs(q_gpu.sum(axis=(1, 2)) - qx.sum(axis=(1, 2))).max() < 2e-6
+
+
+def test_arbitrary_dense_inputs(golden_dir):
+    """Inputs gen_padded_init_state never produces: non-symmetric e, non-zero diagonal, fractional and
+    non-symmetric masks, atoms with e but no mask.  The pair list must not assume symmetry."""
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    nx, T, B, N = 9, 2, 3, 12
+    rng = np.random.default_rng(3)
+    w = random_weights(nx, T, seed=9, scale=0.35)
+    n_real = [12, 9, 5]
+    e = np.zeros((B, N, N, 48), dtype=np.float32)
+    mask = np.zeros((B, N, N, 1), dtype=np.float32)
+    x = np.zeros((B, N, nx), dtype=np.float32)
+    h = np.zeros((B, N, 48), dtype=np.float32)
+    q = np.zeros((B, N, 1), dtype=np.float32)
+    for b, n in enumerate(n_real):
+        dense = rng.random((n, n)) < 0.5
+        ev = (rng.random((n, n, 48)) * 0.3 * dense[..., None]).astype(np.float32)
+        sym = rng.random((n, n)) < 0.5                       # half of the pairs symmetric, the rest not
+        evs = np.where(sym[..., None] & sym.T[..., None], np.maximum(ev, ev.transpose(1, 0, 2)), ev)
+        e[b, :n, :n] = evs
+        mask[b, :n, :n, 0] = rng.choice([0.0, 0.5, 1.0], size=(n, n), p=[0.1, 0.2, 0.7])
+        x[b, :n, 0] = rng.choice([1, 6, 7, 8], size=n)
+        x[b, np.arange(n), 1 + rng.integers(0, 4, size=n)] = 1
+        h[b, :n] = rng.normal(size=(n, 48)) * 0.2
+        q[b, :n, 0] = rng.normal(size=n) * 0.1
+    e[1, 3, 3] = 0.2                                           # diagonal entry
+    gnn = charge_gn.GNN_layer(charge_gn.MLP_layer, charge_gn.MLP_layer([32, 32], out_dim=48), T)
+    epn = charge_gn.EPN_layer(charge_gn.MLP_layer, T=T)
+    for t in range(T):
+        gnn.message_fns[t].set_weights(w["msg"][t])
+        epn.pass_fns[t].set_weights(w["pas"][t])
+    gnn.update_fn.set_weights(w["upd"])
+    h_gpu = gnn.call(h, e, x, q, mask)
+    h_ref = orc.gnn_layer(h, e, x, q, mask, w["msg"], w["upd"], dtype=np.float64)
+    h_r32 = orc.gnn_layer(h, e, x, q, mask, w["msg"], w["upd"], dtype=np.float32)
+    assert np.abs(h_gpu - h_ref).max() <= max(TOL, 3 * np.abs(h_r32 - h_ref).max())
+    q_gpu = epn.call(h, e, x, q, mask)
+    q_ref = orc.epn_layer(h, e, x, q, mask, w["pas"], dtype=np.float64)
+    q_r32 = orc.epn_layer(h, e, x, q, mask, w["pas"], dtype=np.float32)
+    err, noise = np.abs(q_gpu - q_ref).max(), np.abs(q_r32 - q_ref).max()
+    print(f"arbitrary dense inputs: |dq| {err:.3e} (noise {noise:.3e})")
+    assert err <= max(TOL, 3 * noise)
+
+
+def test_mlp_layer_call():
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    rng = np.random.default_rng(0)
+    for n_in, n_out, rows in [(164, 32, 1000), (80, 48, 77), (166, 1, 5)]:
+        mlp = charge_gn.MLP_layer([32, 32], out_dim=n_out)
+        xs = rng.normal(size=(rows, n_in)).astype(np.float32)
+        out = mlp(xs)
+        ref = orc.mlp(xs.astype(np.float64), [(k.astype(np.float64), b.astype(np.float64)) for k, b in mlp.get_weights()])
+        assert out.shape == (rows, n_out)
+        assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_edges_device_vs_host(golden_dir):
+    from epnn_amd import charge_gn
+    from epnn_amd.engine import Engine
+    fx = np.load(os.path.join(golden_dir, "edges_081300.npz"))
+    eng = Engine(nx=9, T=1)
+    e_dev = eng.edges(fx["xyz"])
+    eng.close()
+    assert e_dev.shape == fx["e"].shape
+    # float64 cos/exp on the device vs glibc: identical after rounding to float32 except at rounding boundaries
+    assert np.abs(e_dev - fx["e"]).max() <= 1e-7
+    assert np.mean(e_dev != fx["e"]) < 1e-3
+    assert np.array_equal(e_dev > 1e-5, fx["e"] > 1e-5)
+
+
+def test_infer_entry_point(tmp_path):
+    """infer.py flow end to end (BASELINE.json configs[0] plumbing) in a subprocess."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "infer.py"), "--batched", "--repeats", "2"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "avg inference time:" in out.stdout and "avg feature time:" in out.stdout
+    assert os.path.exists(tmp_path / "test_names.npy")
+    line = [l for l in out.stdout.splitlines() if l.startswith("batched compact entry")][0]
+    assert float(line.rsplit(" ", 1)[1]) <= 2e-6
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
