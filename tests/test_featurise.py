@@ -1,0 +1,54 @@
+"""Host featuriser (epnn_amd.charge_gn) and the oracle's restatement vs arrays produced by the reference's own
+NumPy/SciPy code (tests/golden/make_fixtures.py imported charge_gn.get_init_edges / gen_padded_init_state). CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("nx", [9, 10])
+def test_gen_padded_init_state_matches_reference(golden_dir, nx):
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    fx = np.load(os.path.join(golden_dir, f"featurise_qm9_small_nx{nx}.npz"))
+    path = os.path.join(golden_dir, "qm9_small") + "/"
+    x, h, q, e, Q, y, mask, names = charge_gn.gen_padded_init_state(path, 48, 48, n_elems=nx)
+    assert list(names) == list(fx["names"])
+    assert x.dtype == np.float64 and e.dtype == np.float64 and mask.shape == fx["mask"].shape
+    assert np.array_equal(x, fx["x"]) and np.array_equal(h, fx["h"]) and np.array_equal(mask, fx["mask"])
+    assert np.array_equal(q, fx["q"]) and np.array_equal(y, fx["y"])
+    assert np.array_equal(e.astype(np.float32), fx["e"])
+    assert np.array_equal(np.array(Q, dtype=np.float32), fx["Q"])
+    # the oracle's independent restatement agrees too
+    x2, h2, q2, e2, Q2, y2, mask2, names2 = orc.gen_padded_init_state(path, 48, 48, nx)
+    assert np.array_equal(x2, fx["x"]) and np.array_equal(e2.astype(np.float32), fx["e"])
+    assert np.array_equal(q2, fx["q"]) and np.array_equal(mask2, fx["mask"]) and np.array_equal(y2, fx["y"])
+
+
+def test_get_init_edges_matches_reference(golden_dir):
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    fx = np.load(os.path.join(golden_dir, "edges_081300.npz"))
+    e, C = charge_gn.get_init_edges(fx["xyz"], np.array([]), num=48)
+    assert e.dtype == np.float32 and np.array_equal(e, fx["e"]) and np.array_equal(C[:, :, 0], fx["C"])
+    e2, C2 = orc.get_init_edges(fx["xyz"], num=48)
+    assert np.array_equal(e2, fx["e"]) and np.array_equal(C2, fx["C"])
+    # properties the kernels rely on: symmetric, zero diagonal, zero beyond the cutoff
+    assert np.array_equal(e, e.transpose(1, 0, 2)) and np.all(e[np.arange(18), np.arange(18)] == 0)
+    with pytest.raises(ValueError):
+        charge_gn.get_init_edges(fx["xyz"], np.array([3, 7]))     # the reference exit()s here (charge_gn.py:134-145)
+
+
+def test_xyz_parsing_rules(tmp_path):
+    """Atom count comes from the line count, not the header; total charge is the first token of line 2; extra
+    columns are ignored (charge_gn.py:317-323)."""
+    from epnn_amd import charge_gn
+    (tmp_path / "m.xyz").write_text("99\n-1 2\nO 0.0 0.0 0.0 0.5\nH 0.96 0.0 0.0 junk\nCl 0.0 1.1 0.0\n")
+    xyz, x, Q, nlines = charge_gn.read_xyz(str(tmp_path / "m.xyz"), 9)
+    assert xyz.shape == (3, 3) and xyz.dtype == np.float32 and float(Q) == -1.0 and nlines == 5
+    assert x.shape == (3, 9) and x[0, 0] == 8 and x[0, 4] == 1 and x[2, 0] == 17 and x[2, 7] == 1
+    _, x10, _, _ = charge_gn.read_xyz(str(tmp_path / "m.xyz"), 10)
+    assert x10.shape == (3, 10) and x10[2, 8] == 1
+    with pytest.raises(KeyError):
+        (tmp_path / "p.xyz").write_text("1\n0 1\nP 0 0 0\n")
+        charge_gn.read_xyz(str(tmp_path / "p.xyz"), 9)           # P is not in infer.py's table
