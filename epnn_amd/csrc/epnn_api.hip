@@ -48,7 +48,7 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
         EPNN_FAIL("epnn_create: h_dim and e_dim must both be %d (charge_gn.py:377 requires e_dim == h_dim)", EPNN_EDIM);
     if (cfg->hidden != EPNN_HID) EPNN_FAIL("epnn_create: hidden must be %d", EPNN_HID);
     if (cfg->T < 1 || cfg->T > EPNN_MAXT) EPNN_FAIL("epnn_create: T must be in 1..%d", EPNN_MAXT);
-    if (cfg->nx < 1 || cfg->nx + EPNN_EDIM + 1 > 2 * EPNN_KA) EPNN_FAIL("epnn_create: nx must be in 1..%d", 2 * EPNN_KA - EPNN_EDIM - 1);
+    if (cfg->nx < 1 || cfg->nx + EPNN_EDIM + 1 > EPNN_F1) EPNN_FAIL("epnn_create: nx must be in 1..%d", EPNN_F1 - EPNN_EDIM - 1);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         EPNN_FAIL("epnn_create: no HIP device visible; the EPNN hot path has no CPU fallback");
@@ -64,6 +64,11 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev_t0));
     HIPCHK(hipEventCreate(&h->ev_t1));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int k = 0; k < EPNN_NSTREAM; ++k) {
+        HIPCHK(hipStreamCreateWithFlags(&h->cstream[k], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+    }
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_status), 4 * sizeof(int), hipHostMallocDefault));
     memset(h->h_status, 0, 4 * sizeof(int));
     if (h->d_status.ensure(4 * sizeof(int))) return 1;
@@ -99,6 +104,12 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipEventDestroy(h->ev_t0);
     (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(h->ev_fork);
+    for (int k = 0; k < EPNN_NSTREAM; ++k) {
+        (void)hipStreamSynchronize(h->cstream[k]);
+        (void)hipEventDestroy(h->ev_join[k]);
+        (void)hipStreamDestroy(h->cstream[k]);
+    }
     (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -156,7 +167,7 @@ static int pack_weights(epnn_handle *h) {
         for (int s = 0; s < EPNN_KA; ++s)
             for (int l = 0; l < 64; ++l) {
                 const int c = l & 31, hh = l >> 5, f = 2 * s + hh;
-                buf[pk.wiF + s * 64 + l] = f < F ? W1[(size_t)f * 32 + c] : 0.f;
+                buf[pk.wiF + s * 64 + l] = f < F ? W1[(size_t)f * 32 + c] : (f == EPNN_F1 ? b1[c] : 0.f);
                 buf[pk.wjF + s * 64 + l] = f < F ? W1[(size_t)(F + f) * 32 + c] : 0.f;
             }
         pk.b1p = alloc(32);
@@ -307,7 +318,7 @@ static int ensure_pairs(epnn_handle *h, int pcap) {
     return 0;
 }
 
-static SmallLds small_layout(int gcap) {
+static SmallLds small_layout(int nmax, int gcap) {
     SmallLds L;
     int o = 0;
     auto take = [&](int words) {
@@ -315,19 +326,24 @@ static SmallLds small_layout(int gcap) {
         o += (words + 3) & ~3;
         return r;
     };
-    L.a_eo = take(32 * EPNN_AST);
-    L.P = take(32 * EPNN_PST);
-    L.R = take(40 * EPNN_PST);
-    L.Sw = take(4 * 32 * EPNN_SST);
-    L.zp = take(32 * EPNN_SST);
+    const int nr = std::max(1, std::min(32, nmax)), npadmax = 4 * ((nr + 4) / 4);
+    L.nr = nr;
+    L.npadmax = npadmax;
+    L.a_eo = take(nr * EPNN_AST);
+    L.P = take(nr * EPNN_PST);
+    L.R = take(npadmax * EPNN_PST);
+    L.Sw = take(2 * nr * EPNN_SST);
+    L.zp = take(nr * EPNN_SST);
     L.G = take(gcap * EPNN_PST);
     L.dl = take(gcap);
     L.pij = take(gcap);
     L.pwi = take(gcap);
     L.pwj = take(gcap);
-    L.pm = take((32 * 36) / 2);
-    L.glut = take(288 / 4);
+    L.pm = take((nr * npadmax + 1) / 2);
+    L.glut = take((nr * npadmax / 4 + 3) / 4);
     L.nm = take(32);
+    L.u1h = take(64 * 16);
+    L.cst = take(64);
     L.total = o;
     return L;
 }
@@ -342,20 +358,18 @@ static int launch_large(epnn_handle *h, const PairSource &S) {
     return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_nm, S.d_q, S.d_hout, S.run_gnn, S.run_epn);
 }
 
+// The fused kernel's LDS footprint (and with it the number of co-resident workgroups per CU) is set by the largest
+// molecule of a launch, so the molecules (sorted by size) are launched in size classes, largest class first, each
+// on its own stream so that the tails overlap.
 static int launch_small(epnn_handle *h, const PairSource &S) {
     const Plan &P = h->plan;
     if (P.small_order.empty()) return 0;
-    const int nmax = P.small_nmax;
-    const int full = nmax * (nmax - 1) / 2 + nmax;   // every unordered pair + diagonal entries (dense front-end)
-    int gcap = h->small_gcap > 0 ? h->small_gcap : std::min(full, std::max(32, 8 * nmax));
-    gcap = std::min(std::max(gcap, 1), full > 0 ? std::max(full, 1) : 1);
     SmallArgs A{};
     A.wpack = h->d_wpack.as<float>();
     A.wi = h->widx;
     A.xin = S.d_x;
     A.Q = S.d_Q;
     A.moff = h->d_moff.as<int>();
-    A.order = h->d_order.as<int>();
     A.row_off = h->d_rowoff.as<int>();
     A.pi = h->d_pi.as<int>();
     A.pj = h->d_pj.as<int>();
@@ -372,16 +386,48 @@ static int launch_small(epnn_handle *h, const PairSource &S) {
     A.N = P.N;
     A.T = h->cfg.T;
     A.nx = h->cfg.nx;
-    A.gcap = gcap;
     A.pcap = h->pcap;
     A.A = P.A;
     A.run_gnn = S.run_gnn;
     A.run_epn = S.run_epn;
-    A.L = small_layout(gcap);
-    const size_t lds = (size_t)A.L.total * 4;
-    if (lds > 160 * 1024) EPNN_FAIL("fused kernel: LDS budget exceeded (%zu bytes)", lds);
-    hipLaunchKernelGGL(k_small_forward, dim3((unsigned)P.small_order.size()), dim3(256), lds, h->stream, A);
+#ifdef EPNN_STAMPS
+    if (h->l_nm.ensure(P.small_order.size() * 4 * 64 * 8)) return 1;
+    A.stamps = h->l_nm.as<unsigned long long>();
+#endif
+    static const int bounds[] = {32, 24, 20, 16, 12};          // class = molecules with bounds[k+1] < n <= bounds[k]
+    const int nclass = (int)(sizeof(bounds) / sizeof(bounds[0]));
+    const bool multi = h->opt_classes != 0 && P.small_order.size() >= 64;
+    if (multi) {
+        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+        for (int k = 0; k < EPNN_NSTREAM; ++k) HIPCHK(hipStreamWaitEvent(h->cstream[k], h->ev_fork, 0));
+    }
+    size_t pos = 0;
+    int used = 0;
+    for (int k = 0; k < nclass && pos < P.small_order.size(); ++k) {
+        const int lo = (multi && k + 1 < nclass) ? bounds[k + 1] : 0;
+        size_t end = pos;
+        while (end < P.small_order.size() && (P.offsets[P.small_order[end] + 1] - P.offsets[P.small_order[end]]) > lo) ++end;
+        if (end == pos) continue;
+        const int nmax = P.offsets[P.small_order[pos] + 1] - P.offsets[P.small_order[pos]];
+        const int full = nmax * (nmax - 1) / 2 + nmax;    // every unordered pair + diagonal entries (dense front-end)
+        int gcap = h->small_gcap > 0 ? h->small_gcap : std::max(32, h->small_pairs_per_atom * nmax);
+        gcap = std::max(1, std::min(gcap, full));
+        A.order = h->d_order.as<int>() + pos;
+        A.gcap = gcap;
+        A.L = small_layout(nmax, gcap);
+        const size_t lds = (size_t)A.L.total * 4;
+        if (lds > 160 * 1024) EPNN_FAIL("fused kernel: LDS budget exceeded (%zu bytes)", lds);
+        hipStream_t st = multi ? h->cstream[used % EPNN_NSTREAM] : h->stream;
+        hipLaunchKernelGGL(k_small_forward, dim3((unsigned)(end - pos)), dim3(256), lds, st, A);
+        ++used;
+        pos = end;
+    }
     HIPCHK(hipGetLastError());
+    if (multi)
+        for (int k = 0; k < std::min(used, (int)EPNN_NSTREAM); ++k) {
+            HIPCHK(hipEventRecord(h->ev_join[k], h->cstream[k]));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
+        }
     return 0;
 }
 
@@ -477,6 +523,7 @@ static int finish_forward(epnn_handle *h) {
                 h->plan.valid = false;
             }
             h->small_gcap = full;
+            h->small_pairs_per_atom = 32;
         }
         if (h->pending.redo()) return 1;
     }
@@ -622,6 +669,8 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "force_path")) { h->opt_force_path = value; h->plan.valid = false; }
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
     else if (!strcmp(name, "small_gcap")) { h->small_gcap = value; }
+    else if (!strcmp(name, "small_pairs_per_atom")) { h->small_pairs_per_atom = std::max(1, value); }
+    else if (!strcmp(name, "size_classes")) { h->opt_classes = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -822,3 +871,13 @@ extern "C" int epnn_mlp_forward(epnn_handle *h, int rows, int n_in, int n_out, c
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
+
+#ifdef EPNN_STAMPS
+// diagnostic build only: copy the per-wave phase stamps of the last fused launch
+extern "C" int epnn_debug_stamps(epnn_handle *h, unsigned long long *out, size_t count) {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->l_nm.p, count * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif

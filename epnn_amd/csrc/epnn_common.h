@@ -17,6 +17,7 @@
 #define EPNN_HID 32          // hidden width of every MLP
 #define EPNN_EDIM 48         // edge channels == h_dim
 #define EPNN_KA 30           // K-steps of the per-atom projection: features f = 2*s + hh, f < 60
+#define EPNN_F1 59           // atom-feature slot holding the constant 1: the first Dense's bias b1 rides in Wi row 59
 #define EPNN_AST 68          // LDS/HBM row stride (floats) of the even/odd atom-feature image a_eo
 #define EPNN_PST 36          // LDS row stride (floats) of kappa-permuted 32-vectors (P, R, G)
 #define EPNN_SST 33          // LDS row stride (floats) of out-major 32-vectors (S partial sums)

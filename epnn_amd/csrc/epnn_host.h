@@ -49,6 +49,8 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+#define EPNN_NSTREAM 5
+
 struct HostDense {            // one Keras Dense: kernel [in][out], bias [out]
     int n_in = 0, n_out = 0;
     std::vector<float> W, b;
@@ -68,6 +70,10 @@ struct epnn_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipStream_t cstream[EPNN_NSTREAM] = {};   // size-class launches of the fused kernel
+    hipEvent_t ev_fork = nullptr, ev_join[EPNN_NSTREAM] = {};
+    int opt_classes = 1;
+    int small_pairs_per_atom = 8;             // LDS slots for near pairs per atom of the largest molecule of a class
     std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)
     int ev_next = 0;                  // forwards recorded since the option was set
     // weights

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void k_lg_init(LargeArgs L) {
             if (f < L.nx) v = L.xin[(size_t)at * L.nx + f];
             else if (f < fq) v = L.h_in ? L.h_in[(size_t)at * EPNN_EDIM + (f - L.nx)] : 0.f;
             else if (f == fq) v = L.q_in ? L.q_in[at] : L.Q[b] / (float)(L.moff[b + 1] - L.moff[b]);
+            else if (f == EPNN_F1) v = 1.f;                      // carries the first Dense's bias (Wi row 59 = b1)
         }
         L.a_eo[idx] = v;
     }
@@ -142,11 +143,7 @@ __global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int
         f32x4 v = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
         bv[4 * q] = v[0]; bv[4 * q + 1] = v[1]; bv[4 * q + 2] = v[2]; bv[4 * q + 3] = v[3];
     }
-    float ci[16];
-    epnn_ld16(wp + M.b1p + hh * 16, ci);
-    f32x16 accP, accR = epnn_splat16(0.f);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accP[r] = ci[r];
+    f32x16 accP = epnn_splat16(0.f), accR = epnn_splat16(0.f);
 #pragma unroll
     for (int s = 0; s < EPNN_KA; ++s) {
         accP = epnn_mfma(wp[M.wiF + s * 64 + lane], bv[s], accP);

@@ -8,14 +8,29 @@
 // (registers 4q..4q+3 of one half-wave) is 4 consecutive rows, every quad belongs to ONE atom i: its relu-sum is
 // added to that atom's partial sum, no per-row masking.  The value of the last row of each i (a padded-partner
 // row) is kept as zp_i and added (N - npad) times: together this is the reference's sum over all N partners.
+// Each wave owns a CONTIGUOUS range of tiles, so an atom's rows are touched by at most two (adjacent) waves:
+// two partial-sum copies (wave parity) are enough and every copy has a single writer per atom -> fixed sum order.
 //
 // EPN (charge_gn.py:98-118): one tile row per UNORDERED near pair; both directions share G; the transfer
 // 0.5*(f_ij - f_ji) is applied as +d to i and -d to j, so total charge is conserved by construction.
+//
+// Weights are never waited for inside a phase: every wave fetches the MFMA fragments of its NEXT task into
+// registers while it works on the current one (global -> VGPR loads are asynchronous until first use).
+//
+// Phase plan (barrier between phases; [w] = wave):
+//   GNN step t:  A   [0] P  [1] R  [2] h-part of the first update Dense  (+ G tiles of msg[0] before step 0)
+//                B   dense pair tiles, contiguous ranges per wave
+//                C1  [0] S-part of the first update Dense   [1..3] G tiles of msg[t+1]
+//                C2  [1] second update Dense      C3  [2] h features 0..31  [3] h features 32..47
+//   EPN step t:  A'  [0] P  [1] R  [2,3] G tiles of pas[t]
+//                B'  near-pair tiles, one per wave round robin
+//                C'  ordered per-atom charge update
 #pragma once
 #include "epnn_common.h"
 
 struct SmallLds {   // offsets in 4-byte words into dynamic LDS
-    int a_eo, P, R, Sw, zp, G, dl, pij, pwi, pwj, pm, glut, nm, total;
+    int a_eo, P, R, Sw, zp, G, dl, pij, pwi, pwj, pm, glut, nm, u1h, cst, total;
+    int nr, npadmax;
 };
 
 struct SmallArgs {
@@ -37,35 +52,51 @@ struct SmallArgs {
     const float *q_in;     // optional [A] initial q (layer-level API), null -> Q/n
     const float *nm_in;    // optional [A] node mask (dense front-end), null -> 1 for every real atom
     SmallLds L;
+    unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][wave][64] s_memtime values
 };
 
-// ---- per-atom projection: out[atom c][kappa-permuted 32] = W^T a_c (+ b)   (one 32-atom tile, K = 60)
-__device__ __forceinline__ void small_proj(const float *__restrict__ wF, const float *__restrict__ cinit,
-                                           const float *a_row, float *out_row, int lane) {
+// Diagnostic build: -DEPNN_STAMPS=1 stamps the GNN phases, =2 the EPN phases (tools/dev_stamps.py).
+#ifdef EPNN_STAMPS
+#define EPNN_STAMP()                                                                                   \
+    do {                                                                                               \
+        if (lane == 0 && A.stamps && nstamp < 62) {                                                    \
+            A.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + nstamp] = __builtin_amdgcn_s_memtime();    \
+            ++nstamp;                                                                                  \
+        }                                                                                              \
+    } while (0)
+#else
+#define EPNN_STAMP() do { } while (0)
+#endif
+#if defined(EPNN_STAMPS) && EPNN_STAMPS == 2
+#define EPNN_STAMPE() EPNN_STAMP()
+#define EPNN_STAMPG() do { } while (0)
+#else
+#define EPNN_STAMPE() do { } while (0)
+#define EPNN_STAMPG() EPNN_STAMP()
+#endif
+#ifndef EPNN_ABL
+#define EPNN_ABL 0     // diagnostic ablations of the pair-tile loop (1: no partial-sum update, 2: no G lookup)
+#endif
+
+// fragment loads: cnt consecutive 256-byte rows of the packed weight buffer -> one register each
+#define EPNN_LDW(dst, off, cnt)                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[s_] = wp[(off) + s_ * 64 + lane]
+
+// ---- per-atom projection: out[atom c][kappa-permuted 32] = W^T a_c   (one 32-atom tile, K = 60; weights in w[])
+__device__ __forceinline__ void small_proj(const float (&w)[32], const float *a_row, float *out_row, bool store) {
     float bv[32];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         f32x4 v = *reinterpret_cast<const f32x4 *>(a_row + 4 * q);
         bv[4 * q] = v[0]; bv[4 * q + 1] = v[1]; bv[4 * q + 2] = v[2]; bv[4 * q + 3] = v[3];
     }
-    float wv[EPNN_KA];
+    f32x16 acc = epnn_splat16(0.f);
 #pragma unroll
-    for (int s = 0; s < EPNN_KA; ++s) wv[s] = wF[s * 64 + lane];
-    f32x16 acc;
-    if (cinit) {
-        float ci[16];
-        epnn_ld16(cinit, ci);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = ci[r];
-    } else {
-        acc = epnn_splat16(0.f);
-    }
-#pragma unroll
-    for (int s = 0; s < EPNN_KA; ++s) acc = epnn_mfma(wv[s], bv[s], acc);
-    epnn_st16(out_row, acc);
+    for (int s = 0; s < EPNN_KA; ++s) acc = epnn_mfma(w[s], bv[s], acc);
+    if (store) epnn_st16(out_row, acc);
 }
 
-// ---- G^T tile: acc[r] = G[pair c][kappa(hh,r)] = sum_ch We[ch][k] e[pair][ch]
+// ---- G^T tile: acc[r] = G[pair c][kappa(hh,r)] = sum_ch We[ch][k] e[pair][ch]   (weights read from global)
 __device__ __forceinline__ f32x16 small_gtile(const float *__restrict__ weF, const float *__restrict__ erow,
                                               bool valid, int lane) {
     float ev[24];
@@ -85,17 +116,42 @@ __device__ __forceinline__ f32x16 small_gtile(const float *__restrict__ weF, con
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_small_forward(SmallArgs A) {
+// G tiles first, first+stride, ... with the We fragments already in registers -> LDS
+__device__ __forceinline__ void small_gtiles_reg(const float (&w)[32], const float *pe, int p0, int np, float *Gl,
+                                                 int first, int stride, int lane) {
+    const int c = lane & 31, hh = lane >> 5;
+    const int ngt = (np + 31) >> 5;
+    for (int gt = first; gt < ngt; gt += stride) {
+        const int slot = gt * 32 + c;
+        const bool valid = slot < np;
+        const float *erow = pe + (size_t)(p0 + (valid ? slot : 0)) * EPNN_EDIM + hh * 24;
+        float ev[24];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(erow + 4 * q);
+            ev[4 * q] = v[0]; ev[4 * q + 1] = v[1]; ev[4 * q + 2] = v[2]; ev[4 * q + 3] = v[3];
+        }
+        f32x16 acc = epnn_splat16(0.f);
+#pragma unroll
+        for (int s = 0; s < 24; ++s) acc = epnn_mfma(w[s], valid ? ev[s] : 0.f, acc);
+        if (valid) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
     const SmallLds &L = A.L;
     float *a_eo = sm + L.a_eo, *Pl = sm + L.P, *Rl = sm + L.R, *Sw = sm + L.Sw, *zp = sm + L.zp;
-    float *Gl = sm + L.G, *dl = sm + L.dl, *lwi = sm + L.pwi, *lwj = sm + L.pwj, *nm = sm + L.nm;
-    int *lpij = reinterpret_cast<int *>(sm + L.pij);
+    float *Gl = sm + L.G, *nm = sm + L.nm, *ubuf = sm + L.u1h, *cst = sm + L.cst;
+    f32x4 *prec = reinterpret_cast<f32x4 *>(sm + L.dl);   // per near pair: {li | lj<<8 (bits), w_i, w_j, delta}
     unsigned short *pm = reinterpret_cast<unsigned short *>(sm + L.pm);
     unsigned char *glut = reinterpret_cast<unsigned char *>(sm + L.glut);
 
     if (*A.status & EPNN_ST_PAIR_OVERFLOW) return;
+    int nstamp = 0;
+    (void)nstamp;
+    EPNN_STAMP();
     const int b = A.order[blockIdx.x];
     const int a0 = A.moff[b], n = A.moff[b + 1] - a0;
     const int npad = 4 * ((n + 4) / 4);                   // multiple of 4, >= n+1
@@ -105,15 +161,44 @@ __global__ __launch_bounds__(256) void k_small_forward(SmallArgs A) {
         if (tid == 0) atomicOr(A.status, EPNN_ST_SMALL_OVERFLOW);
         return;
     }
+    const int nr = L.nr;                                  // LDS rows of the per-atom arrays (largest n of the launch)
     const int nx = A.nx, fq = nx + EPNN_EDIM;             // feature index of q
     const int nrows = n * npad, ntile = (nrows + 31) >> 5, ngroups = nrows >> 2;
     const int ngt = (np + 31) >> 5;
     const float inv_npad = 1.0f / (float)npad;
+    const int cr = c < nr ? c : nr - 1;                   // lanes beyond the last LDS row re-read it (results dropped)
+    const bool catom = c < n;
+    const float *wp = A.wpack;
+    const int Tg = A.run_gnn ? A.T : 0, Te = A.run_epn ? A.T : 0;
+
+    // registers that carry weights from the phase in which they are fetched to the phase that uses them
+    float pw[32];      // phase A / A' task (Wi | Wj | update h-part | We) and the G tiles of phase C1
+    float pinit[16];   // wave 2: cb3 of the update MLP
+    float pb[16];      // W2 fragments of the pair tiles
+    float pc[16];      // update-MLP chain: [0] U1 S-part (per step)  [1] U2  [2] U3 tile 0  [3] U3 tile 1
+    float pcb[16];     // matching bias vector
+    float pb2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) pw[s] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { pinit[s] = 0.f; pb[s] = 0.f; pc[s] = 0.f; pcb[s] = 0.f; }
+
+    // first G tiles need We of the first pair MLP: fetch it before the LDS init so the latency overlaps
+    {
+        const int weF0 = Tg > 0 ? A.wi.msg[0].weF : A.wi.pas[0].weF;
+        if (Tg > 0 || wave >= 2) { EPNN_LDW(pw, weF0, 24); }
+        if (Tg > 0) {
+            const UpdPack &U0 = A.wi.upd[0];
+            if (wave == 1) { EPNN_LDW(pc, U0.u2F, 16); epnn_ld16(wp + U0.bu2p + hh * 16, pcb); }
+            if (wave == 2) { EPNN_LDW(pc, U0.u3F, 16); epnn_ld16(wp + U0.bu3p + hh * 16, pcb); }
+            if (wave == 3) { EPNN_LDW(pc, U0.u3F + 16 * 64, 16); epnn_ld16(wp + U0.bu3p + 32 + hh * 16, pcb); }
+        }
+    }
 
     // ------------------------------------------------------------------ init
-    for (int i = tid; i < 32 * EPNN_AST; i += 256) a_eo[i] = 0.f;
-    for (int i = tid; i < 40 * EPNN_PST; i += 256) Rl[i] = 0.f;
-    for (int i = tid; i < (32 * 36) / 2; i += 256) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < nr * EPNN_AST; i += 256) a_eo[i] = 0.f;
+    for (int i = tid; i < L.npadmax * EPNN_PST; i += 256) Rl[i] = 0.f;
+    for (int i = tid; i < (nr * L.npadmax + 1) / 2; i += 256) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
     __syncthreads();
     for (int i = tid; i < n * nx; i += 256) {
         const int at = i / nx, f = i - at * nx;
@@ -126,14 +211,19 @@ __global__ __launch_bounds__(256) void k_small_forward(SmallArgs A) {
         }
     if (tid < 32) {
         nm[tid] = tid < n ? (A.nm_in ? A.nm_in[a0 + tid] : 1.f) : 0.f;
-        if (tid < n)   // charge_gn.py:337-338: q0 = float32(Q) / n
+        if (tid < n) {  // charge_gn.py:337-338: q0 = float32(Q) / n
             a_eo[tid * EPNN_AST + epnn_aeo(fq)] = A.q_in ? A.q_in[a0 + tid] : A.Q[b] / (float)n;
+            a_eo[tid * EPNN_AST + epnn_aeo(EPNN_F1)] = 1.f;      // carries b1 (Wi row 59)
+        }
     }
     for (int p = tid; p < np; p += 256) {
         const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
-        lpij[p] = li | (lj << 8);
-        lwi[p] = A.pwi[p0 + p];
-        lwj[p] = A.pwj[p0 + p];
+        f32x4 rec;
+        rec[0] = __int_as_float(li | (lj << 8));
+        rec[1] = A.pwi[p0 + p];
+        rec[2] = A.pwj[p0 + p];
+        rec[3] = 0.f;
+        prec[p] = rec;
         pm[li * npad + lj] = (unsigned short)p;
         if (A.psym[p0 + p]) pm[lj * npad + li] = (unsigned short)p;
     }
@@ -143,130 +233,207 @@ __global__ __launch_bounds__(256) void k_small_forward(SmallArgs A) {
     }
     __syncthreads();
 
-    const float *wp = A.wpack;
     const float Nf = (float)A.N;
     const float padw = (float)(A.N - npad);               // how many more padded-partner rows the reference sums
+    // contiguous tile range of this wave
+    const int tlo = (ntile * wave) >> 2, thi = (ntile * (wave + 1)) >> 2;
+    EPNN_STAMP();   // 1: init done
+
+    if (Tg > 0) {
+        // G tiles of msg[0] (all waves), then the phase-A weights of step 0
+        small_gtiles_reg(pw, A.pe, p0, np, Gl, 3 - wave, 4, lane);
+        const PairMlpPack &M0 = A.wi.msg[0];
+        if (wave == 0) { EPNN_LDW(pw, M0.wiF, EPNN_KA); }
+        else if (wave == 1) { EPNN_LDW(pw, M0.wjF, EPNN_KA); }
+        else if (wave == 2) { EPNN_LDW(pw, A.wi.upd[0].u1F, 24); epnn_ld16(wp + A.wi.upd[0].cb3p + hh * 16, pinit); }
+    } else if (Te > 0) {
+        const PairMlpPack &M0 = A.wi.pas[0];
+        if (wave == 0) { EPNN_LDW(pw, M0.wiF, EPNN_KA); }
+        else if (wave == 1) { EPNN_LDW(pw, M0.wjF, EPNN_KA); }
+    }
 
     // ================================================================== GNN steps (charge_gn.py:60-74)
-    for (int t = 0; t < (A.run_gnn ? A.T : 0); ++t) {
+    for (int t = 0; t < Tg; ++t) {
         const PairMlpPack &M = A.wi.msg[t];
         const UpdPack &U = A.wi.upd[t];
-        // ---- phase A: P, R (waves 0,1) and the G tiles (round robin), zero the partial sums
-        for (int i = tid; i < 4 * 32 * EPNN_SST; i += 256) Sw[i] = 0.f;
-        for (int task = wave; task < 2 + ngt; task += 4) {
-            if (task == 0) {
-                small_proj(wp + M.wiF, wp + M.b1p + hh * 16, a_eo + c * EPNN_AST + hh * 32,
-                           Pl + c * EPNN_PST + hh * 16, lane);
-            } else if (task == 1) {
-                small_proj(wp + M.wjF, nullptr, a_eo + c * EPNN_AST + hh * 32, Rl + c * EPNN_PST + hh * 16, lane);
-            } else {
-                const int slot = (task - 2) * 32 + c;
-                const bool valid = slot < np;
-                f32x16 g = small_gtile(wp + M.weF, A.pe + (size_t)(p0 + (valid ? slot : 0)) * EPNN_EDIM + hh * 24,
-                                       valid, lane);
-                if (valid) epnn_st16(Gl + slot * EPNN_PST + hh * 16, g);
-            }
+        const bool lastg = t + 1 == Tg;
+        // ---- phase A: [0] P  [1] R  [2] h-part of the first update Dense.  W2/b2 of the tiles are fetched now.
+        EPNN_LDW(pb, M.w2F, 16);
+        pb2 = wp[M.b2 + c];
+        for (int i = tid; i < 2 * nr * EPNN_SST; i += 256) Sw[i] = 0.f;
+        if (wave == 0) {
+            small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Pl + cr * EPNN_PST + hh * 16, catom);
+            EPNN_LDW(pc, U.u1F + 24 * 64, 16);                      // for phase C1
+            epnn_ld16(wp + U.bu1p + hh * 16, pcb);
+        } else if (wave == 1) {
+            small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Rl + cr * EPNN_PST + hh * 16, catom);
+        } else if (wave == 2) {
+            const int u0 = (nx - hh + 1) >> 1;
+            const float *arow = a_eo + cr * EPNN_AST + hh * 32 + u0;
+            float hv[24];
+#pragma unroll
+            for (int s = 0; s < 24; ++s) hv[s] = arow[s];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = Nf * pinit[r];
+#pragma unroll
+            for (int s = 0; s < 24; ++s) acc = epnn_mfma(pw[s], hv[s], acc);
+            epnn_st16(ubuf + lane * 16, acc);
         }
+        if (wave >= 1) {                                            // We of the next pair MLP for phase C1 / A'
+            if (!lastg) { EPNN_LDW(pw, A.wi.msg[t + 1].weF, 24); }
+            else if (Te > 0 && wave >= 2) { EPNN_LDW(pw, A.wi.pas[0].weF, 24); }
+        }
+        EPNN_STAMPG();   // end of own phase-A work
         __syncthreads();
+        EPNN_STAMPG();   // phase B starts
         // ---- phase B: dense pair tiles
         {
-            float w2[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
-            const f32x16 cb2 = epnn_splat16(wp[M.b2 + c]);
-            float *Smine = Sw + wave * 32 * EPNN_SST;
-            for (int tau = wave; tau < ntile; tau += 4) {
+            const f32x16 cb2 = epnn_splat16(pb2);
+            float *Smine = Sw + (wave & 1) * nr * EPNN_SST;
+            for (int tau = tlo; tau < thi; ++tau) {
                 const int p = tau * 32 + c;
-                const int pc = p < nrows ? p : 0;
-                const int i = (int)(((float)pc + 0.5f) * inv_npad);
-                const int j = pc - i * npad;
-                const unsigned slot = pm[pc];
+                const int pc_ = p < nrows ? p : 0;
+                const int i = (int)(((float)pc_ + 0.5f) * inv_npad);
+                const int j = pc_ - i * npad;
+                const unsigned slot = pm[pc_];
+                int info[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = tau * 8 + 2 * q + hh;
+                    info[q] = g < ngroups ? glut[g] : 0x7F;
+                }
                 float z[16], rj[16];
                 epnn_ld16(Pl + i * EPNN_PST + hh * 16, z);
                 epnn_ld16(Rl + j * EPNN_PST + hh * 16, rj);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] += rj[r];
+#if EPNN_ABL != 2
                 if (slot != 0xFFFFu) {
                     float g[16];
                     epnn_ld16(Gl + slot * EPNN_PST + hh * 16, g);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) z[r] += g[r];
                 }
+#endif
                 f32x16 acc = cb2;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc = epnn_mfma(fmaxf(z[s], 0.f), w2[s], acc);
+                for (int s = 0; s < 16; ++s) acc = epnn_mfma(fmaxf(z[s], 0.f), pb[s], acc);
                 // rows = pairs kappa(hh,r), col = out feature c.  Quad q of this half-wave = rows 8q+4hh .. +3.
+                // Quad sums -> this wave's partial sums.  LDS float atomics cost ~400 cycles per wave-instruction on
+                // gfx950, so this is a plain read-modify-write: consecutive quads of one half-wave that belong to
+                // the same atom are merged in registers first (the surviving quads then have distinct addresses),
+                // and the two half-waves, which may share an atom, update one after the other.
+                float v[4];
+                int gi[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int g = tau * 8 + 2 * q + hh;
                     const float last = fmaxf(acc[4 * q + 3], 0.f);
-                    const float v = ((fmaxf(acc[4 * q], 0.f) + fmaxf(acc[4 * q + 1], 0.f)) + fmaxf(acc[4 * q + 2], 0.f)) + last;
-                    const int info = g < ngroups ? glut[g] : 0x7F;
-                    const int gi = info & 0x7F;
-                    // two half-waves may target the same (i, out): serialise them in a fixed order
-                    if (hh == 0 && gi != 0x7F) atomicAdd(Smine + gi * EPNN_SST + c, v);
-                    if (hh == 1 && gi != 0x7F) atomicAdd(Smine + gi * EPNN_SST + c, v);
-                    if ((info & 0x80) && gi != 0x7F) zp[gi * EPNN_SST + c] = last;
+                    v[q] = ((fmaxf(acc[4 * q], 0.f) + fmaxf(acc[4 * q + 1], 0.f)) + fmaxf(acc[4 * q + 2], 0.f)) + last;
+                    gi[q] = info[q] & 0x7F;
+                    if ((info[q] & 0x80) && gi[q] != 0x7F) zp[gi[q] * EPNN_SST + c] = last;
                 }
+#if EPNN_ABL == 1
+                asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
+                bool wr[4];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const bool same = gi[q] == gi[q + 1];
+                    if (same) v[q + 1] += v[q];
+                    wr[q] = !same && gi[q] != 0x7F;
+                }
+                wr[3] = gi[3] != 0x7F;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (hh == half) {
+                        float old[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) old[q] = wr[q] ? Smine[gi[q] * EPNN_SST + c] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (wr[q]) Smine[gi[q] * EPNN_SST + c] = old[q] + v[q];
+                    }
+                }
+#endif
             }
         }
+        EPNN_STAMPG();   // end of own phase-B work
         __syncthreads();
-        // ---- phase C: update MLP (charge_gn.py:71-74) on wave 0, atoms on MFMA columns
+        EPNN_STAMPG();   // phase C starts
+        // ---- phase C1: [0] first update Dense (S-part on top of the stashed h-part)   [1..3] next G tiles
         if (wave == 0) {
-            const int u0 = (nx - hh + 1) >> 1;
-            const float *arow = a_eo + c * EPNN_AST + hh * 32 + u0;
-            float hv[24], sv[16];
-#pragma unroll
-            for (int s = 0; s < 24; ++s) hv[s] = arow[s];
+            float sv[16], a1[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int o = 2 * s + hh;
-                const float s4 = ((Sw[(0 * 32 + c) * EPNN_SST + o] + Sw[(1 * 32 + c) * EPNN_SST + o]) +
-                                  Sw[(2 * 32 + c) * EPNN_SST + o]) + Sw[(3 * 32 + c) * EPNN_SST + o];
-                sv[s] = s4 + padw * zp[c * EPNN_SST + o];
+                sv[s] = (Sw[cr * EPNN_SST + o] + Sw[(nr + cr) * EPNN_SST + o]) + padw * zp[cr * EPNN_SST + o];
             }
-            float cb[16], b1[16];
-            epnn_ld16(wp + U.cb3p + hh * 16, cb);
-            epnn_ld16(wp + U.bu1p + hh * 16, b1);
+            epnn_ld16(ubuf + lane * 16, a1);
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = Nf * cb[r];
+            for (int r = 0; r < 16; ++r) acc[r] = a1[r];
 #pragma unroll
-            for (int s = 0; s < 24; ++s) acc = epnn_mfma(wp[U.u1F + s * 64 + lane], hv[s], acc);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = epnn_mfma(wp[U.u1F + (24 + s) * 64 + lane], sv[s], acc);
+            for (int s = 0; s < 16; ++s) acc = epnn_mfma(pc[s], sv[s], acc);
             const float nmc = nm[c];
-            float u1[16];
+            f32x16 u1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u1[r] = fmaxf(nmc * acc[r] + b1[r], 0.f);
-            float b2v[16];
-            epnn_ld16(wp + U.bu2p + hh * 16, b2v);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = b2v[r];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = epnn_mfma(wp[U.u2F + s * 64 + lane], u1[s], acc);
-            float u2[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) u2[r] = fmaxf(acc[r], 0.f);
-            f32x16 o0, o1;
-            float b3a[16], b3b[16];
-            epnn_ld16(wp + U.bu3p + hh * 16, b3a);
-            epnn_ld16(wp + U.bu3p + 32 + hh * 16, b3b);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] = b3a[r]; o1[r] = b3b[r]; }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                o0 = epnn_mfma(wp[U.u3F + s * 64 + lane], u2[s], o0);
-                o1 = epnn_mfma(wp[U.u3F + (16 + s) * 64 + lane], u2[s], o1);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = epnn_kappa(hh, r);
-                a_eo[c * EPNN_AST + epnn_aeo(nx + f)] = nmc * o0[r];
-                if (r < 8) a_eo[c * EPNN_AST + epnn_aeo(nx + 32 + f)] = nmc * o1[r];
+            for (int r = 0; r < 16; ++r) u1[r] = fmaxf(nmc * acc[r] + pcb[r], 0.f);
+            epnn_st16(ubuf + lane * 16, u1);
+            // phase-A weights of the next step
+            if (!lastg) { EPNN_LDW(pw, A.wi.msg[t + 1].wiF, EPNN_KA); }
+            else if (Te > 0) { EPNN_LDW(pw, A.wi.pas[0].wiF, EPNN_KA); }
+        } else {
+            if (!lastg) small_gtiles_reg(pw, A.pe, p0, np, Gl, wave - 1, 3, lane);
+            if (wave == 1) {
+                if (!lastg) { EPNN_LDW(pw, A.wi.msg[t + 1].wjF, EPNN_KA); }
+                else if (Te > 0) { EPNN_LDW(pw, A.wi.pas[0].wjF, EPNN_KA); }
+            } else if (wave == 2 && !lastg) {
+                EPNN_LDW(pw, A.wi.upd[t + 1].u1F, 24);
+                epnn_ld16(wp + A.wi.upd[t + 1].cb3p + hh * 16, pinit);
             }
         }
+        EPNN_STAMPG();
         __syncthreads();
+        EPNN_STAMPG();
+        // ---- phase C2: [1] second update Dense
+        if (wave == 1) {
+            float u1[16];
+            epnn_ld16(ubuf + lane * 16, u1);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = pcb[r];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = epnn_mfma(pc[s], u1[s], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+            epnn_st16(ubuf + lane * 16, acc);
+        }
+        EPNN_STAMPG();
+        __syncthreads();
+        EPNN_STAMPG();
+        // ---- phase C3: [2] h features 0..31   [3] h features 32..47   (charge_gn.py:73-74)
+        if (wave >= 2) {
+            float u2[16];
+            epnn_ld16(ubuf + lane * 16, u2);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = pcb[r];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = epnn_mfma(pc[s], u2[s], acc);
+            if (catom) {
+                const float nmc = nm[c];
+                const int fb = wave == 2 ? 0 : 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = fb + epnn_kappa(hh, r);
+                    if (f < EPNN_EDIM) a_eo[c * EPNN_AST + epnn_aeo(nx + f)] = nmc * acc[r];
+                }
+            }
+        }
+        EPNN_STAMPG();   // end of own phase-C work
+        __syncthreads();
+        EPNN_STAMPG();   // next step starts
     }
     if (A.h_out)
         for (int i = tid; i < n * EPNN_EDIM; i += 256) {
@@ -275,68 +442,95 @@ __global__ __launch_bounds__(256) void k_small_forward(SmallArgs A) {
         }
 
     // ================================================================== EPN steps (charge_gn.py:98-118)
-    for (int t = 0; t < (A.run_epn ? A.T : 0); ++t) {
+    for (int t = 0; t < Te; ++t) {
         const PairMlpPack &M = A.wi.pas[t];
-        if (wave == 0)
-            small_proj(wp + M.wiF, wp + M.b1p + hh * 16, a_eo + c * EPNN_AST + hh * 32, Pl + c * EPNN_PST + hh * 16, lane);
-        else if (wave == 1)
-            small_proj(wp + M.wjF, nullptr, a_eo + c * EPNN_AST + hh * 32, Rl + c * EPNN_PST + hh * 16, lane);
-        __syncthreads();
-        {
-            float w2[16], b2v[16], w3[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
-            epnn_ld16(wp + M.b2p + hh * 16, b2v);
-            epnn_ld16(wp + M.w3p + hh * 16, w3);
-            for (int gt = 3 - wave; gt < ngt; gt += 4) {       // waves 3,2 first: waves 0,1 just did P,R
-                const int slot = gt * 32 + c;
-                const bool valid = slot < np;
-                const f32x16 g = small_gtile(wp + M.weF, A.pe + (size_t)(p0 + (valid ? slot : 0)) * EPNN_EDIM + hh * 24,
-                                             valid, lane);
-                const int ij = valid ? lpij[slot] : 0;
-                const int li = ij & 0xFF, lj = ij >> 8;
-                float pi_[16], rj_[16], pj_[16], ri_[16];
-                epnn_ld16(Pl + li * EPNN_PST + hh * 16, pi_);
-                epnn_ld16(Rl + lj * EPNN_PST + hh * 16, rj_);
-                epnn_ld16(Pl + lj * EPNN_PST + hh * 16, pj_);
-                epnn_ld16(Rl + li * EPNN_PST + hh * 16, ri_);
-                f32x16 au, av;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
-                // rows = out feature kappa(hh,r), col = pair c
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    au = epnn_mfma(w2[s], fmaxf((g[s] + pi_[s]) + rj_[s], 0.f), au);
-                    av = epnn_mfma(w2[s], fmaxf((g[s] + pj_[s]) + ri_[s], 0.f), av);
-                }
-                float fu = 0.f, fv = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
-                    fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
-                }
-                fu += epnn_swap32(fu);
-                fv += epnn_swap32(fv);
-                if (hh == 0 && valid) dl[slot] = 0.5f * (fu - fv);     // charge_gn.py:116
-            }
+        const bool laste = t + 1 == Te;
+        // ---- phase A': [0] P  [1] R  [2,3] G tiles;  W2 for the pair tiles and the step's small vectors fetched now
+        EPNN_LDW(pb, M.w2F, 16);
+        float cv = 0.f;
+        if (wave == 0) cv = hh == 0 ? wp[M.b2p + c] : wp[M.w3p + c];
+        if (wave == 0) {
+            small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Pl + cr * EPNN_PST + hh * 16, catom);
+            cst[lane] = cv;                                          // [0..31] b2 (kappa order)  [32..63] w3
+            if (!laste) { EPNN_LDW(pw, A.wi.pas[t + 1].wiF, EPNN_KA); }
+        } else if (wave == 1) {
+            small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Rl + cr * EPNN_PST + hh * 16, catom);
+            if (!laste) { EPNN_LDW(pw, A.wi.pas[t + 1].wjF, EPNN_KA); }
+        } else {
+            small_gtiles_reg(pw, A.pe, p0, np, Gl, wave - 2, 2, lane);
+            if (!laste) { EPNN_LDW(pw, A.wi.pas[t + 1].weF, 24); }
         }
+        EPNN_STAMPE();
         __syncthreads();
+        EPNN_STAMPE();
+        for (int gt = wave; gt < ngt; gt += 4) {
+            const int slot = gt * 32 + c;
+            const bool valid = slot < np;
+            const int sl = valid ? slot : 0;
+            const int ij = __float_as_int(reinterpret_cast<const float *>(prec + sl)[0]);
+            const int li = ij & 0xFF, lj = ij >> 8;
+            float g[16], ta[16], tb[16], zu[16], zv[16];
+            epnn_ld16(Gl + sl * EPNN_PST + hh * 16, g);
+            epnn_ld16(Pl + li * EPNN_PST + hh * 16, ta);
+            epnn_ld16(Rl + lj * EPNN_PST + hh * 16, tb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zu[r] = fmaxf((g[r] + ta[r]) + tb[r], 0.f);
+            epnn_ld16(Pl + lj * EPNN_PST + hh * 16, ta);
+            epnn_ld16(Rl + li * EPNN_PST + hh * 16, tb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zv[r] = fmaxf((g[r] + ta[r]) + tb[r], 0.f);
+            float b2v[16];
+            epnn_ld16(cst + hh * 16, b2v);
+            f32x16 au, av;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
+            // rows = out feature kappa(hh,r), col = pair c
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                au = epnn_mfma(pb[s], zu[s], au);
+                av = epnn_mfma(pb[s], zv[s], av);
+            }
+            float w3[16];
+            epnn_ld16(cst + 32 + hh * 16, w3);
+            float fu = 0.f, fv = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
+                fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
+            }
+            fu += epnn_swap32(fu);
+            fv += epnn_swap32(fv);
+            if (hh == 0 && valid) reinterpret_cast<float *>(prec + slot)[3] = 0.5f * (fu - fv);     // charge_gn.py:116
+        }
+        EPNN_STAMPE();
+        __syncthreads();
+        EPNN_STAMPE();
         // q_i += sum_j antisym_ij  (charge_gn.py:118): 8 lanes per atom, fixed combination order
         {
             const int i = tid >> 3, part = tid & 7;
             float acc = 0.f;
+#pragma unroll 4
             for (int p = part; p < np; p += 8) {
-                const int ij = lpij[p];
-                const float d = dl[p];
-                if ((ij & 0xFF) == i) acc += lwi[p] * d;
-                if ((ij >> 8) == i) acc -= lwj[p] * d;
+                const f32x4 rec = prec[p];
+                const int ij = __float_as_int(rec[0]);
+                if ((ij & 0xFF) == i) acc += rec[1] * rec[3];
+                if ((ij >> 8) == i) acc -= rec[2] * rec[3];
             }
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             acc += __shfl_xor(acc, 4, 64);
             if (part == 0 && i < n) a_eo[i * EPNN_AST + epnn_aeo(fq)] += acc;
         }
+        EPNN_STAMPE();
         __syncthreads();
+        EPNN_STAMPE();
     }
+    EPNN_STAMP();
     if (tid < n) A.q_out[a0 + tid] = a_eo[tid * EPNN_AST + epnn_aeo(fq)];
+#ifdef EPNN_STAMPS
+    if (lane == 0 && A.stamps) {
+        A.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + 62] = (unsigned long long)nstamp;
+        A.stamps[((size_t)blockIdx.x * 4 + wave) * 64 + 63] = ((unsigned long long)n << 32) | (unsigned)np;
+    }
+#endif
 }

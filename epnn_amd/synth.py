@@ -29,16 +29,24 @@ def features(symbols):
     return x
 
 
-def _grow_molecule(rng, n, min_sep=0.95, lo=1.0, hi=1.6):
+def _grow_molecule(rng, n, min_sep=0.95, lo=1.0, hi=1.6, max_links=2):
+    """Random sequential addition: each new atom sits 1.0-1.6 A from an existing atom that has fewer than
+    `max_links` attachments yet, and at least `min_sep` from every atom.  max_links=2 (chain-like growth) is
+    calibrated to the real QM9 subset of the reference's `mixed` set: ~8 partners within 3 A per atom, near
+    fraction ~0.45 of all ordered pairs (unrestricted attachment gives compact blobs with 10.6 partners)."""
     pts = np.zeros((n, 3))
+    links = np.zeros(n, dtype=np.int64)
     k = 1
     while k < n:
-        base = pts[rng.integers(k)]
+        free = np.flatnonzero(links[:k] < max_links)
+        bi = int(free[rng.integers(len(free))]) if len(free) else int(rng.integers(k))
         v = rng.normal(size=3)
         v /= np.linalg.norm(v)
-        cand = base + v * rng.uniform(lo, hi)
+        cand = pts[bi] + v * rng.uniform(lo, hi)
         if np.min(np.linalg.norm(pts[:k] - cand, axis=1)) >= min_sep:
             pts[k] = cand
+            links[bi] += 1
+            links[k] += 1
             k += 1
     return pts
 
