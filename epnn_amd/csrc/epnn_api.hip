@@ -93,10 +93,10 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
-                      &h->d_status, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
+                      &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
-                      &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
+                      &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
                       &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
     for (DevBuf *b : bufs) b->release();
@@ -455,7 +455,12 @@ static int run_frontend_xyz(epnn_handle *h, const float *d_xyz) {
     F.status = h->d_status.as<int>();
     const unsigned rows = (unsigned)((P.A + 3) / 4);
     hipLaunchKernelGGL(k_front_count, dim3(rows), dim3(256), 0, h->stream, F);
-    hipLaunchKernelGGL(k_front_scan, dim3(1), dim3(1024), 0, h->stream, F);
+    {
+        const unsigned nsb = (unsigned)((F.A + EPNN_SCAN_ELEMS - 1) / EPNN_SCAN_ELEMS);
+        if (h->d_bsum.ensure((size_t)nsb * sizeof(int))) return 1;
+        hipLaunchKernelGGL(k_front_scan1, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+        hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+    }
     hipLaunchKernelGGL(k_front_fill, dim3(rows), dim3(256), 0, h->stream, F);
     HIPCHK(hipGetLastError());
     return 0;
@@ -749,7 +754,12 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     F.row_off = h->d_rowoff.as<int>();
     F.pcap = h->pcap;
     F.status = h->d_status.as<int>();
-    hipLaunchKernelGGL(k_front_scan, dim3(1), dim3(1024), 0, h->stream, F);
+    {
+        const unsigned nsb = (unsigned)((F.A + EPNN_SCAN_ELEMS - 1) / EPNN_SCAN_ELEMS);
+        if (h->d_bsum.ensure((size_t)nsb * sizeof(int))) return 1;
+        hipLaunchKernelGGL(k_front_scan1, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+        hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+    }
     hipLaunchKernelGGL(k_dn_pairs<1>, dim3(rows), dim3(256), 0, h->stream, D);
     HIPCHK(hipGetLastError());
     PairSource S;

@@ -50,35 +50,54 @@ __global__ __launch_bounds__(256) void k_front_count(FrontArgs F) {
     if (lane == 0) F.row_cnt[row] = cnt;
 }
 
-// exclusive scan of row_cnt[0..A) -> row_off[0..A]; single block of 1024 threads
-__global__ __launch_bounds__(1024) void k_front_scan(FrontArgs F) {
-    __shared__ int wsum[16];
-    __shared__ int carry;
+// exclusive scan of row_cnt[0..A) -> row_off[0..A] in two passes: (1) every block of 256 threads scans 2048
+// elements locally and publishes its total, (2) every block adds the totals of the blocks before it.
+#define EPNN_SCAN_ELEMS 2048
+__global__ __launch_bounds__(256) void k_front_scan1(FrontArgs F, int *bsum) {
+    __shared__ int wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < F.A; base += 1024) {
-        const int idx = base + tid;
-        const int v = idx < F.A ? F.row_cnt[idx] : 0;
-        int incl = v;
+    const int base = blockIdx.x * EPNN_SCAN_ELEMS + tid * 8;
+    int v[8], tot = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const int c0 = carry;
-        if (idx < F.A) F.row_off[idx] = c0 + woff + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry = c0 + woff + incl;
-        __syncthreads();
+    for (int k = 0; k < 8; ++k) {
+        v[k] = base + k < F.A ? F.row_cnt[base + k] : 0;
+        tot += v[k];
     }
-    if (tid == 0) {
-        F.row_off[F.A] = carry;
-        if (carry > F.pcap) atomicOr(F.status, EPNN_ST_PAIR_OVERFLOW);
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + incl - tot;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (base + k < F.A) F.row_off[base + k] = run;
+        run += v[k];
+    }
+    if (tid == 255) bsum[blockIdx.x] = run;
+}
+__global__ __launch_bounds__(256) void k_front_scan2(FrontArgs F, const int *bsum) {
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int part = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) part += bsum[b];
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    const int boff = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int base = blockIdx.x * EPNN_SCAN_ELEMS + tid * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (base + k < F.A) F.row_off[base + k] += boff;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const int total = boff + bsum[blockIdx.x];
+        F.row_off[F.A] = total;
+        if (total > F.pcap) atomicOr(F.status, EPNN_ST_PAIR_OVERFLOW);
     }
 }
 

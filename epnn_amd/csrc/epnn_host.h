@@ -72,7 +72,7 @@ struct epnn_handle {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     hipStream_t cstream[EPNN_NSTREAM] = {};   // size-class launches of the fused kernel
     hipEvent_t ev_fork = nullptr, ev_join[EPNN_NSTREAM] = {};
-    int opt_classes = 1;
+    int opt_classes = 0;                      // multi-stream size classes: measured slower than one launch (fork/join cost)
     int small_pairs_per_atom = 8;             // LDS slots for near pairs per atom of the largest molecule of a class
     std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)
     int ev_next = 0;                  // forwards recorded since the option was set
@@ -84,7 +84,7 @@ struct epnn_handle {
     DevBuf d_mu;
     // plan + workspace
     Plan plan;
-    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status;
+    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status, d_bsum;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     int pcap = 0;
     int pair_cap_per_atom = 16;
@@ -94,7 +94,7 @@ struct epnn_handle {
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc;
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
-    DevBuf l_mflag, l_stasks, l_schunk;
+    DevBuf l_mflag, l_stasks, l_schunk, l_sfin;
     int l_natiles = 0, l_nstasks = 0, l_maxchunk = 0;
     // options / stats
     int opt_profile = 0, opt_force_path = 0;

@@ -281,8 +281,32 @@ __global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
 }
 
 // ------------------------------------------------------------------------------------------------ update
-// workgroup = up to 4 atom tiles; all threads reduce S, then one wave per tile runs the update MLP
-__global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int maxchunk) {
+// S_i = sum_chunk S0 + sum of the atom's corrections + (N-n) zp_i, one thread per (atom, out), fixed order.
+// Written as its own wide launch: the update kernel has only natiles/4 workgroups, far too few to hide ~50
+// dependent global loads per element.
+__global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin) {
+    if (L.row_off[L.A] > L.pcap) return;
+    const int it = blockIdx.x;                 // one workgroup per 8 atoms of a tile list entry
+    const int o = threadIdx.x & 31, a8 = threadIdx.x >> 5;
+    const int4 tl = L.atiles[it >> 2];
+    const int a = (it & 3) * 8 + a8;
+    if (a >= tl.y) return;
+    const int at = tl.x + a;
+    const int n = L.moff[tl.z + 1] - L.moff[tl.z];
+    const int nchunk = tl.w;
+    float s = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) s += L.S0[((size_t)ch * L.A + at) * 32 + o];
+    for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) s += L.corr[((size_t)p * 2 + 0) * 32 + o];
+    for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
+        const int p = L.dn_ent[e];
+        if (L.psym[p]) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
+    }
+    s += (float)(L.N - n) * L.zp[(size_t)at * 32 + o];
+    Sfin[(size_t)at * 32 + o] = s;
+}
+
+// workgroup = up to 4 atom tiles, one wave per tile runs the update MLP on the reduced S
+__global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int maxchunk, const float *Sfin) {
     __shared__ float Ss[4 * 32 * EPNN_SST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
     const int t0 = blockIdx.x * 4;
@@ -293,19 +317,7 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
         float s = 0.f;
         if (t0 + w < L.natiles) {
             const int4 tl = L.atiles[t0 + w];
-            if (a < tl.y) {
-                const int at = tl.x + a;
-                const int b = tl.z;
-                const int n = L.moff[b + 1] - L.moff[b];
-                const int nchunk = tl.w;
-                for (int ch = 0; ch < nchunk; ++ch) s += L.S0[((size_t)ch * L.A + at) * 32 + o];
-                for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) s += L.corr[((size_t)p * 2 + 0) * 32 + o];
-                for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
-                    const int p = L.dn_ent[e];
-                    if (L.psym[p]) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
-                }
-                s += (float)(L.N - n) * L.zp[(size_t)at * 32 + o];
-            }
+            if (a < tl.y) s = Sfin[(size_t)(tl.x + a) * 32 + o];
         }
         Ss[(w * 32 + a) * EPNN_SST + o] = s;
     }
@@ -447,7 +459,7 @@ static int large_plan(epnn_handle *h) {
         h->l_schunk.ensure(lp.stask_chunk.size() * sizeof(int)) || h->l_a.ensure(A * EPNN_AST * 4) ||
         h->l_P.ensure(A * 32 * 4) || h->l_R.ensure(A * 32 * 4) || h->l_zp.ensure(A * 32 * 4) ||
         h->l_S0.ensure((size_t)lp.maxchunk * A * 32 * 4) || h->l_csr_off.ensure((A + 1) * sizeof(int)) ||
-        h->l_cnt.ensure((A + 1) * sizeof(int)))
+        h->l_cnt.ensure((A + 1) * sizeof(int)) || h->l_sfin.ensure(A * 32 * 4))
         return 1;
     HIPCHK(hipMemcpyAsync(h->l_tiles.p, lp.atiles.data(), lp.atiles.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->l_stasks.p, lp.stasks.data(), lp.stasks.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
@@ -521,7 +533,8 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
         hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[t], 1);
         hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->widx.msg[t]);
         hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
-        hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk);
+        hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
+        hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk, h->l_sfin.as<float>());
     }
     if (d_hout) hipLaunchKernelGGL(k_lg_export_h, dim3(gA), dim3(256), 0, st, L);
     for (int t = 0; t < (run_epn ? L.T : 0); ++t) {

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Large-system timings (BASELINE.json configs[3] and [4]): the 2220-atom protein and a synthetic box.
+    python tools/bench_large.py protein | box100k | box<N>k
+"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from epnn_amd import checkpoint, synth, charge_gn
+from epnn_amd.engine import Engine
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "protein"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    w = checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights"))
+    eng = Engine(nx=9, T=5)
+    eng.set_weights(w)
+    if what == "protein":
+        xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(ROOT, "tests/golden/protein/6qlp_capped.xyz"), 9)
+        offsets = np.array([0, len(x)], dtype=np.int32)
+        Q = np.array([Q], dtype=np.float32)
+        N = len(x)
+    else:
+        n = int(what.replace("box", "").replace("k", "")) * 1000
+        t0 = time.time()
+        offsets, xyz, x, Q, N = synth.box_system(n_atoms=n, seed=0)
+        print(f"generated {n} atoms in {time.time()-t0:.1f} s", flush=True)
+    A = int(offsets[-1])
+    d = [eng.to_device(a) for a in (xyz, x, Q)]
+    dq = eng.alloc(A * 4)
+    eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, N)
+    eng.sync()
+    eng.set_option("profile", steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, N)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    st = np.array([eng.timing_at(k) for k in range(steps)]).mean(0)
+    stats = eng.last_stats()
+    q = dq.download((A,))
+    flops = synth.algorithmic_flops([A], int(stats[0]))
+    print(f"{what}: {A} atoms, {stats[0]} near pairs; {dt*1e3:.3f} ms/forward wall, device stages front/fused/tiled/total ms = {np.round(st,3)}; "
+          f"{A/dt:.3e} atoms/s; algorithmic {flops/1e9:.1f} Gflop -> {flops/(st[3]*1e-3)/1e12:.1f} TFLOP/s; sum q = {q.sum(dtype=np.float64):.6f}", flush=True)
+    eng.close()
+
+if __name__ == "__main__":
+    main()
