@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
 
     // registers that carry weights from the phase in which they are fetched to the phase that uses them
     float pw[32];      // phase A / A' task (Wi | Wj | update h-part | We) and the G tiles of phase C1
-    float pinit[16];   // wave 2: cb3 of the update MLP
     float pb[16];      // W2 fragments of the pair tiles
     float pc[16];      // update-MLP chain: [0] U1 S-part (per step)  [1] U2  [2] U3 tile 0  [3] U3 tile 1
     float pcb[16];     // matching bias vector
@@ -181,18 +180,12 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
 #pragma unroll
     for (int s = 0; s < 32; ++s) pw[s] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { pinit[s] = 0.f; pb[s] = 0.f; pc[s] = 0.f; pcb[s] = 0.f; }
+    for (int s = 0; s < 16; ++s) { pb[s] = 0.f; pc[s] = 0.f; pcb[s] = 0.f; }
 
     // first G tiles need We of the first pair MLP: fetch it before the LDS init so the latency overlaps
     {
         const int weF0 = Tg > 0 ? A.wi.msg[0].weF : A.wi.pas[0].weF;
         if (Tg > 0 || wave >= 2) { EPNN_LDW(pw, weF0, 24); }
-        if (Tg > 0) {
-            const UpdPack &U0 = A.wi.upd[0];
-            if (wave == 1) { EPNN_LDW(pc, U0.u2F, 16); epnn_ld16(wp + U0.bu2p + hh * 16, pcb); }
-            if (wave == 2) { EPNN_LDW(pc, U0.u3F, 16); epnn_ld16(wp + U0.bu3p + hh * 16, pcb); }
-            if (wave == 3) { EPNN_LDW(pc, U0.u3F + 16 * 64, 16); epnn_ld16(wp + U0.bu3p + 32 + hh * 16, pcb); }
-        }
     }
 
     // ------------------------------------------------------------------ init
@@ -245,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
         const PairMlpPack &M0 = A.wi.msg[0];
         if (wave == 0) { EPNN_LDW(pw, M0.wiF, EPNN_KA); }
         else if (wave == 1) { EPNN_LDW(pw, M0.wjF, EPNN_KA); }
-        else if (wave == 2) { EPNN_LDW(pw, A.wi.upd[0].u1F, 24); epnn_ld16(wp + A.wi.upd[0].cb3p + hh * 16, pinit); }
+        else if (wave == 2) { EPNN_LDW(pw, A.wi.upd[0].u1F, 24); }
     } else if (Te > 0) {
         const PairMlpPack &M0 = A.wi.pas[0];
         if (wave == 0) { EPNN_LDW(pw, M0.wiF, EPNN_KA); }
@@ -263,14 +256,13 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
         for (int i = tid; i < 2 * nr * EPNN_SST; i += 256) Sw[i] = 0.f;
         if (wave == 0) {
             small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Pl + cr * EPNN_PST + hh * 16, catom);
-            EPNN_LDW(pc, U.u1F + 24 * 64, 16);                      // for phase C1
-            epnn_ld16(wp + U.bu1p + hh * 16, pcb);
         } else if (wave == 1) {
             small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Rl + cr * EPNN_PST + hh * 16, catom);
         } else if (wave == 2) {
             const int u0 = (nx - hh + 1) >> 1;
             const float *arow = a_eo + cr * EPNN_AST + hh * 32 + u0;
-            float hv[24];
+            float hv[24], pinit[16];
+            epnn_ld16(wp + U.cb3p + hh * 16, pinit);
 #pragma unroll
             for (int s = 0; s < 24; ++s) hv[s] = arow[s];
             f32x16 acc;
@@ -279,10 +271,6 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
 #pragma unroll
             for (int s = 0; s < 24; ++s) acc = epnn_mfma(pw[s], hv[s], acc);
             epnn_st16(ubuf + lane * 16, acc);
-        }
-        if (wave >= 1) {                                            // We of the next pair MLP for phase C1 / A'
-            if (!lastg) { EPNN_LDW(pw, A.wi.msg[t + 1].weF, 24); }
-            else if (Te > 0 && wave >= 2) { EPNN_LDW(pw, A.wi.pas[0].weF, 24); }
         }
         EPNN_STAMPG();   // end of own phase-A work
         __syncthreads();
@@ -358,6 +346,18 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
 #endif
             }
         }
+        // fetch what phase C1 needs while the other waves finish their tiles
+        if (wave == 0) {
+            EPNN_LDW(pc, U.u1F + 24 * 64, 16);
+            epnn_ld16(wp + U.bu1p + hh * 16, pcb);
+        } else {                                                    // We of the next pair MLP for phase C1 / A'
+            if (!lastg) { EPNN_LDW(pw, A.wi.msg[t + 1].weF, 24); }
+            else if (Te > 0 && wave >= 2) { EPNN_LDW(pw, A.wi.pas[0].weF, 24); }
+            // this wave's layer of the update chain (used in C2 / C3, i.e. after C1's matrix work)
+            if (wave == 1) { EPNN_LDW(pc, U.u2F, 16); epnn_ld16(wp + U.bu2p + hh * 16, pcb); }
+            else if (wave == 2) { EPNN_LDW(pc, U.u3F, 16); epnn_ld16(wp + U.bu3p + hh * 16, pcb); }
+            else { EPNN_LDW(pc, U.u3F + 16 * 64, 16); epnn_ld16(wp + U.bu3p + 32 + hh * 16, pcb); }
+        }
         EPNN_STAMPG();   // end of own phase-B work
         __syncthreads();
         EPNN_STAMPG();   // phase C starts
@@ -390,7 +390,6 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
                 else if (Te > 0) { EPNN_LDW(pw, A.wi.pas[0].wjF, EPNN_KA); }
             } else if (wave == 2 && !lastg) {
                 EPNN_LDW(pw, A.wi.upd[t + 1].u1F, 24);
-                epnn_ld16(wp + A.wi.upd[t + 1].cb3p + hh * 16, pinit);
             }
         }
         EPNN_STAMPG();
