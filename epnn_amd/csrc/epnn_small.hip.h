@@ -451,13 +451,10 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
         if (wave == 0) {
             small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Pl + cr * EPNN_PST + hh * 16, catom);
             cst[lane] = cv;                                          // [0..31] b2 (kappa order)  [32..63] w3
-            if (!laste) { EPNN_LDW(pw, A.wi.pas[t + 1].wiF, EPNN_KA); }
         } else if (wave == 1) {
             small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Rl + cr * EPNN_PST + hh * 16, catom);
-            if (!laste) { EPNN_LDW(pw, A.wi.pas[t + 1].wjF, EPNN_KA); }
         } else {
             small_gtiles_reg(pw, A.pe, p0, np, Gl, wave - 2, 2, lane);
-            if (!laste) { EPNN_LDW(pw, A.wi.pas[t + 1].weF, 24); }
         }
         EPNN_STAMPE();
         __syncthreads();
@@ -468,38 +465,38 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
             const int sl = valid ? slot : 0;
             const int ij = __float_as_int(reinterpret_cast<const float *>(prec + sl)[0]);
             const int li = ij & 0xFF, lj = ij >> 8;
-            float g[16], ta[16], tb[16], zu[16], zv[16];
+            // the two directions one after the other: a dependent chain of this MFMA already runs at the issue
+            // rate, and keeping only one direction live saves 48 registers
+            float g[16], b2v[16], w3[16];
             epnn_ld16(Gl + sl * EPNN_PST + hh * 16, g);
-            epnn_ld16(Pl + li * EPNN_PST + hh * 16, ta);
-            epnn_ld16(Rl + lj * EPNN_PST + hh * 16, tb);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zu[r] = fmaxf((g[r] + ta[r]) + tb[r], 0.f);
-            epnn_ld16(Pl + lj * EPNN_PST + hh * 16, ta);
-            epnn_ld16(Rl + li * EPNN_PST + hh * 16, tb);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zv[r] = fmaxf((g[r] + ta[r]) + tb[r], 0.f);
-            float b2v[16];
             epnn_ld16(cst + hh * 16, b2v);
-            f32x16 au, av;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
-            // rows = out feature kappa(hh,r), col = pair c
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                au = epnn_mfma(pb[s], zu[s], au);
-                av = epnn_mfma(pb[s], zv[s], av);
-            }
-            float w3[16];
             epnn_ld16(cst + 32 + hh * 16, w3);
             float fu = 0.f, fv = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
-                fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
+            for (int dir = 0; dir < 2; ++dir) {
+                const int ai = dir == 0 ? li : lj, aj = dir == 0 ? lj : li;
+                float ta[16], tb[16];
+                epnn_ld16(Pl + ai * EPNN_PST + hh * 16, ta);
+                epnn_ld16(Rl + aj * EPNN_PST + hh * 16, tb);
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = b2v[r];
+                // rows = out feature kappa(hh,r), col = pair c
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) acc = epnn_mfma(pb[s2], fmaxf((g[s2] + ta[s2]) + tb[s2], 0.f), acc);
+                float f = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) f = fmaf(w3[r], fmaxf(acc[r], 0.f), f);
+                if (dir == 0) fu = f; else fv = f;
             }
             fu += epnn_swap32(fu);
             fv += epnn_swap32(fv);
             if (hh == 0 && valid) reinterpret_cast<float *>(prec + slot)[3] = 0.5f * (fu - fv);     // charge_gn.py:116
+        }
+        if (!laste) {                                                // weights of the next step's phase A'
+            if (wave == 0) { EPNN_LDW(pw, A.wi.pas[t + 1].wiF, EPNN_KA); }
+            else if (wave == 1) { EPNN_LDW(pw, A.wi.pas[t + 1].wjF, EPNN_KA); }
+            else { EPNN_LDW(pw, A.wi.pas[t + 1].weF, 24); }
         }
         EPNN_STAMPE();
         __syncthreads();
