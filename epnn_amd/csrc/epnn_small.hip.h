@@ -342,6 +342,10 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
                         for (int q = 0; q < 4; ++q)
                             if (wr[q]) Smine[gi[q] * EPNN_SST + c] = old[q] + v[q];
                     }
+                    // the upper half-wave reads what the lower one just wrote: a cross-lane dependence the compiler
+                    // cannot see (for one thread the two branches are exclusive), so pin the order explicitly
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
 #endif
             }
