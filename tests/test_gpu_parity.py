@@ -172,3 +172,25 @@ def test_model_weights_vs_oracle_noise_scaled(gpu_engine_factory, weights_full, 
     noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
     print(f"model_weights: worst |dq| {worst:.3e}; float32 oracle noise {noise:.3e}")
     assert worst <= max(TOL, 3 * noise)
+
+
+def test_box_system_vs_oracle(gpu_engine_factory):
+    """BASELINE.json configs[4] at a size the oracle finishes in seconds: a 1500-atom piece of the synthetic
+    periodic-like box (density 0.1 / A^3, min separation 0.9 A) on the tiled kernels vs the float64 oracle, with
+    non-degenerate weights; plus charge conservation of the full-size recipe's statistics."""
+    from epnn_amd import synth
+    from oracle import epnn_oracle as orc
+    nx, T = 9, 2
+    w = random_weights(nx, T, seed=21, scale=0.35)
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+    offsets, xyz, x, Q, N = synth.box_system(n_atoms=1500, seed=0)
+    q = eng.forward_xyz(offsets, xyz, x, Q, N=N)
+    st = eng.last_stats()
+    assert st[2] == 1 and 6.0 < 2.0 * st[0] / 1500 < 14.0          # ~11 partners within 3 A per atom
+    ref = orc.forward_xyz(xyz, x, Q[0], w, N=N, dtype=np.float64, row_block=128)
+    ref32 = orc.forward_xyz(xyz, x, Q[0], w, N=N, dtype=np.float32, row_block=128)
+    err, noise = np.abs(q - ref).max(), np.abs(ref32 - ref).max()
+    print(f"box 1500 atoms: |dq| {err:.3e}; float32 oracle noise {noise:.3e}; sum q {q.sum(dtype=np.float64):.2e}")
+    assert err <= max(TOL, 3 * noise)
+    assert abs(float(q.sum(dtype=np.float64))) < 1e-4
