@@ -44,6 +44,15 @@ SIGNATURES = {
     "epnn_gnn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_epn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_mlp_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "epnn_train_init": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "epnn_param_count": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "epnn_train_step_dense": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int]),
+    "epnn_train_step_xyz": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int]),
+    "epnn_get_gradients": (C.c_int, [_vp, _fp, C.c_int64]),
+    "epnn_set_gradients": (C.c_int, [_vp, _fp, C.c_int64]),
+    "epnn_train_apply": (C.c_int, [_vp]),
+    "epnn_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "epnn_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     "epnn_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "epnn_dev_free": (C.c_int, [_vp, _vp]),
     "epnn_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

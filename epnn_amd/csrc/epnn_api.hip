@@ -9,6 +9,7 @@
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
 #include "epnn_mlp.hip.h"
+#include "epnn_train.hip.h"
 
 thread_local std::string g_epnn_err;
 
@@ -100,6 +101,13 @@ extern "C" int epnn_destroy(epnn_handle *h) {
                       &h->dn_flag, &h->dn_neff, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
                       &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
     for (DevBuf *b : bufs) b->release();
+    if (h->train) {
+        TrainState *ts = train_state(h);
+        if (ts->comm) (void)ncclCommDestroy(ts->comm);
+        for (DevBuf *b : {&ts->theta, &ts->grad, &ts->m, &ts->v, &ts->part, &ts->arena, &ts->loss}) b->release();
+        delete ts;
+        h->train = nullptr;
+    }
     if (h->h_status) (void)hipHostFree(h->h_status);
     (void)hipEventDestroy(h->ev_t0);
     (void)hipEventDestroy(h->ev_t1);
@@ -136,6 +144,7 @@ extern "C" int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, in
 extern "C" int epnn_set_weights(epnn_handle *h, int which, int t, int layer, const float *kernel, const float *bias) {
     HostDense *d = find_layer(h, which, t, layer);
     if (!d || !kernel || !bias) EPNN_FAIL("epnn_set_weights: bad (which=%d, t=%d, layer=%d) or null pointer", which, t, layer);
+    if (h->train) { if (train_sync_to_host(h)) return 1; train_state(h)->ready = false; }   // masters are stale now
     memcpy(d->W.data(), kernel, d->W.size() * sizeof(float));
     memcpy(d->b.data(), bias, d->b.size() * sizeof(float));
     h->weights_dirty = true;
@@ -145,6 +154,7 @@ extern "C" int epnn_set_weights(epnn_handle *h, int which, int t, int layer, con
 extern "C" int epnn_get_weights(epnn_handle *h, int which, int t, int layer, float *kernel, float *bias) {
     HostDense *d = find_layer(h, which, t, layer);
     if (!d) EPNN_FAIL("epnn_get_weights: bad (which=%d, t=%d, layer=%d)", which, t, layer);
+    if (train_sync_to_host(h)) return 1;
     if (kernel) memcpy(kernel, d->W.data(), d->W.size() * sizeof(float));
     if (bias) memcpy(bias, d->b.data(), d->b.size() * sizeof(float));
     return 0;
@@ -152,6 +162,7 @@ extern "C" int epnn_get_weights(epnn_handle *h, int which, int t, int layer, flo
 
 // Re-lay the Keras kernels into MFMA fragment order (see epnn_common.h) and upload.
 static int pack_weights(epnn_handle *h) {
+    if (train_sync_to_host(h)) return 1;          // weights trained on the device are the current ones
     if (!h->weights_dirty) return 0;
     const int nx = h->cfg.nx, F = nx + EPNN_EDIM + 1, T = h->cfg.T;
     std::vector<float> buf;
@@ -891,3 +902,194 @@ extern "C" int epnn_debug_stamps(epnn_handle *h, unsigned long long *out, size_t
     return 0;
 }
 #endif
+
+// ------------------------------------------------------------------------------------------------ training
+// dense (B,N,N,.) make_model inputs from a flat coordinate batch: what gen_padded_init_state builds on the host
+__global__ __launch_bounds__(256) void k_t_pad_inputs(const float *xyz, const float *x, const float *Q, const float *y,
+                                                      const int *moff, int B, int N, int nx, int E, double cutoff, double eta,
+                                                      const double *mu, float *e, float *mask, float *xs, float *hs, float *qs,
+                                                      float *ys) {
+    const size_t pairs = (size_t)B * N * N;
+    const double pi_d = 3.141592653589793;
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < pairs; r += (size_t)gridDim.x * 256) {
+        const int j = (int)(r % N), i = (int)((r / N) % N), b = (int)(r / ((size_t)N * N));
+        const int a0 = moff[b], n = moff[b + 1] - a0;
+        const bool real = i < n && j < n;
+        mask[r] = real ? 1.f : 0.f;
+        double D = 0, Cc = 0;
+        if (real) {
+            D = epnn_dist(xyz, a0 + i, a0 + j);
+            Cc = (cos(pi_d * (D - 0.0) / cutoff) + 1.0) / 2.0;
+            if (D >= cutoff) Cc = 0.0;
+            if (D <= 0.0) Cc = 1.0;
+            if (i == j) Cc = 0.0;
+        }
+        for (int ch = 0; ch < E; ++ch) {
+            const double d = D - mu[ch];
+            e[r * E + ch] = real ? (float)(Cc * exp(-eta * (d * d))) : 0.f;
+        }
+        if (j == 0) {
+            const size_t at = (size_t)b * N + i;
+            for (int f = 0; f < nx; ++f) xs[at * nx + f] = i < n ? x[(size_t)(a0 + i) * nx + f] : 0.f;
+            for (int f = 0; f < EPNN_EDIM; ++f) hs[at * EPNN_EDIM + f] = 0.f;
+            qs[at] = i < n ? Q[b] / (float)n : 0.f;
+            ys[at] = i < n ? y[a0 + i] : 0.f;
+        }
+    }
+}
+
+extern "C" int epnn_train_init(epnn_handle *h, float lr, float beta1, float beta2, float eps) {
+    if (!h) EPNN_FAIL("epnn_train_init: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    return train_init(h, lr, beta1, beta2, eps);
+}
+extern "C" int epnn_param_count(epnn_handle *h, int64_t *out) {
+    if (!h || !out) EPNN_FAIL("epnn_param_count: null argument");
+    TrainState ts;
+    train_layout(h, &ts);
+    *out = ts.P;
+    return 0;
+}
+extern "C" int epnn_get_gradients(epnn_handle *h, float *out, int64_t count) {
+    if (!h || !out) EPNN_FAIL("epnn_get_gradients: null argument");
+    TrainState *ts = train_state(h);
+    if (!ts->ready || count != ts->P) EPNN_FAIL("epnn_get_gradients: training not initialised or wrong count (%d parameters)", ts->P);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out, ts->grad.p, (size_t)ts->P * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int epnn_set_gradients(epnn_handle *h, const float *in, int64_t count) {
+    if (!h || !in) EPNN_FAIL("epnn_set_gradients: null argument");
+    TrainState *ts = train_state(h);
+    if (!ts->ready || count != ts->P) EPNN_FAIL("epnn_set_gradients: training not initialised or wrong count (%d parameters)", ts->P);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(ts->grad.p, in, (size_t)ts->P * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+// all-reduce (when a communicator is attached) + Adam on the current gradient buffer
+extern "C" int epnn_train_apply(epnn_handle *h) {
+    if (!h) EPNN_FAIL("epnn_train_apply: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!train_state(h)->ready) EPNN_FAIL("epnn_train_apply: call epnn_train_init first");
+    if (train_apply(h)) return 1;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// shared tail of the two train-step entry points: slot arrays are on the device
+static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
+                            const float *d_h0, const float *d_q0, const float *d_y, float *pred_host, float *loss_host, int apply) {
+    TrainState *ts = train_state(h);
+    if (!ts->ready) EPNN_FAIL("train step: call epnn_train_init first");
+    if (ts->loss.ensure((size_t)B * 4 + (size_t)B * N * 4)) return 1;
+    float *d_loss = ts->loss.as<float>(), *d_pred = d_loss + B;
+    HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));
+    if (train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss)) return 1;
+    if (apply && train_apply(h)) return 1;
+    if (pred_host) HIPCHK(hipMemcpyAsync(pred_host, d_pred, (size_t)B * N * 4, hipMemcpyDeviceToHost, h->stream));
+    std::vector<float> lb(B);
+    HIPCHK(hipMemcpyAsync(lb.data(), d_loss, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (loss_host) {
+        double s = 0;
+        for (float v : lb) s += v;
+        *loss_host = (float)s;
+    }
+    return 0;
+}
+
+// train_step (charge_gn.py:393-402) on the literal make_model inputs; y and pred are (B,N,1).  apply = 0 leaves the
+// gradient in place (epnn_get_gradients) without touching the weights.
+extern "C" int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *h_inp, const float *e_inp, const float *x_inp,
+                                     const float *q_inp, const float *mask_inp, const float *y, float *pred_out,
+                                     float *loss_out, int apply) {
+    if (!h || !h_inp || !e_inp || !x_inp || !q_inp || !mask_inp || !y) EPNN_FAIL("epnn_train_step_dense: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    const int nx = h->cfg.nx;
+    const size_t pairs = (size_t)B * N * N, slots = (size_t)B * N;
+    if (h->sd_h.ensure(pairs * EPNN_EDIM * 4) || h->sd_e.ensure(pairs * EPNN_EDIM * 4) || h->sd_x.ensure(pairs * nx * 4) ||
+        h->sd_q.ensure(pairs * 4) || h->sd_mask.ensure(pairs * 4) || h->sd_out.ensure(slots * 4) ||
+        h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) || h->dn_qs.ensure(slots * 4) ||
+        h->dn_nms.ensure(slots * 4) || h->dn_flag.ensure(slots * 4))
+        return 1;
+    HIPCHK(hipMemcpyAsync(h->sd_h.p, h_inp, pairs * EPNN_EDIM * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_e.p, e_inp, pairs * EPNN_EDIM * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_x.p, x_inp, pairs * nx * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_q.p, q_inp, pairs * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_mask.p, mask_inp, pairs * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sd_out.p, y, slots * 4, hipMemcpyHostToDevice, h->stream));
+    DenseArgs D{};
+    D.B = B; D.N = N; D.nx = nx; D.model_level = 1;
+    D.h_in = h->sd_h.as<float>(); D.e_in = h->sd_e.as<float>(); D.x_in = h->sd_x.as<float>();
+    D.q_in = h->sd_q.as<float>(); D.mask_in = h->sd_mask.as<float>();
+    D.xs = h->dn_xs.as<float>(); D.hs = h->dn_hs.as<float>(); D.qs = h->dn_qs.as<float>(); D.nms = h->dn_nms.as<float>();
+    D.flag = h->dn_flag.as<int>(); D.tol = h->cfg.near_tol;
+    hipLaunchKernelGGL(k_dn_atoms, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, h->stream, D);   // charge_gn.py:382-384
+    HIPCHK(hipGetLastError());
+    return train_step_slots(h, B, N, D.e_in, D.mask_in, D.xs, D.hs, D.qs, h->sd_out.as<float>(), pred_out, loss_out, apply);
+}
+
+// train_step from a flat coordinate batch: y_flat / q_out_flat are per real atom [A]
+extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz, const float *x,
+                                   const float *Q, const float *y_flat, float *q_out_flat, float *loss_out, int apply) {
+    if (!h || !offsets || !xyz || !x || !Q || !y_flat) EPNN_FAIL("epnn_train_step_xyz: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    const int nx = h->cfg.nx, A = offsets[B];
+    for (int b = 0; b < B; ++b)
+        if (offsets[b + 1] - offsets[b] > N || offsets[b + 1] - offsets[b] < 1) EPNN_FAIL("epnn_train_step_xyz: molecule %d does not fit N=%d", b, N);
+    const size_t pairs = (size_t)B * N * N, slots = (size_t)B * N;
+    if (h->s_xyz.ensure((size_t)A * 3 * 4) || h->s_x.ensure((size_t)A * nx * 4) || h->s_Q.ensure((size_t)B * 4) ||
+        h->s_q.ensure((size_t)A * 4) || h->d_moff.ensure((size_t)(B + 1) * 4) || h->sd_e.ensure(pairs * EPNN_EDIM * 4) ||
+        h->sd_mask.ensure(pairs * 4) || h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) ||
+        h->dn_qs.ensure(slots * 4) || h->sd_out.ensure(slots * 4))
+        return 1;
+    h->plan.valid = false;                       // d_moff is shared with the inference plan
+    HIPCHK(hipMemcpyAsync(h->s_xyz.p, xyz, (size_t)A * 3 * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_x.p, x, (size_t)A * nx * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_Q.p, Q, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_q.p, y_flat, (size_t)A * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_moff.p, offsets, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_t_pad_inputs, dim3(t_grid(pairs)), dim3(256), 0, h->stream, h->s_xyz.as<float>(), h->s_x.as<float>(),
+                       h->s_Q.as<float>(), h->s_q.as<float>(), h->d_moff.as<int>(), B, N, nx, h->cfg.e_dim, (double)h->cfg.cutoff,
+                       (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),
+                       h->dn_xs.as<float>(), h->dn_hs.as<float>(), h->dn_qs.as<float>(), h->sd_out.as<float>());
+    HIPCHK(hipGetLastError());
+    std::vector<float> pred(q_out_flat ? slots : 0);
+    if (train_step_slots(h, B, N, h->sd_e.as<float>(), h->sd_mask.as<float>(), h->dn_xs.as<float>(), h->dn_hs.as<float>(),
+                         h->dn_qs.as<float>(), h->sd_out.as<float>(), q_out_flat ? pred.data() : nullptr, loss_out, apply))
+        return 1;
+    if (q_out_flat)
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < offsets[b + 1] - offsets[b]; ++i) q_out_flat[offsets[b] + i] = pred[(size_t)b * N + i];
+    return 0;
+}
+
+// RCCL communicator for the gradient all-reduce (one rank per GPU).  The 128-byte id is created on rank 0 and
+// handed to the other ranks by the caller (torch.distributed broadcast, a file, ...).
+extern "C" int epnn_comm_unique_id(char *out128) {
+    if (!out128) EPNN_FAIL("epnn_comm_unique_id: null argument");
+    ncclUniqueId id;
+    ncclResult_t rc = ncclGetUniqueId(&id);
+    if (rc != ncclSuccess) EPNN_FAIL("ncclGetUniqueId failed: %s", ncclGetErrorString(rc));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out128, &id, 128);
+    return 0;
+}
+extern "C" int epnn_comm_init(epnn_handle *h, const char *id128, int rank, int world) {
+    if (!h || !id128 || world < 1 || rank < 0 || rank >= world) EPNN_FAIL("epnn_comm_init: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    TrainState *ts = train_state(h);
+    if (ts->comm) { (void)ncclCommDestroy(ts->comm); ts->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t rc = ncclCommInitRank(&ts->comm, world, id, rank);
+    if (rc != ncclSuccess) EPNN_FAIL("ncclCommInitRank failed: %s", ncclGetErrorString(rc));
+    ts->world = world;
+    ts->rank = rank;
+    return 0;
+}

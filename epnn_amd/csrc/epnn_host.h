@@ -109,6 +109,7 @@ struct epnn_handle {
     DevBuf dn_xs, dn_hs, dn_qs, dn_nms, dn_flag, dn_neff, dn_xf, dn_hf, dn_qf, dn_nmf, dn_out;
     DevBuf sd_h, sd_e, sd_x, sd_q, sd_mask, sd_out;
     std::vector<int> dn_neff_host;
+    void *train = nullptr;            // TrainState (epnn_train.hip.h)
     bool force_tmp = false;           // force_path was switched to the tiled kernels for one call only
     int force_saved = 0;
 };

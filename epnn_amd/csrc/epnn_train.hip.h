@@ -1,0 +1,464 @@
+// Training step (reference charge_gn.py:393-402): forward, loss = sum_atoms (y - p)^2, backward, Adam.
+//
+// The reference trains with ONE molecule per optimizer step (charge_gn.py:443-451); data-parallel training puts
+// one molecule (or a few) on each GPU and sums the gradients with one RCCL all-reduce of the flat 296 KB gradient.
+// At that size a step is launch/latency-bound, not throughput-bound, so this path keeps the reference's literal
+// formulation -- materialised [a_i | a_j | e_ij] rows and three Dense layers per sweep -- because its backward is
+// the textbook Dense backward and every intermediate can be checked against the oracle.  (The fused / tiled
+// inference kernels are not used here.)  All reductions have a fixed order: gradients are bit-reproducible.
+//
+// Master weights, gradients and Adam moments live on the device as flat float32 vectors in the order of Keras'
+// model.trainable_variables (charge_gn.py:371-374): update MLP, message MLPs t=0.., pass MLPs t=0..; kernel, bias.
+#pragma once
+#include "epnn_host.h"
+
+struct TDense {            // one Dense inside the flat parameter vector
+    int offW, offB, n_in, n_out;
+};
+
+// ------------------------------------------------------------------------------------------------ kernels
+// X[(b,i,j)] = swap ? [a_j | a_i | e_ij] : [a_i | a_j | e_ij]          (charge_gn.py:62-66, 101-108)
+__global__ __launch_bounds__(256) void k_t_rows(const float *a, const float *e, float *X, int B, int N, int F, int E, int swap) {
+    const int D = 2 * F + E;
+    const size_t total = (size_t)B * N * N * D;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % D);
+        const size_t r = idx / D;
+        const int j = (int)(r % N), i = (int)((r / N) % N), b = (int)(r / ((size_t)N * N));
+        float v;
+        if (k < F) v = a[((size_t)b * N + (swap ? j : i)) * F + k];
+        else if (k < 2 * F) v = a[((size_t)b * N + (swap ? i : j)) * F + (k - F)];
+        else v = e[r * E + (k - 2 * F)];
+        X[idx] = v;
+    }
+}
+// Y = act(X W + b)      X [R][K], W [K][O], Y [R][O]
+__global__ __launch_bounds__(256) void k_t_dense(const float *X, const float *W, const float *b, float *Y, int R, int K,
+                                                 int O, int relu) {
+    const size_t total = (size_t)R * O;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int o = (int)(idx % O);
+        const size_t r = idx / O;
+        const float *x = X + r * K;
+        float s = b[o];
+        for (int k = 0; k < K; ++k) s = fmaf(x[k], W[(size_t)k * O + o], s);
+        Y[idx] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+// dX = (dY * [Ypost > 0]) W^T        (Ypost == nullptr: linear layer)
+__global__ __launch_bounds__(256) void k_t_dense_dx(const float *dY, const float *Ypost, const float *W, float *dX, int R,
+                                                    int K, int O) {
+    const size_t total = (size_t)R * K;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % K);
+        const size_t r = idx / K;
+        float s = 0.f;
+        for (int o = 0; o < O; ++o) {
+            float g = dY[r * O + o];
+            if (Ypost && !(Ypost[r * O + o] > 0.f)) g = 0.f;
+            s = fmaf(g, W[(size_t)k * O + o], s);
+        }
+        dX[idx] = s;
+    }
+}
+// partial dW[slice][k][o] = sum_{r in slice} X[r][k] * dYp[r][o];  k == K: bias row (sum of dYp)
+__global__ __launch_bounds__(256) void k_t_dense_dw(const float *X, const float *dY, const float *Ypost, float *part, int R,
+                                                    int K, int O, int nslice) {
+    const int slice = blockIdx.y;
+    const int rlo = (int)((size_t)R * slice / nslice), rhi = (int)((size_t)R * (slice + 1) / nslice);
+    const int total = (K + 1) * O;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int o = idx % O, k = idx / O;
+        float s = 0.f;
+        for (int r = rlo; r < rhi; ++r) {
+            float g = dY[(size_t)r * O + o];
+            if (Ypost && !(Ypost[(size_t)r * O + o] > 0.f)) g = 0.f;
+            s = fmaf(k < K ? X[(size_t)r * K + k] : 1.f, g, s);
+        }
+        part[(size_t)slice * total + idx] = s;
+    }
+}
+// grad[offW..] += sum_slices part (fixed order); bias row goes to offB
+__global__ __launch_bounds__(256) void k_t_dw_reduce(const float *part, float *grad, int offW, int offB, int K, int O, int nslice) {
+    const int total = (K + 1) * O;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        float s = 0.f;
+        for (int sl = 0; sl < nslice; ++sl) s += part[(size_t)sl * total + idx];
+        const int o = idx % O, k = idx / O;
+        if (k < K) grad[offW + k * O + o] += s;
+        else grad[offB + o] += s;
+    }
+}
+// da[(b,i)][f] += sum over the pair rows in which atom i appears: block 0 of X is atom `first`, block 1 the other
+__global__ __launch_bounds__(256) void k_t_rows_bwd(const float *dX, float *da, int B, int N, int F, int E, int swap) {
+    const int D = 2 * F + E;
+    const size_t total = (size_t)B * N * F;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int f = (int)(idx % F);
+        const int i = (int)((idx / F) % N), b = (int)(idx / ((size_t)F * N));
+        const size_t mb = (size_t)b * N * N;
+        float s = 0.f;
+        // rows (i, j): atom i sits in block (swap ? 1 : 0);  rows (j, i): atom i sits in block (swap ? 0 : 1)
+        for (int j = 0; j < N; ++j) s += dX[(mb + (size_t)i * N + j) * D + (swap ? F : 0) + f];
+        for (int j = 0; j < N; ++j) s += dX[(mb + (size_t)j * N + i) * D + (swap ? 0 : F) + f];
+        da[idx] += s;
+    }
+}
+// M[(b,i)][o] = sum_j Mij[(b,i,j)][o]      (charge_gn.py:70)
+__global__ __launch_bounds__(256) void k_t_sumj(const float *Mij, float *M, int B, int N, int O) {
+    const size_t total = (size_t)B * N * O;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int o = (int)(idx % O);
+        const size_t bi = idx / O;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += Mij[(bi * N + j) * O + o];
+        M[idx] = s;
+    }
+}
+// a = [x | h | q]
+__global__ __launch_bounds__(256) void k_t_assemble(const float *x, const float *h, const float *q, float *a, int BN, int nx, int H) {
+    const int F = nx + H + 1;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < BN * F; idx += gridDim.x * 256) {
+        const int f = idx % F, at = idx / F;
+        a[idx] = f < nx ? x[at * nx + f] : (f < nx + H ? h[at * H + (f - nx)] : q[at]);
+    }
+}
+// U0 = [h | M] * nm            (charge_gn.py:71-72)
+__global__ __launch_bounds__(256) void k_t_u0(const float *h, const float *M, const float *nm, float *U0, int BN, int H, int O) {
+    const int W = H + O;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < BN * W; idx += gridDim.x * 256) {
+        const int f = idx % W, at = idx / W;
+        U0[idx] = (f < H ? h[at * H + f] : M[at * O + (f - H)]) * nm[at];
+    }
+}
+__global__ __launch_bounds__(256) void k_t_scale_rows(const float *src, const float *nm, float *dst, int BN, int W) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < BN * W; idx += gridDim.x * 256) dst[idx] = src[idx] * nm[idx / W];
+}
+// wgt = max(mask, -1) * is_near(e)        (charge_gn.py:90-94,116)
+__global__ __launch_bounds__(256) void k_t_wgt(const float *e, const float *mask, float *wgt, int R, int E, float tol) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+        float mx = 0.f;
+        for (int k = 0; k < E; ++k) mx = fmaxf(mx, e[(size_t)r * E + k]);
+        wgt[r] = mx > tol ? mask[r] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void k_t_nodemask(const float *mask, float *nm, int B, int N) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * N; idx += gridDim.x * 256) {
+        const int k = idx % N, b = idx / N;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += mask[((size_t)b * N + j) * N + k];
+        nm[idx] = fminf(fmaxf(s, 0.f), 1.f);
+    }
+}
+// q_new[i] = q[i] + sum_j 0.5 (fN - fT) wgt      (charge_gn.py:116-118)
+__global__ __launch_bounds__(256) void k_t_epn_q(const float *fN, const float *fT, const float *wgt, const float *q, float *qn, int BN, int N) {
+    for (int at = blockIdx.x * 256 + threadIdx.x; at < BN; at += gridDim.x * 256) {
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const size_t r = (size_t)at * N + j;
+            s += 0.5f * (fN[r] - fT[r]) * wgt[r];
+        }
+        qn[at] = q[at] + s;
+    }
+}
+// dfN = 0.5 gq_i wgt, dfT = -dfN
+__global__ __launch_bounds__(256) void k_t_epn_df(const float *gq, const float *wgt, float *dfN, float *dfT, int BN, int N) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < BN * N; r += gridDim.x * 256) {
+        const float g = 0.5f * gq[r / N] * wgt[r];
+        dfN[r] = g;
+        dfT[r] = -g;
+    }
+}
+// gq = -2 (y - q); loss per molecule (fixed order)
+__global__ __launch_bounds__(64) void k_t_loss(const float *y, const float *q, float *gq, float *loss, int N) {
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < N; ++i) {
+            const float d = y[b * N + i] - q[b * N + i];
+            s += d * d;
+            gq[b * N + i] = -2.f * d;
+        }
+        loss[b] = s;
+    }
+}
+// dm_ij = gM_i  (broadcast over j);  gM = second block of dU0 * nm
+__global__ __launch_bounds__(256) void k_t_bcast_gm(const float *dU0, const float *nm, float *dm, int BN, int N, int H, int O) {
+    const size_t total = (size_t)BN * N * O;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int o = (int)(idx % O);
+        const size_t at = idx / ((size_t)N * O);
+        dm[idx] = dU0[at * (H + O) + H + o] * nm[at];
+    }
+}
+// gh_prev = dU0[:, :H] * nm + da[:, nx:nx+H]
+__global__ __launch_bounds__(256) void k_t_gh_prev(const float *dU0, const float *nm, const float *da, float *gh, int BN, int nx, int H, int O) {
+    const int F = nx + H + 1;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < BN * H; idx += gridDim.x * 256) {
+        const int f = idx % H, at = idx / H;
+        gh[idx] = dU0[at * (H + O) + f] * nm[at] + da[at * F + nx + f];
+    }
+}
+// after one EPN step's backward: gfeat += da[h part]; gq += da[q part]
+__global__ __launch_bounds__(256) void k_t_epn_fold(const float *da, float *gfeat, float *gq, int BN, int nx, int H) {
+    const int F = nx + H + 1;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < BN * (H + 1); idx += gridDim.x * 256) {
+        const int f = idx % (H + 1), at = idx / (H + 1);
+        if (f < H) gfeat[at * H + f] += da[at * F + nx + f];
+        else gq[at] += da[at * F + nx + H];
+    }
+}
+// Keras-2 Adam (charge_gn.py:419): theta -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void k_t_adam(float *theta, const float *grad, float *m, float *v, int n, float alpha,
+                                                float b1, float b2, float eps) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float g = grad[i];
+        const float mi = b1 * m[i] + (1.f - b1) * g;
+        const float vi = b2 * v[i] + (1.f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] -= alpha * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ================================================================================================ host side
+#include <rccl/rccl.h>
+
+struct TrainState {
+    bool ready = false;
+    int P = 0;                                   // number of parameters
+    TDense upd[3], msg[EPNN_MAXT][3], pas[EPNN_MAXT][3];
+    DevBuf theta, grad, m, v, part, arena, loss;
+    long step = 0;
+    float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    bool dev_newer = false;                      // device masters are ahead of the host copies
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+};
+
+static TrainState *train_state(epnn_handle *h) {
+    if (!h->train) h->train = new TrainState();
+    return reinterpret_cast<TrainState *>(h->train);
+}
+
+static void train_layout(epnn_handle *h, TrainState *ts) {
+    int off = 0;
+    auto put = [&](TDense &d, const HostDense &hd) {
+        d.n_in = hd.n_in;
+        d.n_out = hd.n_out;
+        d.offW = off;
+        off += hd.n_in * hd.n_out;
+        d.offB = off;
+        off += hd.n_out;
+    };
+    for (int l = 0; l < 3; ++l) put(ts->upd[l], h->upd[l]);
+    for (int t = 0; t < h->cfg.T; ++t)
+        for (int l = 0; l < 3; ++l) put(ts->msg[t][l], h->msg[t][l]);
+    for (int t = 0; t < h->cfg.T; ++t)
+        for (int l = 0; l < 3; ++l) put(ts->pas[t][l], h->pas[t][l]);
+    ts->P = off;
+}
+
+// host copies <-> flat vector (Keras trainable_variables order)
+static void train_gather_host(epnn_handle *h, TrainState *ts, std::vector<float> &flat) {
+    flat.assign(ts->P, 0.f);
+    auto cp = [&](const TDense &d, const HostDense &hd) {
+        memcpy(flat.data() + d.offW, hd.W.data(), hd.W.size() * 4);
+        memcpy(flat.data() + d.offB, hd.b.data(), hd.b.size() * 4);
+    };
+    for (int l = 0; l < 3; ++l) cp(ts->upd[l], h->upd[l]);
+    for (int t = 0; t < h->cfg.T; ++t)
+        for (int l = 0; l < 3; ++l) { cp(ts->msg[t][l], h->msg[t][l]); cp(ts->pas[t][l], h->pas[t][l]); }
+}
+static void train_scatter_host(epnn_handle *h, TrainState *ts, const std::vector<float> &flat) {
+    auto cp = [&](const TDense &d, HostDense &hd) {
+        memcpy(hd.W.data(), flat.data() + d.offW, hd.W.size() * 4);
+        memcpy(hd.b.data(), flat.data() + d.offB, hd.b.size() * 4);
+    };
+    for (int l = 0; l < 3; ++l) cp(ts->upd[l], h->upd[l]);
+    for (int t = 0; t < h->cfg.T; ++t)
+        for (int l = 0; l < 3; ++l) { cp(ts->msg[t][l], h->msg[t][l]); cp(ts->pas[t][l], h->pas[t][l]); }
+}
+
+// pull the trained masters back into the host copies (so inference / get_weights / save_weights see them)
+static int train_sync_to_host(epnn_handle *h) {
+    if (!h->train) return 0;
+    TrainState *ts = train_state(h);
+    if (!ts->ready || !ts->dev_newer) return 0;
+    std::vector<float> flat(ts->P);
+    HIPCHK(hipMemcpyAsync(flat.data(), ts->theta.p, (size_t)ts->P * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    train_scatter_host(h, ts, flat);
+    ts->dev_newer = false;
+    h->weights_dirty = true;
+    return 0;
+}
+
+static int train_init(epnn_handle *h, float lr, float b1, float b2, float eps) {
+    TrainState *ts = train_state(h);
+    if (train_sync_to_host(h)) return 1;
+    train_layout(h, ts);
+    const size_t bytes = (size_t)ts->P * 4;
+    if (ts->theta.ensure(bytes) || ts->grad.ensure(bytes) || ts->m.ensure(bytes) || ts->v.ensure(bytes)) return 1;
+    std::vector<float> flat;
+    train_gather_host(h, ts, flat);
+    HIPCHK(hipMemcpyAsync(ts->theta.p, flat.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(ts->grad.p, 0, bytes, h->stream));
+    HIPCHK(hipMemsetAsync(ts->m.p, 0, bytes, h->stream));
+    HIPCHK(hipMemsetAsync(ts->v.p, 0, bytes, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ts->lr = lr; ts->b1 = b1; ts->b2 = b2; ts->eps = eps;
+    ts->step = 0;
+    ts->ready = true;
+    ts->dev_newer = false;
+    return 0;
+}
+
+static inline unsigned t_grid(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 16384); }
+
+// Forward + backward of the literal dense algorithm for B molecules padded to N.  Device pointers:
+// e [B][N][N][48], mask [B][N][N], x [B][N][nx], h0 [B][N][48], q0 [B][N], y [B][N] -> pred [B][N], loss [B];
+// gradients are ADDED into ts->grad (caller zeroes it).
+static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
+                         const float *d_h0, const float *d_q0, const float *d_y, float *d_pred, float *d_loss) {
+    TrainState *ts = train_state(h);
+    if (!ts->ready) EPNN_FAIL("training: call epnn_train_init first");
+    const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, E = EPNN_EDIM, F = nx + H + 1, D = 2 * F + E;
+    const int BN = B * N;
+    const size_t R = (size_t)BN * N;
+    hipStream_t st = h->stream;
+    const float *theta = ts->theta.as<float>();
+    float *grad = ts->grad.as<float>();
+    const int NSL = 8;
+    if (ts->part.ensure((size_t)NSL * (D + 1) * 48 * 4)) return 1;
+    // ---- arena
+    size_t need = 0;
+    auto sz = [&](size_t n) { size_t o = need; need += (n + 63) & ~size_t(63); return o; };
+    struct GStep { size_t a, X, H1, H2, Mij, M, U0, U1, U2, hraw, hn; } gs[EPNN_MAXT];
+    struct EStep { size_t a, XN, H1N, H2N, fN, XT, H1T, H2T, fT, qn; } es[EPNN_MAXT];
+    const size_t o_nm = sz(BN), o_wgt = sz(R);
+    for (int t = 0; t < T; ++t) {
+        gs[t] = {sz((size_t)BN * F), sz(R * D), sz(R * 32), sz(R * 32), sz(R * 32), sz((size_t)BN * 32), sz((size_t)BN * 80),
+                 sz((size_t)BN * 32), sz((size_t)BN * 32), sz((size_t)BN * H), sz((size_t)BN * H)};
+    }
+    for (int t = 0; t < T; ++t) {
+        es[t] = {sz((size_t)BN * F), sz(R * D), sz(R * 32), sz(R * 32), sz(R), sz(R * D), sz(R * 32), sz(R * 32), sz(R), sz(BN)};
+    }
+    const size_t o_dX = sz(R * D), o_dA = sz(R * 32), o_dB = sz(R * 32), o_dC = sz(R * 32), o_da = sz((size_t)BN * F),
+                 o_dU0 = sz((size_t)BN * 80), o_dU1 = sz((size_t)BN * 32), o_dU2 = sz((size_t)BN * 32), o_dh = sz((size_t)BN * H),
+                 o_gh = sz((size_t)BN * H), o_gfeat = sz((size_t)BN * H), o_gq = sz(BN), o_dfN = sz(R), o_dfT = sz(R);
+    if (ts->arena.ensure(need * 4)) return 1;
+    float *ar = ts->arena.as<float>();
+    auto P = [&](size_t off) { return ar + off; };
+    float *nm = P(o_nm), *wgt = P(o_wgt);
+
+    auto dense = [&](const float *X, const TDense &d, float *Y, size_t rows, int relu) {
+        hipLaunchKernelGGL(k_t_dense, dim3(t_grid(rows * d.n_out)), dim3(256), 0, st, X, theta + d.offW, theta + d.offB, Y,
+                           (int)rows, d.n_in, d.n_out, relu);
+    };
+    // backward of one Dense: dX (optional) and gradient accumulation
+    auto dense_bwd = [&](const float *X, const float *dY, const float *Ypost, const TDense &d, float *dX, size_t rows) {
+        if (dX)
+            hipLaunchKernelGGL(k_t_dense_dx, dim3(t_grid(rows * d.n_in)), dim3(256), 0, st, dY, Ypost, theta + d.offW, dX,
+                               (int)rows, d.n_in, d.n_out);
+        const int nsl = rows >= 64 ? NSL : 1;
+        const int tot = (d.n_in + 1) * d.n_out;
+        hipLaunchKernelGGL(k_t_dense_dw, dim3((tot + 255) / 256, nsl), dim3(256), 0, st, X, dY, Ypost, ts->part.as<float>(),
+                           (int)rows, d.n_in, d.n_out, nsl);
+        hipLaunchKernelGGL(k_t_dw_reduce, dim3((tot + 255) / 256), dim3(256), 0, st, ts->part.as<float>(), grad, d.offW,
+                           d.offB, d.n_in, d.n_out, nsl);
+    };
+
+    hipLaunchKernelGGL(k_t_nodemask, dim3(t_grid(BN)), dim3(256), 0, st, d_mask, nm, B, N);
+    hipLaunchKernelGGL(k_t_wgt, dim3(t_grid(R)), dim3(256), 0, st, d_e, d_mask, wgt, (int)R, E, h->cfg.near_tol);
+    // ================================================================ forward: GNN (charge_gn.py:60-74)
+    const float *hcur = d_h0;
+    for (int t = 0; t < T; ++t) {
+        const GStep &g = gs[t];
+        hipLaunchKernelGGL(k_t_assemble, dim3(t_grid((size_t)BN * F)), dim3(256), 0, st, d_x, hcur, d_q0, P(g.a), BN, nx, H);
+        hipLaunchKernelGGL(k_t_rows, dim3(t_grid(R * D)), dim3(256), 0, st, P(g.a), d_e, P(g.X), B, N, F, E, 0);
+        dense(P(g.X), ts->msg[t][0], P(g.H1), R, 1);
+        dense(P(g.H1), ts->msg[t][1], P(g.H2), R, 1);
+        dense(P(g.H2), ts->msg[t][2], P(g.Mij), R, 0);
+        hipLaunchKernelGGL(k_t_sumj, dim3(t_grid((size_t)BN * 32)), dim3(256), 0, st, P(g.Mij), P(g.M), B, N, 32);
+        hipLaunchKernelGGL(k_t_u0, dim3(t_grid((size_t)BN * 80)), dim3(256), 0, st, hcur, P(g.M), nm, P(g.U0), BN, H, 32);
+        dense(P(g.U0), ts->upd[0], P(g.U1), BN, 1);
+        dense(P(g.U1), ts->upd[1], P(g.U2), BN, 1);
+        dense(P(g.U2), ts->upd[2], P(g.hraw), BN, 0);
+        hipLaunchKernelGGL(k_t_scale_rows, dim3(t_grid((size_t)BN * H)), dim3(256), 0, st, P(g.hraw), nm, P(g.hn), BN, H);
+        hcur = P(g.hn);
+    }
+    const float *feats = hcur;
+    // ================================================================ forward: EPN (charge_gn.py:98-118)
+    const float *qcur = d_q0;
+    for (int t = 0; t < T; ++t) {
+        const EStep &s = es[t];
+        hipLaunchKernelGGL(k_t_assemble, dim3(t_grid((size_t)BN * F)), dim3(256), 0, st, d_x, feats, qcur, P(s.a), BN, nx, H);
+        hipLaunchKernelGGL(k_t_rows, dim3(t_grid(R * D)), dim3(256), 0, st, P(s.a), d_e, P(s.XN), B, N, F, E, 0);
+        hipLaunchKernelGGL(k_t_rows, dim3(t_grid(R * D)), dim3(256), 0, st, P(s.a), d_e, P(s.XT), B, N, F, E, 1);
+        dense(P(s.XN), ts->pas[t][0], P(s.H1N), R, 1);
+        dense(P(s.H1N), ts->pas[t][1], P(s.H2N), R, 1);
+        dense(P(s.H2N), ts->pas[t][2], P(s.fN), R, 0);
+        dense(P(s.XT), ts->pas[t][0], P(s.H1T), R, 1);
+        dense(P(s.H1T), ts->pas[t][1], P(s.H2T), R, 1);
+        dense(P(s.H2T), ts->pas[t][2], P(s.fT), R, 0);
+        hipLaunchKernelGGL(k_t_epn_q, dim3(t_grid(BN)), dim3(256), 0, st, P(s.fN), P(s.fT), wgt, qcur, P(s.qn), BN, N);
+        qcur = P(s.qn);
+    }
+    HIPCHK(hipMemcpyAsync(d_pred, qcur, (size_t)BN * 4, hipMemcpyDeviceToDevice, st));
+    // ================================================================ loss (charge_gn.py:397-398)
+    float *gq = P(o_gq), *gfeat = P(o_gfeat), *gh = P(o_gh), *da = P(o_da);
+    hipLaunchKernelGGL(k_t_loss, dim3(B), dim3(64), 0, st, d_y, qcur, gq, d_loss, N);
+    HIPCHK(hipMemsetAsync(gfeat, 0, (size_t)BN * H * 4, st));
+    // ================================================================ backward: EPN
+    for (int t = T - 1; t >= 0; --t) {
+        const EStep &s = es[t];
+        hipLaunchKernelGGL(k_t_epn_df, dim3(t_grid(R)), dim3(256), 0, st, gq, wgt, P(o_dfN), P(o_dfT), BN, N);
+        HIPCHK(hipMemsetAsync(da, 0, (size_t)BN * F * 4, st));
+        for (int dir = 0; dir < 2; ++dir) {
+            const float *X = P(dir ? s.XT : s.XN), *H1 = P(dir ? s.H1T : s.H1N), *H2 = P(dir ? s.H2T : s.H2N);
+            const float *df = P(dir ? o_dfT : o_dfN);
+            dense_bwd(H2, df, nullptr, ts->pas[t][2], P(o_dA), R);          // dH2 (post-activation gradient)
+            dense_bwd(H1, P(o_dA), H2, ts->pas[t][1], P(o_dB), R);          // masks dH2 by H2 > 0
+            dense_bwd(X, P(o_dB), H1, ts->pas[t][0], P(o_dX), R);
+            hipLaunchKernelGGL(k_t_rows_bwd, dim3(t_grid((size_t)BN * F)), dim3(256), 0, st, P(o_dX), da, B, N, F, E, dir);
+        }
+        hipLaunchKernelGGL(k_t_epn_fold, dim3(t_grid((size_t)BN * (H + 1))), dim3(256), 0, st, da, gfeat, gq, BN, nx, H);
+    }
+    // ================================================================ backward: GNN
+    HIPCHK(hipMemcpyAsync(gh, gfeat, (size_t)BN * H * 4, hipMemcpyDeviceToDevice, st));
+    for (int t = T - 1; t >= 0; --t) {
+        const GStep &g = gs[t];
+        // h_{t+1} = hraw * nm
+        hipLaunchKernelGGL(k_t_scale_rows, dim3(t_grid((size_t)BN * H)), dim3(256), 0, st, gh, nm, P(o_dh), BN, H);
+        dense_bwd(P(g.U2), P(o_dh), nullptr, ts->upd[2], P(o_dU2), BN);
+        dense_bwd(P(g.U1), P(o_dU2), P(g.U2), ts->upd[1], P(o_dU1), BN);
+        dense_bwd(P(g.U0), P(o_dU1), P(g.U1), ts->upd[0], P(o_dU0), BN);
+        // U0 = [h | M] * nm ; M_i = sum_j m_ij
+        hipLaunchKernelGGL(k_t_bcast_gm, dim3(t_grid(R * 32)), dim3(256), 0, st, P(o_dU0), nm, P(o_dC), BN, N, H, 32);
+        dense_bwd(P(g.H2), P(o_dC), nullptr, ts->msg[t][2], P(o_dA), R);
+        dense_bwd(P(g.H1), P(o_dA), P(g.H2), ts->msg[t][1], P(o_dB), R);
+        dense_bwd(P(g.X), P(o_dB), P(g.H1), ts->msg[t][0], P(o_dX), R);
+        HIPCHK(hipMemsetAsync(da, 0, (size_t)BN * F * 4, st));
+        hipLaunchKernelGGL(k_t_rows_bwd, dim3(t_grid((size_t)BN * F)), dim3(256), 0, st, P(o_dX), da, B, N, F, E, 0);
+        hipLaunchKernelGGL(k_t_gh_prev, dim3(t_grid((size_t)BN * H)), dim3(256), 0, st, P(o_dU0), nm, da, gh, BN, nx, H, 32);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int train_apply(epnn_handle *h) {
+    TrainState *ts = train_state(h);
+    if (ts->comm && ts->world > 1) {
+        ncclResult_t rc = ncclAllReduce(ts->grad.p, ts->grad.p, (size_t)ts->P, ncclFloat, ncclSum, ts->comm, h->stream);
+        if (rc != ncclSuccess) EPNN_FAIL("ncclAllReduce failed: %s", ncclGetErrorString(rc));
+    }
+    ts->step += 1;
+    const double t = (double)ts->step;
+    const float alpha = (float)((double)ts->lr * std::sqrt(1.0 - std::pow((double)ts->b2, t)) / (1.0 - std::pow((double)ts->b1, t)));
+    hipLaunchKernelGGL(k_t_adam, dim3(t_grid(ts->P)), dim3(256), 0, h->stream, ts->theta.as<float>(), ts->grad.as<float>(),
+                       ts->m.as<float>(), ts->v.as<float>(), ts->P, alpha, ts->b1, ts->b2, ts->eps);
+    HIPCHK(hipGetLastError());
+    ts->dev_newer = true;
+    return 0;
+}

@@ -169,6 +169,65 @@ class Engine:
                                         fptr(b2), fptr(W3), fptr(b3), fptr(rows), fptr(out)), self.lib)
         return out
 
+    # ------------------------------------------------------------------ training (charge_gn.py:393-402)
+    def train_init(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+        check(self.lib.epnn_train_init(self.h, lr, beta1, beta2, eps), self.lib)
+
+    def param_count(self):
+        n = C.c_int64()
+        check(self.lib.epnn_param_count(self.h, C.byref(n)), self.lib)
+        return n.value
+
+    def train_step_dense(self, h_inp, e_inp, x_inp, q_inp, mask_inp, y, apply=True):
+        """Returns (predictions (B,N,1), summed loss)."""
+        e_inp = _f32(e_inp)
+        B, N = e_inp.shape[0], e_inp.shape[1]
+        h_inp, e_inp, x_inp, q_inp, mask_inp = self._dense_args(
+            B, N, (h_inp, e_inp, x_inp, q_inp, mask_inp),
+            ((N, N, self.h_dim), (N, N, self.e_dim), (N, N, self.nx), (N, N, 1), (N, N, 1)))
+        y = _f32(np.asarray(y).reshape(B, N, 1))
+        pred = np.empty((B, N, 1), dtype=np.float32)
+        loss = C.c_float()
+        check(self.lib.epnn_train_step_dense(self.h, B, N, fptr(h_inp), fptr(e_inp), fptr(x_inp), fptr(q_inp), fptr(mask_inp),
+                                             fptr(y), fptr(pred), C.byref(loss), int(bool(apply))), self.lib)
+        return pred, loss.value
+
+    def train_step_xyz(self, offsets, xyz, x, Q, y, N, apply=True):
+        """Flat batch; y per real atom (A,). Returns (q (A,), summed loss)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        xyz, x, Q, y = _f32(xyz), _f32(x), _f32(Q), _f32(y)
+        B, A = len(offsets) - 1, int(offsets[-1])
+        if xyz.shape != (A, 3) or x.shape != (A, self.nx) or Q.shape != (B,) or y.shape != (A,):
+            raise EpnnError("train_step_xyz: array shapes do not match offsets")
+        q = np.empty((A,), dtype=np.float32)
+        loss = C.c_float()
+        check(self.lib.epnn_train_step_xyz(self.h, B, int(N), iptr(offsets), fptr(xyz), fptr(x), fptr(Q), fptr(y), fptr(q),
+                                           C.byref(loss), int(bool(apply))), self.lib)
+        return q, loss.value
+
+    def get_gradients(self):
+        g = np.empty((self.param_count(),), dtype=np.float32)
+        check(self.lib.epnn_get_gradients(self.h, fptr(g), g.size), self.lib)
+        return g
+
+    def set_gradients(self, g):
+        g = _f32(g)
+        check(self.lib.epnn_set_gradients(self.h, fptr(g), g.size), self.lib)
+
+    def train_apply(self):
+        check(self.lib.epnn_train_apply(self.h), self.lib)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        check(self.lib.epnn_comm_init(self.h, unique_id, rank, world), self.lib)
+
+    @staticmethod
+    def comm_unique_id():
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        check(lib.epnn_comm_unique_id(buf), lib)
+        return buf.raw
+
     # ------------------------------------------------------------------ device-resident plumbing
     def alloc(self, nbytes):
         return DeviceArray(self, nbytes)

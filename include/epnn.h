@@ -95,6 +95,27 @@ int epnn_epn_forward(epnn_handle *h, int B, int N, const float *hin, const float
 int epnn_mlp_forward(epnn_handle *h, int rows, int n_in, int n_out, const float *W1, const float *b1,
                      const float *W2, const float *b2, const float *W3, const float *b3, const float *x, float *out);
 
+/* ---- training (charge_gn.py:393-402, 419): master weights, gradients and Adam moments live on the device as flat
+ * vectors in model.trainable_variables order (update MLP, message MLPs t=0.., pass MLPs t=0..; kernel then bias).
+ * epnn_train_init copies the current weights to the device and zeroes the Adam state (Keras-2 defaults are
+ * lr 1e-3, beta1 0.9, beta2 0.999, eps 1e-7). */
+int epnn_train_init(epnn_handle *h, float lr, float beta1, float beta2, float eps);
+int epnn_param_count(epnn_handle *h, int64_t *out);
+/* train_step on the literal make_model inputs (B,N,N,.), y and pred_out (B,N,1): loss = sum (y-p)^2, gradient of the
+ * summed loss; apply != 0: all-reduce the gradient over the attached communicator (if any) and take one Adam step. */
+int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *h_inp, const float *e_inp, const float *x_inp,
+                          const float *q_inp, const float *mask_inp, const float *y, float *pred_out, float *loss_out,
+                          int apply);
+/* same from a flat coordinate batch (y_flat, q_out_flat per real atom) */
+int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz, const float *x,
+                        const float *Q, const float *y_flat, float *q_out_flat, float *loss_out, int apply);
+int epnn_get_gradients(epnn_handle *h, float *out, int64_t count);
+int epnn_set_gradients(epnn_handle *h, const float *in, int64_t count);
+int epnn_train_apply(epnn_handle *h);
+/* RCCL communicator (one rank per GPU): the gradient is summed with ONE ncclAllReduce of the flat vector. */
+int epnn_comm_unique_id(char *out128);
+int epnn_comm_init(epnn_handle *h, const char *id128, int rank, int world);
+
 /* Device memory and stream plumbing for callers that keep inputs resident (bench.py). */
 int epnn_dev_alloc(epnn_handle *h, size_t bytes, void **out);
 int epnn_dev_free(epnn_handle *h, void *p);
