@@ -283,6 +283,7 @@ class EPNNModel(_Stack):
             m.build(2 * F + h_dim)
         self._graph_bytes = None
         self._dirty = True
+        self._training = False
 
     # ---- weights
     def _eng(self):
@@ -294,6 +295,7 @@ class EPNNModel(_Stack):
         return eng
 
     def weights_dict(self):
+        _refresh_from_device(self)
         return {"msg": [m.get_weights() for m in self.graph_net.message_fns],
                 "upd": self.update_fn.get_weights(),
                 "pas": [m.get_weights() for m in self.electron_net.pass_fns]}
@@ -311,6 +313,8 @@ class EPNNModel(_Stack):
             self.electron_net.pass_fns[t].set_weights(w["pas"][t])
         self.update_fn.set_weights(w["upd"])
         self._dirty = True
+        self._training = False
+        self._weights_version = getattr(self, "_weights_version", 0) + 1
 
     def load_weights(self, prefix):
         """infer.py:57 -- reads the TensorFlow tensor-bundle files directly."""
@@ -323,6 +327,10 @@ class EPNNModel(_Stack):
 
     @property
     def trainable_variables(self):
+        _refresh_from_device(self)
+        return self._trainable_variables()
+
+    def _trainable_variables(self):
         """Keras creation order (charge_gn.py:371-374): update MLP, message MLPs t=0.., pass MLPs t=0..;
         kernel then bias per Dense."""
         out = []
@@ -360,3 +368,72 @@ def test_step(model, h, e, x, q, y, mask):
 
 
 test_step.__test__ = False   # not a pytest test
+
+
+# --------------------------------------------------------------------------------------------- training
+class Adam:
+    """tf.keras.optimizers.Adam() with the Keras-2 defaults the reference uses (charge_gn.py:419)."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+        self._bound = None
+
+    def bind(self, model):
+        """Copy the model's weights to the device as training masters and zero the moments (once per model)."""
+        key = (id(model), getattr(model, "_weights_version", 0))
+        if self._bound != key:
+            model.engine().train_init(self.learning_rate, self.beta_1, self.beta_2, self.epsilon)
+            self._bound = key
+        model._training = True
+        return model.engine()
+
+
+class Mean:
+    """tf.keras.metrics.Mean (charge_gn.py:420,422)."""
+
+    def __init__(self, name="mean"):
+        self.name = name
+        self.reset_states()
+
+    def reset_states(self):
+        self._sum, self._n = 0.0, 0
+
+    def __call__(self, values):
+        v = np.asarray(values, dtype=np.float64)
+        self._sum += float(v.sum())
+        self._n += v.size
+
+    def result(self):
+        return self._sum / self._n if self._n else 0.0
+
+
+class MeanAbsoluteError(Mean):
+    """tf.keras.metrics.MeanAbsoluteError (charge_gn.py:421,423); averages over all N padded slots like Keras."""
+
+    def __call__(self, a, b):
+        d = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))
+        self._sum += float(d.sum())
+        self._n += d.size
+
+
+def train_step(model, optimizer, h, e, x, q, y, mask, train_loss=None, train_acc=None):
+    """charge_gn.py:393-402 with the globals made arguments: forward, loss = MSE over the size-1 last axis (a (B,N)
+    tensor of (y-p)^2), gradient of its SUM, one Adam step; updates the metrics the reference updates."""
+    eng = optimizer.bind(model)
+    y = np.asarray(y)
+    pred, _ = eng.train_step_dense(h, e, x, q, mask, y, apply=True)
+    if train_loss is not None:
+        train_loss((y.reshape(pred.shape) - pred) ** 2)
+    if train_acc is not None:
+        train_acc(pred, y.reshape(pred.shape))
+    return pred
+
+
+def _refresh_from_device(model):
+    """After training steps the current weights live on the device: pull them into the Python layers."""
+    if getattr(model, "_training", False):
+        w = model.engine().get_weights()
+        for t in range(model.T):
+            model.graph_net.message_fns[t].set_weights(w["msg"][t])
+            model.electron_net.pass_fns[t].set_weights(w["pas"][t])
+        model.update_fn.set_weights(w["upd"])

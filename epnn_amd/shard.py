@@ -65,3 +65,19 @@ def forward_sharded(compute, offsets, xyz, x, Q, N, rank=0, world=1, dist=None):
     for r_rows, r_q in gathered:
         out[r_rows] = r_q
     return out
+
+
+# --------------------------------------------------------------------------------------------- data-parallel training
+def dp_step_molecules(order, world, step):
+    """Molecules of optimizer step `step` when `world` ranks each take one molecule (train.py): rank r gets
+    order[step*world + r].  Returns the `world` indices (the global batch of that step)."""
+    return [int(order[step * world + r]) for r in range(world)]
+
+
+def allreduce_sum_host(vec, dist):
+    """Gradient all-reduce through the host (gloo) -- the portable counterpart of the RCCL all-reduce the library does
+    on the device (epnn_comm_init / epnn_train_apply); used by CPU tests and as a fallback without RCCL."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()

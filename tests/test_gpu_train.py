@@ -128,3 +128,32 @@ def test_rccl_single_rank_allreduce(gpu_engine_factory):
     eng.train_apply()
     assert np.array_equal(eng.get_gradients(), g0)
     assert not np.array_equal(eng.get_weights()["pas"][0][0][0], w["pas"][0][0][0])
+
+
+def test_train_script_and_mirror(tmp_path, golden_dir):
+    """train.py end to end on the four-file fixture directory (two epochs), and the charge_gn.train_step mirror."""
+    import subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), os.path.join(golden_dir, "qm9_small"), "--epochs", "2",
+                          "--n-elems", "9", "--init", os.path.join(ROOT, "models", "decay_model_weights"), "--out", str(tmp_path / "w")],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("Epoch")]
+    assert len(lines) == 2 and "Test Acc" in lines[0]
+    assert os.path.exists(tmp_path / "w.index") and os.path.exists(tmp_path / "val_names.npy")
+    from epnn_amd import charge_gn, checkpoint
+    w = checkpoint.load_epnn_weights(str(tmp_path / "w"))            # the file train.py wrote is a readable bundle
+    assert len(w["msg"]) == 5
+    x, h, q, e, Q, y, mask, names = charge_gn.gen_padded_init_state(os.path.join(golden_dir, "qm9_small") + "/", 48, 48, n_elems=9)
+    model = charge_gn.make_model([32, 32], 48, 5, 9, x.shape[1])
+    model.load_weights(os.path.join(ROOT, "models", "decay_model_weights"))
+    opt = charge_gn.Adam()
+    before = model([h[:1], e[:1], x[:1], q[:1], mask[:1]])
+    loss, acc = charge_gn.Mean(), charge_gn.MeanAbsoluteError()
+    for _ in range(3):
+        pred = charge_gn.train_step(model, opt, h[:1], e[:1], x[:1], q[:1], y[:1], mask[:1], loss, acc)
+    assert pred.shape == before.shape and np.isfinite(loss.result())
+    after = model([h[:1], e[:1], x[:1], q[:1], mask[:1]])
+    assert np.abs(after - before).max() > 0                          # weights moved, inference sees them
+    tv = model.trainable_variables
+    assert len(tv) == 66 and sum(v.size for v in tv) == 74037

@@ -88,3 +88,51 @@ def test_algorithmic_flops_matches_survey_figure():
     from epnn_amd import synth
     fl = synth.algorithmic_flops([18], 145 / 2)
     assert abs(fl / 1e6 - 10.8) < 0.1, fl
+
+
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+import torch.distributed as dist
+from epnn_amd import shard
+from oracle import epnn_oracle_train as ot      # test stand-in for the per-rank engine
+from conftest import random_weights
+from test_train_oracle import _tiny_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+nx, T, N = 9, 1, 6
+w = random_weights(nx, T, seed=2, scale=0.5)
+h, e, x, q, mask, y = _tiny_batch(nx, N, [5, 4, 6, 3], seed=7)
+order = np.array([2, 0, 3, 1])
+theta = ot.flatten(w); opt = ot.Adam(theta.size)
+for step in range(2):
+    mine = shard.dp_step_molecules(order, world, step)[rank]
+    sl = slice(mine, mine + 1)
+    _, _, g = ot.loss_and_grads(h[sl], e[sl], x[sl], q[sl], mask[sl], y[sl], ot.unflatten(theta, w))
+    gsum = shard.allreduce_sum_host(ot.flatten(g), dist)          # what ncclAllReduce(sum) does on the GPUs
+    theta = opt.step(theta, gsum)
+if rank == 0:
+    # single process, the same global batches of two molecules with summed gradients
+    theta1 = ot.flatten(w); opt1 = ot.Adam(theta1.size)
+    for step in range(2):
+        idx = shard.dp_step_molecules(order, world, step)
+        _, _, g = ot.loss_and_grads(h[idx], e[idx], x[idx], q[idx], mask[idx], y[idx], ot.unflatten(theta1, w))
+        theta1 = opt1.step(theta1, ot.flatten(g))
+    assert np.abs(theta - theta1).max() < 1e-12, np.abs(theta - theta1).max()
+    print("DP_OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_gradient_sum_world2_gloo(tmp_path):
+    """SURVEY.md section 8e (training): one molecule per rank, gradients summed by an all-reduce, identical Adam step on
+    every rank == single-process step on the summed batch.  gloo on CPU stands in for RCCL."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", str(script), ROOT],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "DP_OK" in out.stdout

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Training-step timing (BASELINE.json configs[2] shape: one molecule of the `mixed` set per GPU per step, N=41)."""
+import os, sys, time, tarfile, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from epnn_amd import checkpoint, charge_gn
+from epnn_amd.engine import Engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+d = tempfile.mkdtemp(); tarfile.open(os.path.join(ROOT, "tests/golden/mixed_val.tar.gz")).extractall(d)
+names = [str(n) for n in np.load(os.path.join(ROOT, "tests/golden/val_names.npy"), allow_pickle=True)][:64]
+mols = [charge_gn.read_xyz(os.path.join(d, "mixed_val", nm + ".xyz"), 9) for nm in names]
+labels = [np.load(os.path.join(d, "mixed_val", nm + ".npy")).astype(np.float32).ravel() if os.path.exists(os.path.join(d, "mixed_val", nm + ".npy")) else np.zeros(len(m[1]), np.float32) for nm, m in zip(names, mols)]
+eng = Engine(nx=9, T=5); eng.set_weights(checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights")))
+eng.train_init()
+def batch(k):
+    ms = mols[k * B:(k + 1) * B]; ys = labels[k * B:(k + 1) * B]
+    off = np.zeros(len(ms) + 1, np.int32); off[1:] = np.cumsum([len(m[1]) for m in ms])
+    return off, np.concatenate([m[0] for m in ms]), np.concatenate([m[1] for m in ms]), np.array([m[2] for m in ms], np.float32), np.concatenate(ys)
+for k in range(2): eng.train_step_xyz(*batch(k), 41)
+t0 = time.perf_counter(); nst = min(20, 64 // B); tot = 0.0
+for k in range(nst):
+    q, loss = eng.train_step_xyz(*batch(k), 41); tot += loss
+dt = (time.perf_counter() - t0) / nst
+print(f"train step: B={B} molecule(s) per step, N=41: {dt*1e3:.2f} ms/step ({1/dt:.1f} steps/s, {B/dt:.1f} molecules/s); mean loss {tot/nst:.4f}")
