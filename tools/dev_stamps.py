@@ -6,8 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "epnn_amd", "libepnn_hip_stamps.so")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DEPNN_STAMPS=" + os.environ.get("STAMPS", "1"), "-DEPNN_ABL=" + os.environ.get("ABL", "0"),
-                "-o", so, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip")], check=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-shared", "-fPIC", "-DEPNN_STAMPS=" + os.environ.get("STAMPS", "1"), "-DEPNN_ABL=" + os.environ.get("ABL", "0"),
+                "-o", so, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"), "-L/opt/rocm/lib", "-lrccl"], check=True)
 from epnn_amd import _lib
 _lib.LIB_PATH = so
 from epnn_amd import checkpoint, synth
