@@ -83,7 +83,11 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
     HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
     shape_layers(h);
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward<true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward<true, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward<false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = h;
     return 0;
@@ -95,7 +99,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
-                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
+                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_hsplit, &h->s_gx, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
@@ -329,7 +333,8 @@ static int ensure_pairs(epnn_handle *h, int pcap) {
     return 0;
 }
 
-static SmallLds small_layout(int nmax, int gcap) {
+// variant: 0 = both stacks in one launch, 1 = GNN half, 2 = EPN half (the halves leave out what they never touch)
+static SmallLds small_layout(int nmax, int gcap, int glds, int variant) {
     SmallLds L;
     int o = 0;
     auto take = [&](int words) {
@@ -338,22 +343,23 @@ static SmallLds small_layout(int nmax, int gcap) {
         return r;
     };
     const int nr = std::max(1, std::min(32, nmax)), npadmax = 4 * ((nr + 4) / 4);
+    const bool gnn = variant != 2, epn = variant != 1;
     L.nr = nr;
     L.npadmax = npadmax;
     L.a_eo = take(nr * EPNN_AST);
     L.P = take(nr * EPNN_PST);
     L.R = take(npadmax * EPNN_PST);
-    L.Sw = take(2 * nr * EPNN_SST);
-    L.zp = take(nr * EPNN_SST);
-    L.G = take(gcap * EPNN_PST);
-    L.dl = take(gcap);
-    L.pij = take(gcap);
-    L.pwi = take(gcap);
-    L.pwj = take(gcap);
-    L.pm = take((nr * npadmax + 1) / 2);
-    L.glut = take((nr * npadmax / 4 + 3) / 4);
+    L.Sw = take(gnn ? 2 * nr * EPNN_SST : 4);
+    L.zp = take(gnn ? nr * EPNN_SST : 4);
+    L.G = take(std::max(1, glds) * EPNN_PST);
+    L.dl = take(epn ? gcap : 4);
+    L.pij = take(epn ? gcap : 4);
+    L.pwi = take(epn ? gcap : 4);
+    L.pwj = take(epn ? gcap : 4);
+    L.pm = take(gnn ? (nr * npadmax + 1) / 2 : 4);
+    L.glut = take(gnn ? (nr * npadmax / 4 + 3) / 4 : 4);
     L.nm = take(32);
-    L.u1h = take(64 * 16);
+    L.u1h = take(gnn ? 64 * 16 : 4);
     L.cst = take(64);
     L.total = o;
     return L;
@@ -425,11 +431,40 @@ static int launch_small(epnn_handle *h, const PairSource &S) {
         gcap = std::max(1, std::min(gcap, full));
         A.order = h->d_order.as<int>() + pos;
         A.gcap = gcap;
-        A.L = small_layout(nmax, gcap);
-        const size_t lds = (size_t)A.L.total * 4;
+        // Split launches + a trimmed G buffer let three workgroups share a CU (<= 53 KB LDS, <= 168 VGPRs each).
+        // That pays once there are several rounds of workgroups (measured: +9 % at 4096 molecules, +12 % at 8192);
+        // with exactly four molecules per CU (1024) two rounds of two are as good, so "auto" keeps one launch there.
+        const bool can_split = A.run_gnn && A.run_epn && !A.h_out;
+        const bool split = can_split && (h->opt_split == 1 || (h->opt_split < 0 && P.small_order.size() >= 2304));
+        int glds = gcap;
+        if (h->small_glds > 0) glds = std::min(gcap, h->small_glds);
+        else if (split) {
+            const int base = small_layout(nmax, gcap, 1, 1).total * 4;          // GNN half without G rows
+            glds = std::max(32, std::min(gcap, (51 * 1024 - base) / (EPNN_PST * 4)));   // 3 x 51 KB leaves room for allocation granularity
+        }
+        A.glds = glds;
+        if (h->s_gx.ensure((size_t)h->pcap * 32 * 4)) return 1;
+        A.gx = h->s_gx.as<float>();
+        A.L = small_layout(nmax, gcap, glds, 0);
+        size_t lds = (size_t)A.L.total * 4;
         if (lds > 160 * 1024) EPNN_FAIL("fused kernel: LDS budget exceeded (%zu bytes)", lds);
         hipStream_t st = multi ? h->cstream[used % EPNN_NSTREAM] : h->stream;
-        hipLaunchKernelGGL(k_small_forward, dim3((unsigned)(end - pos)), dim3(256), lds, st, A);
+        const dim3 grid((unsigned)(end - pos));
+        if (split) {
+            // two launches: the GNN half leaves h in HBM, the EPN half picks it up
+            if (h->s_hsplit.ensure((size_t)P.A * EPNN_EDIM * 4)) return 1;
+            SmallArgs G = A, E = A;
+            G.run_epn = 0;
+            G.h_out = h->s_hsplit.as<float>();
+            G.L = small_layout(nmax, gcap, glds, 1);
+            E.run_gnn = 0;
+            E.h_in = h->s_hsplit.as<float>();
+            E.L = small_layout(nmax, gcap, glds, 2);
+            hipLaunchKernelGGL((k_small_forward<true, false>), grid, dim3(256), (size_t)G.L.total * 4, st, G);
+            hipLaunchKernelGGL((k_small_forward<false, true>), grid, dim3(256), (size_t)E.L.total * 4, st, E);
+        } else {
+            hipLaunchKernelGGL((k_small_forward<true, true>), grid, dim3(256), lds, st, A);
+        }
         ++used;
         pos = end;
     }
@@ -687,6 +722,8 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "small_gcap")) { h->small_gcap = value; }
     else if (!strcmp(name, "small_pairs_per_atom")) { h->small_pairs_per_atom = std::max(1, value); }
     else if (!strcmp(name, "size_classes")) { h->opt_classes = value; }
+    else if (!strcmp(name, "split")) { h->opt_split = value; }
+    else if (!strcmp(name, "small_glds")) { h->small_glds = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }

@@ -91,7 +91,9 @@ struct epnn_handle {
     int small_gcap = 0;           // 0 = heuristic
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
     // staging for the host-pointer entry points
-    DevBuf s_xyz, s_x, s_Q, s_q, s_misc;
+    DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_hsplit, s_gx;
+    int small_glds = 0;               // G rows kept in LDS per molecule (0 = all of them; smaller values trade LDS for HBM overflow rows)
+    int opt_split = -1;               // fused kernel as a GNN launch + an EPN launch: 0 never, 1 always, -1 auto (big batches)
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
     DevBuf l_mflag, l_stasks, l_schunk, l_sfin;

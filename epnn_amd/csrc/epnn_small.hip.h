@@ -52,6 +52,8 @@ struct SmallArgs {
     const float *q_in;     // optional [A] initial q (layer-level API), null -> Q/n
     const float *nm_in;    // optional [A] node mask (dense front-end), null -> 1 for every real atom
     SmallLds L;
+    float *gx;             // [pcap][32] overflow rows of G for pairs beyond the LDS slots of the launch
+    int glds;              // near-pair slots of G kept in LDS (<= gcap)
     unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][wave][64] s_memtime values
 };
 
@@ -73,6 +75,9 @@ struct SmallArgs {
 #else
 #define EPNN_STAMPE() do { } while (0)
 #define EPNN_STAMPG() EPNN_STAMP()
+#endif
+#ifndef EPNN_SMALL_WAVES
+#define EPNN_SMALL_WAVES 3   // waves per SIMD the register allocation of the split halves is sized for (both stacks in one launch: 2)
 #endif
 #ifndef EPNN_ABL
 #define EPNN_ABL 0     // diagnostic ablations of the pair-tile loop (1: no partial-sum update, 2: no G lookup)
@@ -117,8 +122,10 @@ __device__ __forceinline__ f32x16 small_gtile(const float *__restrict__ weF, con
 }
 
 // G tiles first, first+stride, ... with the We fragments already in registers -> LDS
+// (slots >= glds do not fit the LDS budget of the launch and go to the per-pair overflow rows in HBM; a later
+// __syncthreads() makes them visible to the other waves of the workgroup)
 __device__ __forceinline__ void small_gtiles_reg(const float (&w)[32], const float *pe, int p0, int np, float *Gl,
-                                                 int first, int stride, int lane) {
+                                                 int glds, float *Gx, int first, int stride, int lane) {
     const int c = lane & 31, hh = lane >> 5;
     const int ngt = (np + 31) >> 5;
     for (int gt = first; gt < ngt; gt += stride) {
@@ -134,11 +141,17 @@ __device__ __forceinline__ void small_gtiles_reg(const float (&w)[32], const flo
         f32x16 acc = epnn_splat16(0.f);
 #pragma unroll
         for (int s = 0; s < 24; ++s) acc = epnn_mfma(w[s], valid ? ev[s] : 0.f, acc);
-        if (valid) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
+        if (valid) {
+            if (slot < glds) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
+            else epnn_st16(Gx + (size_t)(p0 + slot) * 32 + hh * 16, acc);
+        }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
+// GNN / EPN select which stack is compiled in: <true,true> runs both in one launch, the split pair <true,false> +
+// <false,true> hands h over through HBM and gives each half its own (smaller) register allocation.
+template <bool GNN, bool EPN>
+__global__ __launch_bounds__(256, (GNN && EPN) ? 2 : EPNN_SMALL_WAVES) void k_small_forward(SmallArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
     const SmallLds &L = A.L;
@@ -165,11 +178,12 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
     const int nx = A.nx, fq = nx + EPNN_EDIM;             // feature index of q
     const int nrows = n * npad, ntile = (nrows + 31) >> 5, ngroups = nrows >> 2;
     const int ngt = (np + 31) >> 5;
+    const int glds = A.glds;
     const float inv_npad = 1.0f / (float)npad;
     const int cr = c < nr ? c : nr - 1;                   // lanes beyond the last LDS row re-read it (results dropped)
     const bool catom = c < n;
     const float *wp = A.wpack;
-    const int Tg = A.run_gnn ? A.T : 0, Te = A.run_epn ? A.T : 0;
+    const int Tg = (GNN && A.run_gnn) ? A.T : 0, Te = (EPN && A.run_epn) ? A.T : 0;
 
     // registers that carry weights from the phase in which they are fetched to the phase that uses them
     float pw[32];      // phase A / A' task (Wi | Wj | update h-part | We) and the G tiles of phase C1
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
 
     if (Tg > 0) {
         // G tiles of msg[0] (all waves), then the phase-A weights of step 0
-        small_gtiles_reg(pw, A.pe, p0, np, Gl, 3 - wave, 4, lane);
+        small_gtiles_reg(pw, A.pe, p0, np, Gl, glds, A.gx, 3 - wave, 4, lane);
         const PairMlpPack &M0 = A.wi.msg[0];
         if (wave == 0) { EPNN_LDW(pw, M0.wiF, EPNN_KA); }
         else if (wave == 1) { EPNN_LDW(pw, M0.wjF, EPNN_KA); }
@@ -299,7 +313,8 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
 #if EPNN_ABL != 2
                 if (slot != 0xFFFFu) {
                     float g[16];
-                    epnn_ld16(Gl + slot * EPNN_PST + hh * 16, g);
+                    if ((int)slot < glds) epnn_ld16(Gl + slot * EPNN_PST + hh * 16, g);
+                    else epnn_ld16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, g);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) z[r] += g[r];
                 }
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
             if (!lastg) { EPNN_LDW(pw, A.wi.msg[t + 1].wiF, EPNN_KA); }
             else if (Te > 0) { EPNN_LDW(pw, A.wi.pas[0].wiF, EPNN_KA); }
         } else {
-            if (!lastg) small_gtiles_reg(pw, A.pe, p0, np, Gl, wave - 1, 3, lane);
+            if (!lastg) small_gtiles_reg(pw, A.pe, p0, np, Gl, glds, A.gx, wave - 1, 3, lane);
             if (wave == 1) {
                 if (!lastg) { EPNN_LDW(pw, A.wi.msg[t + 1].wjF, EPNN_KA); }
                 else if (Te > 0) { EPNN_LDW(pw, A.wi.pas[0].wjF, EPNN_KA); }
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
         } else if (wave == 1) {
             small_proj(pw, a_eo + cr * EPNN_AST + hh * 32, Rl + cr * EPNN_PST + hh * 16, catom);
         } else {
-            small_gtiles_reg(pw, A.pe, p0, np, Gl, wave - 2, 2, lane);
+            small_gtiles_reg(pw, A.pe, p0, np, Gl, glds, A.gx, wave - 2, 2, lane);
         }
         EPNN_STAMPE();
         __syncthreads();
@@ -472,7 +487,8 @@ __global__ __launch_bounds__(256, 2) void k_small_forward(SmallArgs A) {
             // the two directions one after the other: a dependent chain of this MFMA already runs at the issue
             // rate, and keeping only one direction live saves 48 registers
             float g[16], b2v[16], w3[16];
-            epnn_ld16(Gl + sl * EPNN_PST + hh * 16, g);
+            if (sl < glds) epnn_ld16(Gl + sl * EPNN_PST + hh * 16, g);
+            else epnn_ld16(A.gx + (size_t)(p0 + sl) * 32 + hh * 16, g);
             epnn_ld16(cst + hh * 16, b2v);
             epnn_ld16(cst + 32 + hh * 16, w3);
             float fu = 0.f, fv = 0.f;

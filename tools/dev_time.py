@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from epnn_amd import checkpoint, synth
 from epnn_amd.engine import Engine
 
-def run(opts, steps=30, B=1024, seed=0):
+def run(opts, steps=30, B=int(os.environ.get("B", "1024")), seed=0):
     w = checkpoint.load_epnn_weights("models/decay_model_weights")
     eng = Engine(nx=9, T=5)
     eng.set_weights(w)
