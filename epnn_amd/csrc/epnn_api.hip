@@ -102,7 +102,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_hsplit, &h->s_gx, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
-                      &h->dn_flag, &h->dn_neff, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
+                      &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
                       &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
     for (DevBuf *b : bufs) b->release();
     if (h->train) {
@@ -730,6 +730,28 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
 
 
 // ------------------------------------------------------------------------------------------------ dense entries
+// per-slot atom features, node mask and "non-trivial" flags from the dense inputs (replaces one monolithic kernel:
+// every pass below is a coalesced stream)
+static int launch_dense_atoms(epnn_handle *h, DenseArgs &D) {
+    const size_t slots = (size_t)D.B * D.N;
+    if (h->dn_den.ensure(slots * 4)) return 1;
+    float *den = h->dn_den.as<float>();
+    HIPCHK(hipMemsetAsync(D.flag, 0, slots * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_dn_den, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->stream, D, den);
+    if (D.model_level) {
+        const int N = D.N;
+        hipLaunchKernelGGL(k_dn_feat<0>, dim3((unsigned)((N * EPNN_EDIM + 255) / 256), (unsigned)D.B), dim3(256), 0, h->stream, D, den);
+        hipLaunchKernelGGL(k_dn_feat<1>, dim3((unsigned)((N * D.nx + 255) / 256), (unsigned)D.B), dim3(256), 0, h->stream, D, den);
+        hipLaunchKernelGGL(k_dn_feat<2>, dim3((unsigned)((N + 255) / 256), (unsigned)D.B), dim3(256), 0, h->stream, D, den);
+    } else {
+        hipLaunchKernelGGL(k_dn_copy_atoms, dim3((unsigned)std::min<size_t>((slots * (D.nx + EPNN_EDIM + 1) + 255) / 256, 8192)),
+                           dim3(256), 0, h->stream, D);
+    }
+    hipLaunchKernelGGL(k_dn_escan, dim3((unsigned)std::min<size_t>((slots * D.N + 255) / 256, 16384)), dim3(256), 0, h->stream, D);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // mode 0: make_model (model-level inputs, both stacks); 1: GNN_layer.call; 2: EPN_layer.call.  Device pointers.
 static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_h, const float *d_e, const float *d_x,
                          const float *d_q, const float *d_mask, float *d_out) {
@@ -758,7 +780,7 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     D.flag = h->dn_flag.as<int>();
     D.neff = h->dn_neff.as<int>();
     D.tol = h->cfg.near_tol;
-    hipLaunchKernelGGL(k_dn_atoms, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, h->stream, D);
+    if (launch_dense_atoms(h, D)) return 1;
     hipLaunchKernelGGL(k_dn_neff, dim3((unsigned)B), dim3(64), 0, h->stream, D);
     HIPCHK(hipGetLastError());
     h->dn_neff_host.resize(B);
@@ -1065,8 +1087,7 @@ extern "C" int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *
     D.q_in = h->sd_q.as<float>(); D.mask_in = h->sd_mask.as<float>();
     D.xs = h->dn_xs.as<float>(); D.hs = h->dn_hs.as<float>(); D.qs = h->dn_qs.as<float>(); D.nms = h->dn_nms.as<float>();
     D.flag = h->dn_flag.as<int>(); D.tol = h->cfg.near_tol;
-    hipLaunchKernelGGL(k_dn_atoms, dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, h->stream, D);   // charge_gn.py:382-384
-    HIPCHK(hipGetLastError());
+    if (launch_dense_atoms(h, D)) return 1;                                                         // charge_gn.py:382-384
     return train_step_slots(h, B, N, D.e_in, D.mask_in, D.xs, D.hs, D.qs, h->sd_out.as<float>(), pred_out, loss_out, apply);
 }
 

@@ -38,49 +38,74 @@ struct DenseArgs {
     int C;
 };
 
-// one wave per slot (b,k): per-atom features, node mask and the "non-trivial" flag
-__global__ __launch_bounds__(256) void k_dn_atoms(DenseArgs D) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wave;
+// node mask / denominator per slot (b,k): sum_j mask[b,j,k]  (charge_gn.py:59, 382-384); one thread per slot, the
+// 64 threads of a wave read 64 consecutive k of one row j at a time (coalesced)
+__global__ __launch_bounds__(256) void k_dn_den(DenseArgs D, float *den) {
+    const int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= D.B * D.N) return;
-    const int b = slot / D.N, k = slot - b * D.N, N = D.N, nx = D.nx;
+    const int b = slot / D.N, k = slot - b * D.N, N = D.N;
     const size_t mb = (size_t)b * N * N;
-    // node mask / denominator: sum_j mask[b,j,k]   (sequential-in-lane then tree; order fixed)
-    float den = 0.f;
-    for (int j = lane; j < N; j += 64) den += D.mask_in[mb + (size_t)j * N + k];
-    for (int d = 32; d >= 1; d >>= 1) den += __shfl_xor(den, d, 64);
-    int nontriv = den != 0.f;
-    // any non-zero in row k / column k of e, or in row k of mask
-    const float *erow = D.e_in + (mb + (size_t)k * N) * EPNN_EDIM;
-    for (int i = lane; i < N * EPNN_EDIM; i += 64) nontriv |= erow[i] != 0.f;
-    for (int i = lane; i < N * EPNN_EDIM; i += 64) {
-        const int j = i / EPNN_EDIM, ch = i - j * EPNN_EDIM;
-        nontriv |= D.e_in[(mb + (size_t)j * N + k) * EPNN_EDIM + ch] != 0.f;
-    }
-    // per-atom features
-    const int F = nx + EPNN_EDIM + 1;
-    for (int f = lane; f < F; f += 64) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < N; ++j) s += D.mask_in[mb + (size_t)j * N + k];
+    den[slot] = s;
+    D.nms[slot] = fminf(fmaxf(s, 0.f), 1.f);
+    if (s != 0.f) atomicOr(&D.flag[slot], 1);
+}
+
+// per-atom features of the model-level entry: x, h, q = sum over axis 1 / den (tf.math.divide_no_nan).  Threads run
+// over the contiguous (k, channel) plane of one molecule and loop over j, so every step of the loop is one fully
+// coalesced row of the input tensor -- this kernel is a pure HBM stream (the (N,N,.) inputs are read exactly once).
+template <int WHICH>   // 0: h_inp (48 channels), 1: x_inp (nx), 2: q_inp (1)
+__global__ __launch_bounds__(256) void k_dn_feat(DenseArgs D, const float *den) {
+    const int N = D.N, C = WHICH == 0 ? EPNN_EDIM : (WHICH == 1 ? D.nx : 1);
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (k, c) flattened
+    if (idx >= N * C) return;
+    const float *src = (WHICH == 0 ? D.h_in : (WHICH == 1 ? D.x_in : D.q_in)) + (size_t)b * N * N * C;
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < N; ++j) s += src[(size_t)j * N * C + idx];      // summation order = j order (fixed)
+    const int k = idx / C, c = idx - k * C;
+    const float dn = den[b * N + k];
+    const float v = dn != 0.f ? s / dn : 0.f;
+    const size_t slot = (size_t)b * N + k;
+    if (WHICH == 0) D.hs[slot * EPNN_EDIM + c] = v;
+    else if (WHICH == 1) D.xs[slot * D.nx + c] = v;
+    else D.qs[slot] = v;
+    if (v != 0.f) atomicOr(&D.flag[slot], 1);
+}
+
+// layer-level entry: per-atom tensors are given; copy and flag
+__global__ __launch_bounds__(256) void k_dn_copy_atoms(DenseArgs D) {
+    const int F = D.nx + EPNN_EDIM + 1;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < D.B * D.N * F; idx += gridDim.x * 256) {
+        const int slot = idx / F, f = idx - slot * F;
         float v;
-        if (D.model_level) {
-            float s = 0.f;
-            if (f < nx) for (int j = 0; j < N; ++j) s += D.x_in[(mb + (size_t)j * N + k) * nx + f];
-            else if (f < nx + EPNN_EDIM) for (int j = 0; j < N; ++j) s += D.h_in[(mb + (size_t)j * N + k) * EPNN_EDIM + (f - nx)];
-            else for (int j = 0; j < N; ++j) s += D.q_in[mb + (size_t)j * N + k];
-            v = den != 0.f ? s / den : 0.f;                       // tf.math.divide_no_nan
-        } else {
-            if (f < nx) v = D.x_in[(size_t)slot * nx + f];
-            else if (f < nx + EPNN_EDIM) v = D.h_in[(size_t)slot * EPNN_EDIM + (f - nx)];
-            else v = D.q_in[slot];
-        }
-        nontriv |= v != 0.f;
-        if (f < nx) D.xs[(size_t)slot * nx + f] = v;
-        else if (f < nx + EPNN_EDIM) D.hs[(size_t)slot * EPNN_EDIM + (f - nx)] = v;
-        else D.qs[slot] = v;
+        if (f < D.nx) { v = D.x_in[(size_t)slot * D.nx + f]; D.xs[(size_t)slot * D.nx + f] = v; }
+        else if (f < D.nx + EPNN_EDIM) { v = D.h_in[(size_t)slot * EPNN_EDIM + (f - D.nx)]; D.hs[(size_t)slot * EPNN_EDIM + (f - D.nx)] = v; }
+        else { v = D.q_in[slot]; D.qs[slot] = v; }
+        if (v != 0.f) atomicOr(&D.flag[slot], 1);
     }
-    const int any = __ballot(nontriv != 0) != 0ull;
-    if (lane == 0) {
-        D.nms[slot] = fminf(fmaxf(den, 0.f), 1.f);                // charge_gn.py:59
-        D.flag[slot] = any;
+}
+
+// e scan: one thread per ordered pair (b,i,j) reads its 48 channels as 12 x 16 B; a non-zero e[i][j] marks both atom i
+// and atom j (integer atomics, order-free; only the ~7 % near pairs issue any)
+__global__ __launch_bounds__(256) void k_dn_escan(DenseArgs D) {
+    const size_t pairs = (size_t)D.B * D.N * D.N;
+    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < pairs; r += (size_t)gridDim.x * 256) {
+        const f32x4 *e4 = reinterpret_cast<const f32x4 *>(D.e_in + r * EPNN_EDIM);
+        bool nz = false;
+#pragma unroll
+        for (int q = 0; q < EPNN_EDIM / 4; ++q) {
+            const f32x4 v = e4[q];
+            nz |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
+        }
+        if (nz) {
+            const int j = (int)(r % D.N), i = (int)((r / D.N) % D.N), b = (int)(r / ((size_t)D.N * D.N));
+            atomicOr(&D.flag[b * D.N + i], 1);
+            atomicOr(&D.flag[b * D.N + j], 1);
+        }
     }
 }
 

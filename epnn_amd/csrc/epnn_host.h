@@ -108,6 +108,7 @@ struct epnn_handle {
         std::function<int()> redo;    // re-enqueues the same forward after a capacity regrow
     } pending;
     // dense front-end workspace (epnn_dense.hip.h)
+    DevBuf dn_den;
     DevBuf dn_xs, dn_hs, dn_qs, dn_nms, dn_flag, dn_neff, dn_xf, dn_hf, dn_qf, dn_nmf, dn_out;
     DevBuf sd_h, sd_e, sd_x, sd_q, sd_mask, sd_out;
     std::vector<int> dn_neff_host;
