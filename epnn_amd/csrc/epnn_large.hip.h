@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, PairMlpPack M) {
         for (int i = tid; i < nj * 32; i += 256) Rs[i] = L.R[(size_t)j0 * 32 + i];
         __syncthreads();
         if (active)
+#pragma unroll 2
             for (int j = 0; j < nj; ++j) {
                 float rj[16];
                 epnn_ld16(Rs + j * 32 + hh * 16, rj);
@@ -432,9 +433,14 @@ static int large_plan(epnn_handle *h) {
         const int first_tile = (int)lp.atiles.size();
         const int ntile = (n + 31) / 32, ngroup = (ntile + 3) / 4;
         // split the j range so that the sweep has a few thousand workgroups, in pieces of EPNN_LG_JC atoms
-        const int want = std::max(1, (4096 + ngroup - 1) / ngroup);
-        int nchunk = std::min(want, (n + EPNN_LG_JC - 1) / EPNN_LG_JC);
-        int clen = ((n + nchunk - 1) / nchunk + EPNN_LG_JC - 1) / EPNN_LG_JC * EPNN_LG_JC;
+        // workgroups of the sweep = ngroup * nchunk.  Measured on the 2220-atom protein: a whole number of rounds of 512
+        // workgroups (two per CU) beats 1024 smaller ones (per-workgroup prologue and more partial sums to reduce);
+        // big systems get >= 2048 workgroups for a fine-grained tail.
+        int want;
+        if (ngroup >= 512) want = std::max(1, (4096 + ngroup - 1) / ngroup);
+        else want = std::max(1, (int)std::lround(512.0 * std::max(1, (int)std::lround(ngroup / 64.0)) / ngroup));
+        int nchunk = std::max(1, std::min(want, (n + 15) / 16));
+        int clen = (n + nchunk - 1) / nchunk;
         nchunk = (n + clen - 1) / clen;
         for (int i0 = 0; i0 < n; i0 += 32) lp.atiles.push_back(make_int4(a0 + i0, std::min(32, n - i0), b, nchunk));
         lp.maxchunk = std::max(lp.maxchunk, nchunk);
