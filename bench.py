@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight per GPU (handles/streams used round robin)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,50 +67,70 @@ def main():
 
     dist = None
     torch = None
+    device = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # RCCL on ROCm
-            sync_dev = torch.device("cuda", local_rank)
-        except Exception:
+        ndev = torch.cuda.device_count()
+        if ndev >= world:
+            torch.cuda.set_device(local_rank)
+            try:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))       # RCCL on ROCm
+                sync_dev = torch.device("cuda", local_rank)
+            except Exception:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+                sync_dev = torch.device("cpu")
+        else:
+            # fewer GPUs than ranks (rehearsal on a one-GPU box): ranks share devices, timing exchange over gloo
+            device = local_rank % max(1, ndev)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             sync_dev = torch.device("cpu")
 
     from epnn_amd import checkpoint, synth
-    from epnn_amd.engine import Engine
+    from epnn_amd.engine import Pipeline
 
     weights = checkpoint.load_epnn_weights(os.path.join(ROOT, "models", "decay_model_weights"))
-    eng = Engine(nx=9, T=5, device=local_rank)
-    eng.set_weights(weights)
+    pipe = Pipeline(depth=args.depth, nx=9, T=5, device=device)
+    pipe.set_weights(weights)
 
     B = args.molecules
     offsets, xyz, x, Q, N = synth.qm9_like_batch(B=B, seed=rank, N=29)
     A = int(offsets[-1])
-    d_xyz, d_x, d_Q = eng.to_device(xyz), eng.to_device(x), eng.to_device(Q)
-    d_q = eng.alloc(A * 4)
+    # every lane keeps its own resident copy of the (identical) inputs and its own output buffer
+    lanes = [(e, e.to_device(xyz), e.to_device(x), e.to_device(Q), e.alloc(A * 4)) for e in pipe.engines]
+
+    def step(k):
+        e, d_xyz, d_x, d_Q, d_q = lanes[k % len(lanes)]
+        e.forward_xyz_dev(offsets, d_xyz, d_x, d_Q, d_q, N)
 
     def barrier():
-        eng.sync()
+        pipe.sync()
         if dist is not None:
-            if torch.cuda.is_available():
+            if sync_dev.type == "cuda":
                 torch.cuda.synchronize()
             dist.barrier()
 
-    for _ in range(args.warmup):
-        eng.forward_xyz_dev(offsets, d_xyz, d_x, d_Q, d_q, N)
-    eng.sync()
-    eng.set_option("profile", args.steps)      # stage events of every timed step, read after the final sync
+    for k in range(max(args.warmup, len(lanes))):
+        step(k)
+    pipe.sync()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward_xyz_dev(offsets, d_xyz, d_x, d_Q, d_q, N)
+    for k in range(args.steps):
+        step(k)
     barrier()
     dt = time.perf_counter() - t0
-    stage = np.array([eng.timing_at(k) for k in range(args.steps)])     # ms: front-end, fused kernel, tiled, total
-    eng.set_option("profile", 0)
+    # Kernel durations for the roofline: the SAME K steps again, right after the timed region, this time with
+    # hipEvents recorded around every stage on the stream the kernels run on (four event records per forward cost
+    # ~20 us of host time per step, which would otherwise be charged to `value`).
+    pipe.set_option("profile", args.steps)
+    for k in range(args.steps):
+        step(k)
+    pipe.sync()
+    per_lane = [sum(1 for k in range(args.steps) if k % len(lanes) == l) for l in range(len(lanes))]
+    stage = np.array([lanes[l][0].timing_at(i) for l in range(len(lanes)) for i in range(per_lane[l])])
+    pipe.set_option("profile", 0)
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=sync_dev)
@@ -121,6 +142,7 @@ def main():
     else:
         dt_max, atoms_total = dt, float(A)
 
+    eng, d_q = lanes[0][0], lanes[0][4]
     q = d_q.download((A,))
     stats = eng.last_stats()
     # sanity inside the bench: charges finite and every molecule's total charge conserved
@@ -158,7 +180,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"qm9_like_b{B}_N{N}", "molecules_per_gpu": B, "atoms_per_gpu": A, "N": N,
                        "near_pairs_per_gpu": int(stats[0]), "entry": "epnn_forward_xyz_dev (coordinates in HBM)",
-                       "weights": "decay_model_weights", "parallelism": f"molecule-sharded x{world}"},
+                       "weights": "decay_model_weights", "parallelism": f"molecule-sharded x{world}",
+                       "batches_in_flight_per_gpu": len(lanes)},
             "roofline": {"bound": "mfma", "kernel": "k_small_forward", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (PMC)", "algorithmic_gflop_per_launch": flops / 1e9,
@@ -169,9 +192,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(offsets, xyz, x, Q, N, weights)
         print(json.dumps(out), flush=True)
 
-    for d in (d_xyz, d_x, d_Q, d_q):
-        d.free()
-    eng.close()
+    for lane in lanes:
+        for d in lane[1:]:
+            d.free()
+    pipe.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

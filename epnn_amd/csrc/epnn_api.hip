@@ -65,11 +65,6 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev_t0));
     HIPCHK(hipEventCreate(&h->ev_t1));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    for (int k = 0; k < EPNN_NSTREAM; ++k) {
-        HIPCHK(hipStreamCreateWithFlags(&h->cstream[k], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
-    }
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_status), 4 * sizeof(int), hipHostMallocDefault));
     memset(h->h_status, 0, 4 * sizeof(int));
     if (h->d_status.ensure(4 * sizeof(int))) return 1;
@@ -116,11 +111,13 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipEventDestroy(h->ev_t0);
     (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < EPNN_NSTREAM; ++k) {
-        (void)hipStreamSynchronize(h->cstream[k]);
-        (void)hipEventDestroy(h->ev_join[k]);
-        (void)hipStreamDestroy(h->cstream[k]);
+    if (h->ev_fork) {
+        (void)hipEventDestroy(h->ev_fork);
+        for (int k = 0; k < EPNN_NSTREAM; ++k) {
+            (void)hipStreamSynchronize(h->cstream[k]);
+            (void)hipEventDestroy(h->ev_join[k]);
+            (void)hipStreamDestroy(h->cstream[k]);
+        }
     }
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -415,6 +412,14 @@ static int launch_small(epnn_handle *h, const PairSource &S) {
     const int nclass = (int)(sizeof(bounds) / sizeof(bounds[0]));
     const bool multi = h->opt_classes != 0 && P.small_order.size() >= 64;
     if (multi) {
+        if (!h->ev_fork) {          // the extra streams exist only when size classes are switched on: every stream a
+                                    // handle owns takes a hardware queue away from other handles' pipelining
+            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            for (int k = 0; k < EPNN_NSTREAM; ++k) {
+                HIPCHK(hipStreamCreateWithFlags(&h->cstream[k], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
+            }
+        }
         HIPCHK(hipEventRecord(h->ev_fork, h->stream));
         for (int k = 0; k < EPNN_NSTREAM; ++k) HIPCHK(hipStreamWaitEvent(h->cstream[k], h->ev_fork, 0));
     }

@@ -269,3 +269,34 @@ class Engine:
         out = np.zeros(4, dtype=np.int64)
         check(self.lib.epnn_last_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_int64))), self.lib)
         return out
+
+
+class Pipeline:
+    """Keeps `depth` batches in flight on one GPU: `depth` handles (each with its own HIP stream and workspace) take
+    the calls round robin, so the front-end kernels and launch gaps of one batch overlap the fused kernel of the
+    previous one.  All handles carry the same weights.  Results of call k are complete after `sync()`."""
+
+    def __init__(self, depth=2, **engine_kwargs):
+        self.engines = [Engine(**engine_kwargs) for _ in range(max(1, int(depth)))]
+        self._next = 0
+
+    def set_weights(self, weights):
+        for e in self.engines:
+            e.set_weights(weights)
+
+    def set_option(self, name, value):
+        for e in self.engines:
+            e.set_option(name, value)
+
+    def lane(self):
+        e = self.engines[self._next % len(self.engines)]
+        self._next += 1
+        return e
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+
+    def close(self):
+        for e in self.engines:
+            e.close()
