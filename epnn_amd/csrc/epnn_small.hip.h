@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, (GNN && EPN) ? 2 : EPNN_SMALL_WAVES) void k_sm
     // ------------------------------------------------------------------ init
     for (int i = tid; i < nr * EPNN_AST; i += 256) a_eo[i] = 0.f;
     for (int i = tid; i < L.npadmax * EPNN_PST; i += 256) Rl[i] = 0.f;
-    for (int i = tid; i < (nr * L.npadmax + 1) / 2; i += 256) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
+    if (GNN)
+        for (int i = tid; i < (nr * L.npadmax + 1) / 2; i += 256) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
     __syncthreads();
     for (int i = tid; i < n * nx; i += 256) {
         const int at = i / nx, f = i - at * nx;
@@ -225,19 +226,24 @@ __global__ __launch_bounds__(256, (GNN && EPN) ? 2 : EPNN_SMALL_WAVES) void k_sm
     }
     for (int p = tid; p < np; p += 256) {
         const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
-        f32x4 rec;
-        rec[0] = __int_as_float(li | (lj << 8));
-        rec[1] = A.pwi[p0 + p];
-        rec[2] = A.pwj[p0 + p];
-        rec[3] = 0.f;
-        prec[p] = rec;
-        pm[li * npad + lj] = (unsigned short)p;
-        if (A.psym[p0 + p]) pm[lj * npad + li] = (unsigned short)p;
+        if (EPN) {          // pair records are an EPN structure (the GNN half of a split launch has no room for them)
+            f32x4 rec;
+            rec[0] = __int_as_float(li | (lj << 8));
+            rec[1] = A.pwi[p0 + p];
+            rec[2] = A.pwj[p0 + p];
+            rec[3] = 0.f;
+            prec[p] = rec;
+        }
+        if (GNN) {          // pair map of the dense tiles
+            pm[li * npad + lj] = (unsigned short)p;
+            if (A.psym[p0 + p]) pm[lj * npad + li] = (unsigned short)p;
+        }
     }
-    for (int g = tid; g < ngroups; g += 256) {
-        const int i = g / npq;
-        glut[g] = (unsigned char)(i | (((g + 1) % npq == 0) ? 0x80 : 0));
-    }
+    if (GNN)
+        for (int g = tid; g < ngroups; g += 256) {
+            const int i = g / npq;
+            glut[g] = (unsigned char)(i | (((g + 1) % npq == 0) ? 0x80 : 0));
+        }
     __syncthreads();
 
     const float Nf = (float)A.N;
