@@ -466,6 +466,10 @@ static int launch_small(epnn_handle *h, const PairSource &S) {
             E.h_in = h->s_hsplit.as<float>();
             E.L = small_layout(nmax, gcap, glds, 2);
             hipLaunchKernelGGL((k_small_forward<true, false>), grid, dim3(256), (size_t)G.L.total * 4, st, G);
+            if (h->ev_mid && !multi && pos == 0 && end == P.small_order.size()) {
+                HIPCHK(hipEventRecord(h->ev_mid, st));
+                h->ev_mid_used = true;
+            }
             hipLaunchKernelGGL((k_small_forward<false, true>), grid, dim3(256), (size_t)E.L.total * 4, st, E);
         } else {
             hipLaunchKernelGGL((k_small_forward<true, true>), grid, dim3(256), lds, st, A);
@@ -527,7 +531,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     hipEvent_t *ev = nullptr;
     if (h->opt_profile > 0) {
-        ev = h->evpool.data() + 4 * (h->ev_next % h->opt_profile);
+        ev = h->evpool.data() + 5 * (h->ev_next % h->opt_profile);
         h->ev_next += 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
@@ -537,7 +541,11 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     S.d_x = d_x;
     S.d_Q = d_Q;
     S.d_q = d_q;
+    h->ev_mid = ev ? ev[4] : nullptr;             // recorded between the two halves of a split launch
+    h->ev_mid_used = false;
     if (launch_small(h, S)) return 1;
+    if (ev && !h->ev_mid_used) HIPCHK(hipEventRecord(ev[4], h->stream));
+    h->ev_mid = nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
     if (launch_large(h, S)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
@@ -688,15 +696,19 @@ extern "C" int epnn_timer_end(epnn_handle *h, float *elapsed_ms) {
     return 0;
 }
 extern "C" int epnn_timing_at(epnn_handle *h, int idx, float *out4) {
+    return epnn_timing_at5(h, idx, out4, nullptr);
+}
+extern "C" int epnn_timing_at5(epnn_handle *h, int idx, float *out4, float *gnn_half_ms) {
     if (!h || !out4) EPNN_FAIL("epnn_timing_at: null argument");
     if (h->opt_profile <= 0) EPNN_FAIL("epnn_timing_at: profiling is off (epnn_set_option(\"profile\", pool_size))");
     if (idx < 0 || idx >= h->ev_next || idx < h->ev_next - h->opt_profile)
         EPNN_FAIL("epnn_timing_at: forward %d is not in the event pool (recorded %d, pool %d)", idx, h->ev_next, h->opt_profile);
     HIPCHK(hipSetDevice(h->device));
     if (finish_forward(h)) return 1;
-    hipEvent_t *ev = h->evpool.data() + 4 * (idx % h->opt_profile);
+    hipEvent_t *ev = h->evpool.data() + 5 * (idx % h->opt_profile);
     for (int k = 0; k < 3; ++k) HIPCHK(hipEventElapsedTime(&out4[k], ev[k], ev[k + 1]));
     HIPCHK(hipEventElapsedTime(&out4[3], ev[0], ev[3]));
+    if (gnn_half_ms) HIPCHK(hipEventElapsedTime(gnn_half_ms, ev[1], ev[4]));   // == out4[1] for a single launch
     return 0;
 }
 extern "C" int epnn_last_timing(epnn_handle *h, float *out4) {
@@ -714,7 +726,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
         HIPCHK(hipSetDevice(h->device));
         if (finish_forward(h)) return 1;
         value = std::max(0, std::min(value, 4096));
-        while ((int)h->evpool.size() < 4 * value) {
+        while ((int)h->evpool.size() < 5 * value) {
             hipEvent_t e;
             HIPCHK(hipEventCreate(&e));
             h->evpool.push_back(e);

@@ -74,8 +74,10 @@ struct epnn_handle {
     hipEvent_t ev_fork = nullptr, ev_join[EPNN_NSTREAM] = {};
     int opt_classes = 0;                      // multi-stream size classes: measured slower than one launch (fork/join cost)
     int small_pairs_per_atom = 8;             // LDS slots for near pairs per atom of the largest molecule of a class
-    std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)
+    std::vector<hipEvent_t> evpool;   // 5 stage events per profiled forward ("profile" option = pool size)
     int ev_next = 0;                  // forwards recorded since the option was set
+    hipEvent_t ev_mid = nullptr;      // event between the GNN and EPN halves of a split fused launch (profiling)
+    bool ev_mid_used = false;
     // weights
     HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
     bool weights_dirty = true;

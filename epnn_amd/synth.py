@@ -110,7 +110,7 @@ def box_system(n_atoms=100_000, seed=0, density=0.1, min_sep=0.9):
     return offsets, pts.astype(np.float32), features(symbols), np.zeros(1, dtype=np.float32), n_atoms
 
 
-def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32):
+def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=False):
     """Forward flop count of the factorised exact algorithm (flop = 2*MAC).
 
     ns: atom count per molecule; near_unordered_pairs: total number of unordered pairs with D < cutoff."""
@@ -120,4 +120,6 @@ def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32):
     n1, n2 = ns.sum(), (ns * ns).sum()
     gnn = n1 * 2 * F * H + nnz * E * H + n2 * H * H + n1 * H * H + n1 * H * H + n1 * (80 * H + H * H + H * 48)
     epn = n1 * 2 * F * H + (nnz / 2) * (E * H + 2 * H * H + 2 * H)
+    if parts:
+        return 2.0 * T * gnn, 2.0 * T * epn
     return 2.0 * T * (gnn + epn)
