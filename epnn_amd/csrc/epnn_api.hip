@@ -6,6 +6,7 @@
 #include "epnn_host.h"
 #include "epnn_frontend.hip.h"
 #include "epnn_small.hip.h"
+#include "epnn_wave.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
 #include "epnn_mlp.hip.h"
@@ -264,6 +265,124 @@ static int pack_weights(epnn_handle *h) {
                 buf[U.u3F + (16 + s) * 64 + l] = 32 + c < EPNN_EDIM ? Wu3[(size_t)k * EPNN_EDIM + 32 + c] : 0.f;
             }
     }
+    // ------------------------------------------------------------ fragments of the wave-autonomous kernel
+    {
+        WaveIndex &X = h->wvidx;
+        const float *bu1 = h->upd[0].b.data(), *bu2 = h->upd[1].b.data(), *bu3 = h->upd[2].b.data();
+        auto kvec = [&](auto &&fn) {              // [2][16] vector in kappa order
+            const int off = alloc(32);
+            for (int hh = 0; hh < 2; ++hh)
+                for (int r = 0; r < 16; ++r) buf[off + hh * 16 + r] = (float)fn(epnn_kappa(hh, r));
+            return off;
+        };
+        auto frag = [&](int steps, auto &&fn) {   // [steps][64]: lane (m,kk) of step s = fn(s, kk, m)
+            const int off = alloc((size_t)steps * 64);
+            for (int s = 0; s < steps; ++s)
+                for (int l = 0; l < 64; ++l) buf[off + s * 64 + l] = (float)fn(s, l >> 5, l & 31);
+            return off;
+        };
+        // xq row phi of a first-Dense block M (rows of W1 starting at r0: [x(nx), h(48), q]); nmrow = value of the node-mask row
+        auto xq_row = [&](const float *W1, const float *b1, int r0, int phi, int m, double nmrow) -> double {
+            if (phi == 0) return nmrow;
+            if (phi <= nx) return W1[(size_t)(r0 + phi - 1) * 32 + m];
+            if (phi == nx + 1) return W1[(size_t)(r0 + nx + EPNN_EDIM) * 32 + m];
+            if (phi == nx + 2) return b1 ? b1[m] : 0.0;
+            return 0.0;
+        };
+        auto unfolded = [&](const float *W1, const float *b1, int r0) {      // [KX+24][64]: xq rows, hk rows
+            return frag(EPNN_KX + 24, [&](int s, int kk, int m) -> double {
+                if (s < EPNN_KX) return xq_row(W1, b1, r0, 2 * s + kk, m, 0.0);
+                return W1[(size_t)(r0 + nx + epnn_hkf(kk, s - EPNN_KX)) * 32 + m];
+            });
+        };
+        auto folded = [&](const float *W1, const float *b1, int r0) {        // [16+KX][64]: Wu3 M_h rows, xq rows
+            std::vector<double> prod(32 * 32), cb(32);
+            for (int k = 0; k < 32; ++k)
+                for (int m = 0; m < 32; ++m) {
+                    double a = 0;
+                    for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
+                    prod[k * 32 + m] = a;
+                }
+            for (int m = 0; m < 32; ++m) {
+                double a = 0;
+                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
+                cb[m] = a;
+            }
+            return frag(16 + EPNN_KX, [&](int s, int kk, int m) -> double {
+                if (s < 16) return prod[epnn_kappa(kk, s) * 32 + m];
+                return xq_row(W1, b1, r0, 2 * (s - 16) + kk, m, cb[m]);
+            });
+        };
+        // Wu3 Wu1_H and Wu1_H^T bu3 (the update MLP is one instance shared by all steps)
+        std::vector<double> pu1(32 * 32), cu3(32);
+        for (int k = 0; k < 32; ++k)
+            for (int m = 0; m < 32; ++m) {
+                double a = 0;
+                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)Wu1[(size_t)f * 32 + m];
+                pu1[k * 32 + m] = a;
+            }
+        for (int m = 0; m < 32; ++m) {
+            double a = 0;
+            for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)Wu1[(size_t)f * 32 + m];
+            cu3[m] = a;
+        }
+        const int off_pu1 = frag(16, [&](int s, int kk, int m) { return pu1[epnn_kappa(kk, s) * 32 + m]; });
+        const int off_cu3 = kvec([&](int k) { return cu3[k]; });
+        const int off_u2 = frag(16, [&](int s, int kk, int m) { return (double)Wu2[(size_t)epnn_kappa(kk, s) * 32 + m]; });
+        const int off_bu1 = kvec([&](int k) { return (double)bu1[k]; });
+        const int off_bu2 = kvec([&](int k) { return (double)bu2[k]; });
+        for (int t = 0; t < T; ++t) {
+            WaveGnnPack &G = X.g[t];
+            const float *W1 = h->msg[t][0].W.data(), *W2 = h->msg[t][1].W.data(), *b2 = h->msg[t][1].b.data();
+            const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
+            G.we = h->widx.msg[t].weF;
+            G.w2 = h->widx.msg[t].w2F;
+            G.b2k = h->widx.msg[t].b2p;
+            (void)W2; (void)b2;
+            std::vector<double> fold(32 * 32), cb3(32);
+            for (int k = 0; k < 32; ++k)
+                for (int m = 0; m < 32; ++m) {
+                    double a = 0;
+                    for (int j = 0; j < 32; ++j) a += (double)W3[k * 32 + j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
+                    fold[k * 32 + m] = a;
+                }
+            for (int m = 0; m < 32; ++m) {
+                double a = 0;
+                for (int j = 0; j < 32; ++j) a += (double)b3[j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
+                cb3[m] = a;
+            }
+            G.u1s = frag(16, [&](int s, int kk, int m) { return fold[epnn_kappa(kk, s) * 32 + m]; });
+            G.cb3k = kvec([&](int k) { return cb3[k]; });
+            G.bu1k = off_bu1;
+            G.u2 = off_u2;
+            G.bu2k = off_bu2;
+            G.pu1 = off_pu1;
+            G.cu3k = off_cu3;
+            if (t + 1 < T) {
+                const float *N1 = h->msg[t + 1][0].W.data(), *nb1 = h->msg[t + 1][0].b.data();
+                G.pwi = folded(N1, nb1, 0);
+                G.pwj = folded(N1, nullptr, F);
+            } else {
+                G.pwi = G.pwj = 0;
+            }
+            (void)W1;
+        }
+        X.wi0 = unfolded(h->msg[0][0].W.data(), h->msg[0][0].b.data(), 0);
+        X.wj0 = unfolded(h->msg[0][0].W.data(), nullptr, F);
+        X.u1h0 = frag(24, [&](int s, int kk, int m) { return (double)Wu1[(size_t)epnn_hkf(kk, s) * 32 + m]; });
+        X.u3 = h->widx.upd[0].u3F;
+        X.bu3k = h->widx.upd[0].bu3p;
+        for (int t = 0; t < T; ++t) {
+            WaveEpnPack &E = X.e[t];
+            const float *W1 = h->pas[t][0].W.data(), *b1 = h->pas[t][0].b.data();
+            E.we = h->widx.pas[t].weF;
+            E.w2 = h->widx.pas[t].w2F;
+            E.b2k = h->widx.pas[t].b2p;
+            E.w3k = h->widx.pas[t].w3p;
+            E.wi = unfolded(W1, b1, 0);
+            E.wj = unfolded(W1, nullptr, F);
+        }
+    }
     if (h->d_wpack.ensure(buf.size() * sizeof(float))) return 1;
     HIPCHK(hipMemcpyAsync(h->d_wpack.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // buf is a local
@@ -372,12 +491,58 @@ static int launch_large(epnn_handle *h, const PairSource &S) {
     return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_nm, S.d_q, S.d_hout, S.run_gnn, S.run_epn);
 }
 
+
+// Wave-autonomous fused kernel: one 64-thread workgroup (one wavefront) per molecule, fixed LDS budget per wave.
+static int launch_wave(epnn_handle *h, const PairSource &S) {
+    const Plan &P = h->plan;
+    WaveArgs A{};
+    A.wpack = h->d_wpack.as<float>();
+    A.wx = h->wvidx;
+    A.xin = S.d_x;
+    A.Q = S.d_Q;
+    A.moff = h->d_moff.as<int>();
+    A.order = h->d_order.as<int>();
+    A.row_off = h->d_rowoff.as<int>();
+    A.pi = h->d_pi.as<int>();
+    A.pj = h->d_pj.as<int>();
+    A.psym = h->d_psym.as<int>();
+    A.pe = h->d_pe.as<float>();
+    A.pwi = h->d_pwi.as<float>();
+    A.pwj = h->d_pwj.as<float>();
+    A.q_out = S.d_q;
+    A.h_out = S.d_hout;
+    A.h_in = S.d_hin;
+    A.q_in = S.d_qin;
+    A.nm_in = S.d_nm;
+    A.status = h->d_status.as<int>();
+    A.N = P.N;
+    A.T = h->cfg.T;
+    A.nx = h->cfg.nx;
+    A.A = P.A;
+    if (h->s_gx.ensure((size_t)h->pcap * 32 * 4)) return 1;
+    A.gx = h->s_gx.as<float>();
+    // worst case inside the budget: n = 32, every unordered pair + diagonal entries (528 records) and >= 1 G row
+    const int lds = std::max(h->wave_lds, 16384) & ~15;
+    A.lds_words = lds / 4;
+#ifdef EPNN_STAMPS
+    if (h->l_nm.ensure(P.small_order.size() * 4 * 64 * 8)) return 1;
+    A.stamps = h->l_nm.as<unsigned long long>();
+#endif
+    const dim3 grid((unsigned)P.small_order.size());
+    if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true>), grid, dim3(64), (size_t)lds, h->stream, A);
+    else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
+    else hipLaunchKernelGGL((k_wave_forward<false, true>), grid, dim3(64), (size_t)lds, h->stream, A);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // The fused kernel's LDS footprint (and with it the number of co-resident workgroups per CU) is set by the largest
 // molecule of a launch, so the molecules (sorted by size) are launched in size classes, largest class first, each
 // on its own stream so that the tails overlap.
 static int launch_small(epnn_handle *h, const PairSource &S) {
     const Plan &P = h->plan;
     if (P.small_order.empty()) return 0;
+    if (h->opt_wave && h->cfg.nx + 3 <= 2 * EPNN_KX) return launch_wave(h, S);
     SmallArgs A{};
     A.wpack = h->d_wpack.as<float>();
     A.wi = h->widx;
@@ -740,6 +905,8 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "small_pairs_per_atom")) { h->small_pairs_per_atom = std::max(1, value); }
     else if (!strcmp(name, "size_classes")) { h->opt_classes = value; }
     else if (!strcmp(name, "split")) { h->opt_split = value; }
+    else if (!strcmp(name, "wave")) { h->opt_wave = value; }
+    else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "small_glds")) { h->small_glds = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;

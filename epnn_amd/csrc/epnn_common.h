@@ -53,7 +53,40 @@ struct WeightIndex {
     UpdPack upd[EPNN_MAXT];
 };
 
+// ---- wave-autonomous kernel (epnn_wave.hip.h): every fragment is an MFMA A operand, [K-step][64 lanes], lane
+// (m = lane & 31, kk = lane >> 5) holds W[k(s,kk)][m].  K orders:  "xq": k = 2s+kk over [node_mask, x_0.., q, 1];
+// "kappa": k = kappa(kk,s);  "hk": s<16 feature kappa(kk,s), s>=16 feature 32+kappa(kk,s-16);  "e": k = 24kk+s.
+#define EPNN_KX 7            // K-steps of the xq block: nx + 3 <= 14
+struct WaveGnnPack {      // GNN step t
+    int we;               // [24][64]  e order          We_t
+    int w2;               // [16][64]  kappa order      W2_t
+    int b2k;              // [2][16]   b2[kappa(hh,r)]
+    int u1s;              // [16][64]  kappa order      W3_t Wu1_M   (last message Dense folded into the update)
+    int cb3k;             // [2][16]   (Wu1_M^T b3_t)[kappa]   (times N at run time)
+    int bu1k;             // [2][16]
+    int u2;               // [16][64]  kappa order      Wu2
+    int bu2k;             // [2][16]
+    int pwi, pwj;         // [16+KX][64]  kappa rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]   (M = Wi / Wj of step t+1)
+    int pu1;              // [16][64]  kappa order      Wu3 Wu1_H
+    int cu3k;             // [2][16]   (Wu1_H^T bu3)[kappa]
+};
+struct WaveEpnPack {      // EPN step t
+    int we, w2, b2k, w3k;
+    int wi, wj;           // [KX+24][64]  xq rows, then hk rows
+};
+struct WaveIndex {
+    WaveGnnPack g[EPNN_MAXT];
+    WaveEpnPack e[EPNN_MAXT];
+    int wi0, wj0;         // [KX+24][64]  first GNN step: xq rows, then hk rows (h given by the caller, usually zeros)
+    int u1h0;             // [24][64]     hk order  Wu1_H
+    int u3;               // [2][16][64]  kappa order  Wu3[.][32*tile + m]
+    int bu3k;             // [2][2][16]
+};
+
 __host__ __device__ static inline int epnn_kappa(int hh, int r) { return 4 * hh + (r & 3) + 8 * (r >> 2); }
+
+// feature held by register s of half kk in the hk order
+__host__ __device__ static inline int epnn_hkf(int kk, int s) { return s < 16 ? epnn_kappa(kk, s) : 32 + epnn_kappa(kk, s - 16); }
 
 // position of atom feature f inside the even/odd image row: half (f&1), slot f>>1
 __host__ __device__ static inline int epnn_aeo(int f) { return (f & 1) * 32 + (f >> 1); }

@@ -82,6 +82,7 @@ struct epnn_handle {
     HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
     bool weights_dirty = true;
     WeightIndex widx{};
+    WaveIndex wvidx{};
     DevBuf d_wpack;
     DevBuf d_mu;
     // plan + workspace
@@ -95,6 +96,8 @@ struct epnn_handle {
     // staging for the host-pointer entry points
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_hsplit, s_gx;
     int small_glds = 0;               // G rows kept in LDS per molecule (0 = all of them; smaller values trade LDS for HBM overflow rows)
+    int opt_wave = 1;                 // fused path: 1 = wave-autonomous kernel (one wavefront per molecule), 0 = 4-wave workgroup kernel
+    int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     int opt_split = -1;               // fused kernel as a GNN launch + an EPN launch: 0 never, 1 always, -1 auto (big batches)
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
