@@ -57,6 +57,7 @@ struct WeightIndex {
 // (m = lane & 31, kk = lane >> 5) holds W[k(s,kk)][m].  K orders:  "xq": k = 2s+kk over [node_mask, x_0.., q, 1];
 // "kappa": k = kappa(kk,s);  "hk": s<16 feature kappa(kk,s), s>=16 feature 32+kappa(kk,s-16);  "e": k = 24kk+s.
 #define EPNN_KX 7            // K-steps of the xq block: nx + 3 <= 14
+#define EPNN_DST 33          // LDS row stride (floats) of the per-molecule charge-transfer matrix
 struct WaveGnnPack {      // GNN step t
     int we;               // [24][64]  e order          We_t
     int w2;               // [16][64]  kappa order      W2_t

@@ -20,6 +20,8 @@
 //   h itself is produced once, after the last step (for the EPN stack / GNN_layer output).
 // EPN (charge_gn.py:98-118): one tile column per UNORDERED near pair, both directions share G; +d to i, -d to j.
 #pragma once
+#include <type_traits>
+
 #include "epnn_common.h"
 
 struct WaveArgs {
@@ -72,11 +74,29 @@ __device__ __forceinline__ void wave_sync_all() {
 // first feature of the g-th group of four of the hk order
 __device__ __forceinline__ int wave_hk_f0(int hh, int g) { return g < 4 ? 4 * hh + 8 * g : 32 + 4 * hh + 8 * (g - 4); }
 
+// A dependent chain of v_mfma_f32_32x32x2_f32 issues one MFMA per ~100 cycles (measured), the pipe takes one per 64:
+// every chain is therefore run as TWO independent accumulators, either the two halves of its own K range ...
 template <int K>
 __device__ __forceinline__ f32x16 wave_chain(const float (&w)[K], const float (&b)[K], f32x16 acc) {
+    f32x16 acc1 = epnn_splat16(0.f);
 #pragma unroll
-    for (int s = 0; s < K; ++s) acc = epnn_mfma(w[s], b[s], acc);
+    for (int s = 0; s < K; ++s) {
+        if (s & 1) acc1 = epnn_mfma(w[s], b[s], acc1);
+        else acc = epnn_mfma(w[s], b[s], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
     return acc;
+}
+// ... or two chains that share their B operand (P and R of the same atoms)
+template <int K>
+__device__ __forceinline__ void wave_chain2(const float (&wa)[K], const float (&wb)[K], const float (&b)[K], f32x16 &a0,
+                                            f32x16 &a1) {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+        a0 = epnn_mfma(wa[s], b[s], a0);
+        a1 = epnn_mfma(wb[s], b[s], a1);
+    }
 }
 
 // e rows of G tile gt: lane (c,hh) takes channels 24hh..24hh+23 of pair gt*32+c
@@ -90,31 +110,8 @@ __device__ __forceinline__ void wave_load_e(const float *pe, int p0, int np, int
     }
 }
 
-// G rows of all near pairs of the molecule for the pair MLP whose We fragments are in w[]: LDS rows [0, glds),
-// the rest to the overflow rows in HBM
-__device__ __forceinline__ void wave_gtiles(const float (&w)[24], const float *pe, int p0, int np, float *Gl, int glds,
-                                            float *Gx, int c, int hh) {
-    const int ngt = (np + 31) >> 5;
-    float ev[24];
-    if (ngt > 0) wave_load_e(pe, p0, np, 0, c, hh, ev);
-#pragma unroll 1
-    for (int gt = 0; gt < ngt; ++gt) {
-        float en[24];
-        if (gt + 1 < ngt) wave_load_e(pe, p0, np, gt + 1, c, hh, en);
-        else {
-#pragma unroll
-            for (int s = 0; s < 24; ++s) en[s] = 0.f;
-        }
-        f32x16 acc = wave_chain<24>(w, ev, epnn_splat16(0.f));
-        const int slot = gt * 32 + c;
-        if (slot < np) {
-            if (slot < glds) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
-            else epnn_st16(Gx + (size_t)(p0 + slot) * 32 + hh * 16, acc);
-        }
-#pragma unroll
-        for (int s = 0; s < 24; ++s) ev[s] = en[s];
-    }
-}
+// keep the loads issued above this point above it: the next chain's operands are fetched while the current chain runs
+#define WAVE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <bool GNN, bool EPN>
 __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
@@ -131,7 +128,6 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     (void)nstamp;
     WAVE_STAMP();
     const bool catom = c < n;
-    const int cr = catom ? c : n - 1;                      // lanes without an atom re-read the last row (results dropped)
 
     // ---- LDS layout of THIS molecule inside the wave's fixed budget
     float *Rl = sm;                                        // [n][PST]   R_j rows
@@ -140,13 +136,12 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     int o = 2 * n * EPNN_PST;
     unsigned short *eij = reinterpret_cast<unsigned short *>(sm + o); // [np]  li | lj << 8
     o += EPN ? ((((np + 1) >> 1) + 3) & ~3) : 0;
-    float *edi = sm + o;                                   // [np]  w_i * delta
-    o += EPN ? ((np + 3) & ~3) : 0;
-    float *edj = sm + o;                                   // [np]  w_j * delta
-    o += EPN ? ((np + 3) & ~3) : 0;
+    float *Dm = sm + o;                                    // [n][DST]  weighted transfers: Dm[i][j] = what i receives from j
+    o += EPN ? ((n * EPNN_DST + 3) & ~3) : 0;
     float *Gl = sm + o;                                    // [glds + 1][PST]; row glds is all zeros
     const int glds = min(np, (A.lds_words - o) / EPNN_PST - 1);
     const bool gover = np > glds;                          // some G rows live in HBM
+    const int ngt = (np + 31) >> 5;
 
     // ---- per-atom registers
     const float nmv = catom ? (A.nm_in ? A.nm_in[a0 + c] : 1.f) : 0.f;
@@ -178,8 +173,16 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
         }
     }
 
+    // first G tiles: We and the first e rows are on their way while the LDS tables are built
+    float gw[24], ge[24];
+    EPNN_WLD(gw, GNN ? X.g[0].we : X.e[0].we, 24);
+    if (ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
+    WAVE_FENCE();
+
     // ---- LDS init
     for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;
+    if (EPN)
+        for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
     if (GNN) {
         for (int i = lane; i < n * 16; i += 64) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
         wave_sync_lds();
@@ -189,40 +192,70 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             if (A.psym[p0 + p]) pm[li * 32 + lj] = (unsigned short)p;
         }
     }
+    if (EPN)
+        for (int p = lane; p < np; p += 64) {
+            const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
+            eij[p] = (unsigned short)(li | (lj << 8));
+        }
     wave_sync_lds();
 
     WAVE_STAMP();   // init done
     const float Nf = (float)A.N, padw = (float)(A.N - n);
     const int Tg = GNN ? A.T : 0, Te = EPN ? A.T : 0;
 
+    // G rows of every near pair for the pair MLP whose We is in gw[] (first e rows in ge[]); rows >= glds go to HBM
+    auto gtiles = [&]() {
+#pragma unroll 1
+        for (int gt = 0; gt < ngt; ++gt) {
+            float en[24];
+            wave_load_e(A.pe, p0, np, min(gt + 1, ngt - 1), c, hh, en);
+            WAVE_FENCE();
+            f32x16 acc = wave_chain<24>(gw, ge, epnn_splat16(0.f));
+            const int slot = gt * 32 + c;
+            if (slot < np) {
+                if (slot < glds) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
+                else epnn_st16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, acc);
+            }
+#pragma unroll
+            for (int s = 0; s < 24; ++s) ge[s] = en[s];
+        }
+    };
+    // start fetching what the NEXT gtiles() needs
+    auto gprefetch = [&](int weoff) {
+        EPNN_WLD(gw, weoff, 24);
+        if (ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
+    };
+
     // ================================================================== GNN steps (charge_gn.py:60-74)
     if (GNN) {
-        float P[16], u1pre[16];
-        // ---- step 0 projections from (xq | hk)
+        float P[16], u1pre[16], pb[16], b2k[16], bn[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bn[r] = 0.f;
+        // ---- step 0: G rows, then P / R / u1pre from (xq | hk)
         {
-            float w[24];
-            EPNN_WLD(w, X.g[0].we, 24);
-            wave_gtiles(w, A.pe, p0, np, Gl, glds, A.gx, c, hh);
-        }
-        {
-            float wa[EPNN_KX], wb[24];
-            f32x16 acc = epnn_splat16(0.f);
+            float wa[EPNN_KX], wb[24], wc[EPNN_KX], wd[24];
             EPNN_WLD(wa, X.wi0, EPNN_KX);
-            acc = wave_chain<EPNN_KX>(wa, xq, acc);
-            if (have_h) { EPNN_WLD(wb, X.wi0 + EPNN_KX * 64, 24); acc = wave_chain<24>(wb, hk, acc); }
+            if (have_h) { EPNN_WLD(wb, X.wi0 + EPNN_KX * 64, 24); }
+            WAVE_FENCE();
+            gtiles();
+            EPNN_WLD(wc, X.wj0, EPNN_KX);
+            if (have_h) { EPNN_WLD(wd, X.wj0 + EPNN_KX * 64, 24); }
+            WAVE_FENCE();
+            f32x16 acc = epnn_splat16(0.f), acr = epnn_splat16(0.f);
+            wave_chain2<EPNN_KX>(wa, wc, xq, acc, acr);
+            if (have_h) wave_chain2<24>(wb, wd, hk, acc, acr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[r] = acc[r];
-            acc = epnn_splat16(0.f);
-            EPNN_WLD(wa, X.wj0, EPNN_KX);
-            acc = wave_chain<EPNN_KX>(wa, xq, acc);
-            if (have_h) { EPNN_WLD(wb, X.wj0 + EPNN_KX * 64, 24); acc = wave_chain<24>(wb, hk, acc); }
-            if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acc);
+            if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
+            EPNN_WLD(pb, X.g[0].w2, 16);
+            epnn_ld16(wp + X.g[0].b2k + hh * 16, b2k);
+            if (have_h) { EPNN_WLD(wb, X.u1h0, 24); }
+            WAVE_FENCE();
             acc = epnn_splat16(0.f);
             if (have_h) {
                 float hm[24];
 #pragma unroll
                 for (int s = 0; s < 24; ++s) hm[s] = nmv * hk[s];       // masked_input = [h, m] * node_mask (charge_gn.py:72)
-                EPNN_WLD(wb, X.u1h0, 24);
                 acc = wave_chain<24>(wb, hm, acc);
             }
 #pragma unroll
@@ -235,117 +268,190 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
         for (int t = 0; t < Tg; ++t) {
             const WaveGnnPack &M = X.g[t];
             const bool lastg = t + 1 == Tg;
-            float S[16];
+            float S[16], u1s[16], w2[16], cv[16], bv[16];
             {
-                float pb[16], b2k[16];
-                EPNN_WLD(pb, M.w2, 16);
-                epnn_ld16(wp + M.b2k + hh * 16, b2k);
                 f32x16 cb2;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { cb2[r] = b2k[r]; S[r] = 0.f; }
-                // ---- partner tiles j = 0..n-1
-#pragma unroll 2
-                for (int j = 0; j < n; ++j) {
-                    float rj[16], g[16];
-                    epnn_ld16(Rl + j * EPNN_PST + hh * 16, rj);
-                    const int slot = pm[j * 32 + c];
-                    if (!gover) {
-                        epnn_ld16(Gl + min(slot, glds) * EPNN_PST + hh * 16, g);      // 0xFFFF -> the zero row
-                    } else {
-                        if (slot >= glds && slot != 0xFFFF) epnn_ld16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, g);
-                        else epnn_ld16(Gl + min(slot, glds) * EPNN_PST + hh * 16, g);
+                // ---- partner tiles j = 0..n-1, operands of tile j+1 (and the slot of j+2) fetched during tile j.
+                //      Two instances: every G row in LDS (the usual case) / some rows in HBM (both sources read, one is 0)
+                auto sweep = [&](auto over_tag) {
+                    constexpr bool OVER = decltype(over_tag)::value;
+                    auto gload = [&](int slot, float (&g)[16], float (&gh)[16]) {
+                        epnn_ld16(Gl + min(slot, glds) * EPNN_PST + hh * 16, g);          // 0xFFFF / overflow -> the zero row
+                        if (OVER) {
+                            if (slot >= glds && slot != 0xFFFF) epnn_ld16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, gh);
+                            else {
+#pragma unroll
+                                for (int s = 0; s < 16; ++s) gh[s] = 0.f;
+                            }
+                        }
+                    };
+                    // tile index jt in [0, n]: partner jt, or (jt == n) the reference's zero-padded partner (R = 0, G = 0,
+                    // charge_gn.py:70) which counts N - n times.  Tiles go through the matrix pipe two at a time.
+                    const float *zrow = Gl + glds * EPNN_PST + hh * 16;
+                    auto rload = [&](int jt, float (&r)[16]) { epnn_ld16(jt < n ? Rl + jt * EPNN_PST + hh * 16 : zrow, r); };
+                    auto slot_of = [&](int jt) -> int { return jt < n ? (int)pm[jt * 32 + c] : 0xFFFF; };
+                    auto two_tiles = [&](const float (&z0)[16], const float (&z1)[16], float w1) {
+                        f32x16 acc0 = cb2, acc1 = cb2;
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            acc0 = epnn_mfma(pb[s], z0[s], acc0);
+                            acc1 = epnn_mfma(pb[s], z1[s], acc1);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[r] = fmaf(w1, fmaxf(acc1[r], 0.f), S[r] + fmaxf(acc0[r], 0.f));
+                    };
+                    auto one_tile = [&](const float (&z0)[16], float w0) {       // K split over two accumulators
+                        f32x16 acc0 = cb2, acc1 = epnn_splat16(0.f);
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            if (s & 1) acc1 = epnn_mfma(pb[s], z0[s], acc1);
+                            else acc0 = epnn_mfma(pb[s], z0[s], acc0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[r] = fmaf(w0, fmaxf(acc0[r] + acc1[r], 0.f), S[r]);
+                    };
+                    auto upd_prefetch = [&]() {          // the update MLP's first operand, fetched under the last tiles
+                        EPNN_WLD(u1s, M.u1s, 16);
+                    };
+                    const int ntile = n + 1;
+                    float rA[16], gA[16], rB[16], gB[16];
+                    int sA = 0xFFFF, sB = 0xFFFF;
+                    if (!OVER) {                                  // operands of the first two tiles, slots of the next two
+                        rload(0, rA);
+                        gload(slot_of(0), gA, gA);
+                        rload(1, rB);
+                        gload(slot_of(1), gB, gB);
+                        sA = slot_of(min(2, n));
+                        sB = slot_of(min(3, n));
                     }
-                    f32x16 acc = cb2;
+                    auto step2 = [&](int jt, bool prefetch) {     // tiles jt, jt+1; then fetch jt+2, jt+3
+                        float z0[16], z1[16];
+                        if (OVER) {                               // rare (large molecules): no fetch-ahead, fewer registers
+                            float hA[16], hB[16];
+                            rload(jt, rA);
+                            gload(slot_of(jt), gA, hA);
+                            rload(jt + 1, rB);
+                            gload(slot_of(jt + 1), gB, hB);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc = epnn_mfma(pb[s], fmaxf((P[s] + rj[s]) + g[s], 0.f), acc);
+                            for (int s = 0; s < 16; ++s) {
+                                z0[s] = fmaxf(((P[s] + rA[s]) + gA[s]) + hA[s], 0.f);
+                                z1[s] = fmaxf(((P[s] + rB[s]) + gB[s]) + hB[s], 0.f);
+                            }
+                        } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) S[r] += fmaxf(acc[r], 0.f);
-                }
-                // ---- the zero-padded partners of the reference (R = 0, G = 0), N - n of them (charge_gn.py:70)
-                {
-                    f32x16 acc = cb2;
+                            for (int s = 0; s < 16; ++s) {
+                                z0[s] = fmaxf((P[s] + rA[s]) + gA[s], 0.f);
+                                z1[s] = fmaxf((P[s] + rB[s]) + gB[s], 0.f);
+                            }
+                            if (prefetch) {
+                                rload(min(jt + 2, n), rA);
+                                gload(sA, gA, gA);
+                                rload(min(jt + 3, n), rB);
+                                gload(sB, gB, gB);
+                                sA = slot_of(min(jt + 4, n));
+                                sB = slot_of(min(jt + 5, n));
+                            }
+                            WAVE_FENCE();
+                        }
+                        two_tiles(z0, z1, jt + 1 == n ? padw : 1.f);
+                    };
+                    const int nfull = ntile >> 1;                 // >= 1
+                    const bool odd = ntile & 1;                   // the padded-partner tile is left over
+                    int jt = 0;
+#pragma unroll 1
+                    for (int k = 0; k + 1 < nfull; ++k, jt += 2) step2(jt, true);
+                    if (odd) {
+                        step2(jt, true);
+                        jt += 2;
+                        upd_prefetch();
+                        WAVE_FENCE();
+                        float z0[16];
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc = epnn_mfma(pb[s], fmaxf(P[s], 0.f), acc);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[r] = fmaf(padw, fmaxf(acc[r], 0.f), S[r]);
-                }
+                        for (int s = 0; s < 16; ++s) z0[s] = fmaxf(P[s], 0.f);
+                        one_tile(z0, padw);
+                    } else {
+                        upd_prefetch();
+                        step2(jt, false);
+                    }
+                };
+                if (gover) sweep(std::true_type{});
+                else sweep(std::false_type{});
             }
             if (t < 2) WAVE_STAMP();   // pair tiles
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
-            float bn[16];
             {
-                float w[16], cv[16], bv[16];
-                EPNN_WLD(w, M.u1s, 16);
+                EPNN_WLD(w2, M.u2, 16);
                 epnn_ld16(wp + M.cb3k + hh * 16, cv);
                 epnn_ld16(wp + M.bu1k + hh * 16, bv);
+                WAVE_FENCE();
                 f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = fmaf(Nf, cv[r], u1pre[r]);
-                acc = wave_chain<16>(w, S, acc);
+                for (int r = 0; r < 16; ++r) acc[r] = u1pre[r];
+                acc = wave_chain<16>(u1s, S, acc);
                 float u1[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u1[r] = fmaxf(fmaf(nmv, acc[r], bv[r]), 0.f);
-                EPNN_WLD(w, M.u2, 16);
+                for (int r = 0; r < 16; ++r) u1[r] = fmaxf(fmaf(nmv, fmaf(Nf, cv[r], acc[r]), bv[r]), 0.f);
                 epnn_ld16(wp + M.bu2k + hh * 16, bv);
+                if (!lastg) gprefetch(X.g[t + 1].we);
+                else if (Te > 0) gprefetch(X.e[0].we);
+                WAVE_FENCE();
+                acc = wave_chain<16>(w2, u1, epnn_splat16(0.f));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = bv[r];
-                acc = wave_chain<16>(w, u1, acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) bn[r] = fmaxf(acc[r], 0.f);
+                for (int r = 0; r < 16; ++r) bn[r] = fmaxf(acc[r] + bv[r], 0.f);
             }
             if (t < 2) WAVE_STAMP();   // U1, U2
             if (!lastg) {
                 // next step: G rows, then P / R / u1pre from (nm*u2 | xq) through the folded matrices
-                {
-                    float w[24];
-                    EPNN_WLD(w, X.g[t + 1].we, 24);
-                    wave_gtiles(w, A.pe, p0, np, Gl, glds, A.gx, c, hh);
-                }
+                float wa[16 + EPNN_KX], wb[16 + EPNN_KX];
+                EPNN_WLD(wa, M.pwi, 16 + EPNN_KX);
+                WAVE_FENCE();
+                gtiles();
                 if (t < 2) WAVE_STAMP();   // G tiles
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bn[r] *= nmv;
-                float w[16], wa[EPNN_KX];
-                f32x16 acc = epnn_splat16(0.f);
-                EPNN_WLD(w, M.pwi, 16);
-                EPNN_WLD(wa, M.pwi + 16 * 64, EPNN_KX);
-                acc = wave_chain<16>(w, bn, acc);
-                acc = wave_chain<EPNN_KX>(wa, xq, acc);
+                float in[16 + EPNN_KX];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) in[s] = bn[s];
+#pragma unroll
+                for (int s = 0; s < EPNN_KX; ++s) in[16 + s] = xq[s];
+                EPNN_WLD(wb, M.pwj, 16 + EPNN_KX);
+                float cu[16], wu[16];
+                EPNN_WLD(wu, M.pu1, 16);
+                epnn_ld16(wp + M.cu3k + hh * 16, cu);
+                WAVE_FENCE();
+                f32x16 acc = epnn_splat16(0.f), acr = epnn_splat16(0.f);
+                wave_chain2<16 + EPNN_KX>(wa, wb, in, acc, acr);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P[r] = acc[r];
-                acc = epnn_splat16(0.f);
-                EPNN_WLD(w, M.pwj, 16);
-                EPNN_WLD(wa, M.pwj + 16 * 64, EPNN_KX);
-                acc = wave_chain<16>(w, bn, acc);
-                acc = wave_chain<EPNN_KX>(wa, xq, acc);
-                if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acc);
-                float cu[16];
-                epnn_ld16(wp + M.cu3k + hh * 16, cu);
+                if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
+                EPNN_WLD(pb, X.g[t + 1].w2, 16);
+                epnn_ld16(wp + X.g[t + 1].b2k + hh * 16, b2k);
+                WAVE_FENCE();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = nmv * cu[r];
-                EPNN_WLD(w, M.pu1, 16);
-                acc = wave_chain<16>(w, bn, acc);
+                acc = wave_chain<16>(wu, bn, acc);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) u1pre[r] = acc[r];
                 wave_sync_all();
-            } else {
-                // h = node_mask * (Wu3^T u2 + bu3)  (charge_gn.py:73-74), straight into the hk registers
-                float w[16], bv[16];
-                f32x16 acc;
-                EPNN_WLD(w, X.u3, 16);
-                epnn_ld16(wp + X.bu3k + hh * 16, bv);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = bv[r];
-                acc = wave_chain<16>(w, bn, acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hk[r] = nmv * acc[r];
-                EPNN_WLD(w, X.u3 + 16 * 64, 16);
-                epnn_ld16(wp + X.bu3k + 32 + hh * 16, bv);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = bv[r];
-                acc = wave_chain<16>(w, bn, acc);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) hk[16 + r] = nmv * acc[r];
+                if (t < 2) WAVE_STAMP();   // projections
             }
+        }
+        {
+            // h = node_mask * (Wu3^T u2 + bu3)  (charge_gn.py:73-74) after the last step, straight into the hk registers
+            float w[16], w2[16], bv[16], bw[16];
+            EPNN_WLD(w, X.u3, 16);
+            EPNN_WLD(w2, X.u3 + 16 * 64, 16);
+            epnn_ld16(wp + X.bu3k + hh * 16, bv);
+            epnn_ld16(wp + X.bu3k + 32 + hh * 16, bw);
+            WAVE_FENCE();
+            f32x16 acc = epnn_splat16(0.f), ac2 = epnn_splat16(0.f);
+            wave_chain2<16>(w, w2, bn, acc, ac2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hk[r] = nmv * (acc[r] + bv[r]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) hk[16 + r] = nmv * (ac2[r] + bw[r]);
         }
         if (A.h_out && catom) {
 #pragma unroll
@@ -361,43 +467,35 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     // ================================================================== EPN steps (charge_gn.py:98-118)
     if (EPN) {
         wave_sync_lds();                                    // the pair map is dead: its rows become P rows
-        for (int p = lane; p < np; p += 64) {
-            const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
-            eij[p] = (unsigned short)(li | (lj << 8));
-        }
         const int qs = (nx + 1) >> 1, qh = (nx + 1) & 1;    // register / half-wave of xq that holds q
-        const int ngt = (np + 31) >> 5;
 #pragma unroll 1
         for (int t = 0; t < Te; ++t) {
             const WaveEpnPack &M = X.e[t];
+            float in[EPNN_KX + 24];
+#pragma unroll
+            for (int s = 0; s < EPNN_KX; ++s) in[s] = xq[s];
+#pragma unroll
+            for (int s = 0; s < 24; ++s) in[EPNN_KX + s] = hk[s];
             {
-                float w[24];
-                EPNN_WLD(w, M.we, 24);
-                wave_gtiles(w, A.pe, p0, np, Gl, glds, A.gx, c, hh);
-            }
-            if (t < 2) WAVE_STAMP();   // EPN G tiles
-            {
-                float wa[EPNN_KX], wb[24];
-                f32x16 acc = epnn_splat16(0.f);
-                EPNN_WLD(wa, M.wi, EPNN_KX);
-                EPNN_WLD(wb, M.wi + EPNN_KX * 64, 24);
-                acc = wave_chain<EPNN_KX>(wa, xq, acc);
-                acc = wave_chain<24>(wb, hk, acc);
+                float wa[EPNN_KX + 24], wb[EPNN_KX + 24];
+                EPNN_WLD(wa, M.wi, EPNN_KX + 24);
+                WAVE_FENCE();
+                gtiles();
+                if (t < 2) WAVE_STAMP();   // EPN G tiles
+                EPNN_WLD(wb, M.wj, EPNN_KX + 24);
+                WAVE_FENCE();
+                f32x16 acc = epnn_splat16(0.f), acr = epnn_splat16(0.f);
+                wave_chain2<EPNN_KX + 24>(wa, wb, in, acc, acr);
                 if (catom) epnn_st16(Pl + c * EPNN_PST + hh * 16, acc);
-                acc = epnn_splat16(0.f);
-                EPNN_WLD(wa, M.wj, EPNN_KX);
-                EPNN_WLD(wb, M.wj + EPNN_KX * 64, 24);
-                acc = wave_chain<EPNN_KX>(wa, xq, acc);
-                acc = wave_chain<24>(wb, hk, acc);
-                if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acc);
+                if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
             }
+            float pb[16], b2v[16], w3[16];
+            EPNN_WLD(pb, M.w2, 16);
+            epnn_ld16(wp + M.b2k + hh * 16, b2v);
+            epnn_ld16(wp + M.w3k + hh * 16, w3);
             wave_sync_all();
             if (t < 2) WAVE_STAMP();   // EPN P, R
             {
-                float pb[16], b2v[16], w3[16];
-                EPNN_WLD(pb, M.w2, 16);
-                epnn_ld16(wp + M.b2k + hh * 16, b2v);
-                epnn_ld16(wp + M.w3k + hh * 16, w3);
 #pragma unroll 1
                 for (int gt = 0; gt < ngt; ++gt) {
                     const int slot = gt * 32 + c;
@@ -406,43 +504,51 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                     const int ij = eij[sl];
                     const int li = ij & 0xFF, lj = ij >> 8;
                     const float wi = A.pwi[p0 + sl], wj = A.pwj[p0 + sl];
-                    float g[16];
+                    float g[16], pi_[16], rj_[16], pj_[16], ri_[16];
                     if (sl < glds) epnn_ld16(Gl + sl * EPNN_PST + hh * 16, g);
                     else epnn_ld16(A.gx + (size_t)(p0 + sl) * 32 + hh * 16, g);
+                    epnn_ld16(Pl + li * EPNN_PST + hh * 16, pi_);
+                    epnn_ld16(Rl + lj * EPNN_PST + hh * 16, rj_);
+                    epnn_ld16(Pl + lj * EPNN_PST + hh * 16, pj_);
+                    epnn_ld16(Rl + li * EPNN_PST + hh * 16, ri_);
+                    // the two directions of the pair are independent chains: interleaved (rows = out feature, col = pair)
+                    f32x16 au, av;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        au = epnn_mfma(pb[s], fmaxf((g[s] + pi_[s]) + rj_[s], 0.f), au);
+                        av = epnn_mfma(pb[s], fmaxf((g[s] + pj_[s]) + ri_[s], 0.f), av);
+                    }
                     float fu = 0.f, fv = 0.f;
 #pragma unroll
-                    for (int dir = 0; dir < 2; ++dir) {
-                        const int ai = dir == 0 ? li : lj, aj = dir == 0 ? lj : li;
-                        float ta[16], tb[16];
-                        epnn_ld16(Pl + ai * EPNN_PST + hh * 16, ta);
-                        epnn_ld16(Rl + aj * EPNN_PST + hh * 16, tb);
-                        f32x16 acc;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = b2v[r];
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) acc = epnn_mfma(pb[s], fmaxf((g[s] + ta[s]) + tb[s], 0.f), acc);
-                        float f = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) f = fmaf(w3[r], fmaxf(acc[r], 0.f), f);
-                        if (dir == 0) fu = f; else fv = f;
+                    for (int r = 0; r < 16; ++r) {
+                        fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
+                        fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
                     }
                     fu += epnn_swap32(fu);
                     fv += epnn_swap32(fv);
                     const float d = 0.5f * (fu - fv);                  // charge_gn.py:116
-                    if (hh == 0 && valid) { edi[slot] = wi * d; edj[slot] = wj * d; }
+                    // entries with weight 0 are never written (they stay 0): a one-sided entry (j,i) of the dense
+                    // front-end must not clear what the entry (i,j) wrote
+                    if (hh == 0 && valid && wi != 0.f) Dm[li * EPNN_DST + lj] = wi * d;
+                    if (hh == 1 && valid && wj != 0.f) Dm[lj * EPNN_DST + li] = -(wj * d);
                 }
             }
             wave_sync_lds();
+            if (t + 1 < Te) gprefetch(X.e[t + 1].we);     // on its way during the charge update
+            WAVE_FENCE();
             if (t < 2) WAVE_STAMP();   // EPN pair tiles
-            // q_i += sum_j antisym_ij (charge_gn.py:118): each half-wave scans every other pair, fixed order
+            // q_i += sum_j antisym_ij (charge_gn.py:118): lane (i, hh) adds row i of the transfer matrix, columns j = hh mod 2
             {
-                float dq = 0.f;
-                for (int p = hh; p < np; p += 2) {
-                    const int ij = eij[p];
-                    const float di = edi[p], dj = edj[p];
-                    dq += ((ij & 0xFF) == c) ? di : 0.f;
-                    dq -= ((ij >> 8) == c) ? dj : 0.f;
+                float dq0 = 0.f, dq1 = 0.f;
+                const float *drow = Dm + (catom ? c : 0) * EPNN_DST + hh;
+#pragma unroll 4
+                for (int j = 0; j + hh < n; j += 4) {
+                    dq0 += drow[j];
+                    dq1 += (j + 2 + hh < n) ? drow[j + 2] : 0.f;
                 }
+                float dq = dq0 + dq1;
                 dq += epnn_swap32(dq);
 #pragma unroll
                 for (int s = 0; s < EPNN_KX; ++s)
@@ -467,5 +573,5 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
         A.stamps[(size_t)blockIdx.x * 64 + 63] = ((unsigned long long)n << 32) | (unsigned)np;
     }
 #endif
-    (void)cr; (void)Tg;
+    (void)Tg;
 }
