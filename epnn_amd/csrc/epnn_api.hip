@@ -94,7 +94,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
-                      &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
+                      &h->d_status, &h->d_bsum, &h->d_pbase, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_hsplit, &h->s_gx, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
@@ -421,6 +421,20 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
             P.large_list.push_back(b);
         }
     }
+    {   // pair slots of the in-kernel front-end: every i<j pair of every molecule
+        std::vector<int> pbase(B);
+        long long run = 0;
+        for (int b = 0; b < B; ++b) {
+            const long long n = offsets[b + 1] - offsets[b];
+            pbase[b] = (int)run;
+            run += n <= EPNN_SMALL_NMAX ? n * (n - 1) / 2 : 0;
+        }
+        if (run > 0x7fffffffLL / 64) EPNN_FAIL("forward: batch too large (%lld pair slots)", run);
+        P.pair_slots = (int)run;
+        if (h->d_pbase.ensure((size_t)B * sizeof(int))) return 1;
+        HIPCHK(hipMemcpyAsync(h->d_pbase.p, pbase.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));        // pbase is a local
+    }
     std::stable_sort(P.small_order.begin(), P.small_order.end(), [&](int a, int b) {
         return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
     });
@@ -485,6 +499,7 @@ struct PairSource {     // where the fused / tiled kernels read atoms and pairs 
     const float *d_x = nullptr, *d_Q = nullptr, *d_hin = nullptr, *d_qin = nullptr, *d_nm = nullptr;
     float *d_q = nullptr, *d_hout = nullptr;
     int run_gnn = 1, run_epn = 1;
+    const float *d_xyz = nullptr;    // set: the wave kernel builds the pair list itself (no front-end kernels ran)
 };
 
 static int launch_large(epnn_handle *h, const PairSource &S) {
@@ -528,10 +543,17 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     if (h->l_nm.ensure(P.small_order.size() * 4 * 64 * 8)) return 1;
     A.stamps = h->l_nm.as<unsigned long long>();
 #endif
+    A.xyz = S.d_xyz;
+    A.pbase = h->d_pbase.as<int>();
+    A.mu = h->d_mu.as<double>();
+    A.cutoff = (double)h->cfg.cutoff;
+    A.eta = (double)h->cfg.eta;
+    A.tol = h->cfg.near_tol;
     const dim3 grid((unsigned)P.small_order.size());
-    if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true>), grid, dim3(64), (size_t)lds, h->stream, A);
-    else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
-    else hipLaunchKernelGGL((k_wave_forward<false, true>), grid, dim3(64), (size_t)lds, h->stream, A);
+    if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A);
+    else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
+    else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A);
+    else hipLaunchKernelGGL((k_wave_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -692,7 +714,12 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     if (pack_weights(h)) return 1;
     if (build_plan(h, B, N, offsets)) return 1;
     const Plan &P = h->plan;
-    if (ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
+    // Batches of small molecules only: the wave kernel builds each molecule's pair list itself (slots for every i<j
+    // pair of the molecule, so nothing can overflow) and no front-end kernel runs.
+    const bool wave_front = h->opt_wave && h->opt_wave_front && P.large_list.empty() && h->cfg.nx + 3 <= 2 * EPNN_KX &&
+                            h->cfg.e_dim == EPNN_EDIM;
+    if (ensure_pairs(h, wave_front ? std::max(h->pcap, P.pair_slots)
+                                   : std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     hipEvent_t *ev = nullptr;
     if (h->opt_profile > 0) {
@@ -700,12 +727,13 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
         h->ev_next += 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
-    if (run_frontend_xyz(h, d_xyz)) return 1;
+    if (!wave_front && run_frontend_xyz(h, d_xyz)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[1], h->stream));
     PairSource S;
     S.d_x = d_x;
     S.d_Q = d_Q;
     S.d_q = d_q;
+    S.d_xyz = wave_front ? d_xyz : nullptr;
     h->ev_mid = ev ? ev[4] : nullptr;             // recorded between the two halves of a split launch
     h->ev_mid_used = false;
     if (launch_small(h, S)) return 1;
@@ -716,7 +744,8 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
     // status + pair count come back with the results
     HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_status + 1, wave_front ? h->d_status.as<int>() + 1 : h->d_rowoff.as<int>() + P.A, sizeof(int),
+                          hipMemcpyDeviceToHost, h->stream));
     h->stats[1] = (int64_t)P.small_order.size();
     h->stats[2] = (int64_t)P.large_list.size();
     return 0;
@@ -907,6 +936,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "split")) { h->opt_split = value; }
     else if (!strcmp(name, "wave")) { h->opt_wave = value; }
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
+    else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
     else if (!strcmp(name, "small_glds")) { h->small_glds = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;

@@ -62,6 +62,7 @@ struct Plan {                 // what the host derives from `offsets`
     std::vector<int> small_order;   // molecules on the fused path, largest first
     std::vector<int> large_list;    // molecules on the tiled path
     int small_nmax = 0;
+    int pair_slots = 0;             // sum of n(n-1)/2 over the small molecules (capacity of the in-kernel front-end)
     bool valid = false;
 };
 
@@ -87,7 +88,7 @@ struct epnn_handle {
     DevBuf d_mu;
     // plan + workspace
     Plan plan;
-    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status, d_bsum;
+    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status, d_bsum, d_pbase;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     int pcap = 0;
     int pair_cap_per_atom = 16;
@@ -97,6 +98,7 @@ struct epnn_handle {
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_hsplit, s_gx;
     int small_glds = 0;               // G rows kept in LDS per molecule (0 = all of them; smaller values trade LDS for HBM overflow rows)
     int opt_wave = 1;                 // fused path: 1 = wave-autonomous kernel (one wavefront per molecule), 0 = 4-wave workgroup kernel
+    int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     int opt_split = -1;               // fused kernel as a GNN launch + an EPN launch: 0 never, 1 always, -1 auto (big batches)
     // large path workspace (epnn_large.hip.h)

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "epnn_common.h"
+#include "epnn_frontend.hip.h"
 
 struct WaveArgs {
     const float *wpack;
@@ -33,7 +34,7 @@ struct WaveArgs {
     const int *order;      // molecules of this launch (largest first)
     const int *row_off;    // [A+1]
     const int *pi, *pj, *psym;
-    const float *pe, *pwi, *pwj;
+    float *pe, *pwi, *pwj;  // written by the kernel itself with the in-kernel front-end, read-only otherwise
     float *q_out;          // [A]
     float *h_out;          // optional [A][48]
     int *status;
@@ -43,6 +44,12 @@ struct WaveArgs {
     const float *nm_in;    // optional [A]
     float *gx;             // [pcap][32] rows of G that do not fit the wave's LDS budget
     int lds_words;         // LDS budget of one wave (floats)
+    // in-kernel front-end (FRONT): the wave builds its molecule's near-pair list itself (get_init_edges, charge_gn.py:122-163)
+    const float *xyz;      // [A][3]
+    const int *pbase;      // [B] first pair slot of molecule b: sum of n(n-1)/2 over the molecules before it
+    const double *mu;      // [48]
+    double cutoff, eta;
+    float tol;
     unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][64] s_memtime values
 };
 
@@ -69,6 +76,13 @@ __device__ __forceinline__ void wave_sync_lds() {
 __device__ __forceinline__ void wave_sync_all() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// distance exactly as scipy.spatial.distance_matrix on float32 coordinates promoted to float64 (charge_gn.py:124),
+// same operation order as epnn_dist (epnn_frontend.hip.h)
+__device__ __forceinline__ double wave_dist(const double *xs, int i, int j) {
+    const double dx = xs[3 * j + 0] - xs[3 * i + 0], dy = xs[3 * j + 1] - xs[3 * i + 1], dz = xs[3 * j + 2] - xs[3 * i + 2];
+    return sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
 }
 
 // first feature of the g-th group of four of the hk order
@@ -113,14 +127,15 @@ __device__ __forceinline__ void wave_load_e(const float *pe, int p0, int np, int
 // keep the loads issued above this point above it: the next chain's operands are fetched while the current chain runs
 #define WAVE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <bool GNN, bool EPN>
+template <bool GNN, bool EPN, bool FRONT>
 __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
     if (*A.status & EPNN_ST_PAIR_OVERFLOW) return;
     const int b = A.order[blockIdx.x];
     const int a0 = A.moff[b], n = A.moff[b + 1] - a0;
-    const int p0 = A.row_off[a0], np = A.row_off[a0 + n] - p0;
+    const int p0 = FRONT ? A.pbase[b] : A.row_off[a0];
+    int np = FRONT ? 0 : A.row_off[a0 + n] - p0;
     const int nx = A.nx;
     const float *wp = A.wpack;
     const WaveIndex &X = A.wx;
@@ -129,6 +144,21 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     WAVE_STAMP();
     const bool catom = c < n;
 
+    // ---- in-kernel front-end, pass 1: coordinates -> LDS, number of pairs with D < cutoff (row-major i < j)
+    double *xs = reinterpret_cast<double *>(sm);           // [n][3] float32 coordinates promoted like SciPy does
+    if (FRONT) {
+        if (hh == 0 && c < n) {
+            xs[3 * c + 0] = (double)A.xyz[3 * (size_t)(a0 + c) + 0];
+            xs[3 * c + 1] = (double)A.xyz[3 * (size_t)(a0 + c) + 1];
+            xs[3 * c + 2] = (double)A.xyz[3 * (size_t)(a0 + c) + 2];
+        }
+        wave_sync_lds();
+        for (int i0 = 0; i0 + 1 < n; i0 += 2) {            // half hh takes row i0 + hh, lane c is partner j = c
+            const int i = i0 + hh;
+            const bool near = c > i && c < n && wave_dist(xs, i, c) < A.cutoff;
+            np += __popcll(__ballot(near));
+        }
+    }
     // ---- LDS layout of THIS molecule inside the wave's fixed budget
     float *Rl = sm;                                        // [n][PST]   R_j rows
     float *Pl = sm + n * EPNN_PST;                         // [n][PST]   P_i rows (EPN); the GNN keeps its pair map here
@@ -176,27 +206,84 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     // first G tiles: We and the first e rows are on their way while the LDS tables are built
     float gw[24], ge[24];
     EPNN_WLD(gw, GNN ? X.g[0].we : X.e[0].we, 24);
-    if (ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
+    if (!FRONT && ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
     WAVE_FENCE();
 
     // ---- LDS init
-    for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;
     if (EPN)
         for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
-    if (GNN) {
+    if (GNN)
         for (int i = lane; i < n * 16; i += 64) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
+    wave_sync_lds();
+    if (FRONT) {
+        // ---- pass 2: slots in row-major order (rows i0, i0+1 per step; the lower row's pairs first)
+        int base = 0;
+        for (int i0 = 0; i0 + 1 < n; i0 += 2) {
+            const int i = i0 + hh;
+            const bool near = c > i && c < n && wave_dist(xs, i, c) < A.cutoff;
+            const unsigned long long bal = __ballot(near);
+            const unsigned lo = (unsigned)bal, hi = (unsigned)(bal >> 32);
+            if (near) {
+                const int slot = base + (hh ? __popc(lo) : 0) + __popc((hh ? hi : lo) & ((1u << c) - 1u));
+                eij[slot] = (unsigned short)(i | (c << 8));
+                pm[c * 32 + i] = (unsigned short)slot;                 // e is symmetric: both directions share the entry
+                pm[i * 32 + c] = (unsigned short)slot;
+            }
+            base += __popc(lo) + __popc(hi);
+        }
         wave_sync_lds();
-        for (int p = lane; p < np; p += 64) {
-            const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
-            pm[lj * 32 + li] = (unsigned short)p;                       // message into i = li from j = lj
-            if (A.psym[p0 + p]) pm[li * 32 + lj] = (unsigned short)p;
+        // ---- pass 3: Gaussian edge features of 64 pairs at a time (charge_gn.py:148-161, float64 like NumPy, cast to
+        //      float32), near flag = max_k e_k > tol (charge_gn.py:90-94; the largest e_k belongs to the mu closest to D)
+        double *Dc = reinterpret_cast<double *>(Gl);                    // [64] D, [64] C of the chunk (G rows come later)
+        double *Cc = Dc + 64;
+        const double pi_d = 3.141592653589793;
+        for (int s0 = 0; s0 < np; s0 += 64) {
+            const int m = min(64, np - s0);
+            if (lane < m) {
+                const int ij = eij[s0 + lane];
+                const double D = wave_dist(xs, ij & 0xFF, ij >> 8);
+                double C = (cos(pi_d * (D - 0.0) / A.cutoff) + 1.0) / 2.0;
+                if (D <= 0.0) C = 1.0;
+                double best = 1e300;
+                int kb = 0;
+                for (int k = 0; k < EPNN_EDIM; ++k) {
+                    const double d = D - A.mu[k];
+                    if (d * d < best) { best = d * d; kb = k; }
+                }
+                const double db = D - A.mu[kb];
+                const float emax = (float)(C * exp(-A.eta * (db * db)));
+                const float w = emax > A.tol ? 1.0f : 0.0f;
+                A.pwi[p0 + s0 + lane] = w;
+                A.pwj[p0 + s0 + lane] = w;
+                Dc[lane] = D;
+                Cc[lane] = C;
+            }
+            wave_sync_lds();
+            for (int idx = lane; idx < m * EPNN_EDIM; idx += 64) {
+                const int pr = idx / EPNN_EDIM, ch = idx - pr * EPNN_EDIM;
+                const double d = Dc[pr] - A.mu[ch];
+                A.pe[(size_t)(p0 + s0 + pr) * EPNN_EDIM + ch] = (float)(Cc[pr] * exp(-A.eta * (d * d)));     // charge_gn.py:160-161
+            }
+            wave_sync_lds();
         }
+        if (lane == 0) atomicAdd(A.status + 1, np);                    // statistics: near pairs of the batch
+        wave_sync_all();
+        if (ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
+    } else {
+        if (GNN)
+            for (int p = lane; p < np; p += 64) {
+                const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
+                pm[lj * 32 + li] = (unsigned short)p;                   // message into i = li from j = lj
+                if (A.psym[p0 + p]) pm[li * 32 + lj] = (unsigned short)p;
+            }
+        if (EPN)
+            for (int p = lane; p < np; p += 64) {
+                const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
+                eij[p] = (unsigned short)(li | (lj << 8));
+            }
     }
-    if (EPN)
-        for (int p = lane; p < np; p += 64) {
-            const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
-            eij[p] = (unsigned short)(li | (lj << 8));
-        }
+    // the G zero row and the transfer matrix last: the front-end used those words as scratch
+    for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;
     wave_sync_lds();
 
     WAVE_STAMP();   // init done
