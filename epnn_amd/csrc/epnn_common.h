@@ -26,6 +26,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Offsets (in floats) into the packed weight buffer.
 struct PairMlpPack {      // one message_fns[t] / pass_fns[t]

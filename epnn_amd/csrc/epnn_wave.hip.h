@@ -232,39 +232,48 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             base += __popc(lo) + __popc(hi);
         }
         wave_sync_lds();
-        // ---- pass 3: Gaussian edge features of 64 pairs at a time (charge_gn.py:148-161, float64 like NumPy, cast to
-        //      float32), near flag = max_k e_k > tol (charge_gn.py:90-94; the largest e_k belongs to the mu closest to D)
-        double *Dc = reinterpret_cast<double *>(Gl);                    // [64] D, [64] C of the chunk (G rows come later)
-        double *Cc = Dc + 64;
+        // ---- pass 3: Gaussian edge features, one lane per pair (charge_gn.py:148-161: float64, then cast to float32).
+        //      e_k = C exp(-eta (D - mu_k)^2) over the evenly spaced mu_k is a geometric-like sequence:
+        //      e_{k+1} = e_k rho_k, rho_{k+1} = rho_k exp(-2 eta dmu^2): two exp per pair instead of 48 (float64 products;
+        //      the accumulated rounding stays below 1e-12 relative, far inside the float32 cast).
+        //      near flag = max_k e_k > tol (charge_gn.py:90-94), evaluated exactly at the mu closest to D.
         const double pi_d = 3.141592653589793;
+        const double mu0 = A.mu[0], dmu = (A.mu[EPNN_EDIM - 1] - A.mu[0]) / (double)(EPNN_EDIM - 1);
+        const double qq = exp(-2.0 * A.eta * dmu * dmu);
         for (int s0 = 0; s0 < np; s0 += 64) {
-            const int m = min(64, np - s0);
-            if (lane < m) {
+            if (s0 + lane < np) {
                 const int ij = eij[s0 + lane];
                 const double D = wave_dist(xs, ij & 0xFF, ij >> 8);
                 double C = (cos(pi_d * (D - 0.0) / A.cutoff) + 1.0) / 2.0;
                 if (D <= 0.0) C = 1.0;
+                int kb = min(EPNN_EDIM - 1, max(0, (int)((D - mu0) / dmu + 0.5)));
                 double best = 1e300;
-                int kb = 0;
-                for (int k = 0; k < EPNN_EDIM; ++k) {
+                int kbest = kb;
+                for (int k = max(0, kb - 1); k <= min(EPNN_EDIM - 1, kb + 1); ++k) {
                     const double d = D - A.mu[k];
-                    if (d * d < best) { best = d * d; kb = k; }
+                    if (d * d < best) { best = d * d; kbest = k; }
                 }
-                const double db = D - A.mu[kb];
+                const double db = D - A.mu[kbest];
                 const float emax = (float)(C * exp(-A.eta * (db * db)));
                 const float w = emax > A.tol ? 1.0f : 0.0f;
                 A.pwi[p0 + s0 + lane] = w;
                 A.pwj[p0 + s0 + lane] = w;
-                Dc[lane] = D;
-                Cc[lane] = C;
+                const double t0 = D - mu0;
+                double e = C * exp(-A.eta * (t0 * t0));
+                double rho = exp(A.eta * dmu * (2.0 * t0 - dmu));
+                float *erow = A.pe + (size_t)(p0 + s0 + lane) * EPNN_EDIM;
+#pragma unroll 1
+                for (int k4 = 0; k4 < EPNN_EDIM; k4 += 4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[u] = (float)e;
+                        e *= rho;
+                        rho *= qq;
+                    }
+                    *reinterpret_cast<f32x4 *>(erow + k4) = v;
+                }
             }
-            wave_sync_lds();
-            for (int idx = lane; idx < m * EPNN_EDIM; idx += 64) {
-                const int pr = idx / EPNN_EDIM, ch = idx - pr * EPNN_EDIM;
-                const double d = Dc[pr] - A.mu[ch];
-                A.pe[(size_t)(p0 + s0 + pr) * EPNN_EDIM + ch] = (float)(Cc[pr] * exp(-A.eta * (d * d)));     // charge_gn.py:160-161
-            }
-            wave_sync_lds();
         }
         if (lane == 0) atomicAdd(A.status + 1, np);                    // statistics: near pairs of the batch
         wave_sync_all();
@@ -299,9 +308,12 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             WAVE_FENCE();
             f32x16 acc = wave_chain<24>(gw, ge, epnn_splat16(0.f));
             const int slot = gt * 32 + c;
-            if (slot < np) {
-                if (slot < glds) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
-                else epnn_st16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, acc);
+            // two separate predicated stores: merged into one `cond ? lds : global` pointer they become flat stores,
+            // whose completion wait also waits for the e rows fetched ahead
+            if (slot < min(np, glds)) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
+            if (gover) {
+                asm volatile("" ::: "memory");
+                if (slot >= glds && slot < np) epnn_st16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, acc);
             }
 #pragma unroll
             for (int s = 0; s < 24; ++s) ge[s] = en[s];
@@ -387,7 +399,12 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                             acc1 = epnn_mfma(pb[s], z1[s], acc1);
                         }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) S[r] = fmaf(w1, fmaxf(acc1[r], 0.f), S[r] + fmaxf(acc0[r], 0.f));
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2 m0 = {fmaxf(acc0[r], 0.f), fmaxf(acc0[r + 1], 0.f)};
+                            const f32x2 m1 = {fmaxf(acc1[r], 0.f), fmaxf(acc1[r + 1], 0.f)};
+                            const f32x2 sv = (f32x2{S[r], S[r + 1]} + m0) + f32x2{w1, w1} * m1;
+                            S[r] = sv[0]; S[r + 1] = sv[1];
+                        }
                     };
                     auto one_tile = [&](const float (&z0)[16], float w0) {       // K split over two accumulators
                         f32x16 acc0 = cb2, acc1 = epnn_splat16(0.f);
@@ -428,9 +445,12 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                             }
                         } else {
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) {
-                                z0[s] = fmaxf((P[s] + rA[s]) + gA[s], 0.f);
-                                z1[s] = fmaxf((P[s] + rB[s]) + gB[s], 0.f);
+                            for (int s = 0; s < 16; s += 2) {                  // packed adds (v_pk_add_f32)
+                                const f32x2 p = {P[s], P[s + 1]};
+                                const f32x2 a = (p + f32x2{rA[s], rA[s + 1]}) + f32x2{gA[s], gA[s + 1]};
+                                const f32x2 bq = (p + f32x2{rB[s], rB[s + 1]}) + f32x2{gB[s], gB[s + 1]};
+                                z0[s] = fmaxf(a[0], 0.f); z0[s + 1] = fmaxf(a[1], 0.f);
+                                z1[s] = fmaxf(bq[0], 0.f); z1[s + 1] = fmaxf(bq[1], 0.f);
                             }
                             if (prefetch) {
                                 rload(min(jt + 2, n), rA);
@@ -583,14 +603,23 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             wave_sync_all();
             if (t < 2) WAVE_STAMP();   // EPN P, R
             {
+                // pair record of the next tile (indices in LDS, weights in HBM) fetched one tile ahead
+                int ij_n = eij[c < np ? c : 0];
+                float wi_n = A.pwi[p0 + (c < np ? c : 0)], wj_n = A.pwj[p0 + (c < np ? c : 0)];
 #pragma unroll 1
                 for (int gt = 0; gt < ngt; ++gt) {
                     const int slot = gt * 32 + c;
                     const bool valid = slot < np;
                     const int sl = valid ? slot : 0;
-                    const int ij = eij[sl];
+                    const int ij = ij_n;
+                    const float wi = wi_n, wj = wj_n;
+                    {
+                        const int sn = slot + 32 < np ? slot + 32 : 0;
+                        ij_n = eij[sn];
+                        wi_n = A.pwi[p0 + sn];
+                        wj_n = A.pwj[p0 + sn];
+                    }
                     const int li = ij & 0xFF, lj = ij >> 8;
-                    const float wi = A.pwi[p0 + sl], wj = A.pwj[p0 + sl];
                     float g[16], pi_[16], rj_[16], pj_[16], ri_[16];
                     if (sl < glds) epnn_ld16(Gl + sl * EPNN_PST + hh * 16, g);
                     else epnn_ld16(A.gx + (size_t)(p0 + sl) * 32 + hh * 16, g);
