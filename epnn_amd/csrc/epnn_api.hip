@@ -549,6 +549,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.cutoff = (double)h->cfg.cutoff;
     A.eta = (double)h->cfg.eta;
     A.tol = h->cfg.near_tol;
+    A.host_status = h->h_status;          // pinned, device-visible
     const dim3 grid((unsigned)P.small_order.size());
     if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A);
     else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
@@ -720,7 +721,10 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
                             h->cfg.e_dim == EPNN_EDIM;
     if (ensure_pairs(h, wave_front ? std::max(h->pcap, P.pair_slots)
                                    : std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
-    HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    // the in-kernel front-end keeps the control words zeroed itself (last wave) and writes status + pair count to the
+    // pinned host words: no memset kernel before and no copy kernels after the launch
+    if (!wave_front || !h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    h->ctl_clean = wave_front;
     hipEvent_t *ev = nullptr;
     if (h->opt_profile > 0) {
         ev = h->evpool.data() + 5 * (h->ev_next % h->opt_profile);
@@ -743,9 +747,10 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     if (launch_large(h, S)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
     // status + pair count come back with the results
-    HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_status + 1, wave_front ? h->d_status.as<int>() + 1 : h->d_rowoff.as<int>() + P.A, sizeof(int),
-                          hipMemcpyDeviceToHost, h->stream));
+    if (!wave_front) {
+        HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
     h->stats[1] = (int64_t)P.small_order.size();
     h->stats[2] = (int64_t)P.large_list.size();
     return 0;
@@ -1028,6 +1033,7 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     D.pwj = h->d_pwj.as<float>();
     D.status = h->d_status.as<int>();
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    h->ctl_clean = false;
     const unsigned gA = (unsigned)std::min<size_t>((A * (nx + EPNN_EDIM + 2) + 255) / 256, 4096);
     const unsigned rows = (unsigned)((P.A + 3) / 4);
     hipLaunchKernelGGL(k_dn_compact, dim3(gA), dim3(256), 0, h->stream, D);

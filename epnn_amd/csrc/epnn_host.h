@@ -98,6 +98,7 @@ struct epnn_handle {
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_hsplit, s_gx;
     int small_glds = 0;               // G rows kept in LDS per molecule (0 = all of them; smaller values trade LDS for HBM overflow rows)
     int opt_wave = 1;                 // fused path: 1 = wave-autonomous kernel (one wavefront per molecule), 0 = 4-wave workgroup kernel
+    bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     int opt_split = -1;               // fused kernel as a GNN launch + an EPN launch: 0 never, 1 always, -1 auto (big batches)

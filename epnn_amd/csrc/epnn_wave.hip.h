@@ -50,6 +50,7 @@ struct WaveArgs {
     const double *mu;      // [48]
     double cutoff, eta;
     float tol;
+    int *host_status;      // pinned host ints [0] status bits [1] near pairs of the batch: written by the last wave to finish
     unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][64] s_memtime values
 };
 
@@ -131,7 +132,7 @@ template <bool GNN, bool EPN, bool FRONT>
 __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
-    if (*A.status & EPNN_ST_PAIR_OVERFLOW) return;
+    if (!FRONT && (*A.status & EPNN_ST_PAIR_OVERFLOW)) return;
     const int b = A.order[blockIdx.x];
     const int a0 = A.moff[b], n = A.moff[b + 1] - a0;
     const int p0 = FRONT ? A.pbase[b] : A.row_off[a0];
@@ -275,7 +276,6 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                 }
             }
         }
-        if (lane == 0) atomicAdd(A.status + 1, np);                    // statistics: near pairs of the batch
         wave_sync_all();
         if (ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
     } else {
@@ -681,6 +681,21 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
         const float qo = epnn_swap32(qout);
         if (qh == 1) qout = qo;
         if (hh == 0 && catom) A.q_out[a0 + c] = qout;
+    }
+    if (FRONT && lane == 0) {
+        // No memset before and no copy after the launch: the last wave to finish hands status + pair count to the host
+        // and leaves the three control words zeroed for the next forward of this handle.
+        atomicAdd(A.status + 1, np);
+        __threadfence();
+        if (atomicAdd(A.status + 2, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            const int st = atomicExch(A.status + 0, 0), cnt = atomicExch(A.status + 1, 0);
+            atomicExch(A.status + 2, 0);
+            volatile int *hs = A.host_status;
+            hs[0] = st;
+            hs[1] = cnt;
+            __threadfence_system();
+        }
     }
     WAVE_STAMP();
 #ifdef EPNN_STAMPS
