@@ -89,29 +89,15 @@ __device__ __forceinline__ double wave_dist(const double *xs, int i, int j) {
 // first feature of the g-th group of four of the hk order
 __device__ __forceinline__ int wave_hk_f0(int hh, int g) { return g < 4 ? 4 * hh + 8 * g : 32 + 4 * hh + 8 * (g - 4); }
 
-// A dependent chain of v_mfma_f32_32x32x2_f32 issues one MFMA per ~100 cycles (measured), the pipe takes one per 64:
-// every chain is therefore run as TWO independent accumulators, either the two halves of its own K range ...
+// A dependent chain of v_mfma_f32_32x32x2_f32 issues back to back (64 cycles per MFMA, tools/micro/mfma_rate.hip): one
+// accumulator per chain is enough.  What does NOT overlap is a wave's own VALU / LDS work with its own MFMAs
+// (tools/micro/mfma_valu.hip), and a co-resident wave's VALU work runs at half rate while the matrix pipe is busy
+// (tools/micro/mfma_covalu.hip): the non-MFMA instruction count is what this kernel is tuned for.
 template <int K>
 __device__ __forceinline__ f32x16 wave_chain(const float (&w)[K], const float (&b)[K], f32x16 acc) {
-    f32x16 acc1 = epnn_splat16(0.f);
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-        if (s & 1) acc1 = epnn_mfma(w[s], b[s], acc1);
-        else acc = epnn_mfma(w[s], b[s], acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+    for (int s = 0; s < K; ++s) acc = epnn_mfma(w[s], b[s], acc);
     return acc;
-}
-// ... or two chains that share their B operand (P and R of the same atoms)
-template <int K>
-__device__ __forceinline__ void wave_chain2(const float (&wa)[K], const float (&wb)[K], const float (&b)[K], f32x16 &a0,
-                                            f32x16 &a1) {
-#pragma unroll
-    for (int s = 0; s < K; ++s) {
-        a0 = epnn_mfma(wa[s], b[s], a0);
-        a1 = epnn_mfma(wb[s], b[s], a1);
-    }
 }
 
 // e rows of G tile gt: lane (c,hh) takes channels 24hh..24hh+23 of pair gt*32+c
@@ -340,9 +326,10 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             EPNN_WLD(wc, X.wj0, EPNN_KX);
             if (have_h) { EPNN_WLD(wd, X.wj0 + EPNN_KX * 64, 24); }
             WAVE_FENCE();
-            f32x16 acc = epnn_splat16(0.f), acr = epnn_splat16(0.f);
-            wave_chain2<EPNN_KX>(wa, wc, xq, acc, acr);
-            if (have_h) wave_chain2<24>(wb, wd, hk, acc, acr);
+            f32x16 acc = wave_chain<EPNN_KX>(wa, xq, epnn_splat16(0.f));
+            if (have_h) acc = wave_chain<24>(wb, hk, acc);
+            f32x16 acr = wave_chain<EPNN_KX>(wc, xq, epnn_splat16(0.f));
+            if (have_h) acr = wave_chain<24>(wd, hk, acr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[r] = acc[r];
             if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
@@ -387,100 +374,61 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                         }
                     };
                     // tile index jt in [0, n]: partner jt, or (jt == n) the reference's zero-padded partner (R = 0, G = 0,
-                    // charge_gn.py:70) which counts N - n times.  Tiles go through the matrix pipe two at a time.
+                    // charge_gn.py:70) which counts N - n times.  Operands of tile jt+1 (and the slot of jt+2) are
+                    // fetched while tile jt is in the matrix pipe.
                     const float *zrow = Gl + glds * EPNN_PST + hh * 16;
                     auto rload = [&](int jt, float (&r)[16]) { epnn_ld16(jt < n ? Rl + jt * EPNN_PST + hh * 16 : zrow, r); };
                     auto slot_of = [&](int jt) -> int { return jt < n ? (int)pm[jt * 32 + c] : 0xFFFF; };
-                    auto two_tiles = [&](const float (&z0)[16], const float (&z1)[16], float w1) {
-                        f32x16 acc0 = cb2, acc1 = cb2;
+                    auto tile = [&](const float (&rj)[16], const float (&g)[16], const float (&gh)[16], float wt) {
+                        f32x16 acc = cb2;
 #pragma unroll
                         for (int s = 0; s < 16; ++s) {
-                            acc0 = epnn_mfma(pb[s], z0[s], acc0);
-                            acc1 = epnn_mfma(pb[s], z1[s], acc1);
+                            float z = (P[s] + rj[s]) + g[s];
+                            if (OVER) z += gh[s];
+                            acc = epnn_mfma(pb[s], fmaxf(z, 0.f), acc);
                         }
 #pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const f32x2 m0 = {fmaxf(acc0[r], 0.f), fmaxf(acc0[r + 1], 0.f)};
-                            const f32x2 m1 = {fmaxf(acc1[r], 0.f), fmaxf(acc1[r + 1], 0.f)};
-                            const f32x2 sv = (f32x2{S[r], S[r + 1]} + m0) + f32x2{w1, w1} * m1;
-                            S[r] = sv[0]; S[r + 1] = sv[1];
+                        for (int r = 0; r < 16; ++r) S[r] = fmaf(wt, fmaxf(acc[r], 0.f), S[r]);
+                    };
+                    if (OVER) {          // rare (large molecules): no fetch-ahead, fewer registers
+#pragma unroll 1
+                        for (int jt = 0; jt <= n; ++jt) {
+                            if (jt == n) { EPNN_WLD(u1s, M.u1s, 16); }        // first operand of the update MLP
+                            float rj[16], g[16], gh[16];
+                            rload(jt, rj);
+                            gload(slot_of(jt), g, gh);
+                            tile(rj, g, gh, jt == n ? padw : 1.f);
                         }
-                    };
-                    auto one_tile = [&](const float (&z0)[16], float w0) {       // K split over two accumulators
-                        f32x16 acc0 = cb2, acc1 = epnn_splat16(0.f);
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) {
-                            if (s & 1) acc1 = epnn_mfma(pb[s], z0[s], acc1);
-                            else acc0 = epnn_mfma(pb[s], z0[s], acc0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) S[r] = fmaf(w0, fmaxf(acc0[r] + acc1[r], 0.f), S[r]);
-                    };
-                    auto upd_prefetch = [&]() {          // the update MLP's first operand, fetched under the last tiles
-                        EPNN_WLD(u1s, M.u1s, 16);
-                    };
-                    const int ntile = n + 1;
-                    float rA[16], gA[16], rB[16], gB[16];
-                    int sA = 0xFFFF, sB = 0xFFFF;
-                    if (!OVER) {                                  // operands of the first two tiles, slots of the next two
+                    } else {
+                        float rA[16], gA[16], rB[16], gB[16];
                         rload(0, rA);
                         gload(slot_of(0), gA, gA);
-                        rload(1, rB);
-                        gload(slot_of(1), gB, gB);
-                        sA = slot_of(min(2, n));
-                        sB = slot_of(min(3, n));
-                    }
-                    auto step2 = [&](int jt, bool prefetch) {     // tiles jt, jt+1; then fetch jt+2, jt+3
-                        float z0[16], z1[16];
-                        if (OVER) {                               // rare (large molecules): no fetch-ahead, fewer registers
-                            float hA[16], hB[16];
-                            rload(jt, rA);
-                            gload(slot_of(jt), gA, hA);
-                            rload(jt + 1, rB);
-                            gload(slot_of(jt + 1), gB, hB);
-#pragma unroll
-                            for (int s = 0; s < 16; ++s) {
-                                z0[s] = fmaxf(((P[s] + rA[s]) + gA[s]) + hA[s], 0.f);
-                                z1[s] = fmaxf(((P[s] + rB[s]) + gB[s]) + hB[s], 0.f);
-                            }
-                        } else {
-#pragma unroll
-                            for (int s = 0; s < 16; s += 2) {                  // packed adds (v_pk_add_f32)
-                                const f32x2 p = {P[s], P[s + 1]};
-                                const f32x2 a = (p + f32x2{rA[s], rA[s + 1]}) + f32x2{gA[s], gA[s + 1]};
-                                const f32x2 bq = (p + f32x2{rB[s], rB[s + 1]}) + f32x2{gB[s], gB[s + 1]};
-                                z0[s] = fmaxf(a[0], 0.f); z0[s + 1] = fmaxf(a[1], 0.f);
-                                z1[s] = fmaxf(bq[0], 0.f); z1[s + 1] = fmaxf(bq[1], 0.f);
-                            }
-                            if (prefetch) {
-                                rload(min(jt + 2, n), rA);
-                                gload(sA, gA, gA);
-                                rload(min(jt + 3, n), rB);
-                                gload(sB, gB, gB);
-                                sA = slot_of(min(jt + 4, n));
-                                sB = slot_of(min(jt + 5, n));
-                            }
-                            WAVE_FENCE();
-                        }
-                        two_tiles(z0, z1, jt + 1 == n ? padw : 1.f);
-                    };
-                    const int nfull = ntile >> 1;                 // >= 1
-                    const bool odd = ntile & 1;                   // the padded-partner tile is left over
-                    int jt = 0;
+                        int snext = slot_of(1);
+                        int jt = 0;
 #pragma unroll 1
-                    for (int k = 0; k + 1 < nfull; ++k, jt += 2) step2(jt, true);
-                    if (odd) {
-                        step2(jt, true);
-                        jt += 2;
-                        upd_prefetch();
-                        WAVE_FENCE();
-                        float z0[16];
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) z0[s] = fmaxf(P[s], 0.f);
-                        one_tile(z0, padw);
-                    } else {
-                        upd_prefetch();
-                        step2(jt, false);
+                        for (; jt + 1 < n; jt += 2) {                          // tiles jt, jt+1 (both real partners)
+                            rload(jt + 1, rB);
+                            gload(snext, gB, gB);
+                            snext = slot_of(jt + 2);
+                            WAVE_FENCE();
+                            tile(rA, gA, gA, 1.f);
+                            rload(jt + 2, rA);
+                            gload(snext, gA, gA);
+                            snext = slot_of(jt + 3);
+                            WAVE_FENCE();
+                            tile(rB, gB, gB, 1.f);
+                        }
+                        EPNN_WLD(u1s, M.u1s, 16);                             // first operand of the update MLP
+                        if (jt < n) {                                          // n odd: last partner, then the padded one
+                            rload(n, rB);
+                            gload(0xFFFF, gB, gB);
+                            WAVE_FENCE();
+                            tile(rA, gA, gA, 1.f);
+                            tile(rB, gB, gB, padw);
+                        } else {
+                            WAVE_FENCE();
+                            tile(rA, gA, gA, padw);                            // rA/gA hold tile n: zero rows
+                        }
                     }
                 };
                 if (gover) sweep(std::true_type{});
@@ -528,8 +476,8 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                 EPNN_WLD(wu, M.pu1, 16);
                 epnn_ld16(wp + M.cu3k + hh * 16, cu);
                 WAVE_FENCE();
-                f32x16 acc = epnn_splat16(0.f), acr = epnn_splat16(0.f);
-                wave_chain2<16 + EPNN_KX>(wa, wb, in, acc, acr);
+                f32x16 acc = wave_chain<16 + EPNN_KX>(wa, in, epnn_splat16(0.f));
+                f32x16 acr = wave_chain<16 + EPNN_KX>(wb, in, epnn_splat16(0.f));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P[r] = acc[r];
                 if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
@@ -553,8 +501,8 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             epnn_ld16(wp + X.bu3k + hh * 16, bv);
             epnn_ld16(wp + X.bu3k + 32 + hh * 16, bw);
             WAVE_FENCE();
-            f32x16 acc = epnn_splat16(0.f), ac2 = epnn_splat16(0.f);
-            wave_chain2<16>(w, w2, bn, acc, ac2);
+            f32x16 acc = wave_chain<16>(w, bn, epnn_splat16(0.f));
+            f32x16 ac2 = wave_chain<16>(w2, bn, epnn_splat16(0.f));
 #pragma unroll
             for (int r = 0; r < 16; ++r) hk[r] = nmv * (acc[r] + bv[r]);
 #pragma unroll
@@ -591,8 +539,8 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                 if (t < 2) WAVE_STAMP();   // EPN G tiles
                 EPNN_WLD(wb, M.wj, EPNN_KX + 24);
                 WAVE_FENCE();
-                f32x16 acc = epnn_splat16(0.f), acr = epnn_splat16(0.f);
-                wave_chain2<EPNN_KX + 24>(wa, wb, in, acc, acr);
+                f32x16 acc = wave_chain<EPNN_KX + 24>(wa, in, epnn_splat16(0.f));
+                f32x16 acr = wave_chain<EPNN_KX + 24>(wb, in, epnn_splat16(0.f));
                 if (catom) epnn_st16(Pl + c * EPNN_PST + hh * 16, acc);
                 if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
             }
