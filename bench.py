@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight per GPU (handles/streams used round robin)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight per GPU (handles/streams used round robin)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
     args = ap.parse_args()
 
@@ -133,8 +133,8 @@ def main():
         step(k)
     pipe.sync()
     per_lane = [sum(1 for k in range(args.steps) if k % len(lanes) == l) for l in range(len(lanes))]
-    # ms per forward: front-end, fused (both halves), tiled kernels, total, GNN half of a two-launch fused stage
-    stage = np.array([lanes[l][0].timing_at5(i) for l in range(len(lanes)) for i in range(per_lane[l])])
+    # ms per forward: front-end kernels (none: the fused kernel builds its pair lists itself), fused kernel, tiled kernels, total
+    stage = np.array([lanes[l][0].timing_at(i) for l in range(len(lanes)) for i in range(per_lane[l])])
     pipe.set_option("profile", 0)
 
     if dist is not None:
@@ -158,14 +158,15 @@ def main():
     if rank == 0:
         ns = np.diff(offsets)
         flops = synth.algorithmic_flops(ns, int(stats[0]))
-        f_gnn, f_epn = synth.algorithmic_flops(ns, int(stats[0]), parts=True)
-        fused_ms, gnn_ms = float(stage[:, 1].mean()), float(stage[:, 4].mean())
-        split = gnn_ms < 0.98 * fused_ms                   # the fused stage ran as a GNN launch + an EPN launch
-        if split:
-            kname, k_flops, k_ms = "k_small_forward<true,false> (GNN half of the fused forward)", f_gnn, gnn_ms
-        else:
-            kname, k_flops, k_ms = "k_small_forward<true,true>", flops, fused_ms
-        achieved = k_flops / (k_ms * 1e-3) / 1e12
+        kname = "k_wave_forward<true,true,true>"
+        k_ms = float(stage[:, 1].mean())                   # duration of one launch (hipEvents on its stream)
+        step_ms = dt_max / args.steps * 1e3
+        # `depth` launches of the SAME kernel share the GPU (one batch is 1024 wavefronts, the machine holds 2048), so
+        # the duration of one launch measures the share of the machine it got, not the kernel's rate.  achieved =
+        # algorithmic flops of a launch / the time the machine spends per launch (= duration / launches in flight).
+        in_flight = max(1.0, k_ms / step_ms)
+        achieved = flops / (k_ms / in_flight * 1e-3) / 1e12
+        per_launch = flops / (k_ms * 1e-3) / 1e12
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
         # command (FETCH_SIZE / WRITE_SIZE in separate passes, profiles/r01_pmc_bench.json); null for other shapes
         traffic = None
@@ -173,7 +174,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")) as f:
                 pmc = json.load(f)
             if pmc.get("workload") == f"qm9_like_b{B}_N{N}":
-                traffic = pmc["dominant"][kname.split(" ")[0]]["hbm_bytes_per_launch"]
+                traffic = pmc["dominant"][kname]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
         out = {
@@ -196,13 +197,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
-                         "algorithmic_gflop_per_launch": k_flops / 1e9, "kernel_ms_avg": k_ms,
-                         "note": "per-launch duration from hipEvents while the other in-flight batch shares the GPU; "
-                                 "whole-forward rate = algorithmic_gflop_per_step / ms_per_step",
-                         "algorithmic_gflop_per_step": flops / 1e9,
-                         "whole_forward_tflops": flops / (dt_max / args.steps) / 1e12,
-                         "whole_forward_frac": flops / (dt_max / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "fused_stage_ms_avg": fused_ms, "frontend_ms_avg": float(stage[:, 0].mean()),
+                         "algorithmic_gflop_per_launch": flops / 1e9, "kernel_ms_avg": k_ms,
+                         "launches_in_flight": in_flight, "tflops_of_one_launch_sharing_the_gpu": per_launch,
+                         "note": "kernel_ms_avg = hipEvent duration of one launch while `launches_in_flight` launches of "
+                                 "the same kernel share the GPU; achieved = algorithmic flops per launch / "
+                                 "(kernel_ms_avg / launches_in_flight) = flops x launches / wall time of the timed region",
                          "device_ms_per_forward_avg": float(stage[:, 3].mean())},
         }
         if not args.no_cpu_baseline:

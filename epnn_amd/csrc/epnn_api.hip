@@ -5,7 +5,6 @@
 
 #include "epnn_host.h"
 #include "epnn_frontend.hip.h"
-#include "epnn_small.hip.h"
 #include "epnn_wave.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
@@ -79,12 +78,6 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
     HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
     shape_layers(h);
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward<true, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward<true, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small_forward<false, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *out = h;
     return 0;
 }
@@ -95,7 +88,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pbase, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
-                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_hsplit, &h->s_gx, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
+                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
@@ -112,14 +105,6 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipEventDestroy(h->ev_t0);
     (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
-    if (h->ev_fork) {
-        (void)hipEventDestroy(h->ev_fork);
-        for (int k = 0; k < EPNN_NSTREAM; ++k) {
-            (void)hipStreamSynchronize(h->cstream[k]);
-            (void)hipEventDestroy(h->ev_join[k]);
-            (void)hipStreamDestroy(h->cstream[k]);
-        }
-    }
     (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -412,8 +397,10 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
         if (n < 1) EPNN_FAIL("forward: molecule %d has %d atoms", b, n);
         if (n > N) EPNN_FAIL("forward: molecule %d has %d atoms but the padded size N is %d", b, n, N);
         for (int a = offsets[b]; a < offsets[b + 1]; ++a) molof[a] = b;
-        const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX);
-        if (small && n > EPNN_SMALL_NMAX) EPNN_FAIL("forward: force_path=1 but molecule %d has %d > %d atoms", b, n, EPNN_SMALL_NMAX);
+        const bool wave_ok = h->cfg.nx + 3 <= 2 * EPNN_KX;       // the fused kernel's xq block holds nx + 3 inputs
+        const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
+        if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
+            EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 2 * EPNN_KX - 3);
         if (small) {
             P.small_order.push_back(b);
             P.small_nmax = std::max(P.small_nmax, n);
@@ -463,38 +450,6 @@ static int ensure_pairs(epnn_handle *h, int pcap) {
     return 0;
 }
 
-// variant: 0 = both stacks in one launch, 1 = GNN half, 2 = EPN half (the halves leave out what they never touch)
-static SmallLds small_layout(int nmax, int gcap, int glds, int variant) {
-    SmallLds L;
-    int o = 0;
-    auto take = [&](int words) {
-        int r = o;
-        o += (words + 3) & ~3;
-        return r;
-    };
-    const int nr = std::max(1, std::min(32, nmax)), npadmax = 4 * ((nr + 4) / 4);
-    const bool gnn = variant != 2, epn = variant != 1;
-    L.nr = nr;
-    L.npadmax = npadmax;
-    L.a_eo = take(nr * EPNN_AST);
-    L.P = take(nr * EPNN_PST);
-    L.R = take(npadmax * EPNN_PST);
-    L.Sw = take(gnn ? 2 * nr * EPNN_SST : 4);
-    L.zp = take(gnn ? nr * EPNN_SST : 4);
-    L.G = take(std::max(1, glds) * EPNN_PST);
-    L.dl = take(epn ? gcap : 4);
-    L.pij = take(epn ? gcap : 4);
-    L.pwi = take(epn ? gcap : 4);
-    L.pwj = take(epn ? gcap : 4);
-    L.pm = take(gnn ? (nr * npadmax + 1) / 2 : 4);
-    L.glut = take(gnn ? (nr * npadmax / 4 + 3) / 4 : 4);
-    L.nm = take(32);
-    L.u1h = take(gnn ? 64 * 16 : 4);
-    L.cst = take(64);
-    L.total = o;
-    return L;
-}
-
 struct PairSource {     // where the fused / tiled kernels read atoms and pairs from
     const float *d_x = nullptr, *d_Q = nullptr, *d_hin = nullptr, *d_qin = nullptr, *d_nm = nullptr;
     float *d_q = nullptr, *d_hout = nullptr;
@@ -537,7 +492,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     if (h->s_gx.ensure((size_t)h->pcap * 32 * 4)) return 1;
     A.gx = h->s_gx.as<float>();
     // worst case inside the budget: n = 32, every unordered pair + diagonal entries (528 records) and >= 1 G row
-    const int lds = std::max(h->wave_lds, 16384) & ~15;
+    const int lds = std::min(std::max(h->wave_lds, 16384), 65536) & ~15;
     A.lds_words = lds / 4;
 #ifdef EPNN_STAMPS
     if (h->l_nm.ensure(P.small_order.size() * 4 * 64 * 8)) return 1;
@@ -559,119 +514,9 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     return 0;
 }
 
-// The fused kernel's LDS footprint (and with it the number of co-resident workgroups per CU) is set by the largest
-// molecule of a launch, so the molecules (sorted by size) are launched in size classes, largest class first, each
-// on its own stream so that the tails overlap.
 static int launch_small(epnn_handle *h, const PairSource &S) {
-    const Plan &P = h->plan;
-    if (P.small_order.empty()) return 0;
-    if (h->opt_wave && h->cfg.nx + 3 <= 2 * EPNN_KX) return launch_wave(h, S);
-    SmallArgs A{};
-    A.wpack = h->d_wpack.as<float>();
-    A.wi = h->widx;
-    A.xin = S.d_x;
-    A.Q = S.d_Q;
-    A.moff = h->d_moff.as<int>();
-    A.row_off = h->d_rowoff.as<int>();
-    A.pi = h->d_pi.as<int>();
-    A.pj = h->d_pj.as<int>();
-    A.psym = h->d_psym.as<int>();
-    A.pe = h->d_pe.as<float>();
-    A.pwi = h->d_pwi.as<float>();
-    A.pwj = h->d_pwj.as<float>();
-    A.q_out = S.d_q;
-    A.h_out = S.d_hout;
-    A.h_in = S.d_hin;
-    A.q_in = S.d_qin;
-    A.nm_in = S.d_nm;
-    A.status = h->d_status.as<int>();
-    A.N = P.N;
-    A.T = h->cfg.T;
-    A.nx = h->cfg.nx;
-    A.pcap = h->pcap;
-    A.A = P.A;
-    A.run_gnn = S.run_gnn;
-    A.run_epn = S.run_epn;
-#ifdef EPNN_STAMPS
-    if (h->l_nm.ensure(P.small_order.size() * 4 * 64 * 8)) return 1;
-    A.stamps = h->l_nm.as<unsigned long long>();
-#endif
-    static const int bounds[] = {32, 24, 20, 16, 12};          // class = molecules with bounds[k+1] < n <= bounds[k]
-    const int nclass = (int)(sizeof(bounds) / sizeof(bounds[0]));
-    const bool multi = h->opt_classes != 0 && P.small_order.size() >= 64;
-    if (multi) {
-        if (!h->ev_fork) {          // the extra streams exist only when size classes are switched on: every stream a
-                                    // handle owns takes a hardware queue away from other handles' pipelining
-            HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            for (int k = 0; k < EPNN_NSTREAM; ++k) {
-                HIPCHK(hipStreamCreateWithFlags(&h->cstream[k], hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
-            }
-        }
-        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-        for (int k = 0; k < EPNN_NSTREAM; ++k) HIPCHK(hipStreamWaitEvent(h->cstream[k], h->ev_fork, 0));
-    }
-    size_t pos = 0;
-    int used = 0;
-    for (int k = 0; k < nclass && pos < P.small_order.size(); ++k) {
-        const int lo = (multi && k + 1 < nclass) ? bounds[k + 1] : 0;
-        size_t end = pos;
-        while (end < P.small_order.size() && (P.offsets[P.small_order[end] + 1] - P.offsets[P.small_order[end]]) > lo) ++end;
-        if (end == pos) continue;
-        const int nmax = P.offsets[P.small_order[pos] + 1] - P.offsets[P.small_order[pos]];
-        const int full = nmax * (nmax - 1) / 2 + nmax;    // every unordered pair + diagonal entries (dense front-end)
-        int gcap = h->small_gcap > 0 ? h->small_gcap : std::max(32, h->small_pairs_per_atom * nmax);
-        gcap = std::max(1, std::min(gcap, full));
-        A.order = h->d_order.as<int>() + pos;
-        A.gcap = gcap;
-        // Split launches + a trimmed G buffer let three workgroups share a CU (<= 53 KB LDS, <= 168 VGPRs each).
-        // That pays once there are several rounds of workgroups (measured: +9 % at 4096 molecules, +12 % at 8192);
-        // with exactly four molecules per CU (1024) two rounds of two are as good, so "auto" keeps one launch there.
-        const bool can_split = A.run_gnn && A.run_epn && !A.h_out;
-        const bool split = can_split && (h->opt_split == 1 || (h->opt_split < 0 && P.small_order.size() >= 2304));
-        int glds = gcap;
-        if (h->small_glds > 0) glds = std::min(gcap, h->small_glds);
-        else if (split) {
-            const int base = small_layout(nmax, gcap, 1, 1).total * 4;          // GNN half without G rows
-            glds = std::max(32, std::min(gcap, (51 * 1024 - base) / (EPNN_PST * 4)));   // 3 x 51 KB leaves room for allocation granularity
-        }
-        A.glds = glds;
-        if (h->s_gx.ensure((size_t)h->pcap * 32 * 4)) return 1;
-        A.gx = h->s_gx.as<float>();
-        A.L = small_layout(nmax, gcap, glds, 0);
-        size_t lds = (size_t)A.L.total * 4;
-        if (lds > 160 * 1024) EPNN_FAIL("fused kernel: LDS budget exceeded (%zu bytes)", lds);
-        hipStream_t st = multi ? h->cstream[used % EPNN_NSTREAM] : h->stream;
-        const dim3 grid((unsigned)(end - pos));
-        if (split) {
-            // two launches: the GNN half leaves h in HBM, the EPN half picks it up
-            if (h->s_hsplit.ensure((size_t)P.A * EPNN_EDIM * 4)) return 1;
-            SmallArgs G = A, E = A;
-            G.run_epn = 0;
-            G.h_out = h->s_hsplit.as<float>();
-            G.L = small_layout(nmax, gcap, glds, 1);
-            E.run_gnn = 0;
-            E.h_in = h->s_hsplit.as<float>();
-            E.L = small_layout(nmax, gcap, glds, 2);
-            hipLaunchKernelGGL((k_small_forward<true, false>), grid, dim3(256), (size_t)G.L.total * 4, st, G);
-            if (h->ev_mid && !multi && pos == 0 && end == P.small_order.size()) {
-                HIPCHK(hipEventRecord(h->ev_mid, st));
-                h->ev_mid_used = true;
-            }
-            hipLaunchKernelGGL((k_small_forward<false, true>), grid, dim3(256), (size_t)E.L.total * 4, st, E);
-        } else {
-            hipLaunchKernelGGL((k_small_forward<true, true>), grid, dim3(256), lds, st, A);
-        }
-        ++used;
-        pos = end;
-    }
-    HIPCHK(hipGetLastError());
-    if (multi)
-        for (int k = 0; k < std::min(used, (int)EPNN_NSTREAM); ++k) {
-            HIPCHK(hipEventRecord(h->ev_join[k], h->cstream[k]));
-            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join[k], 0));
-        }
-    return 0;
+    if (h->plan.small_order.empty()) return 0;
+    return launch_wave(h, S);
 }
 
 static int run_frontend_xyz(epnn_handle *h, const float *d_xyz) {
@@ -717,8 +562,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     const Plan &P = h->plan;
     // Batches of small molecules only: the wave kernel builds each molecule's pair list itself (slots for every i<j
     // pair of the molecule, so nothing can overflow) and no front-end kernel runs.
-    const bool wave_front = h->opt_wave && h->opt_wave_front && P.large_list.empty() && h->cfg.nx + 3 <= 2 * EPNN_KX &&
-                            h->cfg.e_dim == EPNN_EDIM;
+    const bool wave_front = h->opt_wave_front && P.large_list.empty() && !P.small_order.empty() && h->cfg.e_dim == EPNN_EDIM;
     if (ensure_pairs(h, wave_front ? std::max(h->pcap, P.pair_slots)
                                    : std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
     // the in-kernel front-end keeps the control words zeroed itself (last wave) and writes status + pair count to the
@@ -727,7 +571,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     h->ctl_clean = wave_front;
     hipEvent_t *ev = nullptr;
     if (h->opt_profile > 0) {
-        ev = h->evpool.data() + 5 * (h->ev_next % h->opt_profile);
+        ev = h->evpool.data() + 4 * (h->ev_next % h->opt_profile);
         h->ev_next += 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
@@ -738,11 +582,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     S.d_Q = d_Q;
     S.d_q = d_q;
     S.d_xyz = wave_front ? d_xyz : nullptr;
-    h->ev_mid = ev ? ev[4] : nullptr;             // recorded between the two halves of a split launch
-    h->ev_mid_used = false;
     if (launch_small(h, S)) return 1;
-    if (ev && !h->ev_mid_used) HIPCHK(hipEventRecord(ev[4], h->stream));
-    h->ev_mid = nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
     if (launch_large(h, S)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
@@ -765,28 +605,11 @@ static int finish_forward(epnn_handle *h) {
         h->stats[0] = h->h_status[1];
         if (st == 0) {
             h->pending.active = false;
-            if (h->force_tmp) {
-                h->opt_force_path = h->force_saved;
-                h->force_tmp = false;
-                h->plan.valid = false;
-            }
             return 0;
         }
         h->stats[3] += 1;
         if (st & EPNN_ST_PAIR_OVERFLOW) {
             if (ensure_pairs(h, h->h_status[1] + h->h_status[1] / 8 + 1024)) return 1;
-        }
-        if (st & EPNN_ST_SMALL_OVERFLOW) {
-            const int nmax = h->plan.small_nmax;
-            const int full = nmax * (nmax - 1) / 2 + nmax;
-            if (h->small_gcap >= full) {          // one-sided entries beyond the LDS budget: use the tiled kernels
-                if (!h->force_tmp) h->force_saved = h->opt_force_path;
-                h->force_tmp = true;
-                h->opt_force_path = 2;
-                h->plan.valid = false;
-            }
-            h->small_gcap = full;
-            h->small_pairs_per_atom = 32;
         }
         if (h->pending.redo()) return 1;
     }
@@ -895,19 +718,15 @@ extern "C" int epnn_timer_end(epnn_handle *h, float *elapsed_ms) {
     return 0;
 }
 extern "C" int epnn_timing_at(epnn_handle *h, int idx, float *out4) {
-    return epnn_timing_at5(h, idx, out4, nullptr);
-}
-extern "C" int epnn_timing_at5(epnn_handle *h, int idx, float *out4, float *gnn_half_ms) {
     if (!h || !out4) EPNN_FAIL("epnn_timing_at: null argument");
     if (h->opt_profile <= 0) EPNN_FAIL("epnn_timing_at: profiling is off (epnn_set_option(\"profile\", pool_size))");
     if (idx < 0 || idx >= h->ev_next || idx < h->ev_next - h->opt_profile)
         EPNN_FAIL("epnn_timing_at: forward %d is not in the event pool (recorded %d, pool %d)", idx, h->ev_next, h->opt_profile);
     HIPCHK(hipSetDevice(h->device));
     if (finish_forward(h)) return 1;
-    hipEvent_t *ev = h->evpool.data() + 5 * (idx % h->opt_profile);
+    hipEvent_t *ev = h->evpool.data() + 4 * (idx % h->opt_profile);
     for (int k = 0; k < 3; ++k) HIPCHK(hipEventElapsedTime(&out4[k], ev[k], ev[k + 1]));
     HIPCHK(hipEventElapsedTime(&out4[3], ev[0], ev[3]));
-    if (gnn_half_ms) HIPCHK(hipEventElapsedTime(gnn_half_ms, ev[1], ev[4]));   // == out4[1] for a single launch
     return 0;
 }
 extern "C" int epnn_last_timing(epnn_handle *h, float *out4) {
@@ -925,7 +744,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
         HIPCHK(hipSetDevice(h->device));
         if (finish_forward(h)) return 1;
         value = std::max(0, std::min(value, 4096));
-        while ((int)h->evpool.size() < 5 * value) {
+        while ((int)h->evpool.size() < 4 * value) {
             hipEvent_t e;
             HIPCHK(hipEventCreate(&e));
             h->evpool.push_back(e);
@@ -935,14 +754,8 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     }
     else if (!strcmp(name, "force_path")) { h->opt_force_path = value; h->plan.valid = false; }
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
-    else if (!strcmp(name, "small_gcap")) { h->small_gcap = value; }
-    else if (!strcmp(name, "small_pairs_per_atom")) { h->small_pairs_per_atom = std::max(1, value); }
-    else if (!strcmp(name, "size_classes")) { h->opt_classes = value; }
-    else if (!strcmp(name, "split")) { h->opt_split = value; }
-    else if (!strcmp(name, "wave")) { h->opt_wave = value; }
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
-    else if (!strcmp(name, "small_glds")) { h->small_glds = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }

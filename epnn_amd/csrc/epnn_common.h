@@ -95,7 +95,6 @@ __host__ __device__ static inline int epnn_aeo(int f) { return (f & 1) * 32 + (f
 
 // status bits written by kernels
 #define EPNN_ST_PAIR_OVERFLOW 1   // near-pair list capacity exceeded
-#define EPNN_ST_SMALL_OVERFLOW 2  // a molecule on the fused path has more near pairs than its LDS budget
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ f32x16 epnn_mfma(float a, float b, f32x16 c) {

@@ -49,8 +49,6 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-#define EPNN_NSTREAM 5
-
 struct HostDense {            // one Keras Dense: kernel [in][out], bias [out]
     int n_in = 0, n_out = 0;
     std::vector<float> W, b;
@@ -71,14 +69,8 @@ struct epnn_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    hipStream_t cstream[EPNN_NSTREAM] = {};   // size-class launches of the fused kernel
-    hipEvent_t ev_fork = nullptr, ev_join[EPNN_NSTREAM] = {};
-    int opt_classes = 0;                      // multi-stream size classes: measured slower than one launch (fork/join cost)
-    int small_pairs_per_atom = 8;             // LDS slots for near pairs per atom of the largest molecule of a class
-    std::vector<hipEvent_t> evpool;   // 5 stage events per profiled forward ("profile" option = pool size)
+    std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)
     int ev_next = 0;                  // forwards recorded since the option was set
-    hipEvent_t ev_mid = nullptr;      // event between the GNN and EPN halves of a split fused launch (profiling)
-    bool ev_mid_used = false;
     // weights
     HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
     bool weights_dirty = true;
@@ -92,16 +84,12 @@ struct epnn_handle {
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     int pcap = 0;
     int pair_cap_per_atom = 16;
-    int small_gcap = 0;           // 0 = heuristic
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
     // staging for the host-pointer entry points
-    DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_hsplit, s_gx;
-    int small_glds = 0;               // G rows kept in LDS per molecule (0 = all of them; smaller values trade LDS for HBM overflow rows)
-    int opt_wave = 1;                 // fused path: 1 = wave-autonomous kernel (one wavefront per molecule), 0 = 4-wave workgroup kernel
+    DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_gx;
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
-    int opt_split = -1;               // fused kernel as a GNN launch + an EPN launch: 0 never, 1 always, -1 auto (big batches)
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
     DevBuf l_mflag, l_stasks, l_schunk, l_sfin;
@@ -121,6 +109,4 @@ struct epnn_handle {
     DevBuf sd_h, sd_e, sd_x, sd_q, sd_mask, sd_out;
     std::vector<int> dn_neff_host;
     void *train = nullptr;            // TrainState (epnn_train.hip.h)
-    bool force_tmp = false;           // force_path was switched to the tiled kernels for one call only
-    int force_saved = 0;
 };

@@ -1,5 +1,5 @@
 // Tiled path for molecules the fused kernel cannot hold (n > 32: the 2220-atom protein, the 100k-atom box).
-// Same arithmetic as epnn_small.hip.h, split into per-step kernels with the per-atom state in HBM:
+// Same arithmetic as the fused kernel (epnn_wave.hip.h), split into per-step kernels with the per-atom state in HBM:
 //
 //   GNN step (charge_gn.py:60-74)
 //     k_lg_proj   P_i = Wi^T a_i + b1, R_j = Wj^T a_j, zp_i = relu(W2^T relu(P_i) + b2)       per 32-atom tile
@@ -15,7 +15,26 @@
 // against the sweep's term up to the summation order.  All sums are order-fixed (no float atomics).
 #pragma once
 #include "epnn_host.h"
-#include "epnn_small.hip.h"
+#include "epnn_common.h"
+
+// G^T tile: acc[r] = G[pair c][kappa(hh,r)] = sum_ch We[ch][k] e[pair][ch]   (We fragments read from the packed weights)
+__device__ __forceinline__ f32x16 lg_gtile(const float *__restrict__ weF, const float *__restrict__ erow, bool valid, int lane) {
+    float ev[24];
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(erow + 4 * q);
+            ev[4 * q] = v[0]; ev[4 * q + 1] = v[1]; ev[4 * q + 2] = v[2]; ev[4 * q + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 24; ++s) ev[s] = 0.f;
+    }
+    f32x16 acc = epnn_splat16(0.f);
+#pragma unroll
+    for (int s = 0; s < 24; ++s) acc = epnn_mfma(weF[s * 64 + lane], ev[s], acc);
+    return acc;
+}
 
 struct LargeArgs {
     const float *wpack;
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
     }
     if (__ballot(valid) == 0ull) return;
     const float *wp = L.wpack;
-    const f32x16 g = small_gtile(wp + M.weF, L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24, valid, lane);
+    const f32x16 g = lg_gtile(wp + M.weF, L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24, valid, lane);
     float pi_[16], rj_[16], pj_[16], ri_[16], w2[16];
     epnn_ld16(L.P + (size_t)gi * 32 + hh * 16, pi_);
     epnn_ld16(L.R + (size_t)gj * 32 + hh * 16, rj_);

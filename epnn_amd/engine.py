@@ -265,13 +265,6 @@ class Engine:
         check(self.lib.epnn_timing_at(self.h, int(idx), fptr(out)), self.lib)
         return out
 
-    def timing_at5(self, idx):
-        """(front-end, fused, tiled, total, GNN half of a split fused launch) in ms."""
-        out = np.zeros(4, dtype=np.float32)
-        g = C.c_float()
-        check(self.lib.epnn_timing_at5(self.h, int(idx), fptr(out), C.byref(g)), self.lib)
-        return np.append(out, g.value)
-
     def last_stats(self):
         out = np.zeros(4, dtype=np.int64)
         check(self.lib.epnn_last_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_int64))), self.lib)
@@ -280,17 +273,15 @@ class Engine:
 
 class Pipeline:
     """Keeps `depth` batches in flight on one GPU: `depth` handles (each with its own HIP stream and workspace) take
-    the calls round robin, so the front-end kernels and launch gaps of one batch overlap the fused kernel of the
-    previous one.  All handles carry the same weights.  Results of call k are complete after `sync()`."""
+    the calls round robin.  The fused kernel runs one wavefront per molecule and an MI355X holds 2048 of them
+    (8 per CU), so one batch of 1024 molecules fills half the machine and its largest molecules finish long after
+    the smallest: the wavefronts of the next batches fill those slots.  Three batches in flight saturate the GPU
+    (a process gets three hardware queues for its streams; a fourth stream shares one).
+    All handles carry the same weights.  Results of call k are complete after `sync()`."""
 
-    def __init__(self, depth=2, **engine_kwargs):
+    def __init__(self, depth=3, **engine_kwargs):
         self.engines = [Engine(**engine_kwargs) for _ in range(max(1, int(depth)))]
         self._next = 0
-        if len(self.engines) > 1:
-            # with several batches in flight the two-launch form of the fused kernel wins (measured 0.216 vs 0.239
-            # ms/step on 1024 molecules): the EPN half of one batch fills the tail of the next batch's GNN half
-            for e in self.engines:
-                e.set_option("split", 1)
 
     def set_weights(self, weights):
         for e in self.engines:

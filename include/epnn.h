@@ -132,10 +132,9 @@ int epnn_timer_end(epnn_handle *h, float *elapsed_ms);
 int epnn_last_timing(epnn_handle *h, float *out4);
 /* same for the idx-th forward issued since "profile" was set (pool of that many event sets; no sync in between). */
 int epnn_timing_at(epnn_handle *h, int idx, float *out4);
-/* additionally the duration of the GNN half when the fused kernel ran as two launches (else == out4[1]) */
-int epnn_timing_at5(epnn_handle *h, int idx, float *out4, float *gnn_half_ms);
 /* options: "profile" (0 = off, k > 0 = keep stage events of the last k forwards), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
- * "pair_cap_per_atom" (initial capacity of the near-pair list). */
+ * "pair_cap_per_atom" (initial capacity of the near-pair list of the tiled / dense paths), "wave_front" (1: batches of small
+ * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* counters of the most recent forward: out[0]=near pairs, out[1]=molecules on the fused path,
  * out[2]=molecules on the tiled path, out[3]=pair-list regrows. */

@@ -197,28 +197,35 @@ def test_box_system_vs_oracle(gpu_engine_factory):
 
 
 def test_capacity_regrow_and_launch_variants_are_bit_identical(gpu_engine_factory, weights_full, val_dir, val_names):
-    """Every internal capacity / launch-shape choice must give the same bits: pair-list regrow after an overflow,
-    LDS slot overflow of the fused kernel, G rows spilled to HBM, the two-launch (GNN + EPN) form, and the tiled
-    kernels agree with the default fused launch to float32 rounding of a different summation order."""
+    """Internal capacity / launch-shape choices must not change the bits: G rows spilled to HBM (small LDS budget per
+    wavefront) with the in-kernel front-end; with the separate front-end kernels the pair-list regrow after an
+    overflow and the LDS budget.  The two front-ends differ only in how the float64 edge features are evaluated
+    (exp per channel vs. recurrence), the tiled kernels in the summation order: float32 rounding apart."""
     names = val_names[:96]
     mols, offsets, xyz, x, Q = load_molecules(val_dir, names, nx=10)
-    ref_eng = gpu_engine_factory(nx=10, T=5)
-    ref_eng.set_weights(weights_full)
-    ref = ref_eng.forward_xyz(offsets, xyz, x, Q, 41)
-    assert ref_eng.last_stats()[3] == 0
-    for opts, exact in [({"pair_cap_per_atom": 1}, True), ({"small_gcap": 8}, True), ({"small_glds": 16}, True),
-                        ({"split": 1}, True), ({"split": 1, "small_glds": 24}, True), ({"force_path": 2}, False)]:
+
+    def run(opts):
         eng = gpu_engine_factory(nx=10, T=5)
         eng.set_weights(weights_full)
         for k, v in opts.items():
             eng.set_option(k, v)
         q = eng.forward_xyz(offsets, xyz, x, Q, 41)
         st = eng.last_stats()
-        if "pair_cap_per_atom" in opts or "small_gcap" in opts:
-            assert st[3] >= 1, (opts, st)                 # the overflow path really ran
-        if exact:
-            assert np.array_equal(q, ref), (opts, np.abs(q - ref).max())
-        else:
-            assert np.abs(q - ref).max() <= 2e-4          # model_weights: |h| ~ 150, float32 noise ~1e-4
         q2 = eng.forward_xyz(offsets, xyz, x, Q, 41)      # and again with the grown capacities
-        assert np.array_equal(q2, q)
+        assert np.array_equal(q2, q), opts
+        return q, st
+
+    ref, st = run({})
+    assert st[3] == 0 and st[0] > 0
+    q, st = run({"wave_lds": 16384})
+    assert np.array_equal(q, ref), np.abs(q - ref).max()
+    ref_list, st_list = run({"wave_front": 0})
+    assert st_list[0] == st[0]                            # same number of near pairs from both front-ends
+    assert np.abs(ref_list - ref).max() <= 2e-4           # model_weights: |h| ~ 150, float32 noise ~1e-4
+    q, st = run({"wave_front": 0, "pair_cap_per_atom": 1})
+    assert st[3] >= 1, st                                 # the overflow path really ran
+    assert np.array_equal(q, ref_list), np.abs(q - ref_list).max()
+    q, st = run({"wave_front": 0, "wave_lds": 16384})
+    assert np.array_equal(q, ref_list), np.abs(q - ref_list).max()
+    q, st = run({"force_path": 2})
+    assert np.abs(q - ref).max() <= 2e-4

@@ -44,7 +44,7 @@ def main():
         with open(a.merge) as f:
             dominant = json.load(f).get("dominant", {})
     for k, v in kernels.items():
-        if not k.startswith("k_small_forward") and not k.startswith("k_lg_"):
+        if not k.startswith("k_wave_forward") and not k.startswith("k_lg_"):
             continue
         ent = {}
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
