@@ -569,6 +569,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     // pinned host words: no memset kernel before and no copy kernels after the launch
     if (!wave_front || !h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     h->ctl_clean = wave_front;
+    h->last_front = wave_front;
     hipEvent_t *ev = nullptr;
     if (h->opt_profile > 0) {
         ev = h->evpool.data() + 4 * (h->ev_next % h->opt_profile);
@@ -600,7 +601,10 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
 static int finish_forward(epnn_handle *h) {
     for (int attempt = 0; attempt < 8; ++attempt) {
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (!h->pending.active) return 0;
+        if (!h->pending.active) {
+            if (h->last_front) h->stats[0] = h->h_status[1];       // written by the last wave of the last forward
+            return 0;
+        }
         const int st = h->h_status[0];
         h->stats[0] = h->h_status[1];
         if (st == 0) {
@@ -622,6 +626,10 @@ extern "C" int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t 
     if (h->pending.active && finish_forward(h)) return 1;     // previous call may still need a regrow
     if (enqueue_forward_xyz(h, B, N, offsets, d_xyz, d_x, d_Q, d_q_out)) return 1;
     auto &pd = h->pending;
+    if (h->last_front) {          // nothing can overflow with the in-kernel front-end: no need to look at this forward
+        pd.active = false;        // again, the caller may queue the next one right away
+        return 0;
+    }
     pd.active = true;
     std::vector<int> offs(offsets, offsets + B + 1);
     pd.redo = [h, B, N, offs, d_xyz, d_x, d_Q, d_q_out]() {
@@ -847,6 +855,7 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     D.status = h->d_status.as<int>();
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     h->ctl_clean = false;
+    h->last_front = false;
     const unsigned gA = (unsigned)std::min<size_t>((A * (nx + EPNN_EDIM + 2) + 255) / 256, 4096);
     const unsigned rows = (unsigned)((P.A + 3) / 4);
     hipLaunchKernelGGL(k_dn_compact, dim3(gA), dim3(256), 0, h->stream, D);

@@ -20,7 +20,24 @@ __global__ __launch_bounds__(512) void k_co(float *out, unsigned long long *cyc,
             f32x16 acc;
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             float x = lane * 0.001f, y = 1.f + lane * 0.002f;
-            if (mode & 4) {       // accumulators in AGPRs
+            if (mode & 8) {       // 16x16x4 shape (8 passes)
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                f32x4v a4 = {0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a4, 0, 0, 0);
+                }
+                res += a4[0] + a4[1] + a4[2] + a4[3];
+            } else if (mode & 16) {   // 32x32x1 two blocks (16 passes)
+                typedef float f32x32v __attribute__((ext_vector_type(32)));
+                f32x32v a32;
+                for (int r = 0; r < 32; ++r) a32[r] = 0.f;
+                for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a32 = __builtin_amdgcn_mfma_f32_32x32x1f32(x, y, a32, 0, 0, 0);
+                }
+                for (int r = 0; r < 32; ++r) res += a32[r];
+            } else if (mode & 4) {       // accumulators in AGPRs
                 for (int i = 0; i < iters; ++i) {
 #pragma unroll
                     for (int u = 0; u < 16; ++u) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
@@ -85,6 +102,11 @@ int main() {
     run<0>("MFMA + VALU on the same SIMD", 3);
     run<1>("LDS reads alone", 2);
     run<1>("MFMA + LDS reads on the same SIMD", 3);
+    run<0>("16x16x4 alone", 9);
+    run<0>("16x16x4 + VALU", 11);
+    run<1>("16x16x4 + LDS reads", 11);
+    run<0>("32x32x1(2 blocks) alone", 17);
+    run<0>("32x32x1(2 blocks) + VALU", 19);
     run<0>("MFMA(AGPR acc) alone", 5);
     run<0>("MFMA(AGPR acc) + VALU", 7);
     run<1>("MFMA(AGPR acc) + LDS reads", 7);
