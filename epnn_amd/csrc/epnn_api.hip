@@ -503,6 +503,12 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.mu = h->d_mu.as<double>();
     A.cutoff = (double)h->cfg.cutoff;
     A.eta = (double)h->cfg.eta;
+    {   // D < cutoff decided without the sqrt: cut2 = smallest double whose (correctly rounded, monotone) sqrt is >= cutoff
+        double t = A.cutoff * A.cutoff;
+        while (sqrt(t) >= A.cutoff) t = nextafter(t, 0.0);
+        while (sqrt(t) < A.cutoff) t = nextafter(t, INFINITY);
+        A.cut2 = t;
+    }
     A.tol = h->cfg.near_tol;
     A.host_status = h->h_status;          // pinned, device-visible
     const dim3 grid((unsigned)P.small_order.size());

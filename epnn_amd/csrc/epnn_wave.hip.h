@@ -49,6 +49,7 @@ struct WaveArgs {
     const int *pbase;      // [B] first pair slot of molecule b: sum of n(n-1)/2 over the molecules before it
     const double *mu;      // [48]
     double cutoff, eta;
+    double cut2;           // smallest float64 t with sqrt(t) >= cutoff: D < cutoff  <=>  D*D (before the sqrt) < cut2
     float tol;
     int *host_status;      // pinned host ints [0] status bits [1] near pairs of the batch: written by the last wave to finish
     unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][64] s_memtime values
@@ -84,6 +85,12 @@ __device__ __forceinline__ void wave_sync_all() {
 __device__ __forceinline__ double wave_dist(const double *xs, int i, int j) {
     const double dx = xs[3 * j + 0] - xs[3 * i + 0], dy = xs[3 * j + 1] - xs[3 * i + 1], dz = xs[3 * j + 2] - xs[3 * i + 2];
     return sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+}
+
+// its argument: D < cutoff is decided on the squared distance (exactly, see WaveArgs::cut2), the sqrt is taken per near pair only
+__device__ __forceinline__ double wave_dist2(const double *xs, int i, int j) {
+    const double dx = xs[3 * j + 0] - xs[3 * i + 0], dy = xs[3 * j + 1] - xs[3 * i + 1], dz = xs[3 * j + 2] - xs[3 * i + 2];
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
 // first feature of the g-th group of four of the hk order
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     WAVE_STAMP();
     const bool catom = c < n;
 
-    // ---- in-kernel front-end, pass 1: coordinates -> LDS, number of pairs with D < cutoff (row-major i < j)
+    // ---- in-kernel front-end: coordinates -> LDS (the pair slots are assigned once the LDS tables exist)
     double *xs = reinterpret_cast<double *>(sm);           // [n][3] float32 coordinates promoted like SciPy does
     if (FRONT) {
         if (hh == 0 && c < n) {
@@ -140,11 +147,6 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             xs[3 * c + 2] = (double)A.xyz[3 * (size_t)(a0 + c) + 2];
         }
         wave_sync_lds();
-        for (int i0 = 0; i0 + 1 < n; i0 += 2) {            // half hh takes row i0 + hh, lane c is partner j = c
-            const int i = i0 + hh;
-            const bool near = c > i && c < n && wave_dist(xs, i, c) < A.cutoff;
-            np += __popcll(__ballot(near));
-        }
     }
     // ---- LDS layout of THIS molecule inside the wave's fixed budget
     float *Rl = sm;                                        // [n][PST]   R_j rows
@@ -152,13 +154,15 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     unsigned short *pm = reinterpret_cast<unsigned short *>(Pl);      // [j][32]  near-pair slot of (i = lane, j), 0xFFFF = none
     int o = 2 * n * EPNN_PST;
     unsigned short *eij = reinterpret_cast<unsigned short *>(sm + o); // [np]  li | lj << 8
-    o += EPN ? ((((np + 1) >> 1) + 3) & ~3) : 0;
+    const int eij_n = FRONT ? n * (n - 1) / 2 : np;        // in-kernel front-end: np is not known yet, reserve every i<j pair
+    o += EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
     float *Dm = sm + o;                                    // [n][DST]  weighted transfers: Dm[i][j] = what i receives from j
     o += EPN ? ((n * EPNN_DST + 3) & ~3) : 0;
     float *Gl = sm + o;                                    // [glds + 1][PST]; row glds is all zeros
-    const int glds = min(np, (A.lds_words - o) / EPNN_PST - 1);
-    const bool gover = np > glds;                          // some G rows live in HBM
-    const int ngt = (np + 31) >> 5;
+    const int grows = (A.lds_words - o) / EPNN_PST - 1;   // G rows the budget leaves room for
+    int glds = min(np, grows);
+    bool gover = np > glds;                                // some G rows live in HBM
+    int ngt = (np + 31) >> 5;
 
     // ---- per-atom registers
     const float nmv = catom ? (A.nm_in ? A.nm_in[a0 + c] : 1.f) : 0.f;
@@ -203,11 +207,11 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
         for (int i = lane; i < n * 16; i += 64) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
     wave_sync_lds();
     if (FRONT) {
-        // ---- pass 2: slots in row-major order (rows i0, i0+1 per step; the lower row's pairs first)
+        // ---- slots in row-major order (rows i0, i0+1 per step; the lower row's pairs first)
         int base = 0;
         for (int i0 = 0; i0 + 1 < n; i0 += 2) {
             const int i = i0 + hh;
-            const bool near = c > i && c < n && wave_dist(xs, i, c) < A.cutoff;
+            const bool near = c > i && c < n && wave_dist2(xs, i, c) < A.cut2;
             const unsigned long long bal = __ballot(near);
             const unsigned lo = (unsigned)bal, hi = (unsigned)(bal >> 32);
             if (near) {
@@ -218,8 +222,12 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             }
             base += __popc(lo) + __popc(hi);
         }
+        np = base;
+        glds = min(np, grows);
+        gover = np > glds;
+        ngt = (np + 31) >> 5;
         wave_sync_lds();
-        // ---- pass 3: Gaussian edge features, one lane per pair (charge_gn.py:148-161: float64, then cast to float32).
+        // ---- Gaussian edge features, one lane per pair (charge_gn.py:148-161: float64, then cast to float32).
         //      e_k = C exp(-eta (D - mu_k)^2) over the evenly spaced mu_k is a geometric-like sequence:
         //      e_{k+1} = e_k rho_k, rho_{k+1} = rho_k exp(-2 eta dmu^2): two exp per pair instead of 48 (float64 products;
         //      the accumulated rounding stays below 1e-12 relative, far inside the float32 cast).
