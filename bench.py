@@ -204,7 +204,7 @@ def main():
                                  "(kernel_ms_avg / launches_in_flight) = flops x launches / wall time of the timed region",
                          "device_ms_per_forward_avg": float(stage[:, 3].mean())},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # the reported CPU baseline belongs to the N=1 line only
             out["cpu_baseline"] = cpu_baseline(offsets, xyz, x, Q, N, weights)
         print(json.dumps(out), flush=True)
 
