@@ -229,3 +229,46 @@ def test_capacity_regrow_and_launch_variants_are_bit_identical(gpu_engine_factor
     assert np.array_equal(q, ref_list), np.abs(q - ref_list).max()
     q, st = run({"force_path": 2})
     assert np.abs(q - ref).max() <= 2e-4
+
+
+def test_fused_kernel_edge_shapes_vs_oracle(gpu_engine_factory):
+    """Shapes at the limits of the one-wavefront-per-molecule kernel: single atom (no pairs), two atoms, 31 and 32 atoms
+    (every lane owns an atom), and dense clusters in which EVERY pair is under the cutoff (496 near pairs for n = 32:
+    the G rows do not fit the wave's LDS budget, both stacks read them back from HBM) -- random non-degenerate weights,
+    float64 oracle, both front-ends."""
+    from epnn_amd import synth
+    nx, T, N = 9, 3, 35
+    w = random_weights(nx, T, seed=7, scale=0.35)
+    rng = np.random.default_rng(11)
+    mols = []
+    for n, span in [(1, 1.0), (2, 1.2), (31, 9.0), (32, 9.0), (32, 1.9), (24, 1.6), (17, 6.0)]:
+        while True:                      # random points in a cube of edge `span`, minimum separation 0.35 A
+            pts = rng.uniform(0, span, size=(n, 3))
+            d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 10
+            if d.min() > (0.35 if span < 3 else 0.8):
+                break
+        sym = rng.choice(["H", "C", "N", "O", "F"], size=n)
+        mols.append((pts.astype(np.float32), synth.features(sym), float(rng.integers(-1, 2))))
+    off = np.zeros(len(mols) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([m[1].shape[0] for m in mols])
+    xyz, x = np.concatenate([m[0] for m in mols]), np.concatenate([m[1] for m in mols])
+    Q = np.array([m[2] for m in mols], dtype=np.float32)
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    npairs = sum(int(((np.linalg.norm(m[0][:, None].astype(np.float64) - m[0][None].astype(np.float64), axis=-1) < 3.0).sum()
+                      - m[0].shape[0]) // 2) for m in mols)
+    for opts in ({}, {"wave_front": 0}, {"wave_lds": 16384}):
+        eng = gpu_engine_factory(nx=nx, T=T)
+        eng.set_weights(w)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        q = eng.forward_xyz(off, xyz, x, Q, N=N)
+        st = eng.last_stats()
+        assert st[0] == npairs and st[1] == len(mols) and st[2] == 0, (opts, st, npairs)
+        for k, m in enumerate(mols):
+            n = m[1].shape[0]
+            err = np.abs(q[off[k]:off[k + 1]] - ref[k][:n]).max()
+            assert err <= max(TOL, 4 * noise), (opts, k, n, err, noise)
+            assert abs(float(q[off[k]:off[k + 1]].sum(dtype=np.float64)) - m[2]) < 2e-5
+    print(f"edge shapes: {npairs} near pairs, float32 oracle noise {noise:.2e}")
