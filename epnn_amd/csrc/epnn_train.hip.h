@@ -329,7 +329,7 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
     hipStream_t st = h->stream;
     const float *theta = ts->theta.as<float>();
     float *grad = ts->grad.as<float>();
-    const int NSL = 8;
+    const int NSL = 256;          // most row slices of one dW reduction (fixed by the row count: reproducible)
     if (ts->part.ensure((size_t)NSL * (D + 1) * 48 * 4)) return 1;
     // ---- arena
     size_t need = 0;
@@ -361,7 +361,8 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
         if (dX)
             hipLaunchKernelGGL(k_t_dense_dx, dim3(t_grid(rows * d.n_in)), dim3(256), 0, st, dY, Ypost, theta + d.offW, dX,
                                (int)rows, d.n_in, d.n_out);
-        const int nsl = rows >= 64 ? NSL : 1;
+        // ~32 rows per slice: the pair-row GEMMs (B*N*N rows) spread over the whole GPU, the per-atom ones stay small
+        const int nsl = (int)std::min<size_t>(NSL, std::max<size_t>(1, rows / 32));
         const int tot = (d.n_in + 1) * d.n_out;
         hipLaunchKernelGGL(k_t_dense_dw, dim3((tot + 255) / 256, nsl), dim3(256), 0, st, X, dY, Ypost, ts->part.as<float>(),
                            (int)rows, d.n_in, d.n_out, nsl);
