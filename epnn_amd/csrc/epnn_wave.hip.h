@@ -67,8 +67,13 @@ struct WaveArgs {
 #define WAVE_STAMP() do { } while (0)
 #endif
 
+#ifdef EPNN_ABL_W      // diagnostic ablation: every fragment load hits the same few cache lines (results are garbage)
+#define EPNN_WLD(dst, off, cnt)                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[s_] = wp[((off) & 1023) + (s_ & 3) * 64 + lane]
+#else
 #define EPNN_WLD(dst, off, cnt)                                      \
     _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[s_] = wp[(off) + s_ * 64 + lane]
+#endif
 
 // order LDS / global traffic between lanes of the wave (the compiler sees no dependence between different lanes)
 __device__ __forceinline__ void wave_sync_lds() {
