@@ -141,7 +141,14 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     int nstamp = 0;
     (void)nstamp;
     WAVE_STAMP();
-    const bool catom = c < n;
+    // molecules with n <= 16 use the two 16-column halves of every MFMA tile for two copies of their atoms (lane c and
+    // lane c + 16 hold the same atom): all per-atom chains replicate for free and the pair sweep handles TWO partners
+    // per tile (even partners in the lower copy, odd ones in the upper), half the sweep's MFMA and VALU work
+    const bool dual = n <= 16;
+    const int ai = dual ? (c & 15) : c;                     // atom of this lane
+    const bool hi = dual && c >= 16;                        // upper copy
+    const bool catom = ai < n;
+    const bool owner = catom && !hi;                        // the lane that stores the atom's rows / results
 
     // ---- in-kernel front-end: coordinates -> LDS (the pair slots are assigned once the LDS tables exist)
     double *xs = reinterpret_cast<double *>(sm);           // [n][3] float32 coordinates promoted like SciPy does
@@ -170,17 +177,17 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     int ngt = (np + 31) >> 5;
 
     // ---- per-atom registers
-    const float nmv = catom ? (A.nm_in ? A.nm_in[a0 + c] : 1.f) : 0.f;
+    const float nmv = catom ? (A.nm_in ? A.nm_in[a0 + ai] : 1.f) : 0.f;
     float xq[EPNN_KX];
     {
-        const float qv = catom ? (A.q_in ? A.q_in[a0 + c] : A.Q[b] / (float)n) : 0.f;     // charge_gn.py:337-338
+        const float qv = catom ? (A.q_in ? A.q_in[a0 + ai] : A.Q[b] / (float)n) : 0.f;     // charge_gn.py:337-338
 #pragma unroll
         for (int s = 0; s < EPNN_KX; ++s) {
             const int phi = 2 * s + hh;
             float v = 0.f;
             if (catom) {
                 if (phi == 0) v = nmv;
-                else if (phi <= nx) v = A.xin[(size_t)(a0 + c) * nx + phi - 1];
+                else if (phi <= nx) v = A.xin[(size_t)(a0 + ai) * nx + phi - 1];
                 else if (phi == nx + 1) v = qv;
                 else if (phi == nx + 2) v = 1.f;
             }
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     if (have_h && catom) {
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(A.h_in + (size_t)(a0 + c) * EPNN_EDIM + wave_hk_f0(hh, g));
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(A.h_in + (size_t)(a0 + ai) * EPNN_EDIM + wave_hk_f0(hh, g));
             hk[4 * g] = v[0]; hk[4 * g + 1] = v[1]; hk[4 * g + 2] = v[2]; hk[4 * g + 3] = v[3];
         }
     }
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             if (have_h) acr = wave_chain<24>(wd, hk, acr);
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[r] = acc[r];
-            if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
+            if (owner) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
             EPNN_WLD(pb, X.g[0].w2, 16);
             epnn_ld16(wp + X.g[0].b2k + hh * 16, b2k);
             if (have_h) { EPNN_WLD(wb, X.u1h0, 24); }
@@ -386,12 +393,25 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                             }
                         }
                     };
-                    // tile index jt in [0, n]: partner jt, or (jt == n) the reference's zero-padded partner (R = 0, G = 0,
-                    // charge_gn.py:70) which counts N - n times.  Operands of tile jt+1 (and the slot of jt+2) are
-                    // fetched while tile jt is in the matrix pipe.
+                    // partner index jp in [0, n]: atom jp, or (jp == n) the reference's zero-padded partner (R = 0, G = 0,
+                    // charge_gn.py:70) which counts N - n times; beyond n: nothing (weight 0).  Tile t holds partner t of
+                    // every atom, or (dual) partners 2t / 2t+1 in the lower / upper copy.  Operands of tile t+1 (and the
+                    // slot of t+2) are fetched while tile t is in the matrix pipe.
                     const float *zrow = Gl + glds * EPNN_PST + hh * 16;
-                    auto rload = [&](int jt, float (&r)[16]) { epnn_ld16(jt < n ? Rl + jt * EPNN_PST + hh * 16 : zrow, r); };
-                    auto slot_of = [&](int jt) -> int { return jt < n ? (int)pm[jt * 32 + c] : 0xFFFF; };
+                    const int nt = dual ? (n + 2) >> 1 : n + 1;
+                    auto partner = [&](int t) -> int { return dual ? 2 * t + (hi ? 1 : 0) : t; };
+                    auto rload = [&](int t, float (&r)[16]) {
+                        const int jp = partner(t);
+                        epnn_ld16(jp < n ? Rl + jp * EPNN_PST + hh * 16 : zrow, r);
+                    };
+                    auto slot_of = [&](int t) -> int {
+                        const int jp = partner(t);
+                        return jp < n ? (int)pm[jp * 32 + ai] : 0xFFFF;
+                    };
+                    auto weight = [&](int t) -> float {
+                        const int jp = partner(t);
+                        return jp < n ? 1.f : (jp == n ? padw : 0.f);
+                    };
                     auto tile = [&](const float (&rj)[16], const float (&g)[16], const float (&gh)[16], float wt) {
                         f32x16 acc = cb2;
 #pragma unroll
@@ -403,44 +423,51 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) S[r] = fmaf(wt, fmaxf(acc[r], 0.f), S[r]);
                     };
-                    if (OVER) {          // rare (large molecules): no fetch-ahead, fewer registers
+                    if (OVER) {          // rare (large or very dense molecules): no fetch-ahead, fewer registers
 #pragma unroll 1
-                        for (int jt = 0; jt <= n; ++jt) {
-                            if (jt == n) { EPNN_WLD(u1s, M.u1s, 16); }        // first operand of the update MLP
+                        for (int t = 0; t < nt; ++t) {
+                            if (t == nt - 1) { EPNN_WLD(u1s, M.u1s, 16); }    // first operand of the update MLP
                             float rj[16], g[16], gh[16];
-                            rload(jt, rj);
-                            gload(slot_of(jt), g, gh);
-                            tile(rj, g, gh, jt == n ? padw : 1.f);
+                            rload(t, rj);
+                            gload(slot_of(t), g, gh);
+                            tile(rj, g, gh, weight(t));
                         }
                     } else {
                         float rA[16], gA[16], rB[16], gB[16];
                         rload(0, rA);
                         gload(slot_of(0), gA, gA);
                         int snext = slot_of(1);
-                        int jt = 0;
+                        int t = 0;
 #pragma unroll 1
-                        for (; jt + 1 < n; jt += 2) {                          // tiles jt, jt+1 (both real partners)
-                            rload(jt + 1, rB);
+                        for (; t + 2 < nt; t += 2) {                          // tiles t, t+1; neither is the last one
+                            rload(t + 1, rB);
                             gload(snext, gB, gB);
-                            snext = slot_of(jt + 2);
+                            snext = slot_of(t + 2);
                             WAVE_FENCE();
-                            tile(rA, gA, gA, 1.f);
-                            rload(jt + 2, rA);
+                            tile(rA, gA, gA, weight(t));
+                            rload(t + 2, rA);
                             gload(snext, gA, gA);
-                            snext = slot_of(jt + 3);
+                            snext = slot_of(t + 3);
                             WAVE_FENCE();
-                            tile(rB, gB, gB, 1.f);
+                            tile(rB, gB, gB, weight(t + 1));
                         }
                         EPNN_WLD(u1s, M.u1s, 16);                             // first operand of the update MLP
-                        if (jt < n) {                                          // n odd: last partner, then the padded one
-                            rload(n, rB);
-                            gload(0xFFFF, gB, gB);
+                        if (t + 1 < nt) {                                      // two tiles left
+                            rload(t + 1, rB);
+                            gload(snext, gB, gB);
                             WAVE_FENCE();
-                            tile(rA, gA, gA, 1.f);
-                            tile(rB, gB, gB, padw);
+                            tile(rA, gA, gA, weight(t));
+                            tile(rB, gB, gB, weight(t + 1));
                         } else {
                             WAVE_FENCE();
-                            tile(rA, gA, gA, padw);                            // rA/gA hold tile n: zero rows
+                            tile(rA, gA, gA, weight(t));
+                        }
+                    }
+                    if (dual) {          // the two copies of an atom hold the even / odd partners: add them, both copies end up complete
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float other = __shfl_xor(S[r], 16, 64);       // all lanes take part in the exchange
+                            S[r] = hi ? other + S[r] : S[r] + other;           // lower + upper: same order in both copies
                         }
                     }
                 };
@@ -493,7 +520,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                 f32x16 acr = wave_chain<16 + EPNN_KX>(wb, in, epnn_splat16(0.f));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) P[r] = acc[r];
-                if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
+                if (owner) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
                 EPNN_WLD(pb, X.g[t + 1].w2, 16);
                 epnn_ld16(wp + X.g[t + 1].b2k + hh * 16, b2k);
                 WAVE_FENCE();
@@ -521,7 +548,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) hk[16 + r] = nmv * (ac2[r] + bw[r]);
         }
-        if (A.h_out && catom) {
+        if (A.h_out && owner) {
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
                 f32x4 v;
@@ -554,8 +581,8 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                 WAVE_FENCE();
                 f32x16 acc = wave_chain<EPNN_KX + 24>(wa, in, epnn_splat16(0.f));
                 f32x16 acr = wave_chain<EPNN_KX + 24>(wb, in, epnn_splat16(0.f));
-                if (catom) epnn_st16(Pl + c * EPNN_PST + hh * 16, acc);
-                if (catom) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
+                if (owner) epnn_st16(Pl + c * EPNN_PST + hh * 16, acc);
+                if (owner) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
             }
             float pb[16], b2v[16], w3[16];
             EPNN_WLD(pb, M.w2, 16);
@@ -619,7 +646,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             // q_i += sum_j antisym_ij (charge_gn.py:118): lane (i, hh) adds row i of the transfer matrix, columns j = hh mod 2
             {
                 float dq0 = 0.f, dq1 = 0.f;
-                const float *drow = Dm + (catom ? c : 0) * EPNN_DST + hh;
+                const float *drow = Dm + (catom ? ai : 0) * EPNN_DST + hh;
 #pragma unroll 4
                 for (int j = 0; j + hh < n; j += 4) {
                     dq0 += drow[j];
@@ -641,7 +668,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             if (s == qs) qout = xq[s];
         const float qo = epnn_swap32(qout);
         if (qh == 1) qout = qo;
-        if (hh == 0 && catom) A.q_out[a0 + c] = qout;
+        if (hh == 0 && owner) A.q_out[a0 + c] = qout;
     }
     if (FRONT && lane == 0) {
         // No memset before and no copy after the launch: the last wave to finish hands status + pair count to the host
