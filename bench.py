@@ -22,6 +22,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# before anything (torch included) initialises HIP in this process: one hardware queue per batch in flight (epnn_amd/_lib.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
@@ -54,7 +56,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight per GPU (handles/streams used round robin)")
+    ap.add_argument("--depth", type=int, default=6, help="batches in flight per GPU (handles/streams used round robin)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
     args = ap.parse_args()
 

@@ -77,6 +77,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise EpnnError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback for the EPNN hot path.")
+    # Several handles (= HIP streams) keep batches in flight concurrently (engine.Pipeline).  The HIP runtime maps a
+    # process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's): kernels of
+    # streams that share a queue serialise.  Ask for 8 unless the caller decided otherwise; read when HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:
