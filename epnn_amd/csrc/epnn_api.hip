@@ -6,6 +6,7 @@
 #include "epnn_host.h"
 #include "epnn_frontend.hip.h"
 #include "epnn_wave.hip.h"
+#include "epnn_wave16.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
 #include "epnn_mlp.hip.h"
@@ -78,6 +79,7 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
     HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
     shape_layers(h);
+    if (const char *ev = getenv("EPNN_WAVE16")) h->opt_wave16 = atoi(ev);      // development switch
     *out = h;
     return 0;
 }
@@ -368,6 +370,124 @@ static int pack_weights(epnn_handle *h) {
             E.wj = unfolded(W1, nullptr, F);
         }
     }
+    // ------------------------------------------------------------ fragments of the 16x16x4 wave kernel
+    {
+        W16Index &X = h->w16idx;
+        const float *bu1 = h->upd[0].b.data(), *bu2 = h->upd[1].b.data(), *bu3 = h->upd[2].b.data();
+        auto vec = [&](int len, auto &&fn) {
+            const int off = alloc(len);
+            for (int k = 0; k < len; ++k) buf[off + k] = (float)fn(k);
+            return off;
+        };
+        // [nrb][steps][64]: lane (q,m) of (rb, step s) = fn(s, q, 16rb + m)  (input selector, output feature)
+        auto frag = [&](int nrb, int steps, auto &&fn) {
+            const int off = alloc((size_t)nrb * steps * 64);
+            for (int rb = 0; rb < nrb; ++rb)
+                for (int s = 0; s < steps; ++s)
+                    for (int l = 0; l < 64; ++l)
+                        buf[off + (rb * steps + s) * 64 + l] = (float)fn(s, l >> 4, 16 * rb + (l & 15));
+            return off;
+        };
+        auto accf = [](int s, int q) { return 16 * (s >> 2) + 4 * q + (s & 3); };       // "acc" K order
+        auto xq_row = [&](const float *W1, const float *b1, int r0, int phi, int m, double nmrow) -> double {
+            if (phi == 0) return nmrow;
+            if (phi <= nx) return W1[(size_t)(r0 + phi - 1) * 32 + m];
+            if (phi == nx + 1) return W1[(size_t)(r0 + nx + EPNN_EDIM) * 32 + m];
+            if (phi == nx + 2) return b1 ? b1[m] : 0.0;
+            return 0.0;
+        };
+        auto unfolded = [&](const float *W1, const float *b1, int r0) {      // xq steps, then the 12 h steps
+            return frag(2, EPNN_XS + 12, [&](int s, int q, int m) -> double {
+                if (s < EPNN_XS) return xq_row(W1, b1, r0, 4 * s + q, m, 0.0);
+                return W1[(size_t)(r0 + nx + accf(s - EPNN_XS, q)) * 32 + m];
+            });
+        };
+        auto folded = [&](const float *W1, const float *b1, int r0) {        // 8 acc steps (Wu3 M_h), then the xq steps
+            std::vector<double> prod(32 * 32), cb(32);
+            for (int k = 0; k < 32; ++k)
+                for (int m = 0; m < 32; ++m) {
+                    double a = 0;
+                    for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
+                    prod[k * 32 + m] = a;
+                }
+            for (int m = 0; m < 32; ++m) {
+                double a = 0;
+                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
+                cb[m] = a;
+            }
+            return frag(2, 8 + EPNN_XS, [&](int s, int q, int m) -> double {
+                if (s < 8) return prod[accf(s, q) * 32 + m];
+                return xq_row(W1, b1, r0, 4 * (s - 8) + q, m, cb[m]);
+            });
+        };
+        auto pair_common = [&](HostDense (&mm)[3], int &we, int &w2, int &b2) {
+            const float *W1 = mm[0].W.data(), *W2 = mm[1].W.data(), *bb2 = mm[1].b.data();
+            we = frag(2, 12, [&](int s, int q, int m) { return (double)W1[(size_t)(2 * F + 12 * q + s) * 32 + m]; });
+            w2 = frag(2, 8, [&](int s, int q, int m) { return (double)W2[(size_t)accf(s, q) * 32 + m]; });
+            b2 = vec(32, [&](int k) { return (double)bb2[k]; });
+        };
+        std::vector<double> pu1(32 * 32), cu3(32);
+        for (int k = 0; k < 32; ++k)
+            for (int m = 0; m < 32; ++m) {
+                double a = 0;
+                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)Wu1[(size_t)f * 32 + m];
+                pu1[k * 32 + m] = a;
+            }
+        for (int m = 0; m < 32; ++m) {
+            double a = 0;
+            for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)Wu1[(size_t)f * 32 + m];
+            cu3[m] = a;
+        }
+        const int off_pu1 = frag(2, 8, [&](int s, int q, int m) { return pu1[accf(s, q) * 32 + m]; });
+        const int off_cu3 = vec(32, [&](int k) { return cu3[k]; });
+        const int off_u2 = frag(2, 8, [&](int s, int q, int m) { return (double)Wu2[(size_t)accf(s, q) * 32 + m]; });
+        const int off_bu1 = vec(32, [&](int k) { return (double)bu1[k]; });
+        const int off_bu2 = vec(32, [&](int k) { return (double)bu2[k]; });
+        for (int t = 0; t < T; ++t) {
+            W16Gnn &G = X.g[t];
+            pair_common(h->msg[t], G.we, G.w2, G.b2);
+            const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
+            std::vector<double> fold(32 * 32), cb3(32);
+            for (int k = 0; k < 32; ++k)
+                for (int m = 0; m < 32; ++m) {
+                    double a = 0;
+                    for (int j = 0; j < 32; ++j) a += (double)W3[k * 32 + j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
+                    fold[k * 32 + m] = a;
+                }
+            for (int m = 0; m < 32; ++m) {
+                double a = 0;
+                for (int j = 0; j < 32; ++j) a += (double)b3[j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
+                cb3[m] = a;
+            }
+            G.u1s = frag(2, 8, [&](int s, int q, int m) { return fold[accf(s, q) * 32 + m]; });
+            G.cb3 = vec(32, [&](int k) { return cb3[k]; });
+            G.bu1 = off_bu1;
+            G.u2 = off_u2;
+            G.bu2 = off_bu2;
+            G.pu1 = off_pu1;
+            G.cu3 = off_cu3;
+            if (t + 1 < T) {
+                const float *N1 = h->msg[t + 1][0].W.data(), *nb1 = h->msg[t + 1][0].b.data();
+                G.pwi = folded(N1, nb1, 0);
+                G.pwj = folded(N1, nullptr, F);
+            } else {
+                G.pwi = G.pwj = 0;
+            }
+        }
+        X.wi0 = unfolded(h->msg[0][0].W.data(), h->msg[0][0].b.data(), 0);
+        X.wj0 = unfolded(h->msg[0][0].W.data(), nullptr, F);
+        X.u1h0 = frag(2, 12, [&](int s, int q, int m) { return (double)Wu1[(size_t)accf(s, q) * 32 + m]; });
+        X.u3 = frag(3, 8, [&](int s, int q, int m) { return (double)Wu3[(size_t)accf(s, q) * EPNN_EDIM + m]; });
+        X.bu3 = vec(48, [&](int k) { return (double)bu3[k]; });
+        for (int t = 0; t < T; ++t) {
+            W16Epn &E = X.e[t];
+            pair_common(h->pas[t], E.we, E.w2, E.b2);
+            const float *W1 = h->pas[t][0].W.data(), *b1 = h->pas[t][0].b.data();
+            E.w3 = vec(32, [&](int k) { return (double)h->pas[t][2].W[k]; });
+            E.wi = unfolded(W1, b1, 0);
+            E.wj = unfolded(W1, nullptr, F);
+        }
+    }
     if (h->d_wpack.ensure(buf.size() * sizeof(float))) return 1;
     HIPCHK(hipMemcpyAsync(h->d_wpack.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // buf is a local
@@ -512,7 +632,13 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.tol = h->cfg.near_tol;
     A.host_status = h->h_status;          // pinned, device-visible
     const dim3 grid((unsigned)P.small_order.size());
-    if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A);
+    if (h->opt_wave16) {
+        const W16Index &X = h->w16idx;
+        if (S.d_xyz) hipLaunchKernelGGL((k_wave16_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+        else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave16_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+        else if (S.run_gnn) hipLaunchKernelGGL((k_wave16_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+        else hipLaunchKernelGGL((k_wave16_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+    } else if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A);
     else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
     else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A);
     else hipLaunchKernelGGL((k_wave_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
@@ -568,6 +694,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     const Plan &P = h->plan;
     // Batches of small molecules only: the wave kernel builds each molecule's pair list itself (slots for every i<j
     // pair of the molecule, so nothing can overflow) and no front-end kernel runs.
+    if (h->opt_wave16 && h->cfg.nx + 3 > 4 * EPNN_XS) EPNN_FAIL("wave16: nx too large");
     const bool wave_front = h->opt_wave_front && P.large_list.empty() && !P.small_order.empty() && h->cfg.e_dim == EPNN_EDIM;
     if (ensure_pairs(h, wave_front ? std::max(h->pcap, P.pair_slots)
                                    : std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
@@ -770,6 +897,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
+    else if (!strcmp(name, "wave16")) { h->opt_wave16 = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }

@@ -85,6 +85,40 @@ struct WaveIndex {
     int bu3k;             // [2][2][16]
 };
 
+
+// ---- 16x16x4 variant of the wave-autonomous kernel (epnn_wave16.hip.h).  v_mfma_f32_16x16x4_f32: lane l = 16*q + m.
+// A operand lane (q,m) = A[m][k=q], B operand lane (q,n) = B[k=q][n], accumulator register r of lane (q,n) =
+// D[4q + r][n].  A 32-feature x 32-column product is 2 row blocks (rb) x 2 column blocks (cb) of such tiles; lane
+// (q,n) then owns columns n and 16+n and, of each, the 8 features 16rb + 4q + r.  K steps are ordered so that an
+// accumulator set feeds the next product directly: step s = 4rb' + r' pairs lane q with input feature
+// 16rb' + 4q + r' ("acc" order).  Other K orders: "xq" feature 4s + q;  "e" channel 12q + s.
+// Fragment = [rb][step][64 lanes]: lane (q,m) holds W[in(step,q)][16rb + m].  Vectors are in natural feature order.
+#define EPNN_XS 4            // K-steps of the xq block: nx + 3 <= 16
+struct W16Gnn {           // GNN step t
+    int we;               // [2][12][64]  e order       We_t
+    int w2;               // [2][8][64]   acc order     W2_t
+    int b2;               // [32]
+    int u1s;              // [2][8][64]   acc order     W3_t Wu1_M
+    int cb3, bu1;         // [32]         Wu1_M^T b3_t (times N at run time), bu1
+    int u2;               // [2][8][64]   acc order     Wu2
+    int bu2;              // [32]
+    int pwi, pwj;         // [2][8+XS][64]  acc rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]   (M = Wi / Wj of step t+1)
+    int pu1;              // [2][8][64]   acc order     Wu3 Wu1_H
+    int cu3;              // [32]         Wu1_H^T bu3
+};
+struct W16Epn {           // EPN step t
+    int we, w2, b2, w3;   // w3: [32]
+    int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features)
+};
+struct W16Index {
+    W16Gnn g[EPNN_MAXT];
+    W16Epn e[EPNN_MAXT];
+    int wi0, wj0;         // [2][XS+12][64]  first GNN step (h given by the caller, usually zeros)
+    int u1h0;             // [2][12][64]     acc order over 48 features  Wu1_H
+    int u3;               // [3][8][64]      acc order  Wu3 (48 outputs = 3 row blocks)
+    int bu3;              // [48]
+};
+
 __host__ __device__ static inline int epnn_kappa(int hh, int r) { return 4 * hh + (r & 3) + 8 * (r >> 2); }
 
 // feature held by register s of half kk in the hk order

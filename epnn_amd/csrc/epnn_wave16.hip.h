@@ -1,0 +1,657 @@
+// Wave-autonomous fused forward on v_mfma_f32_16x16x4_f32 (see epnn_wave.hip.h for the algorithm; this file is the
+// same program on the 16x16x4 MFMA shape).  Why the smaller shape: while one wavefront keeps the matrix pipe busy the
+// co-resident wavefront's VALU instructions issue every 6.1 cycles instead of every 8.1 with 32x32x2
+// (tools/micro/mfma_covalu.hip), and work comes in 16-column units: molecules with n <= 16 atoms and the last
+// 16 pairs of a pair tile skip their second column block.
+//
+// Lane l = 16*q + n16 owns COLUMNS n16 and 16 + n16 (atoms, or near pairs in the pair tiles) and, of each column, the 8
+// features 16*rb + 4*q + r (rb = 0,1; r = 0..3): that is the accumulator layout of the four 16x16 blocks [rb][cb] of a
+// 32 x 32 product, and with the K steps ordered s = 4*rb' + r' (lane q <-> input feature 16*rb' + 4*q + r') an
+// accumulator set is the next product's B operand as it stands.  LDS rows (R, P, G) are in natural feature order:
+// a lane reads / writes its 4 consecutive features of a row block with one 16-byte access.
+#pragma once
+#include <type_traits>
+
+#include "epnn_common.h"
+#include "epnn_wave.hip.h"
+
+__device__ __forceinline__ f32x4 w16_mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 w16_splat(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ f32x4 w16_relu(f32x4 v) {
+    return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+__device__ __forceinline__ f32x4 w16_ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void w16_st(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// fragment loads: [nrb][stride][64 lanes], steps s0 .. s0+cnt-1 of every row block
+#define W16_LDX(dst, off, nrb, cnt, stride, s0)                                                   \
+    _Pragma("unroll") for (int rb_ = 0; rb_ < (nrb); ++rb_) _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[rb_][s_] = \
+        wp[(off) + (rb_ * (stride) + (s0) + s_) * 64 + lane]
+#define W16_LD(dst, off, nrb, steps) W16_LDX(dst, off, nrb, steps, steps, 0)
+
+// D[rb][CB] += sum_s W[rb][s] * in[s]  for one column block (dependent chain of S MFMAs per row block)
+template <int NRB, int S>
+__device__ __forceinline__ void w16_mm(const float (&w)[NRB][S], const float (&in)[S], f32x4 (&d)[NRB]) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) d[rb] = w16_mfma(w[rb][s], in[s], d[rb]);
+}
+// an accumulator set [2 row blocks] of one column block as the next product's 8 input steps
+__device__ __forceinline__ void w16_feed(const f32x4 (&a)[2], float (&in)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) in[s] = a[s >> 2][s & 3];
+}
+
+template <bool GNN, bool EPN, bool FRONT>
+__global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, q = lane >> 4, n16 = lane & 15;
+    const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
+    if (!FRONT && (*A.status & EPNN_ST_PAIR_OVERFLOW)) return;
+    const int b = A.order[blockIdx.x];
+    const int a0 = A.moff[b], n = A.moff[b + 1] - a0;
+    const int p0 = FRONT ? A.pbase[b] : A.row_off[a0];
+    int np = FRONT ? 0 : A.row_off[a0 + n] - p0;
+    const int nx = A.nx;
+    const float *wp = A.wpack;
+    int nstamp = 0;
+    (void)nstamp;
+    WAVE_STAMP();
+    const bool two = n > 16;                                // the second column block holds atoms
+    const int col1 = 16 + n16;
+    const bool cat0 = n16 < n, cat1 = col1 < n;
+
+    // ---- in-kernel front-end: coordinates -> LDS (the pair slots are assigned once the LDS tables exist)
+    double *xs = reinterpret_cast<double *>(sm);           // [n][3] float32 coordinates promoted like SciPy does
+    if (FRONT) {
+        if (hh == 0 && c < n) {
+            xs[3 * c + 0] = (double)A.xyz[3 * (size_t)(a0 + c) + 0];
+            xs[3 * c + 1] = (double)A.xyz[3 * (size_t)(a0 + c) + 1];
+            xs[3 * c + 2] = (double)A.xyz[3 * (size_t)(a0 + c) + 2];
+        }
+        wave_sync_lds();
+    }
+    // ---- LDS layout of THIS molecule inside the wave's fixed budget
+    float *Rl = sm;                                        // [n][PST]   R_j rows (natural feature order)
+    float *Pl = sm + n * EPNN_PST;                         // [n][PST]   P_i rows (EPN); the GNN keeps its pair map here
+    unsigned short *pm = reinterpret_cast<unsigned short *>(Pl);      // [j][32]  near-pair slot of (i, j), 0xFFFF = none
+    int o = 2 * n * EPNN_PST;
+    unsigned short *eij = reinterpret_cast<unsigned short *>(sm + o); // [np]  li | lj << 8
+    const int eij_n = FRONT ? n * (n - 1) / 2 : np;
+    o += EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
+    float *Dm = sm + o;                                    // [n][DST]  weighted transfers: Dm[i][j] = what i receives from j
+    o += EPN ? ((n * EPNN_DST + 3) & ~3) : 0;
+    float *Gl = sm + o;                                    // [glds + 1][PST]; row glds is all zeros
+    const int grows = (A.lds_words - o) / EPNN_PST - 1;
+    int glds = min(np, grows);
+    bool gover = np > glds;
+    int ngt = (np + 31) >> 5;
+
+    // ---- per-column registers (cb = 0: column n16, cb = 1: column 16 + n16)
+    const float nm0 = cat0 ? (A.nm_in ? A.nm_in[a0 + n16] : 1.f) : 0.f;
+    const float nm1 = cat1 ? (A.nm_in ? A.nm_in[a0 + col1] : 1.f) : 0.f;
+    float xq0[EPNN_XS], xq1[EPNN_XS];
+    {
+        const float qv0 = cat0 ? (A.q_in ? A.q_in[a0 + n16] : A.Q[b] / (float)n) : 0.f;   // charge_gn.py:337-338
+        const float qv1 = cat1 ? (A.q_in ? A.q_in[a0 + col1] : A.Q[b] / (float)n) : 0.f;
+#pragma unroll
+        for (int s = 0; s < EPNN_XS; ++s) {
+            const int phi = 4 * s + q;
+            float v0 = 0.f, v1 = 0.f;
+            if (phi == 0) { v0 = nm0; v1 = nm1; }
+            else if (phi <= nx) {
+                if (cat0) v0 = A.xin[(size_t)(a0 + n16) * nx + phi - 1];
+                if (cat1) v1 = A.xin[(size_t)(a0 + col1) * nx + phi - 1];
+            } else if (phi == nx + 1) { v0 = qv0; v1 = qv1; }
+            else if (phi == nx + 2) { v0 = cat0 ? 1.f : 0.f; v1 = cat1 ? 1.f : 0.f; }
+            xq0[s] = v0;
+            xq1[s] = v1;
+        }
+    }
+    f32x4 hk0[3], hk1[3];                                  // h: features 16*rb + 4*q + r of the two columns
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb) { hk0[rb] = w16_splat(0.f); hk1[rb] = w16_splat(0.f); }
+    const bool have_h = A.h_in != nullptr;
+    if (have_h) {
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            if (cat0) hk0[rb] = w16_ld(A.h_in + (size_t)(a0 + n16) * EPNN_EDIM + 16 * rb + 4 * q);
+            if (cat1) hk1[rb] = w16_ld(A.h_in + (size_t)(a0 + col1) * EPNN_EDIM + 16 * rb + 4 * q);
+        }
+    }
+
+    // e rows of G tile gt: lane (q, n16) takes channels 12q..12q+11 of pairs gt*32 + n16 and gt*32 + 16 + n16
+    auto load_e = [&](int gt, float (&e0)[12], float (&e1)[12]) {
+        const int s0 = gt * 32 + n16, s1 = s0 + 16;
+        const float *r0 = A.pe + (size_t)(p0 + (s0 < np ? s0 : 0)) * EPNN_EDIM + 12 * q;
+        const float *r1 = A.pe + (size_t)(p0 + (s1 < np ? s1 : 0)) * EPNN_EDIM + 12 * q;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const f32x4 v0 = w16_ld(r0 + 4 * k), v1 = w16_ld(r1 + 4 * k);
+            e0[4 * k] = v0[0]; e0[4 * k + 1] = v0[1]; e0[4 * k + 2] = v0[2]; e0[4 * k + 3] = v0[3];
+            e1[4 * k] = v1[0]; e1[4 * k + 1] = v1[1]; e1[4 * k + 2] = v1[2]; e1[4 * k + 3] = v1[3];
+        }
+    };
+    // first G tiles: We and the first e rows are on their way while the LDS tables are built
+    float gw[2][12], ge0[12], ge1[12];
+    W16_LD(gw, GNN ? X.g[0].we : X.e[0].we, 2, 12);
+    if (!FRONT && ngt > 0) load_e(0, ge0, ge1);
+    WAVE_FENCE();
+
+    // ---- LDS init
+    if (EPN)
+        for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
+    if (GNN)
+        for (int i = lane; i < n * 16; i += 64) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
+    wave_sync_lds();
+    if (FRONT) {
+        // ---- slots in row-major order (rows i0, i0+1 per step; the lower row's pairs first)
+        int base = 0;
+        for (int i0 = 0; i0 + 1 < n; i0 += 2) {
+            const int i = i0 + hh;
+            const bool near = c > i && c < n && wave_dist2(xs, i, c) < A.cut2;
+            const unsigned long long bal = __ballot(near);
+            const unsigned lo = (unsigned)bal, hi = (unsigned)(bal >> 32);
+            if (near) {
+                const int slot = base + (hh ? __popc(lo) : 0) + __popc((hh ? hi : lo) & ((1u << c) - 1u));
+                eij[slot] = (unsigned short)(i | (c << 8));
+                pm[c * 32 + i] = (unsigned short)slot;                 // e is symmetric: both directions share the entry
+                pm[i * 32 + c] = (unsigned short)slot;
+            }
+            base += __popc(lo) + __popc(hi);
+        }
+        np = base;
+        glds = min(np, grows);
+        gover = np > glds;
+        ngt = (np + 31) >> 5;
+        wave_sync_lds();
+        // ---- Gaussian edge features, one lane per pair: float64 recurrence over the evenly spaced mu_k (see epnn_wave.hip.h)
+        const double pi_d = 3.141592653589793;
+        const double mu0 = A.mu[0], dmu = (A.mu[EPNN_EDIM - 1] - A.mu[0]) / (double)(EPNN_EDIM - 1);
+        const double qq = exp(-2.0 * A.eta * dmu * dmu);
+        for (int s0 = 0; s0 < np; s0 += 64) {
+            if (s0 + lane < np) {
+                const int ij = eij[s0 + lane];
+                const double D = wave_dist(xs, ij & 0xFF, ij >> 8);
+                double C = (cos(pi_d * (D - 0.0) / A.cutoff) + 1.0) / 2.0;
+                if (D <= 0.0) C = 1.0;
+                int kb = min(EPNN_EDIM - 1, max(0, (int)((D - mu0) / dmu + 0.5)));
+                double best = 1e300;
+                int kbest = kb;
+                for (int k = max(0, kb - 1); k <= min(EPNN_EDIM - 1, kb + 1); ++k) {
+                    const double d = D - A.mu[k];
+                    if (d * d < best) { best = d * d; kbest = k; }
+                }
+                const double db = D - A.mu[kbest];
+                const float emax = (float)(C * exp(-A.eta * (db * db)));
+                const float w = emax > A.tol ? 1.0f : 0.0f;           // charge_gn.py:90-94
+                A.pwi[p0 + s0 + lane] = w;
+                A.pwj[p0 + s0 + lane] = w;
+                const double t0 = D - mu0;
+                double e = C * exp(-A.eta * (t0 * t0));
+                double rho = exp(A.eta * dmu * (2.0 * t0 - dmu));
+                float *erow = A.pe + (size_t)(p0 + s0 + lane) * EPNN_EDIM;
+#pragma unroll 1
+                for (int k4 = 0; k4 < EPNN_EDIM; k4 += 4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[u] = (float)e;                               // charge_gn.py:160-161
+                        e *= rho;
+                        rho *= qq;
+                    }
+                    w16_st(erow + k4, v);
+                }
+            }
+        }
+        wave_sync_all();
+        if (ngt > 0) load_e(0, ge0, ge1);
+    } else {
+        if (GNN)
+            for (int p = lane; p < np; p += 64) {
+                const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
+                pm[lj * 32 + li] = (unsigned short)p;                   // message into i = li from j = lj
+                if (A.psym[p0 + p]) pm[li * 32 + lj] = (unsigned short)p;
+            }
+        if (EPN)
+            for (int p = lane; p < np; p += 64) {
+                const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
+                eij[p] = (unsigned short)(li | (lj << 8));
+            }
+    }
+    // the G zero row last: the front-end used those words as scratch
+    for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;
+    wave_sync_lds();
+
+    WAVE_STAMP();   // init done
+    const float Nf = (float)A.N, padw = (float)(A.N - n);
+    const int Tg = GNN ? A.T : 0, Te = EPN ? A.T : 0;
+    const int fo = 4 * q;                                   // this lane's feature offset inside a 16-feature row block
+
+    // G rows of every near pair for the pair MLP whose We is in gw (first e rows in ge0/ge1); rows >= glds go to HBM
+    auto gtiles = [&]() {
+#pragma unroll 1
+        for (int gt = 0; gt < ngt; ++gt) {
+            float en0[12], en1[12];
+            load_e(min(gt + 1, ngt - 1), en0, en1);
+            WAVE_FENCE();
+            const int s0 = gt * 32 + n16, s1 = s0 + 16;
+            f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
+            w16_mm<2, 12>(gw, ge0, d0);
+            // two separate predicated stores per target (LDS / HBM): merged into one pointer they become flat stores
+            if (s0 < min(np, glds)) { w16_st(Gl + s0 * EPNN_PST + fo, d0[0]); w16_st(Gl + s0 * EPNN_PST + 16 + fo, d0[1]); }
+            if (gover) {
+                asm volatile("" ::: "memory");
+                if (s0 >= glds && s0 < np) { w16_st(A.gx + (size_t)(p0 + s0) * 32 + fo, d0[0]); w16_st(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo, d0[1]); }
+            }
+            if (gt * 32 + 16 < np) {                        // the second 16 pairs of the tile exist
+                f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm<2, 12>(gw, ge1, d1);
+                if (s1 < min(np, glds)) { w16_st(Gl + s1 * EPNN_PST + fo, d1[0]); w16_st(Gl + s1 * EPNN_PST + 16 + fo, d1[1]); }
+                if (gover) {
+                    asm volatile("" ::: "memory");
+                    if (s1 >= glds && s1 < np) { w16_st(A.gx + (size_t)(p0 + s1) * 32 + fo, d1[0]); w16_st(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo, d1[1]); }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 12; ++s) { ge0[s] = en0[s]; ge1[s] = en1[s]; }
+        }
+    };
+    auto gprefetch = [&](int weoff) {
+        W16_LD(gw, weoff, 2, 12);
+        if (ngt > 0) load_e(0, ge0, ge1);
+    };
+    // 32-vector in natural feature order -> this lane's two groups of four
+    auto vec2 = [&](int off, f32x4 (&v)[2]) {
+        v[0] = w16_ld(wp + off + fo);
+        v[1] = w16_ld(wp + off + 16 + fo);
+    };
+
+    // ================================================================== GNN steps (charge_gn.py:60-74)
+    if (GNN) {
+        f32x4 P0[2], P1[2], U0[2], U1[2], B0[2], B1[2];     // P, u1pre, nm*u2 of the two columns
+        float pb[2][8];
+        f32x4 b2v[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) { B0[rb] = w16_splat(0.f); B1[rb] = w16_splat(0.f); }
+        // ---- step 0: G rows, then P / R / u1pre from (xq | h)
+        {
+            float wa[2][EPNN_XS], wc[2][EPNN_XS];
+            W16_LDX(wa, X.wi0, 2, EPNN_XS, EPNN_XS + 12, 0);      // the xq steps; the h steps only when h is given
+            W16_LDX(wc, X.wj0, 2, EPNN_XS, EPNN_XS + 12, 0);
+            WAVE_FENCE();
+            gtiles();
+            W16_LD(pb, X.g[0].w2, 2, 8);
+            vec2(X.g[0].b2, b2v);
+            WAVE_FENCE();
+            f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); U0[rb] = w16_splat(0.f); U1[rb] = w16_splat(0.f); }
+            w16_mm<2, EPNN_XS>(wa, xq0, P0);
+            w16_mm<2, EPNN_XS>(wc, xq0, r0);
+            if (two) { w16_mm<2, EPNN_XS>(wa, xq1, P1); w16_mm<2, EPNN_XS>(wc, xq1, r1); }
+            if (have_h) {                                   // layer-level entry: h given by the caller
+                float wh[2][12], hin0[12], hin1[12], hm0[12], hm1[12];
+#pragma unroll
+                for (int s = 0; s < 12; ++s) {
+                    hin0[s] = hk0[s >> 2][s & 3]; hin1[s] = hk1[s >> 2][s & 3];
+                    hm0[s] = nm0 * hin0[s]; hm1[s] = nm1 * hin1[s];    // masked_input = [h, m] * node_mask (charge_gn.py:72)
+                }
+                W16_LDX(wh, X.wi0, 2, 12, EPNN_XS + 12, EPNN_XS);
+                w16_mm<2, 12>(wh, hin0, P0);
+                if (two) w16_mm<2, 12>(wh, hin1, P1);
+                W16_LDX(wh, X.wj0, 2, 12, EPNN_XS + 12, EPNN_XS);
+                w16_mm<2, 12>(wh, hin0, r0);
+                if (two) w16_mm<2, 12>(wh, hin1, r1);
+                W16_LD(wh, X.u1h0, 2, 12);
+                w16_mm<2, 12>(wh, hm0, U0);
+                if (two) w16_mm<2, 12>(wh, hm1, U1);
+            }
+            if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
+            if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
+        }
+        wave_sync_all();
+        WAVE_STAMP();   // step-0 G tiles + projections
+
+#pragma unroll 1
+        for (int t = 0; t < Tg; ++t) {
+            const W16Gnn &M = X.g[t];
+            const bool lastg = t + 1 == Tg;
+            f32x4 S0[2] = {w16_splat(0.f), w16_splat(0.f)}, S1[2] = {w16_splat(0.f), w16_splat(0.f)};
+            float u1s[2][8];
+            {
+                // ---- partner tiles: tile jp holds partner jp of every atom; jp == n is the reference's zero-padded
+                //      partner (R = 0, G = 0, charge_gn.py:70), counted N - n times
+                const float *zrow = Gl + glds * EPNN_PST;
+                auto sweep = [&](auto over_tag) {
+                    constexpr bool OVER = decltype(over_tag)::value;
+                    struct Ops { f32x4 r[2], g0[2], g1[2]; };
+                    auto load_ops = [&](int jp, int s0, int s1, Ops &o_) {
+                        const float *rrow = jp < n ? Rl + jp * EPNN_PST : zrow;
+                        o_.r[0] = w16_ld(rrow + fo);
+                        o_.r[1] = w16_ld(rrow + 16 + fo);
+                        const float *g0 = Gl + min(s0, glds) * EPNN_PST;         // 0xFFFF / overflow -> the zero row
+                        o_.g0[0] = w16_ld(g0 + fo);
+                        o_.g0[1] = w16_ld(g0 + 16 + fo);
+                        if (OVER && s0 >= glds && s0 != 0xFFFF) {
+                            o_.g0[0] = w16_ld(A.gx + (size_t)(p0 + s0) * 32 + fo);
+                            o_.g0[1] = w16_ld(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo);
+                        }
+                        if (two) {
+                            const float *g1 = Gl + min(s1, glds) * EPNN_PST;
+                            o_.g1[0] = w16_ld(g1 + fo);
+                            o_.g1[1] = w16_ld(g1 + 16 + fo);
+                            if (OVER && s1 >= glds && s1 != 0xFFFF) {
+                                o_.g1[0] = w16_ld(A.gx + (size_t)(p0 + s1) * 32 + fo);
+                                o_.g1[1] = w16_ld(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo);
+                            }
+                        }
+                    };
+                    auto slot0 = [&](int jp) -> int { return jp < n ? (int)pm[jp * 32 + n16] : 0xFFFF; };
+                    auto slot1 = [&](int jp) -> int { return (two && jp < n) ? (int)pm[jp * 32 + col1] : 0xFFFF; };
+                    auto tile = [&](const Ops &o_, float wt) {
+                        float z[8];
+                        f32x4 d[2];
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) z[s] = fmaxf((P0[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g0[s >> 2][s & 3], 0.f);
+                        d[0] = b2v[0]; d[1] = b2v[1];
+                        w16_mm<2, 8>(pb, z, d);
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) S0[rb] += wt * w16_relu(d[rb]);
+                        if (two) {
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) z[s] = fmaxf((P1[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g1[s >> 2][s & 3], 0.f);
+                            d[0] = b2v[0]; d[1] = b2v[1];
+                            w16_mm<2, 8>(pb, z, d);
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb) S1[rb] += wt * w16_relu(d[rb]);
+                        }
+                    };
+                    if (OVER) {          // rare (large or very dense molecules): no fetch-ahead
+#pragma unroll 1
+                        for (int jp = 0; jp <= n; ++jp) {
+                            if (jp == n) { W16_LD(u1s, M.u1s, 2, 8); }
+                            Ops o_;
+                            load_ops(jp, slot0(jp), slot1(jp), o_);
+                            tile(o_, jp == n ? padw : 1.f);
+                        }
+                    } else {
+                        Ops oa, ob;
+                        load_ops(0, slot0(0), slot1(0), oa);
+                        int sn0 = slot0(1), sn1 = slot1(1);
+                        int jp = 0;
+#pragma unroll 1
+                        for (; jp + 2 <= n; jp += 2) {                         // tiles jp, jp+1: neither is the last one
+                            load_ops(jp + 1, sn0, sn1, ob);
+                            sn0 = slot0(jp + 2); sn1 = slot1(jp + 2);
+                            WAVE_FENCE();
+                            tile(oa, 1.f);
+                            load_ops(jp + 2, sn0, sn1, oa);
+                            sn0 = slot0(jp + 3); sn1 = slot1(jp + 3);
+                            WAVE_FENCE();
+                            tile(ob, 1.f);
+                        }
+                        W16_LD(u1s, M.u1s, 2, 8);                             // first operand of the update MLP
+                        if (jp < n) {                                          // n odd: last partner, then the padded one
+                            load_ops(n, 0xFFFF, 0xFFFF, ob);
+                            WAVE_FENCE();
+                            tile(oa, 1.f);
+                            tile(ob, padw);
+                        } else {
+                            WAVE_FENCE();
+                            tile(oa, padw);                                    // oa holds tile n: zero rows
+                        }
+                    }
+                };
+                if (gover) sweep(std::true_type{});
+                else sweep(std::false_type{});
+            }
+            if (t < 2) WAVE_STAMP();   // pair tiles
+            // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
+            {
+                float w2[2][8], in0[8], in1[8];
+                f32x4 cv[2], bv[2];
+                W16_LD(w2, M.u2, 2, 8);
+                vec2(M.cb3, cv);
+                vec2(M.bu1, bv);
+                WAVE_FENCE();
+                f32x4 d0[2] = {U0[0], U0[1]}, d1[2] = {U1[0], U1[1]};
+                w16_feed(S0, in0);
+                w16_mm<2, 8>(u1s, in0, d0);
+                if (two) { w16_feed(S1, in1); w16_mm<2, 8>(u1s, in1, d1); }
+                f32x4 a0_[2], a1_[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    a0_[rb] = w16_relu(nm0 * (d0[rb] + Nf * cv[rb]) + bv[rb]);
+                    a1_[rb] = w16_relu(nm1 * (d1[rb] + Nf * cv[rb]) + bv[rb]);
+                }
+                vec2(M.bu2, bv);
+                if (!lastg) gprefetch(X.g[t + 1].we);
+                else if (Te > 0) gprefetch(X.e[0].we);
+                WAVE_FENCE();
+                d0[0] = bv[0]; d0[1] = bv[1]; d1[0] = bv[0]; d1[1] = bv[1];
+                w16_feed(a0_, in0);
+                w16_mm<2, 8>(w2, in0, d0);
+                if (two) { w16_feed(a1_, in1); w16_mm<2, 8>(w2, in1, d1); }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { B0[rb] = nm0 * w16_relu(d0[rb]); B1[rb] = nm1 * w16_relu(d1[rb]); }
+            }
+            if (t < 2) WAVE_STAMP();   // U1, U2
+            if (!lastg) {
+                // next step: G rows, then P / R / u1pre from (nm*u2 | xq) through the folded matrices
+                float wa[2][8 + EPNN_XS], wb[2][8 + EPNN_XS], in0[8 + EPNN_XS], in1[8 + EPNN_XS];
+                W16_LD(wa, M.pwi, 2, 8 + EPNN_XS);
+                WAVE_FENCE();
+                gtiles();
+                if (t < 2) WAVE_STAMP();   // G tiles
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { in0[s] = B0[s >> 2][s & 3]; in1[s] = B1[s >> 2][s & 3]; }
+#pragma unroll
+                for (int s = 0; s < EPNN_XS; ++s) { in0[8 + s] = xq0[s]; in1[8 + s] = xq1[s]; }
+                W16_LD(wb, M.pwj, 2, 8 + EPNN_XS);
+                float wu[2][8];
+                f32x4 cu[2];
+                W16_LD(wu, M.pu1, 2, 8);
+                vec2(M.cu3, cu);
+                WAVE_FENCE();
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); }
+                w16_mm<2, 8 + EPNN_XS>(wa, in0, P0);
+                if (two) w16_mm<2, 8 + EPNN_XS>(wa, in1, P1);
+                f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm<2, 8 + EPNN_XS>(wb, in0, r0);
+                if (two) w16_mm<2, 8 + EPNN_XS>(wb, in1, r1);
+                if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
+                if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
+                W16_LD(pb, X.g[t + 1].w2, 2, 8);
+                vec2(X.g[t + 1].b2, b2v);
+                WAVE_FENCE();
+                float bin0[8], bin1[8];
+                w16_feed(B0, bin0);
+                w16_feed(B1, bin1);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { U0[rb] = nm0 * cu[rb]; U1[rb] = nm1 * cu[rb]; }
+                w16_mm<2, 8>(wu, bin0, U0);
+                if (two) w16_mm<2, 8>(wu, bin1, U1);
+                wave_sync_all();
+                if (t < 2) WAVE_STAMP();   // projections
+            }
+        }
+        {
+            // h = node_mask * (Wu3^T u2 + bu3)  (charge_gn.py:73-74) after the last step, straight into the h registers
+            float w[3][8], bin0[8], bin1[8];
+            W16_LD(w, X.u3, 3, 8);
+            f32x4 bv[3];
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) bv[rb] = w16_ld(wp + X.bu3 + 16 * rb + fo);
+            WAVE_FENCE();
+            w16_feed(B0, bin0);
+            w16_feed(B1, bin1);
+            // B = nm * u2 already: h = nm * (Wu3^T u2) + nm * bu3
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) { hk0[rb] = nm0 * bv[rb]; hk1[rb] = nm1 * bv[rb]; }
+            w16_mm<3, 8>(w, bin0, hk0);
+            if (two) w16_mm<3, 8>(w, bin1, hk1);
+        }
+        if (A.h_out) {
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                if (cat0) w16_st(A.h_out + (size_t)(a0 + n16) * EPNN_EDIM + 16 * rb + fo, hk0[rb]);
+                if (cat1) w16_st(A.h_out + (size_t)(a0 + col1) * EPNN_EDIM + 16 * rb + fo, hk1[rb]);
+            }
+        }
+    }
+
+    WAVE_STAMP();   // GNN done
+    // ================================================================== EPN steps (charge_gn.py:98-118)
+    if (EPN) {
+        wave_sync_lds();                                    // the pair map is dead: its rows become P rows
+        const int qs = (nx + 1) >> 2, ql = (nx + 1) & 3;    // step / lane group of xq that holds q
+#pragma unroll 1
+        for (int t = 0; t < Te; ++t) {
+            const W16Epn &M = X.e[t];
+            {
+                float wa[2][EPNN_XS + 12], wb[2][EPNN_XS + 12], in0[EPNN_XS + 12], in1[EPNN_XS + 12];
+#pragma unroll
+                for (int s = 0; s < EPNN_XS; ++s) { in0[s] = xq0[s]; in1[s] = xq1[s]; }
+#pragma unroll
+                for (int s = 0; s < 12; ++s) { in0[EPNN_XS + s] = hk0[s >> 2][s & 3]; in1[EPNN_XS + s] = hk1[s >> 2][s & 3]; }
+                W16_LD(wa, M.wi, 2, EPNN_XS + 12);
+                WAVE_FENCE();
+                gtiles();
+                if (t < 2) WAVE_STAMP();   // EPN G tiles
+                W16_LD(wb, M.wj, 2, EPNN_XS + 12);
+                WAVE_FENCE();
+                f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)}, d1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm<2, EPNN_XS + 12>(wa, in0, d0);
+                if (two) w16_mm<2, EPNN_XS + 12>(wa, in1, d1);
+                if (cat0) { w16_st(Pl + n16 * EPNN_PST + fo, d0[0]); w16_st(Pl + n16 * EPNN_PST + 16 + fo, d0[1]); }
+                if (cat1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
+                d0[0] = w16_splat(0.f); d0[1] = w16_splat(0.f); d1[0] = w16_splat(0.f); d1[1] = w16_splat(0.f);
+                w16_mm<2, EPNN_XS + 12>(wb, in0, d0);
+                if (two) w16_mm<2, EPNN_XS + 12>(wb, in1, d1);
+                if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
+                if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
+            }
+            float pb[2][8];
+            f32x4 b2v[2], w3[2];
+            W16_LD(pb, M.w2, 2, 8);
+            vec2(M.b2, b2v);
+            vec2(M.w3, w3);
+            wave_sync_all();
+            if (t < 2) WAVE_STAMP();   // EPN P, R
+            {
+                // one column per UNORDERED near pair, 16 pairs per column block; the pair record of the next block
+                // (indices in LDS, weights in HBM) is fetched one block ahead
+                const int nblk = (np + 15) >> 4;
+                int ij_n = eij[n16 < np ? n16 : 0];
+                float wi_n = A.pwi[p0 + (n16 < np ? n16 : 0)], wj_n = A.pwj[p0 + (n16 < np ? n16 : 0)];
+#pragma unroll 1
+                for (int blk = 0; blk < nblk; ++blk) {
+                    const int slot = blk * 16 + n16;
+                    const bool valid = slot < np;
+                    const int sl = valid ? slot : 0;
+                    const int ij = ij_n;
+                    const float wi = wi_n, wj = wj_n;
+                    {
+                        const int sn = slot + 16 < np ? slot + 16 : 0;
+                        ij_n = eij[sn];
+                        wi_n = A.pwi[p0 + sn];
+                        wj_n = A.pwj[p0 + sn];
+                    }
+                    const int li = ij & 0xFF, lj = ij >> 8;
+                    f32x4 g[2], pi_[2], rj_[2], pj_[2], ri_[2];
+                    if (sl < glds) { g[0] = w16_ld(Gl + sl * EPNN_PST + fo); g[1] = w16_ld(Gl + sl * EPNN_PST + 16 + fo); }
+                    else { g[0] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + fo); g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo); }
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        pi_[rb] = w16_ld(Pl + li * EPNN_PST + 16 * rb + fo);
+                        rj_[rb] = w16_ld(Rl + lj * EPNN_PST + 16 * rb + fo);
+                        pj_[rb] = w16_ld(Pl + lj * EPNN_PST + 16 * rb + fo);
+                        ri_[rb] = w16_ld(Rl + li * EPNN_PST + 16 * rb + fo);
+                    }
+                    float zu[8], zv[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        zu[s] = fmaxf((g[s >> 2][s & 3] + pi_[s >> 2][s & 3]) + rj_[s >> 2][s & 3], 0.f);
+                        zv[s] = fmaxf((g[s >> 2][s & 3] + pj_[s >> 2][s & 3]) + ri_[s >> 2][s & 3], 0.f);
+                    }
+                    f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
+                    w16_mm<2, 8>(pb, zu, au);
+                    w16_mm<2, 8>(pb, zv, av);
+                    float fu = 0.f, fv = 0.f;
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            fu = fmaf(w3[rb][r], fmaxf(au[rb][r], 0.f), fu);
+                            fv = fmaf(w3[rb][r], fmaxf(av[rb][r], 0.f), fv);
+                        }
+                    // the 32 features of a column are spread over the four lanes q = 0..3 (all lanes take part)
+                    fu += __shfl_xor(fu, 16, 64);
+                    fv += __shfl_xor(fv, 16, 64);
+                    fu += __shfl_xor(fu, 32, 64);
+                    fv += __shfl_xor(fv, 32, 64);
+                    const float d = 0.5f * (fu - fv);                  // charge_gn.py:116
+                    // entries with weight 0 are never written (they stay 0): a one-sided entry (j,i) of the dense
+                    // front-end must not clear what the entry (i,j) wrote
+                    if (q == 0 && valid && wi != 0.f) Dm[li * EPNN_DST + lj] = wi * d;
+                    if (q == 1 && valid && wj != 0.f) Dm[lj * EPNN_DST + li] = -(wj * d);
+                }
+            }
+            wave_sync_lds();
+            if (t + 1 < Te) gprefetch(X.e[t + 1].we);     // on its way during the charge update
+            WAVE_FENCE();
+            if (t < 2) WAVE_STAMP();   // EPN pair tiles
+            // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of the rows of its two atoms
+            {
+                float dq0 = 0.f, dq1 = 0.f;
+                const float *row0 = Dm + (cat0 ? n16 : 0) * EPNN_DST, *row1 = Dm + (cat1 ? col1 : 0) * EPNN_DST;
+                for (int j = q; j < n; j += 4) {
+                    dq0 += row0[j];
+                    dq1 += row1[j];
+                }
+                dq0 += __shfl_xor(dq0, 16, 64);
+                dq1 += __shfl_xor(dq1, 16, 64);
+                dq0 += __shfl_xor(dq0, 32, 64);
+                dq1 += __shfl_xor(dq1, 32, 64);
+#pragma unroll
+                for (int s = 0; s < EPNN_XS; ++s)
+                    if (s == qs && q == ql) { xq0[s] += cat0 ? dq0 : 0.f; xq1[s] += cat1 ? dq1 : 0.f; }
+            }
+            wave_sync_lds();
+            if (t < 2) WAVE_STAMP();   // charge update
+        }
+#pragma unroll
+        for (int s = 0; s < EPNN_XS; ++s)
+            if (s == qs && q == ql) {
+                if (cat0) A.q_out[a0 + n16] = xq0[s];
+                if (cat1) A.q_out[a0 + col1] = xq1[s];
+            }
+    }
+    if (FRONT && lane == 0) {
+        // the last wave to finish hands status + pair count to the host and re-zeroes the control words
+        atomicAdd(A.status + 1, np);
+        __threadfence();
+        if (atomicAdd(A.status + 2, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            const int st = atomicExch(A.status + 0, 0), cnt = atomicExch(A.status + 1, 0);
+            atomicExch(A.status + 2, 0);
+            volatile int *hs = A.host_status;
+            hs[0] = st;
+            hs[1] = cnt;
+            __threadfence_system();
+        }
+    }
+    WAVE_STAMP();
+#ifdef EPNN_STAMPS
+    if (lane == 0 && A.stamps) {
+        A.stamps[(size_t)blockIdx.x * 64 + 62] = (unsigned long long)nstamp;
+        A.stamps[(size_t)blockIdx.x * 64 + 63] = ((unsigned long long)n << 32) | (unsigned)np;
+    }
+#endif
+    (void)Tg;
+}

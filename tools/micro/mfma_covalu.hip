@@ -13,6 +13,8 @@ __global__ __launch_bounds__(512) void k_co(float *out, unsigned long long *cyc,
     const bool mfma_role = wave < 4;
     lds[threadIdx.x] = threadIdx.x;
     __syncthreads();
+    if (mode & 32) { if (mfma_role) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+    if (mode & 64) { if (mfma_role) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     float res = 0.f;
     if (mfma_role) {
@@ -102,6 +104,9 @@ int main() {
     run<0>("MFMA + VALU on the same SIMD", 3);
     run<1>("LDS reads alone", 2);
     run<1>("MFMA + LDS reads on the same SIMD", 3);
+    run<0>("MFMA prio0 + VALU prio3", 3 + 32);
+    run<1>("MFMA prio0 + LDS prio3", 3 + 32);
+    run<0>("MFMA prio3 + VALU prio0", 3 + 64);
     run<0>("16x16x4 alone", 9);
     run<0>("16x16x4 + VALU", 11);
     run<1>("16x16x4 + LDS reads", 11);
