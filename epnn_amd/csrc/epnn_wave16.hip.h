@@ -22,6 +22,14 @@ __device__ __forceinline__ f32x4 w16_splat(float v) { return f32x4{v, v, v, v}; 
 __device__ __forceinline__ f32x4 w16_relu(f32x4 v) {
     return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
 }
+// sum over the four lanes q = 0..3 that share a column: two VALU lane swaps (gfx950 v_permlane16/32_swap), no LDS
+// round trip; every lane ends up with the same bits ((q0 + q1) + (q2 + q3))
+__device__ __forceinline__ float w16_sumq(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ f32x4 w16_ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void w16_st(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
@@ -64,8 +72,29 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
     const int col1 = 16 + n16;
     const bool cat0 = n16 < n, cat1 = col1 < n;
 
+    // ---- LDS layout of THIS molecule inside the wave's fixed budget.  The two stacks need different tables, and the G
+    //      rows are recomputed by every step anyway, so each stack has its own layout behind the common part:
+    //        common  eij [pairs] | R [n][PST]
+    //        GNN     pair map [n][32] u16 | G rows ... | zero row        (the sweep reads every G row n times: all in LDS
+    //                                                                     for molecules up to ~24 atoms)
+    //        EPN     P [n][PST] | transfer matrix [n][DST] | G rows ...  (G rows are read once per step: the rest from HBM)
+    unsigned short *eij = reinterpret_cast<unsigned short *>(sm);     // [np]  li | lj << 8
+    const int eij_n = FRONT ? n * (n - 1) / 2 : np;        // in-kernel front-end: np is not known yet, reserve every i<j pair
+    const int o_r = EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
+    float *Rl = sm + o_r;                                  // [n][PST]   R_j rows (natural feature order)
+    const int o_x = o_r + n * EPNN_PST;
+    unsigned short *pm = reinterpret_cast<unsigned short *>(sm + o_x);    // [j][32]  near-pair slot of (i, j), 0xFFFF = none
+    float *Pl = sm + o_x;                                  // [n][PST]   P_i rows
+    float *Dm = sm + o_x + n * EPNN_PST;                   // [n][DST]   weighted transfers: Dm[i][j] = what i receives from j
+    const int o_gg = o_x + ((n * 16 + 3) & ~3), o_ge = o_x + n * EPNN_PST + ((n * EPNN_DST + 3) & ~3);
+    const int grows_g = (A.lds_words - o_gg) / EPNN_PST - 1, grows_e = (A.lds_words - o_ge) / EPNN_PST;
+    float *Gl = sm + (GNN ? o_gg : o_ge);                  // G rows of the stack that is running; GNN: row glds is all zeros
+    int glds = min(np, GNN ? grows_g : grows_e);
+    bool gover = np > glds;                                // some G rows live in HBM
+    int ngt = (np + 31) >> 5;
+
     // ---- in-kernel front-end: coordinates -> LDS (the pair slots are assigned once the LDS tables exist)
-    double *xs = reinterpret_cast<double *>(sm);           // [n][3] float32 coordinates promoted like SciPy does
+    double *xs = reinterpret_cast<double *>(Rl);           // [n][3] float32 coordinates promoted like SciPy does (R rows come later)
     if (FRONT) {
         if (hh == 0 && c < n) {
             xs[3 * c + 0] = (double)A.xyz[3 * (size_t)(a0 + c) + 0];
@@ -74,22 +103,6 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
         }
         wave_sync_lds();
     }
-    // ---- LDS layout of THIS molecule inside the wave's fixed budget
-    float *Rl = sm;                                        // [n][PST]   R_j rows (natural feature order)
-    float *Pl = sm + n * EPNN_PST;                         // [n][PST]   P_i rows (EPN); the GNN keeps its pair map here
-    unsigned short *pm = reinterpret_cast<unsigned short *>(Pl);      // [j][32]  near-pair slot of (i, j), 0xFFFF = none
-    int o = 2 * n * EPNN_PST;
-    unsigned short *eij = reinterpret_cast<unsigned short *>(sm + o); // [np]  li | lj << 8
-    const int eij_n = FRONT ? n * (n - 1) / 2 : np;
-    o += EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
-    float *Dm = sm + o;                                    // [n][DST]  weighted transfers: Dm[i][j] = what i receives from j
-    o += EPN ? ((n * EPNN_DST + 3) & ~3) : 0;
-    float *Gl = sm + o;                                    // [glds + 1][PST]; row glds is all zeros
-    const int grows = (A.lds_words - o) / EPNN_PST - 1;
-    int glds = min(np, grows);
-    bool gover = np > glds;
-    int ngt = (np + 31) >> 5;
-
     // ---- per-column registers (cb = 0: column n16, cb = 1: column 16 + n16)
     const float nm0 = cat0 ? (A.nm_in ? A.nm_in[a0 + n16] : 1.f) : 0.f;
     const float nm1 = cat1 ? (A.nm_in ? A.nm_in[a0 + col1] : 1.f) : 0.f;
@@ -142,8 +155,6 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
     WAVE_FENCE();
 
     // ---- LDS init
-    if (EPN)
-        for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
     if (GNN)
         for (int i = lane; i < n * 16; i += 64) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
     wave_sync_lds();
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
             base += __popc(lo) + __popc(hi);
         }
         np = base;
-        glds = min(np, grows);
+        glds = min(np, grows_g);                            // the in-kernel front-end always runs both stacks: GNN first
         gover = np > glds;
         ngt = (np + 31) >> 5;
         wave_sync_lds();
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
                 eij[p] = (unsigned short)(li | (lj << 8));
             }
     }
-    // the G zero row last: the front-end used those words as scratch
-    for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;
+    if (GNN)
+        for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;        // the sweep's zero row
     wave_sync_lds();
 
     WAVE_STAMP();   // init done
@@ -508,7 +519,12 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
     WAVE_STAMP();   // GNN done
     // ================================================================== EPN steps (charge_gn.py:98-118)
     if (EPN) {
-        wave_sync_lds();                                    // the pair map is dead: its rows become P rows
+        wave_sync_lds();                                    // the GNN's tables are dead: switch to the EPN layout
+        Gl = sm + o_ge;
+        glds = min(np, grows_e);
+        gover = np > glds;
+        for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
+        wave_sync_lds();
         const int qs = (nx + 1) >> 2, ql = (nx + 1) & 3;    // step / lane group of xq that holds q
 #pragma unroll 1
         for (int t = 0; t < Te; ++t) {
@@ -544,62 +560,75 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
             wave_sync_all();
             if (t < 2) WAVE_STAMP();   // EPN P, R
             {
-                // one column per UNORDERED near pair, 16 pairs per column block; the pair record of the next block
-                // (indices in LDS, weights in HBM) is fetched one block ahead
+                // one column per UNORDERED near pair, 16 pairs per column block.  Software pipeline: the pair record
+                // (indices in LDS, weights in HBM) is fetched two blocks ahead, the gathered P / R / G rows one block ahead
                 const int nblk = (np + 15) >> 4;
-                int ij_n = eij[n16 < np ? n16 : 0];
-                float wi_n = A.pwi[p0 + (n16 < np ? n16 : 0)], wj_n = A.pwj[p0 + (n16 < np ? n16 : 0)];
-#pragma unroll 1
-                for (int blk = 0; blk < nblk; ++blk) {
-                    const int slot = blk * 16 + n16;
-                    const bool valid = slot < np;
-                    const int sl = valid ? slot : 0;
-                    const int ij = ij_n;
-                    const float wi = wi_n, wj = wj_n;
-                    {
-                        const int sn = slot + 16 < np ? slot + 16 : 0;
-                        ij_n = eij[sn];
-                        wi_n = A.pwi[p0 + sn];
-                        wj_n = A.pwj[p0 + sn];
-                    }
-                    const int li = ij & 0xFF, lj = ij >> 8;
-                    f32x4 g[2], pi_[2], rj_[2], pj_[2], ri_[2];
-                    if (sl < glds) { g[0] = w16_ld(Gl + sl * EPNN_PST + fo); g[1] = w16_ld(Gl + sl * EPNN_PST + 16 + fo); }
-                    else { g[0] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + fo); g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo); }
+                struct Rec { int ij; float wi, wj; };
+                struct Rows { f32x4 g[2], pi_[2], rj_[2], pj_[2], ri_[2]; };
+                auto load_rec = [&](int blk, Rec &r_) {
+                    const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
+                    r_.ij = eij[sl];
+                    r_.wi = A.pwi[p0 + sl];
+                    r_.wj = A.pwj[p0 + sl];
+                };
+                auto load_rows = [&](int blk, const Rec &r_, Rows &w_) {
+                    const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
+                    const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
+                    if (sl < glds) { w_.g[0] = w16_ld(Gl + sl * EPNN_PST + fo); w_.g[1] = w16_ld(Gl + sl * EPNN_PST + 16 + fo); }
+                    else { w_.g[0] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + fo); w_.g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo); }
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
-                        pi_[rb] = w16_ld(Pl + li * EPNN_PST + 16 * rb + fo);
-                        rj_[rb] = w16_ld(Rl + lj * EPNN_PST + 16 * rb + fo);
-                        pj_[rb] = w16_ld(Pl + lj * EPNN_PST + 16 * rb + fo);
-                        ri_[rb] = w16_ld(Rl + li * EPNN_PST + 16 * rb + fo);
+                        w_.pi_[rb] = w16_ld(Pl + li * EPNN_PST + 16 * rb + fo);
+                        w_.rj_[rb] = w16_ld(Rl + lj * EPNN_PST + 16 * rb + fo);
+                        w_.pj_[rb] = w16_ld(Pl + lj * EPNN_PST + 16 * rb + fo);
+                        w_.ri_[rb] = w16_ld(Rl + li * EPNN_PST + 16 * rb + fo);
                     }
+                };
+                auto block = [&](int blk, const Rec &r_, const Rows &w_) {
+                    const bool valid = blk * 16 + n16 < np;
+                    const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
                     float zu[8], zv[8];
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
-                        zu[s] = fmaxf((g[s >> 2][s & 3] + pi_[s >> 2][s & 3]) + rj_[s >> 2][s & 3], 0.f);
-                        zv[s] = fmaxf((g[s >> 2][s & 3] + pj_[s >> 2][s & 3]) + ri_[s >> 2][s & 3], 0.f);
+                        zu[s] = fmaxf((w_.g[s >> 2][s & 3] + w_.pi_[s >> 2][s & 3]) + w_.rj_[s >> 2][s & 3], 0.f);
+                        zv[s] = fmaxf((w_.g[s >> 2][s & 3] + w_.pj_[s >> 2][s & 3]) + w_.ri_[s >> 2][s & 3], 0.f);
                     }
                     f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
                     w16_mm<2, 8>(pb, zu, au);
                     w16_mm<2, 8>(pb, zv, av);
-                    float fu = 0.f, fv = 0.f;
+                    float fd = 0.f;                                    // w3 . (relu(u) - relu(v)) over this lane's 8 features
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            fu = fmaf(w3[rb][r], fmaxf(au[rb][r], 0.f), fu);
-                            fv = fmaf(w3[rb][r], fmaxf(av[rb][r], 0.f), fv);
-                        }
-                    // the 32 features of a column are spread over the four lanes q = 0..3 (all lanes take part)
-                    fu += __shfl_xor(fu, 16, 64);
-                    fv += __shfl_xor(fv, 16, 64);
-                    fu += __shfl_xor(fu, 32, 64);
-                    fv += __shfl_xor(fv, 32, 64);
-                    const float d = 0.5f * (fu - fv);                  // charge_gn.py:116
+                        for (int r = 0; r < 4; ++r) fd = fmaf(w3[rb][r], fmaxf(au[rb][r], 0.f) - fmaxf(av[rb][r], 0.f), fd);
+                    const float d = 0.5f * w16_sumq(fd);               // charge_gn.py:116; all lanes take part
                     // entries with weight 0 are never written (they stay 0): a one-sided entry (j,i) of the dense
                     // front-end must not clear what the entry (i,j) wrote
-                    if (q == 0 && valid && wi != 0.f) Dm[li * EPNN_DST + lj] = wi * d;
-                    if (q == 1 && valid && wj != 0.f) Dm[lj * EPNN_DST + li] = -(wj * d);
+                    if (q == 0 && valid && r_.wi != 0.f) Dm[li * EPNN_DST + lj] = r_.wi * d;
+                    if (q == 1 && valid && r_.wj != 0.f) Dm[lj * EPNN_DST + li] = -(r_.wj * d);
+                };
+                if (nblk > 0) {
+                    Rec r0, r1;
+                    Rows w0, w1;
+                    load_rec(0, r0);
+                    load_rec(min(1, nblk - 1), r1);
+                    load_rows(0, r0, w0);
+                    int blk = 0;
+#pragma unroll 1
+                    for (; blk + 1 < nblk; blk += 2) {
+                        Rec r2, r3;
+                        load_rows(blk + 1, r1, w1);
+                        load_rec(min(blk + 2, nblk - 1), r2);
+                        WAVE_FENCE();
+                        block(blk, r0, w0);
+                        load_rows(min(blk + 2, nblk - 1), r2, w0);
+                        load_rec(min(blk + 3, nblk - 1), r3);
+                        WAVE_FENCE();
+                        block(blk + 1, r1, w1);
+                        r0 = r2;
+                        r1 = r3;
+                    }
+                    if (blk < nblk) block(blk, r0, w0);
                 }
             }
             wave_sync_lds();
@@ -614,10 +643,8 @@ __global__ __launch_bounds__(64, 2) void k_wave16_forward(WaveArgs A, W16Index X
                     dq0 += row0[j];
                     dq1 += row1[j];
                 }
-                dq0 += __shfl_xor(dq0, 16, 64);
-                dq1 += __shfl_xor(dq1, 16, 64);
-                dq0 += __shfl_xor(dq0, 32, 64);
-                dq1 += __shfl_xor(dq1, 32, 64);
+                dq0 = w16_sumq(dq0);
+                dq1 = w16_sumq(dq1);
 #pragma unroll
                 for (int s = 0; s < EPNN_XS; ++s)
                     if (s == qs && q == ql) { xq0[s] += cat0 ? dq0 : 0.f; xq1[s] += cat1 ? dq1 : 0.f; }
