@@ -6,7 +6,6 @@
 #include "epnn_host.h"
 #include "epnn_frontend.hip.h"
 #include "epnn_wave.hip.h"
-#include "epnn_wave16.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
 #include "epnn_mlp.hip.h"
@@ -79,7 +78,6 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
     HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
     shape_layers(h);
-    if (const char *ev = getenv("EPNN_WAVE16")) h->opt_wave16 = atoi(ev);      // development switch
     *out = h;
     return 0;
 }
@@ -252,127 +250,9 @@ static int pack_weights(epnn_handle *h) {
                 buf[U.u3F + (16 + s) * 64 + l] = 32 + c < EPNN_EDIM ? Wu3[(size_t)k * EPNN_EDIM + 32 + c] : 0.f;
             }
     }
-    // ------------------------------------------------------------ fragments of the wave-autonomous kernel
+    // ------------------------------------------------------------ fragments of the fused kernel (epnn_wave.hip.h)
     {
         WaveIndex &X = h->wvidx;
-        const float *bu1 = h->upd[0].b.data(), *bu2 = h->upd[1].b.data(), *bu3 = h->upd[2].b.data();
-        auto kvec = [&](auto &&fn) {              // [2][16] vector in kappa order
-            const int off = alloc(32);
-            for (int hh = 0; hh < 2; ++hh)
-                for (int r = 0; r < 16; ++r) buf[off + hh * 16 + r] = (float)fn(epnn_kappa(hh, r));
-            return off;
-        };
-        auto frag = [&](int steps, auto &&fn) {   // [steps][64]: lane (m,kk) of step s = fn(s, kk, m)
-            const int off = alloc((size_t)steps * 64);
-            for (int s = 0; s < steps; ++s)
-                for (int l = 0; l < 64; ++l) buf[off + s * 64 + l] = (float)fn(s, l >> 5, l & 31);
-            return off;
-        };
-        // xq row phi of a first-Dense block M (rows of W1 starting at r0: [x(nx), h(48), q]); nmrow = value of the node-mask row
-        auto xq_row = [&](const float *W1, const float *b1, int r0, int phi, int m, double nmrow) -> double {
-            if (phi == 0) return nmrow;
-            if (phi <= nx) return W1[(size_t)(r0 + phi - 1) * 32 + m];
-            if (phi == nx + 1) return W1[(size_t)(r0 + nx + EPNN_EDIM) * 32 + m];
-            if (phi == nx + 2) return b1 ? b1[m] : 0.0;
-            return 0.0;
-        };
-        auto unfolded = [&](const float *W1, const float *b1, int r0) {      // [KX+24][64]: xq rows, hk rows
-            return frag(EPNN_KX + 24, [&](int s, int kk, int m) -> double {
-                if (s < EPNN_KX) return xq_row(W1, b1, r0, 2 * s + kk, m, 0.0);
-                return W1[(size_t)(r0 + nx + epnn_hkf(kk, s - EPNN_KX)) * 32 + m];
-            });
-        };
-        auto folded = [&](const float *W1, const float *b1, int r0) {        // [16+KX][64]: Wu3 M_h rows, xq rows
-            std::vector<double> prod(32 * 32), cb(32);
-            for (int k = 0; k < 32; ++k)
-                for (int m = 0; m < 32; ++m) {
-                    double a = 0;
-                    for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
-                    prod[k * 32 + m] = a;
-                }
-            for (int m = 0; m < 32; ++m) {
-                double a = 0;
-                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
-                cb[m] = a;
-            }
-            return frag(16 + EPNN_KX, [&](int s, int kk, int m) -> double {
-                if (s < 16) return prod[epnn_kappa(kk, s) * 32 + m];
-                return xq_row(W1, b1, r0, 2 * (s - 16) + kk, m, cb[m]);
-            });
-        };
-        // Wu3 Wu1_H and Wu1_H^T bu3 (the update MLP is one instance shared by all steps)
-        std::vector<double> pu1(32 * 32), cu3(32);
-        for (int k = 0; k < 32; ++k)
-            for (int m = 0; m < 32; ++m) {
-                double a = 0;
-                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)Wu1[(size_t)f * 32 + m];
-                pu1[k * 32 + m] = a;
-            }
-        for (int m = 0; m < 32; ++m) {
-            double a = 0;
-            for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)Wu1[(size_t)f * 32 + m];
-            cu3[m] = a;
-        }
-        const int off_pu1 = frag(16, [&](int s, int kk, int m) { return pu1[epnn_kappa(kk, s) * 32 + m]; });
-        const int off_cu3 = kvec([&](int k) { return cu3[k]; });
-        const int off_u2 = frag(16, [&](int s, int kk, int m) { return (double)Wu2[(size_t)epnn_kappa(kk, s) * 32 + m]; });
-        const int off_bu1 = kvec([&](int k) { return (double)bu1[k]; });
-        const int off_bu2 = kvec([&](int k) { return (double)bu2[k]; });
-        for (int t = 0; t < T; ++t) {
-            WaveGnnPack &G = X.g[t];
-            const float *W1 = h->msg[t][0].W.data(), *W2 = h->msg[t][1].W.data(), *b2 = h->msg[t][1].b.data();
-            const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
-            G.we = h->widx.msg[t].weF;
-            G.w2 = h->widx.msg[t].w2F;
-            G.b2k = h->widx.msg[t].b2p;
-            (void)W2; (void)b2;
-            std::vector<double> fold(32 * 32), cb3(32);
-            for (int k = 0; k < 32; ++k)
-                for (int m = 0; m < 32; ++m) {
-                    double a = 0;
-                    for (int j = 0; j < 32; ++j) a += (double)W3[k * 32 + j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
-                    fold[k * 32 + m] = a;
-                }
-            for (int m = 0; m < 32; ++m) {
-                double a = 0;
-                for (int j = 0; j < 32; ++j) a += (double)b3[j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
-                cb3[m] = a;
-            }
-            G.u1s = frag(16, [&](int s, int kk, int m) { return fold[epnn_kappa(kk, s) * 32 + m]; });
-            G.cb3k = kvec([&](int k) { return cb3[k]; });
-            G.bu1k = off_bu1;
-            G.u2 = off_u2;
-            G.bu2k = off_bu2;
-            G.pu1 = off_pu1;
-            G.cu3k = off_cu3;
-            if (t + 1 < T) {
-                const float *N1 = h->msg[t + 1][0].W.data(), *nb1 = h->msg[t + 1][0].b.data();
-                G.pwi = folded(N1, nb1, 0);
-                G.pwj = folded(N1, nullptr, F);
-            } else {
-                G.pwi = G.pwj = 0;
-            }
-            (void)W1;
-        }
-        X.wi0 = unfolded(h->msg[0][0].W.data(), h->msg[0][0].b.data(), 0);
-        X.wj0 = unfolded(h->msg[0][0].W.data(), nullptr, F);
-        X.u1h0 = frag(24, [&](int s, int kk, int m) { return (double)Wu1[(size_t)epnn_hkf(kk, s) * 32 + m]; });
-        X.u3 = h->widx.upd[0].u3F;
-        X.bu3k = h->widx.upd[0].bu3p;
-        for (int t = 0; t < T; ++t) {
-            WaveEpnPack &E = X.e[t];
-            const float *W1 = h->pas[t][0].W.data(), *b1 = h->pas[t][0].b.data();
-            E.we = h->widx.pas[t].weF;
-            E.w2 = h->widx.pas[t].w2F;
-            E.b2k = h->widx.pas[t].b2p;
-            E.w3k = h->widx.pas[t].w3p;
-            E.wi = unfolded(W1, b1, 0);
-            E.wj = unfolded(W1, nullptr, F);
-        }
-    }
-    // ------------------------------------------------------------ fragments of the 16x16x4 wave kernel
-    {
-        W16Index &X = h->w16idx;
         const float *bu1 = h->upd[0].b.data(), *bu2 = h->upd[1].b.data(), *bu3 = h->upd[2].b.data();
         auto vec = [&](int len, auto &&fn) {
             const int off = alloc(len);
@@ -444,7 +324,7 @@ static int pack_weights(epnn_handle *h) {
         const int off_bu1 = vec(32, [&](int k) { return (double)bu1[k]; });
         const int off_bu2 = vec(32, [&](int k) { return (double)bu2[k]; });
         for (int t = 0; t < T; ++t) {
-            W16Gnn &G = X.g[t];
+            WaveGnnPack &G = X.g[t];
             pair_common(h->msg[t], G.we, G.w2, G.b2);
             const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
             std::vector<double> fold(32 * 32), cb3(32);
@@ -480,7 +360,7 @@ static int pack_weights(epnn_handle *h) {
         X.u3 = frag(3, 8, [&](int s, int q, int m) { return (double)Wu3[(size_t)accf(s, q) * EPNN_EDIM + m]; });
         X.bu3 = vec(48, [&](int k) { return (double)bu3[k]; });
         for (int t = 0; t < T; ++t) {
-            W16Epn &E = X.e[t];
+            WaveEpnPack &E = X.e[t];
             pair_common(h->pas[t], E.we, E.w2, E.b2);
             const float *W1 = h->pas[t][0].W.data(), *b1 = h->pas[t][0].b.data();
             E.w3 = vec(32, [&](int k) { return (double)h->pas[t][2].W[k]; });
@@ -517,10 +397,10 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
         if (n < 1) EPNN_FAIL("forward: molecule %d has %d atoms", b, n);
         if (n > N) EPNN_FAIL("forward: molecule %d has %d atoms but the padded size N is %d", b, n, N);
         for (int a = offsets[b]; a < offsets[b + 1]; ++a) molof[a] = b;
-        const bool wave_ok = h->cfg.nx + 3 <= 2 * EPNN_KX;       // the fused kernel's xq block holds nx + 3 inputs
+        const bool wave_ok = h->cfg.nx + 3 <= 4 * EPNN_XS;       // the fused kernel's xq block holds nx + 3 inputs
         const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
-            EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 2 * EPNN_KX - 3);
+            EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
         if (small) {
             P.small_order.push_back(b);
             P.small_nmax = std::max(P.small_nmax, n);
@@ -587,7 +467,6 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     const Plan &P = h->plan;
     WaveArgs A{};
     A.wpack = h->d_wpack.as<float>();
-    A.wx = h->wvidx;
     A.xin = S.d_x;
     A.Q = S.d_Q;
     A.moff = h->d_moff.as<int>();
@@ -632,16 +511,11 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.tol = h->cfg.near_tol;
     A.host_status = h->h_status;          // pinned, device-visible
     const dim3 grid((unsigned)P.small_order.size());
-    if (h->opt_wave16) {
-        const W16Index &X = h->w16idx;
-        if (S.d_xyz) hipLaunchKernelGGL((k_wave16_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
-        else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave16_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
-        else if (S.run_gnn) hipLaunchKernelGGL((k_wave16_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
-        else hipLaunchKernelGGL((k_wave16_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
-    } else if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A);
-    else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
-    else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A);
-    else hipLaunchKernelGGL((k_wave_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A);
+    const WaveIndex &X = h->wvidx;
+    if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+    else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+    else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+    else hipLaunchKernelGGL((k_wave_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -694,7 +568,6 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     const Plan &P = h->plan;
     // Batches of small molecules only: the wave kernel builds each molecule's pair list itself (slots for every i<j
     // pair of the molecule, so nothing can overflow) and no front-end kernel runs.
-    if (h->opt_wave16 && h->cfg.nx + 3 > 4 * EPNN_XS) EPNN_FAIL("wave16: nx too large");
     const bool wave_front = h->opt_wave_front && P.large_list.empty() && !P.small_order.empty() && h->cfg.e_dim == EPNN_EDIM;
     if (ensure_pairs(h, wave_front ? std::max(h->pcap, P.pair_slots)
                                    : std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
@@ -897,7 +770,6 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
-    else if (!strcmp(name, "wave16")) { h->opt_wave16 = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }

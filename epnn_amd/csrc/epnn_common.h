@@ -54,39 +54,7 @@ struct WeightIndex {
     UpdPack upd[EPNN_MAXT];
 };
 
-// ---- wave-autonomous kernel (epnn_wave.hip.h): every fragment is an MFMA A operand, [K-step][64 lanes], lane
-// (m = lane & 31, kk = lane >> 5) holds W[k(s,kk)][m].  K orders:  "xq": k = 2s+kk over [node_mask, x_0.., q, 1];
-// "kappa": k = kappa(kk,s);  "hk": s<16 feature kappa(kk,s), s>=16 feature 32+kappa(kk,s-16);  "e": k = 24kk+s.
-#define EPNN_KX 7            // K-steps of the xq block: nx + 3 <= 14
-#define EPNN_DST 33          // LDS row stride (floats) of the per-molecule charge-transfer matrix
-struct WaveGnnPack {      // GNN step t
-    int we;               // [24][64]  e order          We_t
-    int w2;               // [16][64]  kappa order      W2_t
-    int b2k;              // [2][16]   b2[kappa(hh,r)]
-    int u1s;              // [16][64]  kappa order      W3_t Wu1_M   (last message Dense folded into the update)
-    int cb3k;             // [2][16]   (Wu1_M^T b3_t)[kappa]   (times N at run time)
-    int bu1k;             // [2][16]
-    int u2;               // [16][64]  kappa order      Wu2
-    int bu2k;             // [2][16]
-    int pwi, pwj;         // [16+KX][64]  kappa rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]   (M = Wi / Wj of step t+1)
-    int pu1;              // [16][64]  kappa order      Wu3 Wu1_H
-    int cu3k;             // [2][16]   (Wu1_H^T bu3)[kappa]
-};
-struct WaveEpnPack {      // EPN step t
-    int we, w2, b2k, w3k;
-    int wi, wj;           // [KX+24][64]  xq rows, then hk rows
-};
-struct WaveIndex {
-    WaveGnnPack g[EPNN_MAXT];
-    WaveEpnPack e[EPNN_MAXT];
-    int wi0, wj0;         // [KX+24][64]  first GNN step: xq rows, then hk rows (h given by the caller, usually zeros)
-    int u1h0;             // [24][64]     hk order  Wu1_H
-    int u3;               // [2][16][64]  kappa order  Wu3[.][32*tile + m]
-    int bu3k;             // [2][2][16]
-};
-
-
-// ---- 16x16x4 variant of the wave-autonomous kernel (epnn_wave16.hip.h).  v_mfma_f32_16x16x4_f32: lane l = 16*q + m.
+// ---- wave-autonomous fused kernel (epnn_wave.hip.h).  v_mfma_f32_16x16x4_f32: lane l = 16*q + m.
 // A operand lane (q,m) = A[m][k=q], B operand lane (q,n) = B[k=q][n], accumulator register r of lane (q,n) =
 // D[4q + r][n].  A 32-feature x 32-column product is 2 row blocks (rb) x 2 column blocks (cb) of such tiles; lane
 // (q,n) then owns columns n and 16+n and, of each, the 8 features 16rb + 4q + r.  K steps are ordered so that an
@@ -94,7 +62,8 @@ struct WaveIndex {
 // 16rb' + 4q + r' ("acc" order).  Other K orders: "xq" feature 4s + q;  "e" channel 12q + s.
 // Fragment = [rb][step][64 lanes]: lane (q,m) holds W[in(step,q)][16rb + m].  Vectors are in natural feature order.
 #define EPNN_XS 4            // K-steps of the xq block: nx + 3 <= 16
-struct W16Gnn {           // GNN step t
+#define EPNN_DST 33          // LDS row stride (floats) of the per-molecule charge-transfer matrix
+struct WaveGnnPack {           // GNN step t
     int we;               // [2][12][64]  e order       We_t
     int w2;               // [2][8][64]   acc order     W2_t
     int b2;               // [32]
@@ -106,13 +75,13 @@ struct W16Gnn {           // GNN step t
     int pu1;              // [2][8][64]   acc order     Wu3 Wu1_H
     int cu3;              // [32]         Wu1_H^T bu3
 };
-struct W16Epn {           // EPN step t
+struct WaveEpnPack {           // EPN step t
     int we, w2, b2, w3;   // w3: [32]
     int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features)
 };
-struct W16Index {
-    W16Gnn g[EPNN_MAXT];
-    W16Epn e[EPNN_MAXT];
+struct WaveIndex {
+    WaveGnnPack g[EPNN_MAXT];
+    WaveEpnPack e[EPNN_MAXT];
     int wi0, wj0;         // [2][XS+12][64]  first GNN step (h given by the caller, usually zeros)
     int u1h0;             // [2][12][64]     acc order over 48 features  Wu1_H
     int u3;               // [3][8][64]      acc order  Wu3 (48 outputs = 3 row blocks)
@@ -120,9 +89,6 @@ struct W16Index {
 };
 
 __host__ __device__ static inline int epnn_kappa(int hh, int r) { return 4 * hh + (r & 3) + 8 * (r >> 2); }
-
-// feature held by register s of half kk in the hk order
-__host__ __device__ static inline int epnn_hkf(int kk, int s) { return s < 16 ? epnn_kappa(kk, s) : 32 + epnn_kappa(kk, s - 16); }
 
 // position of atom feature f inside the even/odd image row: half (f&1), slot f>>1
 __host__ __device__ static inline int epnn_aeo(int f) { return (f & 1) * 32 + (f >> 1); }

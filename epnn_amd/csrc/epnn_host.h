@@ -76,7 +76,6 @@ struct epnn_handle {
     bool weights_dirty = true;
     WeightIndex widx{};
     WaveIndex wvidx{};
-    W16Index w16idx{};
     DevBuf d_wpack;
     DevBuf d_mu;
     // plan + workspace
@@ -90,7 +89,6 @@ struct epnn_handle {
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_gx;
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
-    int opt_wave16 = 0;               // development switch: 16x16x4-MFMA version of the fused kernel
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     // large path workspace (epnn_large.hip.h)

@@ -1,24 +1,33 @@
 // Wave-autonomous fused forward: ONE wavefront runs the whole GNN_layer + EPN_layer stack (reference
-// charge_gn.py:56-119, 2T steps) of one molecule with n <= 32 real atoms.  No workgroup barriers, no idle waves:
-// latency is hidden by the other wavefronts of the SIMD (independent molecules), the matrix pipe of every SIMD is fed
-// by whole-molecule dependent chains.
+// charge_gn.py:56-119, 2T steps) of one molecule with n <= 32 real atoms -- and, through the compact entry, the
+// front-end too (near pairs + Gaussian edge features, charge_gn.py:122-163).  No workgroup barriers, no idle waves:
+// latency is hidden by the other wavefront of the SIMD (an independent molecule).
 //
-// Lane l = 32*hh + c owns ATOM c (atom-level quantities are MFMA accumulators: register r = feature kappa(hh,r) of
-// atom c).  Everything that is per atom lives in registers for the whole forward:
-//   xq[KX]   the "small" inputs [node_mask, x_0..x_{nx-1}, q, 1] in even/odd K order (feature 2s+hh in register s)
-//   hk[24]   h (48 features) in accumulator order: s<16 feature kappa(hh,s), s>=16 feature 32+kappa(hh,s-16)
-//   P[16]    P_i = Wi^T a_i + b1 of the current pair MLP;  S[16] the message sum;  u1pre[16] the h-part of the update
-// Only what other lanes must read goes through LDS: R_j rows (broadcast reads), the near-pair terms G, the pair map.
+// MFMA shape: v_mfma_f32_16x16x4_f32.  What the hardware does (tools/micro/): a dependent MFMA chain issues back to
+// back; a wave's own VALU / LDS instructions never overlap its own MFMAs; and while one wave keeps the matrix pipe busy
+// the co-resident wave's VALU instructions issue every 6.1 cycles with this shape (8.1 with 32x32x2, 4.1 alone).  Work
+// also comes in 16-column units: molecules with n <= 16 atoms and the last 16 pairs of a pair tile skip their second
+// column block.
 //
-// GNN pair sweep (charge_gn.py:62-70): tile j = "partner j of every atom": column c of the tile is the pair (i=c, j),
-//   z1 = relu(P_i + R_j + G_ij), acc = W2^T z1 + b2 (16 MFMAs), S_i += relu(acc): plain register accumulation, the
-//   sum over partners never leaves the lane.  One more tile with R = G = 0 is the reference's zero-padded partner; it
-//   is added (N - n) times.
-// Update chain (charge_gn.py:71-74) with h never materialised between steps:  the next step needs h only through
+// Lane l = 16*q + n16 owns COLUMNS n16 and 16 + n16 (atoms, or near pairs in the pair tiles) and, of each column, the 8
+// features 16*rb + 4*q + r (rb = 0,1; r = 0..3): that is the accumulator layout of the four 16x16 blocks [rb][cb] of a
+// 32 x 32 product, and with the K steps ordered s = 4*rb' + r' (lane q <-> input feature 16*rb' + 4*q + r') an
+// accumulator set is the next product's B operand as it stands.  Everything that is per atom lives in registers for
+// the whole forward:  xq (node mask, x, q, 1), P_i = Wi^T a_i + b1, the message sum S, the update's h-part, and h
+// (12 registers per column) during the EPN stack.  LDS holds only what other lanes read, rows in natural feature
+// order (one 16-byte access per lane and row block): the R_j rows, the near-pair terms G, the pair map, and for the
+// EPN the P rows and a per-molecule transfer matrix.
+//
+// GNN pair sweep (charge_gn.py:62-70): tile j = "partner j of every atom": column i of the tile is the pair (i, j),
+//   z1 = relu(P_i + R_j + G_ij), acc = W2^T z1 + b2, S_i += relu(acc): plain register accumulation, the sum over
+//   partners never leaves the lane.  One more tile with R = G = 0 is the reference's zero-padded partner; it is added
+//   (N - n) times.  Operands of tile j+1 are fetched while tile j is in the matrix pipe.
+// Update chain (charge_gn.py:71-74) with h never materialised between steps: the next step needs h only through
 //   Wi_h^T h, Wj_h^T h and Wu1_h^T h, and h = nm (Wu3^T u2 + bu3), so the host folds Wu3 into those three matrices
-//   (float64 products, epnn_api.hip pack_wave): K = 32 (nm*u2) + KX instead of 48 + KX, and no Wu3 GEMM per step.
-//   h itself is produced once, after the last step (for the EPN stack / GNN_layer output).
-// EPN (charge_gn.py:98-118): one tile column per UNORDERED near pair, both directions share G; +d to i, -d to j.
+//   (float64 products, pack_weights): K = 32 (nm*u2) + xq instead of 48 + xq, and no Wu3 GEMM per step.  h itself is
+//   produced once, after the last step (for the EPN stack / GNN_layer output).
+// EPN (charge_gn.py:98-118): one column per UNORDERED near pair, both directions share G; the weighted transfers go to
+//   Dm[i][j] / Dm[j][i] and every atom adds its row in a fixed order.
 #pragma once
 #include <type_traits>
 
@@ -27,7 +36,6 @@
 
 struct WaveArgs {
     const float *wpack;
-    WaveIndex wx;
     const float *xin;      // [A][nx]
     const float *Q;        // [B]
     const int *moff;       // [B+1]
@@ -67,14 +75,6 @@ struct WaveArgs {
 #define WAVE_STAMP() do { } while (0)
 #endif
 
-#ifdef EPNN_ABL_W      // diagnostic ablation: every fragment load hits the same few cache lines (results are garbage)
-#define EPNN_WLD(dst, off, cnt)                                      \
-    _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[s_] = wp[((off) & 1023) + (s_ & 3) * 64 + lane]
-#else
-#define EPNN_WLD(dst, off, cnt)                                      \
-    _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[s_] = wp[(off) + s_ * 64 + lane]
-#endif
-
 // order LDS / global traffic between lanes of the wave (the compiler sees no dependence between different lanes)
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
@@ -98,38 +98,52 @@ __device__ __forceinline__ double wave_dist2(const double *xs, int i, int j) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
-// first feature of the g-th group of four of the hk order
-__device__ __forceinline__ int wave_hk_f0(int hh, int g) { return g < 4 ? 4 * hh + 8 * g : 32 + 4 * hh + 8 * (g - 4); }
-
-// A dependent chain of v_mfma_f32_32x32x2_f32 issues back to back (64 cycles per MFMA, tools/micro/mfma_rate.hip): one
-// accumulator per chain is enough.  What does NOT overlap is a wave's own VALU / LDS work with its own MFMAs
-// (tools/micro/mfma_valu.hip), and a co-resident wave's VALU work runs at half rate while the matrix pipe is busy
-// (tools/micro/mfma_covalu.hip): the non-MFMA instruction count is what this kernel is tuned for.
-template <int K>
-__device__ __forceinline__ f32x16 wave_chain(const float (&w)[K], const float (&b)[K], f32x16 acc) {
-#pragma unroll
-    for (int s = 0; s < K; ++s) acc = epnn_mfma(w[s], b[s], acc);
-    return acc;
-}
-
-// e rows of G tile gt: lane (c,hh) takes channels 24hh..24hh+23 of pair gt*32+c
-__device__ __forceinline__ void wave_load_e(const float *pe, int p0, int np, int gt, int c, int hh, float (&ev)[24]) {
-    const int slot = gt * 32 + c;
-    const float *erow = pe + (size_t)(p0 + (slot < np ? slot : 0)) * EPNN_EDIM + hh * 24;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        f32x4 v = *reinterpret_cast<const f32x4 *>(erow + 4 * q);
-        ev[4 * q] = v[0]; ev[4 * q + 1] = v[1]; ev[4 * q + 2] = v[2]; ev[4 * q + 3] = v[3];
-    }
-}
-
 // keep the loads issued above this point above it: the next chain's operands are fetched while the current chain runs
 #define WAVE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+__device__ __forceinline__ f32x4 w16_mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 w16_splat(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ f32x4 w16_relu(f32x4 v) {
+    return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+// sum over the four lanes q = 0..3 that share a column: two VALU lane swaps (gfx950 v_permlane16/32_swap), no LDS
+// round trip; every lane ends up with the same bits ((q0 + q1) + (q2 + q3))
+__device__ __forceinline__ float w16_sumq(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ f32x4 w16_ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void w16_st(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// fragment loads: [nrb][stride][64 lanes], steps s0 .. s0+cnt-1 of every row block
+#define W16_LDX(dst, off, nrb, cnt, stride, s0)                                                   \
+    _Pragma("unroll") for (int rb_ = 0; rb_ < (nrb); ++rb_) _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[rb_][s_] = \
+        wp[(off) + (rb_ * (stride) + (s0) + s_) * 64 + lane]
+#define W16_LD(dst, off, nrb, steps) W16_LDX(dst, off, nrb, steps, steps, 0)
+
+// D[rb][CB] += sum_s W[rb][s] * in[s]  for one column block (dependent chain of S MFMAs per row block)
+template <int NRB, int S>
+__device__ __forceinline__ void w16_mm(const float (&w)[NRB][S], const float (&in)[S], f32x4 (&d)[NRB]) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) d[rb] = w16_mfma(w[rb][s], in[s], d[rb]);
+}
+// an accumulator set [2 row blocks] of one column block as the next product's 8 input steps
+__device__ __forceinline__ void w16_feed(const f32x4 (&a)[2], float (&in)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) in[s] = a[s >> 2][s & 3];
+}
+
 template <bool GNN, bool EPN, bool FRONT>
-__global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
+__global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x, q = lane >> 4, n16 = lane & 15;
+    const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
     if (!FRONT && (*A.status & EPNN_ST_PAIR_OVERFLOW)) return;
     const int b = A.order[blockIdx.x];
     const int a0 = A.moff[b], n = A.moff[b + 1] - a0;
@@ -137,21 +151,36 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     int np = FRONT ? 0 : A.row_off[a0 + n] - p0;
     const int nx = A.nx;
     const float *wp = A.wpack;
-    const WaveIndex &X = A.wx;
     int nstamp = 0;
     (void)nstamp;
     WAVE_STAMP();
-    // molecules with n <= 16 use the two 16-column halves of every MFMA tile for two copies of their atoms (lane c and
-    // lane c + 16 hold the same atom): all per-atom chains replicate for free and the pair sweep handles TWO partners
-    // per tile (even partners in the lower copy, odd ones in the upper), half the sweep's MFMA and VALU work
-    const bool dual = n <= 16;
-    const int ai = dual ? (c & 15) : c;                     // atom of this lane
-    const bool hi = dual && c >= 16;                        // upper copy
-    const bool catom = ai < n;
-    const bool owner = catom && !hi;                        // the lane that stores the atom's rows / results
+    const bool two = n > 16;                                // the second column block holds atoms
+    const int col1 = 16 + n16;
+    const bool cat0 = n16 < n, cat1 = col1 < n;
+
+    // ---- LDS layout of THIS molecule inside the wave's fixed budget.  The two stacks need different tables, and the G
+    //      rows are recomputed by every step anyway, so each stack has its own layout behind the common part:
+    //        common  eij [pairs] | R [n][PST]
+    //        GNN     pair map [n][32] u16 | G rows ... | zero row        (the sweep reads every G row n times: all in LDS
+    //                                                                     for molecules up to ~24 atoms)
+    //        EPN     P [n][PST] | transfer matrix [n][DST] | G rows ...  (G rows are read once per step: the rest from HBM)
+    unsigned short *eij = reinterpret_cast<unsigned short *>(sm);     // [np]  li | lj << 8
+    const int eij_n = FRONT ? n * (n - 1) / 2 : np;        // in-kernel front-end: np is not known yet, reserve every i<j pair
+    const int o_r = EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
+    float *Rl = sm + o_r;                                  // [n][PST]   R_j rows (natural feature order)
+    const int o_x = o_r + n * EPNN_PST;
+    unsigned short *pm = reinterpret_cast<unsigned short *>(sm + o_x);    // [j][32]  near-pair slot of (i, j), 0xFFFF = none
+    float *Pl = sm + o_x;                                  // [n][PST]   P_i rows
+    float *Dm = sm + o_x + n * EPNN_PST;                   // [n][DST]   weighted transfers: Dm[i][j] = what i receives from j
+    const int o_gg = o_x + ((n * 16 + 3) & ~3), o_ge = o_x + n * EPNN_PST + ((n * EPNN_DST + 3) & ~3);
+    const int grows_g = (A.lds_words - o_gg) / EPNN_PST - 1, grows_e = (A.lds_words - o_ge) / EPNN_PST;
+    float *Gl = sm + (GNN ? o_gg : o_ge);                  // G rows of the stack that is running; GNN: row glds is all zeros
+    int glds = min(np, GNN ? grows_g : grows_e);
+    bool gover = np > glds;                                // some G rows live in HBM
+    int ngt = (np + 31) >> 5;
 
     // ---- in-kernel front-end: coordinates -> LDS (the pair slots are assigned once the LDS tables exist)
-    double *xs = reinterpret_cast<double *>(sm);           // [n][3] float32 coordinates promoted like SciPy does
+    double *xs = reinterpret_cast<double *>(Rl);           // [n][3] float32 coordinates promoted like SciPy does (R rows come later)
     if (FRONT) {
         if (hh == 0 && c < n) {
             xs[3 * c + 0] = (double)A.xyz[3 * (size_t)(a0 + c) + 0];
@@ -160,61 +189,58 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
         }
         wave_sync_lds();
     }
-    // ---- LDS layout of THIS molecule inside the wave's fixed budget
-    float *Rl = sm;                                        // [n][PST]   R_j rows
-    float *Pl = sm + n * EPNN_PST;                         // [n][PST]   P_i rows (EPN); the GNN keeps its pair map here
-    unsigned short *pm = reinterpret_cast<unsigned short *>(Pl);      // [j][32]  near-pair slot of (i = lane, j), 0xFFFF = none
-    int o = 2 * n * EPNN_PST;
-    unsigned short *eij = reinterpret_cast<unsigned short *>(sm + o); // [np]  li | lj << 8
-    const int eij_n = FRONT ? n * (n - 1) / 2 : np;        // in-kernel front-end: np is not known yet, reserve every i<j pair
-    o += EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
-    float *Dm = sm + o;                                    // [n][DST]  weighted transfers: Dm[i][j] = what i receives from j
-    o += EPN ? ((n * EPNN_DST + 3) & ~3) : 0;
-    float *Gl = sm + o;                                    // [glds + 1][PST]; row glds is all zeros
-    const int grows = (A.lds_words - o) / EPNN_PST - 1;   // G rows the budget leaves room for
-    int glds = min(np, grows);
-    bool gover = np > glds;                                // some G rows live in HBM
-    int ngt = (np + 31) >> 5;
-
-    // ---- per-atom registers
-    const float nmv = catom ? (A.nm_in ? A.nm_in[a0 + ai] : 1.f) : 0.f;
-    float xq[EPNN_KX];
+    // ---- per-column registers (cb = 0: column n16, cb = 1: column 16 + n16)
+    const float nm0 = cat0 ? (A.nm_in ? A.nm_in[a0 + n16] : 1.f) : 0.f;
+    const float nm1 = cat1 ? (A.nm_in ? A.nm_in[a0 + col1] : 1.f) : 0.f;
+    float xq0[EPNN_XS], xq1[EPNN_XS];
     {
-        const float qv = catom ? (A.q_in ? A.q_in[a0 + ai] : A.Q[b] / (float)n) : 0.f;     // charge_gn.py:337-338
+        const float qv0 = cat0 ? (A.q_in ? A.q_in[a0 + n16] : A.Q[b] / (float)n) : 0.f;   // charge_gn.py:337-338
+        const float qv1 = cat1 ? (A.q_in ? A.q_in[a0 + col1] : A.Q[b] / (float)n) : 0.f;
 #pragma unroll
-        for (int s = 0; s < EPNN_KX; ++s) {
-            const int phi = 2 * s + hh;
-            float v = 0.f;
-            if (catom) {
-                if (phi == 0) v = nmv;
-                else if (phi <= nx) v = A.xin[(size_t)(a0 + ai) * nx + phi - 1];
-                else if (phi == nx + 1) v = qv;
-                else if (phi == nx + 2) v = 1.f;
-            }
-            xq[s] = v;
+        for (int s = 0; s < EPNN_XS; ++s) {
+            const int phi = 4 * s + q;
+            float v0 = 0.f, v1 = 0.f;
+            if (phi == 0) { v0 = nm0; v1 = nm1; }
+            else if (phi <= nx) {
+                if (cat0) v0 = A.xin[(size_t)(a0 + n16) * nx + phi - 1];
+                if (cat1) v1 = A.xin[(size_t)(a0 + col1) * nx + phi - 1];
+            } else if (phi == nx + 1) { v0 = qv0; v1 = qv1; }
+            else if (phi == nx + 2) { v0 = cat0 ? 1.f : 0.f; v1 = cat1 ? 1.f : 0.f; }
+            xq0[s] = v0;
+            xq1[s] = v1;
         }
     }
-    float hk[24];
+    f32x4 hk0[3], hk1[3];                                  // h: features 16*rb + 4*q + r of the two columns
 #pragma unroll
-    for (int s = 0; s < 24; ++s) hk[s] = 0.f;
+    for (int rb = 0; rb < 3; ++rb) { hk0[rb] = w16_splat(0.f); hk1[rb] = w16_splat(0.f); }
     const bool have_h = A.h_in != nullptr;
-    if (have_h && catom) {
+    if (have_h) {
 #pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(A.h_in + (size_t)(a0 + ai) * EPNN_EDIM + wave_hk_f0(hh, g));
-            hk[4 * g] = v[0]; hk[4 * g + 1] = v[1]; hk[4 * g + 2] = v[2]; hk[4 * g + 3] = v[3];
+        for (int rb = 0; rb < 3; ++rb) {
+            if (cat0) hk0[rb] = w16_ld(A.h_in + (size_t)(a0 + n16) * EPNN_EDIM + 16 * rb + 4 * q);
+            if (cat1) hk1[rb] = w16_ld(A.h_in + (size_t)(a0 + col1) * EPNN_EDIM + 16 * rb + 4 * q);
         }
     }
 
+    // e rows of G tile gt: lane (q, n16) takes channels 12q..12q+11 of pairs gt*32 + n16 and gt*32 + 16 + n16
+    auto load_e = [&](int gt, float (&e0)[12], float (&e1)[12]) {
+        const int s0 = gt * 32 + n16, s1 = s0 + 16;
+        const float *r0 = A.pe + (size_t)(p0 + (s0 < np ? s0 : 0)) * EPNN_EDIM + 12 * q;
+        const float *r1 = A.pe + (size_t)(p0 + (s1 < np ? s1 : 0)) * EPNN_EDIM + 12 * q;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const f32x4 v0 = w16_ld(r0 + 4 * k), v1 = w16_ld(r1 + 4 * k);
+            e0[4 * k] = v0[0]; e0[4 * k + 1] = v0[1]; e0[4 * k + 2] = v0[2]; e0[4 * k + 3] = v0[3];
+            e1[4 * k] = v1[0]; e1[4 * k + 1] = v1[1]; e1[4 * k + 2] = v1[2]; e1[4 * k + 3] = v1[3];
+        }
+    };
     // first G tiles: We and the first e rows are on their way while the LDS tables are built
-    float gw[24], ge[24];
-    EPNN_WLD(gw, GNN ? X.g[0].we : X.e[0].we, 24);
-    if (!FRONT && ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
+    float gw[2][12], ge0[12], ge1[12];
+    W16_LD(gw, GNN ? X.g[0].we : X.e[0].we, 2, 12);
+    if (!FRONT && ngt > 0) load_e(0, ge0, ge1);
     WAVE_FENCE();
 
     // ---- LDS init
-    if (EPN)
-        for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
     if (GNN)
         for (int i = lane; i < n * 16; i += 64) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
     wave_sync_lds();
@@ -235,15 +261,11 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             base += __popc(lo) + __popc(hi);
         }
         np = base;
-        glds = min(np, grows);
+        glds = min(np, grows_g);                            // the in-kernel front-end always runs both stacks: GNN first
         gover = np > glds;
         ngt = (np + 31) >> 5;
         wave_sync_lds();
-        // ---- Gaussian edge features, one lane per pair (charge_gn.py:148-161: float64, then cast to float32).
-        //      e_k = C exp(-eta (D - mu_k)^2) over the evenly spaced mu_k is a geometric-like sequence:
-        //      e_{k+1} = e_k rho_k, rho_{k+1} = rho_k exp(-2 eta dmu^2): two exp per pair instead of 48 (float64 products;
-        //      the accumulated rounding stays below 1e-12 relative, far inside the float32 cast).
-        //      near flag = max_k e_k > tol (charge_gn.py:90-94), evaluated exactly at the mu closest to D.
+        // ---- Gaussian edge features, one lane per pair: float64 recurrence over the evenly spaced mu_k (see epnn_wave.hip.h)
         const double pi_d = 3.141592653589793;
         const double mu0 = A.mu[0], dmu = (A.mu[EPNN_EDIM - 1] - A.mu[0]) / (double)(EPNN_EDIM - 1);
         const double qq = exp(-2.0 * A.eta * dmu * dmu);
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                 }
                 const double db = D - A.mu[kbest];
                 const float emax = (float)(C * exp(-A.eta * (db * db)));
-                const float w = emax > A.tol ? 1.0f : 0.0f;
+                const float w = emax > A.tol ? 1.0f : 0.0f;           // charge_gn.py:90-94
                 A.pwi[p0 + s0 + lane] = w;
                 A.pwj[p0 + s0 + lane] = w;
                 const double t0 = D - mu0;
@@ -274,16 +296,16 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                     f32x4 v;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        v[u] = (float)e;
+                        v[u] = (float)e;                               // charge_gn.py:160-161
                         e *= rho;
                         rho *= qq;
                     }
-                    *reinterpret_cast<f32x4 *>(erow + k4) = v;
+                    w16_st(erow + k4, v);
                 }
             }
         }
         wave_sync_all();
-        if (ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
+        if (ngt > 0) load_e(0, ge0, ge1);
     } else {
         if (GNN)
             for (int p = lane; p < np; p += 64) {
@@ -297,75 +319,96 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
                 eij[p] = (unsigned short)(li | (lj << 8));
             }
     }
-    // the G zero row and the transfer matrix last: the front-end used those words as scratch
-    for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;
+    if (GNN)
+        for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;        // the sweep's zero row
     wave_sync_lds();
 
     WAVE_STAMP();   // init done
     const float Nf = (float)A.N, padw = (float)(A.N - n);
     const int Tg = GNN ? A.T : 0, Te = EPN ? A.T : 0;
+    const int fo = 4 * q;                                   // this lane's feature offset inside a 16-feature row block
 
-    // G rows of every near pair for the pair MLP whose We is in gw[] (first e rows in ge[]); rows >= glds go to HBM
+    // G rows of every near pair for the pair MLP whose We is in gw (first e rows in ge0/ge1); rows >= glds go to HBM
     auto gtiles = [&]() {
 #pragma unroll 1
         for (int gt = 0; gt < ngt; ++gt) {
-            float en[24];
-            wave_load_e(A.pe, p0, np, min(gt + 1, ngt - 1), c, hh, en);
+            float en0[12], en1[12];
+            load_e(min(gt + 1, ngt - 1), en0, en1);
             WAVE_FENCE();
-            f32x16 acc = wave_chain<24>(gw, ge, epnn_splat16(0.f));
-            const int slot = gt * 32 + c;
-            // two separate predicated stores: merged into one `cond ? lds : global` pointer they become flat stores,
-            // whose completion wait also waits for the e rows fetched ahead
-            if (slot < min(np, glds)) epnn_st16(Gl + slot * EPNN_PST + hh * 16, acc);
+            const int s0 = gt * 32 + n16, s1 = s0 + 16;
+            f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
+            w16_mm<2, 12>(gw, ge0, d0);
+            // two separate predicated stores per target (LDS / HBM): merged into one pointer they become flat stores
+            if (s0 < min(np, glds)) { w16_st(Gl + s0 * EPNN_PST + fo, d0[0]); w16_st(Gl + s0 * EPNN_PST + 16 + fo, d0[1]); }
             if (gover) {
                 asm volatile("" ::: "memory");
-                if (slot >= glds && slot < np) epnn_st16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, acc);
+                if (s0 >= glds && s0 < np) { w16_st(A.gx + (size_t)(p0 + s0) * 32 + fo, d0[0]); w16_st(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo, d0[1]); }
+            }
+            if (gt * 32 + 16 < np) {                        // the second 16 pairs of the tile exist
+                f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm<2, 12>(gw, ge1, d1);
+                if (s1 < min(np, glds)) { w16_st(Gl + s1 * EPNN_PST + fo, d1[0]); w16_st(Gl + s1 * EPNN_PST + 16 + fo, d1[1]); }
+                if (gover) {
+                    asm volatile("" ::: "memory");
+                    if (s1 >= glds && s1 < np) { w16_st(A.gx + (size_t)(p0 + s1) * 32 + fo, d1[0]); w16_st(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo, d1[1]); }
+                }
             }
 #pragma unroll
-            for (int s = 0; s < 24; ++s) ge[s] = en[s];
+            for (int s = 0; s < 12; ++s) { ge0[s] = en0[s]; ge1[s] = en1[s]; }
         }
     };
-    // start fetching what the NEXT gtiles() needs
     auto gprefetch = [&](int weoff) {
-        EPNN_WLD(gw, weoff, 24);
-        if (ngt > 0) wave_load_e(A.pe, p0, np, 0, c, hh, ge);
+        W16_LD(gw, weoff, 2, 12);
+        if (ngt > 0) load_e(0, ge0, ge1);
+    };
+    // 32-vector in natural feature order -> this lane's two groups of four
+    auto vec2 = [&](int off, f32x4 (&v)[2]) {
+        v[0] = w16_ld(wp + off + fo);
+        v[1] = w16_ld(wp + off + 16 + fo);
     };
 
     // ================================================================== GNN steps (charge_gn.py:60-74)
     if (GNN) {
-        float P[16], u1pre[16], pb[16], b2k[16], bn[16];
+        f32x4 P0[2], P1[2], U0[2], U1[2], B0[2], B1[2];     // P, u1pre, nm*u2 of the two columns
+        float pb[2][8];
+        f32x4 b2v[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bn[r] = 0.f;
-        // ---- step 0: G rows, then P / R / u1pre from (xq | hk)
+        for (int rb = 0; rb < 2; ++rb) { B0[rb] = w16_splat(0.f); B1[rb] = w16_splat(0.f); }
+        // ---- step 0: G rows, then P / R / u1pre from (xq | h)
         {
-            float wa[EPNN_KX], wb[24], wc[EPNN_KX], wd[24];
-            EPNN_WLD(wa, X.wi0, EPNN_KX);
-            if (have_h) { EPNN_WLD(wb, X.wi0 + EPNN_KX * 64, 24); }
+            float wa[2][EPNN_XS], wc[2][EPNN_XS];
+            W16_LDX(wa, X.wi0, 2, EPNN_XS, EPNN_XS + 12, 0);      // the xq steps; the h steps only when h is given
+            W16_LDX(wc, X.wj0, 2, EPNN_XS, EPNN_XS + 12, 0);
             WAVE_FENCE();
             gtiles();
-            EPNN_WLD(wc, X.wj0, EPNN_KX);
-            if (have_h) { EPNN_WLD(wd, X.wj0 + EPNN_KX * 64, 24); }
+            W16_LD(pb, X.g[0].w2, 2, 8);
+            vec2(X.g[0].b2, b2v);
             WAVE_FENCE();
-            f32x16 acc = wave_chain<EPNN_KX>(wa, xq, epnn_splat16(0.f));
-            if (have_h) acc = wave_chain<24>(wb, hk, acc);
-            f32x16 acr = wave_chain<EPNN_KX>(wc, xq, epnn_splat16(0.f));
-            if (have_h) acr = wave_chain<24>(wd, hk, acr);
+            f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) P[r] = acc[r];
-            if (owner) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
-            EPNN_WLD(pb, X.g[0].w2, 16);
-            epnn_ld16(wp + X.g[0].b2k + hh * 16, b2k);
-            if (have_h) { EPNN_WLD(wb, X.u1h0, 24); }
-            WAVE_FENCE();
-            acc = epnn_splat16(0.f);
-            if (have_h) {
-                float hm[24];
+            for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); U0[rb] = w16_splat(0.f); U1[rb] = w16_splat(0.f); }
+            w16_mm<2, EPNN_XS>(wa, xq0, P0);
+            w16_mm<2, EPNN_XS>(wc, xq0, r0);
+            if (two) { w16_mm<2, EPNN_XS>(wa, xq1, P1); w16_mm<2, EPNN_XS>(wc, xq1, r1); }
+            if (have_h) {                                   // layer-level entry: h given by the caller
+                float wh[2][12], hin0[12], hin1[12], hm0[12], hm1[12];
 #pragma unroll
-                for (int s = 0; s < 24; ++s) hm[s] = nmv * hk[s];       // masked_input = [h, m] * node_mask (charge_gn.py:72)
-                acc = wave_chain<24>(wb, hm, acc);
+                for (int s = 0; s < 12; ++s) {
+                    hin0[s] = hk0[s >> 2][s & 3]; hin1[s] = hk1[s >> 2][s & 3];
+                    hm0[s] = nm0 * hin0[s]; hm1[s] = nm1 * hin1[s];    // masked_input = [h, m] * node_mask (charge_gn.py:72)
+                }
+                W16_LDX(wh, X.wi0, 2, 12, EPNN_XS + 12, EPNN_XS);
+                w16_mm<2, 12>(wh, hin0, P0);
+                if (two) w16_mm<2, 12>(wh, hin1, P1);
+                W16_LDX(wh, X.wj0, 2, 12, EPNN_XS + 12, EPNN_XS);
+                w16_mm<2, 12>(wh, hin0, r0);
+                if (two) w16_mm<2, 12>(wh, hin1, r1);
+                W16_LD(wh, X.u1h0, 2, 12);
+                w16_mm<2, 12>(wh, hm0, U0);
+                if (two) w16_mm<2, 12>(wh, hm1, U1);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) u1pre[r] = acc[r];
+            if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
+            if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
         }
         wave_sync_all();
         WAVE_STAMP();   // step-0 G tiles + projections
@@ -374,100 +417,89 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
         for (int t = 0; t < Tg; ++t) {
             const WaveGnnPack &M = X.g[t];
             const bool lastg = t + 1 == Tg;
-            float S[16], u1s[16], w2[16], cv[16], bv[16];
+            f32x4 S0[2] = {w16_splat(0.f), w16_splat(0.f)}, S1[2] = {w16_splat(0.f), w16_splat(0.f)};
+            float u1s[2][8];
             {
-                f32x16 cb2;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { cb2[r] = b2k[r]; S[r] = 0.f; }
-                // ---- partner tiles j = 0..n-1, operands of tile j+1 (and the slot of j+2) fetched during tile j.
-                //      Two instances: every G row in LDS (the usual case) / some rows in HBM (both sources read, one is 0)
+                // ---- partner tiles: tile jp holds partner jp of every atom; jp == n is the reference's zero-padded
+                //      partner (R = 0, G = 0, charge_gn.py:70), counted N - n times
+                const float *zrow = Gl + glds * EPNN_PST;
                 auto sweep = [&](auto over_tag) {
                     constexpr bool OVER = decltype(over_tag)::value;
-                    auto gload = [&](int slot, float (&g)[16], float (&gh)[16]) {
-                        epnn_ld16(Gl + min(slot, glds) * EPNN_PST + hh * 16, g);          // 0xFFFF / overflow -> the zero row
-                        if (OVER) {
-                            if (slot >= glds && slot != 0xFFFF) epnn_ld16(A.gx + (size_t)(p0 + slot) * 32 + hh * 16, gh);
-                            else {
-#pragma unroll
-                                for (int s = 0; s < 16; ++s) gh[s] = 0.f;
+                    struct Ops { f32x4 r[2], g0[2], g1[2]; };
+                    auto load_ops = [&](int jp, int s0, int s1, Ops &o_) {
+                        const float *rrow = jp < n ? Rl + jp * EPNN_PST : zrow;
+                        o_.r[0] = w16_ld(rrow + fo);
+                        o_.r[1] = w16_ld(rrow + 16 + fo);
+                        const float *g0 = Gl + min(s0, glds) * EPNN_PST;         // 0xFFFF / overflow -> the zero row
+                        o_.g0[0] = w16_ld(g0 + fo);
+                        o_.g0[1] = w16_ld(g0 + 16 + fo);
+                        if (OVER && s0 >= glds && s0 != 0xFFFF) {
+                            o_.g0[0] = w16_ld(A.gx + (size_t)(p0 + s0) * 32 + fo);
+                            o_.g0[1] = w16_ld(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo);
+                        }
+                        if (two) {
+                            const float *g1 = Gl + min(s1, glds) * EPNN_PST;
+                            o_.g1[0] = w16_ld(g1 + fo);
+                            o_.g1[1] = w16_ld(g1 + 16 + fo);
+                            if (OVER && s1 >= glds && s1 != 0xFFFF) {
+                                o_.g1[0] = w16_ld(A.gx + (size_t)(p0 + s1) * 32 + fo);
+                                o_.g1[1] = w16_ld(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo);
                             }
                         }
                     };
-                    // partner index jp in [0, n]: atom jp, or (jp == n) the reference's zero-padded partner (R = 0, G = 0,
-                    // charge_gn.py:70) which counts N - n times; beyond n: nothing (weight 0).  Tile t holds partner t of
-                    // every atom, or (dual) partners 2t / 2t+1 in the lower / upper copy.  Operands of tile t+1 (and the
-                    // slot of t+2) are fetched while tile t is in the matrix pipe.
-                    const float *zrow = Gl + glds * EPNN_PST + hh * 16;
-                    const int nt = dual ? (n + 2) >> 1 : n + 1;
-                    auto partner = [&](int t) -> int { return dual ? 2 * t + (hi ? 1 : 0) : t; };
-                    auto rload = [&](int t, float (&r)[16]) {
-                        const int jp = partner(t);
-                        epnn_ld16(jp < n ? Rl + jp * EPNN_PST + hh * 16 : zrow, r);
-                    };
-                    auto slot_of = [&](int t) -> int {
-                        const int jp = partner(t);
-                        return jp < n ? (int)pm[jp * 32 + ai] : 0xFFFF;
-                    };
-                    auto weight = [&](int t) -> float {
-                        const int jp = partner(t);
-                        return jp < n ? 1.f : (jp == n ? padw : 0.f);
-                    };
-                    auto tile = [&](const float (&rj)[16], const float (&g)[16], const float (&gh)[16], float wt) {
-                        f32x16 acc = cb2;
+                    auto slot0 = [&](int jp) -> int { return jp < n ? (int)pm[jp * 32 + n16] : 0xFFFF; };
+                    auto slot1 = [&](int jp) -> int { return (two && jp < n) ? (int)pm[jp * 32 + col1] : 0xFFFF; };
+                    auto tile = [&](const Ops &o_, float wt) {
+                        float z[8];
+                        f32x4 d[2];
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) {
-                            float z = (P[s] + rj[s]) + g[s];
-                            if (OVER) z += gh[s];
-                            acc = epnn_mfma(pb[s], fmaxf(z, 0.f), acc);
+                        for (int s = 0; s < 8; ++s) z[s] = fmaxf((P0[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g0[s >> 2][s & 3], 0.f);
+                        d[0] = b2v[0]; d[1] = b2v[1];
+                        w16_mm<2, 8>(pb, z, d);
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) S0[rb] += wt * w16_relu(d[rb]);
+                        if (two) {
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) z[s] = fmaxf((P1[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g1[s >> 2][s & 3], 0.f);
+                            d[0] = b2v[0]; d[1] = b2v[1];
+                            w16_mm<2, 8>(pb, z, d);
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb) S1[rb] += wt * w16_relu(d[rb]);
                         }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) S[r] = fmaf(wt, fmaxf(acc[r], 0.f), S[r]);
                     };
-                    if (OVER) {          // rare (large or very dense molecules): no fetch-ahead, fewer registers
+                    if (OVER) {          // rare (large or very dense molecules): no fetch-ahead
 #pragma unroll 1
-                        for (int t = 0; t < nt; ++t) {
-                            if (t == nt - 1) { EPNN_WLD(u1s, M.u1s, 16); }    // first operand of the update MLP
-                            float rj[16], g[16], gh[16];
-                            rload(t, rj);
-                            gload(slot_of(t), g, gh);
-                            tile(rj, g, gh, weight(t));
+                        for (int jp = 0; jp <= n; ++jp) {
+                            if (jp == n) { W16_LD(u1s, M.u1s, 2, 8); }
+                            Ops o_;
+                            load_ops(jp, slot0(jp), slot1(jp), o_);
+                            tile(o_, jp == n ? padw : 1.f);
                         }
                     } else {
-                        float rA[16], gA[16], rB[16], gB[16];
-                        rload(0, rA);
-                        gload(slot_of(0), gA, gA);
-                        int snext = slot_of(1);
-                        int t = 0;
+                        Ops oa, ob;
+                        load_ops(0, slot0(0), slot1(0), oa);
+                        int sn0 = slot0(1), sn1 = slot1(1);
+                        int jp = 0;
 #pragma unroll 1
-                        for (; t + 2 < nt; t += 2) {                          // tiles t, t+1; neither is the last one
-                            rload(t + 1, rB);
-                            gload(snext, gB, gB);
-                            snext = slot_of(t + 2);
+                        for (; jp + 2 <= n; jp += 2) {                         // tiles jp, jp+1: neither is the last one
+                            load_ops(jp + 1, sn0, sn1, ob);
+                            sn0 = slot0(jp + 2); sn1 = slot1(jp + 2);
                             WAVE_FENCE();
-                            tile(rA, gA, gA, weight(t));
-                            rload(t + 2, rA);
-                            gload(snext, gA, gA);
-                            snext = slot_of(t + 3);
+                            tile(oa, 1.f);
+                            load_ops(jp + 2, sn0, sn1, oa);
+                            sn0 = slot0(jp + 3); sn1 = slot1(jp + 3);
                             WAVE_FENCE();
-                            tile(rB, gB, gB, weight(t + 1));
+                            tile(ob, 1.f);
                         }
-                        EPNN_WLD(u1s, M.u1s, 16);                             // first operand of the update MLP
-                        if (t + 1 < nt) {                                      // two tiles left
-                            rload(t + 1, rB);
-                            gload(snext, gB, gB);
+                        W16_LD(u1s, M.u1s, 2, 8);                             // first operand of the update MLP
+                        if (jp < n) {                                          // n odd: last partner, then the padded one
+                            load_ops(n, 0xFFFF, 0xFFFF, ob);
                             WAVE_FENCE();
-                            tile(rA, gA, gA, weight(t));
-                            tile(rB, gB, gB, weight(t + 1));
+                            tile(oa, 1.f);
+                            tile(ob, padw);
                         } else {
                             WAVE_FENCE();
-                            tile(rA, gA, gA, weight(t));
-                        }
-                    }
-                    if (dual) {          // the two copies of an atom hold the even / odd partners: add them, both copies end up complete
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float other = __shfl_xor(S[r], 16, 64);       // all lanes take part in the exchange
-                            S[r] = hi ? other + S[r] : S[r] + other;           // lower + upper: same order in both copies
+                            tile(oa, padw);                                    // oa holds tile n: zero rows
                         }
                     }
                 };
@@ -477,83 +509,95 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
             if (t < 2) WAVE_STAMP();   // pair tiles
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
             {
-                EPNN_WLD(w2, M.u2, 16);
-                epnn_ld16(wp + M.cb3k + hh * 16, cv);
-                epnn_ld16(wp + M.bu1k + hh * 16, bv);
+                float w2[2][8], in0[8], in1[8];
+                f32x4 cv[2], bv[2];
+                W16_LD(w2, M.u2, 2, 8);
+                vec2(M.cb3, cv);
+                vec2(M.bu1, bv);
                 WAVE_FENCE();
-                f32x16 acc;
+                f32x4 d0[2] = {U0[0], U0[1]}, d1[2] = {U1[0], U1[1]};
+                w16_feed(S0, in0);
+                w16_mm<2, 8>(u1s, in0, d0);
+                if (two) { w16_feed(S1, in1); w16_mm<2, 8>(u1s, in1, d1); }
+                f32x4 a0_[2], a1_[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = u1pre[r];
-                acc = wave_chain<16>(u1s, S, acc);
-                float u1[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u1[r] = fmaxf(fmaf(nmv, fmaf(Nf, cv[r], acc[r]), bv[r]), 0.f);
-                epnn_ld16(wp + M.bu2k + hh * 16, bv);
+                for (int rb = 0; rb < 2; ++rb) {
+                    a0_[rb] = w16_relu(nm0 * (d0[rb] + Nf * cv[rb]) + bv[rb]);
+                    a1_[rb] = w16_relu(nm1 * (d1[rb] + Nf * cv[rb]) + bv[rb]);
+                }
+                vec2(M.bu2, bv);
                 if (!lastg) gprefetch(X.g[t + 1].we);
                 else if (Te > 0) gprefetch(X.e[0].we);
                 WAVE_FENCE();
-                acc = wave_chain<16>(w2, u1, epnn_splat16(0.f));
+                d0[0] = bv[0]; d0[1] = bv[1]; d1[0] = bv[0]; d1[1] = bv[1];
+                w16_feed(a0_, in0);
+                w16_mm<2, 8>(w2, in0, d0);
+                if (two) { w16_feed(a1_, in1); w16_mm<2, 8>(w2, in1, d1); }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bn[r] = fmaxf(acc[r] + bv[r], 0.f);
+                for (int rb = 0; rb < 2; ++rb) { B0[rb] = nm0 * w16_relu(d0[rb]); B1[rb] = nm1 * w16_relu(d1[rb]); }
             }
             if (t < 2) WAVE_STAMP();   // U1, U2
             if (!lastg) {
                 // next step: G rows, then P / R / u1pre from (nm*u2 | xq) through the folded matrices
-                float wa[16 + EPNN_KX], wb[16 + EPNN_KX];
-                EPNN_WLD(wa, M.pwi, 16 + EPNN_KX);
+                float wa[2][8 + EPNN_XS], wb[2][8 + EPNN_XS], in0[8 + EPNN_XS], in1[8 + EPNN_XS];
+                W16_LD(wa, M.pwi, 2, 8 + EPNN_XS);
                 WAVE_FENCE();
                 gtiles();
                 if (t < 2) WAVE_STAMP();   // G tiles
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bn[r] *= nmv;
-                float in[16 + EPNN_KX];
+                for (int s = 0; s < 8; ++s) { in0[s] = B0[s >> 2][s & 3]; in1[s] = B1[s >> 2][s & 3]; }
 #pragma unroll
-                for (int s = 0; s < 16; ++s) in[s] = bn[s];
-#pragma unroll
-                for (int s = 0; s < EPNN_KX; ++s) in[16 + s] = xq[s];
-                EPNN_WLD(wb, M.pwj, 16 + EPNN_KX);
-                float cu[16], wu[16];
-                EPNN_WLD(wu, M.pu1, 16);
-                epnn_ld16(wp + M.cu3k + hh * 16, cu);
-                WAVE_FENCE();
-                f32x16 acc = wave_chain<16 + EPNN_KX>(wa, in, epnn_splat16(0.f));
-                f32x16 acr = wave_chain<16 + EPNN_KX>(wb, in, epnn_splat16(0.f));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) P[r] = acc[r];
-                if (owner) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
-                EPNN_WLD(pb, X.g[t + 1].w2, 16);
-                epnn_ld16(wp + X.g[t + 1].b2k + hh * 16, b2k);
+                for (int s = 0; s < EPNN_XS; ++s) { in0[8 + s] = xq0[s]; in1[8 + s] = xq1[s]; }
+                W16_LD(wb, M.pwj, 2, 8 + EPNN_XS);
+                float wu[2][8];
+                f32x4 cu[2];
+                W16_LD(wu, M.pu1, 2, 8);
+                vec2(M.cu3, cu);
                 WAVE_FENCE();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = nmv * cu[r];
-                acc = wave_chain<16>(wu, bn, acc);
+                for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); }
+                w16_mm<2, 8 + EPNN_XS>(wa, in0, P0);
+                if (two) w16_mm<2, 8 + EPNN_XS>(wa, in1, P1);
+                f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm<2, 8 + EPNN_XS>(wb, in0, r0);
+                if (two) w16_mm<2, 8 + EPNN_XS>(wb, in1, r1);
+                if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
+                if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
+                W16_LD(pb, X.g[t + 1].w2, 2, 8);
+                vec2(X.g[t + 1].b2, b2v);
+                WAVE_FENCE();
+                float bin0[8], bin1[8];
+                w16_feed(B0, bin0);
+                w16_feed(B1, bin1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u1pre[r] = acc[r];
+                for (int rb = 0; rb < 2; ++rb) { U0[rb] = nm0 * cu[rb]; U1[rb] = nm1 * cu[rb]; }
+                w16_mm<2, 8>(wu, bin0, U0);
+                if (two) w16_mm<2, 8>(wu, bin1, U1);
                 wave_sync_all();
                 if (t < 2) WAVE_STAMP();   // projections
             }
         }
         {
-            // h = node_mask * (Wu3^T u2 + bu3)  (charge_gn.py:73-74) after the last step, straight into the hk registers
-            float w[16], w2[16], bv[16], bw[16];
-            EPNN_WLD(w, X.u3, 16);
-            EPNN_WLD(w2, X.u3 + 16 * 64, 16);
-            epnn_ld16(wp + X.bu3k + hh * 16, bv);
-            epnn_ld16(wp + X.bu3k + 32 + hh * 16, bw);
+            // h = node_mask * (Wu3^T u2 + bu3)  (charge_gn.py:73-74) after the last step, straight into the h registers
+            float w[3][8], bin0[8], bin1[8];
+            W16_LD(w, X.u3, 3, 8);
+            f32x4 bv[3];
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) bv[rb] = w16_ld(wp + X.bu3 + 16 * rb + fo);
             WAVE_FENCE();
-            f32x16 acc = wave_chain<16>(w, bn, epnn_splat16(0.f));
-            f32x16 ac2 = wave_chain<16>(w2, bn, epnn_splat16(0.f));
+            w16_feed(B0, bin0);
+            w16_feed(B1, bin1);
+            // B = nm * u2 already: h = nm * (Wu3^T u2) + nm * bu3
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hk[r] = nmv * (acc[r] + bv[r]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) hk[16 + r] = nmv * (ac2[r] + bw[r]);
+            for (int rb = 0; rb < 3; ++rb) { hk0[rb] = nm0 * bv[rb]; hk1[rb] = nm1 * bv[rb]; }
+            w16_mm<3, 8>(w, bin0, hk0);
+            if (two) w16_mm<3, 8>(w, bin1, hk1);
         }
-        if (A.h_out && owner) {
+        if (A.h_out) {
 #pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                f32x4 v;
-                v[0] = hk[4 * g]; v[1] = hk[4 * g + 1]; v[2] = hk[4 * g + 2]; v[3] = hk[4 * g + 3];
-                *reinterpret_cast<f32x4 *>(A.h_out + (size_t)(a0 + c) * EPNN_EDIM + wave_hk_f0(hh, g)) = v;
+            for (int rb = 0; rb < 3; ++rb) {
+                if (cat0) w16_st(A.h_out + (size_t)(a0 + n16) * EPNN_EDIM + 16 * rb + fo, hk0[rb]);
+                if (cat1) w16_st(A.h_out + (size_t)(a0 + col1) * EPNN_EDIM + 16 * rb + fo, hk1[rb]);
             }
         }
     }
@@ -561,118 +605,148 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A) {
     WAVE_STAMP();   // GNN done
     // ================================================================== EPN steps (charge_gn.py:98-118)
     if (EPN) {
-        wave_sync_lds();                                    // the pair map is dead: its rows become P rows
-        const int qs = (nx + 1) >> 1, qh = (nx + 1) & 1;    // register / half-wave of xq that holds q
+        wave_sync_lds();                                    // the GNN's tables are dead: switch to the EPN layout
+        Gl = sm + o_ge;
+        glds = min(np, grows_e);
+        gover = np > glds;
+        for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
+        wave_sync_lds();
+        const int qs = (nx + 1) >> 2, ql = (nx + 1) & 3;    // step / lane group of xq that holds q
 #pragma unroll 1
         for (int t = 0; t < Te; ++t) {
             const WaveEpnPack &M = X.e[t];
-            float in[EPNN_KX + 24];
-#pragma unroll
-            for (int s = 0; s < EPNN_KX; ++s) in[s] = xq[s];
-#pragma unroll
-            for (int s = 0; s < 24; ++s) in[EPNN_KX + s] = hk[s];
             {
-                float wa[EPNN_KX + 24], wb[EPNN_KX + 24];
-                EPNN_WLD(wa, M.wi, EPNN_KX + 24);
+                float wa[2][EPNN_XS + 12], wb[2][EPNN_XS + 12], in0[EPNN_XS + 12], in1[EPNN_XS + 12];
+#pragma unroll
+                for (int s = 0; s < EPNN_XS; ++s) { in0[s] = xq0[s]; in1[s] = xq1[s]; }
+#pragma unroll
+                for (int s = 0; s < 12; ++s) { in0[EPNN_XS + s] = hk0[s >> 2][s & 3]; in1[EPNN_XS + s] = hk1[s >> 2][s & 3]; }
+                W16_LD(wa, M.wi, 2, EPNN_XS + 12);
                 WAVE_FENCE();
                 gtiles();
                 if (t < 2) WAVE_STAMP();   // EPN G tiles
-                EPNN_WLD(wb, M.wj, EPNN_KX + 24);
+                W16_LD(wb, M.wj, 2, EPNN_XS + 12);
                 WAVE_FENCE();
-                f32x16 acc = wave_chain<EPNN_KX + 24>(wa, in, epnn_splat16(0.f));
-                f32x16 acr = wave_chain<EPNN_KX + 24>(wb, in, epnn_splat16(0.f));
-                if (owner) epnn_st16(Pl + c * EPNN_PST + hh * 16, acc);
-                if (owner) epnn_st16(Rl + c * EPNN_PST + hh * 16, acr);
+                f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)}, d1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm<2, EPNN_XS + 12>(wa, in0, d0);
+                if (two) w16_mm<2, EPNN_XS + 12>(wa, in1, d1);
+                if (cat0) { w16_st(Pl + n16 * EPNN_PST + fo, d0[0]); w16_st(Pl + n16 * EPNN_PST + 16 + fo, d0[1]); }
+                if (cat1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
+                d0[0] = w16_splat(0.f); d0[1] = w16_splat(0.f); d1[0] = w16_splat(0.f); d1[1] = w16_splat(0.f);
+                w16_mm<2, EPNN_XS + 12>(wb, in0, d0);
+                if (two) w16_mm<2, EPNN_XS + 12>(wb, in1, d1);
+                if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
+                if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
             }
-            float pb[16], b2v[16], w3[16];
-            EPNN_WLD(pb, M.w2, 16);
-            epnn_ld16(wp + M.b2k + hh * 16, b2v);
-            epnn_ld16(wp + M.w3k + hh * 16, w3);
+            float pb[2][8];
+            f32x4 b2v[2], w3[2];
+            W16_LD(pb, M.w2, 2, 8);
+            vec2(M.b2, b2v);
+            vec2(M.w3, w3);
             wave_sync_all();
             if (t < 2) WAVE_STAMP();   // EPN P, R
             {
-                // pair record of the next tile (indices in LDS, weights in HBM) fetched one tile ahead
-                int ij_n = eij[c < np ? c : 0];
-                float wi_n = A.pwi[p0 + (c < np ? c : 0)], wj_n = A.pwj[p0 + (c < np ? c : 0)];
-#pragma unroll 1
-                for (int gt = 0; gt < ngt; ++gt) {
-                    const int slot = gt * 32 + c;
-                    const bool valid = slot < np;
-                    const int sl = valid ? slot : 0;
-                    const int ij = ij_n;
-                    const float wi = wi_n, wj = wj_n;
-                    {
-                        const int sn = slot + 32 < np ? slot + 32 : 0;
-                        ij_n = eij[sn];
-                        wi_n = A.pwi[p0 + sn];
-                        wj_n = A.pwj[p0 + sn];
-                    }
-                    const int li = ij & 0xFF, lj = ij >> 8;
-                    float g[16], pi_[16], rj_[16], pj_[16], ri_[16];
-                    if (sl < glds) epnn_ld16(Gl + sl * EPNN_PST + hh * 16, g);
-                    else epnn_ld16(A.gx + (size_t)(p0 + sl) * 32 + hh * 16, g);
-                    epnn_ld16(Pl + li * EPNN_PST + hh * 16, pi_);
-                    epnn_ld16(Rl + lj * EPNN_PST + hh * 16, rj_);
-                    epnn_ld16(Pl + lj * EPNN_PST + hh * 16, pj_);
-                    epnn_ld16(Rl + li * EPNN_PST + hh * 16, ri_);
-                    // the two directions of the pair are independent chains: interleaved (rows = out feature, col = pair)
-                    f32x16 au, av;
+                // one column per UNORDERED near pair, 16 pairs per column block.  Software pipeline: the pair record
+                // (indices in LDS, weights in HBM) is fetched two blocks ahead, the gathered P / R / G rows one block ahead
+                const int nblk = (np + 15) >> 4;
+                struct Rec { int ij; float wi, wj; };
+                struct Rows { f32x4 g[2], pi_[2], rj_[2], pj_[2], ri_[2]; };
+                auto load_rec = [&](int blk, Rec &r_) {
+                    const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
+                    r_.ij = eij[sl];
+                    r_.wi = A.pwi[p0 + sl];
+                    r_.wj = A.pwj[p0 + sl];
+                };
+                auto load_rows = [&](int blk, const Rec &r_, Rows &w_) {
+                    const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
+                    const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
+                    if (sl < glds) { w_.g[0] = w16_ld(Gl + sl * EPNN_PST + fo); w_.g[1] = w16_ld(Gl + sl * EPNN_PST + 16 + fo); }
+                    else { w_.g[0] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + fo); w_.g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo); }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        au = epnn_mfma(pb[s], fmaxf((g[s] + pi_[s]) + rj_[s], 0.f), au);
-                        av = epnn_mfma(pb[s], fmaxf((g[s] + pj_[s]) + ri_[s], 0.f), av);
+                    for (int rb = 0; rb < 2; ++rb) {
+                        w_.pi_[rb] = w16_ld(Pl + li * EPNN_PST + 16 * rb + fo);
+                        w_.rj_[rb] = w16_ld(Rl + lj * EPNN_PST + 16 * rb + fo);
+                        w_.pj_[rb] = w16_ld(Pl + lj * EPNN_PST + 16 * rb + fo);
+                        w_.ri_[rb] = w16_ld(Rl + li * EPNN_PST + 16 * rb + fo);
                     }
-                    float fu = 0.f, fv = 0.f;
+                };
+                auto block = [&](int blk, const Rec &r_, const Rows &w_) {
+                    const bool valid = blk * 16 + n16 < np;
+                    const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
+                    float zu[8], zv[8];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
-                        fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
+                    for (int s = 0; s < 8; ++s) {
+                        zu[s] = fmaxf((w_.g[s >> 2][s & 3] + w_.pi_[s >> 2][s & 3]) + w_.rj_[s >> 2][s & 3], 0.f);
+                        zv[s] = fmaxf((w_.g[s >> 2][s & 3] + w_.pj_[s >> 2][s & 3]) + w_.ri_[s >> 2][s & 3], 0.f);
                     }
-                    fu += epnn_swap32(fu);
-                    fv += epnn_swap32(fv);
-                    const float d = 0.5f * (fu - fv);                  // charge_gn.py:116
+                    f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
+                    w16_mm<2, 8>(pb, zu, au);
+                    w16_mm<2, 8>(pb, zv, av);
+                    float fd = 0.f;                                    // w3 . (relu(u) - relu(v)) over this lane's 8 features
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) fd = fmaf(w3[rb][r], fmaxf(au[rb][r], 0.f) - fmaxf(av[rb][r], 0.f), fd);
+                    const float d = 0.5f * w16_sumq(fd);               // charge_gn.py:116; all lanes take part
                     // entries with weight 0 are never written (they stay 0): a one-sided entry (j,i) of the dense
                     // front-end must not clear what the entry (i,j) wrote
-                    if (hh == 0 && valid && wi != 0.f) Dm[li * EPNN_DST + lj] = wi * d;
-                    if (hh == 1 && valid && wj != 0.f) Dm[lj * EPNN_DST + li] = -(wj * d);
+                    if (q == 0 && valid && r_.wi != 0.f) Dm[li * EPNN_DST + lj] = r_.wi * d;
+                    if (q == 1 && valid && r_.wj != 0.f) Dm[lj * EPNN_DST + li] = -(r_.wj * d);
+                };
+                if (nblk > 0) {
+                    Rec r0, r1;
+                    Rows w0, w1;
+                    load_rec(0, r0);
+                    load_rec(min(1, nblk - 1), r1);
+                    load_rows(0, r0, w0);
+                    int blk = 0;
+#pragma unroll 1
+                    for (; blk + 1 < nblk; blk += 2) {
+                        Rec r2, r3;
+                        load_rows(blk + 1, r1, w1);
+                        load_rec(min(blk + 2, nblk - 1), r2);
+                        WAVE_FENCE();
+                        block(blk, r0, w0);
+                        load_rows(min(blk + 2, nblk - 1), r2, w0);
+                        load_rec(min(blk + 3, nblk - 1), r3);
+                        WAVE_FENCE();
+                        block(blk + 1, r1, w1);
+                        r0 = r2;
+                        r1 = r3;
+                    }
+                    if (blk < nblk) block(blk, r0, w0);
                 }
             }
             wave_sync_lds();
             if (t + 1 < Te) gprefetch(X.e[t + 1].we);     // on its way during the charge update
             WAVE_FENCE();
             if (t < 2) WAVE_STAMP();   // EPN pair tiles
-            // q_i += sum_j antisym_ij (charge_gn.py:118): lane (i, hh) adds row i of the transfer matrix, columns j = hh mod 2
+            // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of the rows of its two atoms
             {
                 float dq0 = 0.f, dq1 = 0.f;
-                const float *drow = Dm + (catom ? ai : 0) * EPNN_DST + hh;
-#pragma unroll 4
-                for (int j = 0; j + hh < n; j += 4) {
-                    dq0 += drow[j];
-                    dq1 += (j + 2 + hh < n) ? drow[j + 2] : 0.f;
+                const float *row0 = Dm + (cat0 ? n16 : 0) * EPNN_DST, *row1 = Dm + (cat1 ? col1 : 0) * EPNN_DST;
+                for (int j = q; j < n; j += 4) {
+                    dq0 += row0[j];
+                    dq1 += row1[j];
                 }
-                float dq = dq0 + dq1;
-                dq += epnn_swap32(dq);
+                dq0 = w16_sumq(dq0);
+                dq1 = w16_sumq(dq1);
 #pragma unroll
-                for (int s = 0; s < EPNN_KX; ++s)
-                    if (s == qs && hh == qh) xq[s] += dq;
+                for (int s = 0; s < EPNN_XS; ++s)
+                    if (s == qs && q == ql) { xq0[s] += cat0 ? dq0 : 0.f; xq1[s] += cat1 ? dq1 : 0.f; }
             }
             wave_sync_lds();
             if (t < 2) WAVE_STAMP();   // charge update
         }
-        // q sits in half-wave qh; hand it to the lower half for the store
-        float qout = 0.f;
 #pragma unroll
-        for (int s = 0; s < EPNN_KX; ++s)
-            if (s == qs) qout = xq[s];
-        const float qo = epnn_swap32(qout);
-        if (qh == 1) qout = qo;
-        if (hh == 0 && owner) A.q_out[a0 + c] = qout;
+        for (int s = 0; s < EPNN_XS; ++s)
+            if (s == qs && q == ql) {
+                if (cat0) A.q_out[a0 + n16] = xq0[s];
+                if (cat1) A.q_out[a0 + col1] = xq1[s];
+            }
     }
     if (FRONT && lane == 0) {
-        // No memset before and no copy after the launch: the last wave to finish hands status + pair count to the host
-        // and leaves the three control words zeroed for the next forward of this handle.
+        // the last wave to finish hands status + pair count to the host and re-zeroes the control words
         atomicAdd(A.status + 1, np);
         __threadfence();
         if (atomicAdd(A.status + 2, 1) == (int)gridDim.x - 1) {

@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "epnn_amd", "libepnn_hip_stamps.so")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-shared", "-fPIC", "-DEPNN_STAMPS=1", *(["-DEPNN_ABL_W=1"] if os.environ.get("ABL_W") else []),
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-shared", "-fPIC", "-DEPNN_STAMPS=1",
                 "-o", so, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"), "-L/opt/rocm/lib", "-lrccl"], check=True, stderr=subprocess.DEVNULL)
 from epnn_amd import _lib
 _lib.LIB_PATH = so
