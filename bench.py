@@ -52,8 +52,8 @@ def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)     # 400 x 0.13 ms: long enough for the fill / drain of the
+    ap.add_argument("--warmup", type=int, default=24)     # six-deep pipeline (~0.6 ms each) not to weigh on the rate
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight per GPU (handles/streams used round robin)")
