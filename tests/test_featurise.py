@@ -52,3 +52,20 @@ def test_xyz_parsing_rules(tmp_path):
     with pytest.raises(KeyError):
         (tmp_path / "p.xyz").write_text("1\n0 1\nP 0 0 0\n")
         charge_gn.read_xyz(str(tmp_path / "p.xyz"), 9)           # P is not in infer.py's table
+
+
+def test_horton_txt2npy(tmp_path):
+    """Label tooling (reference data/horton_txt2npy.py): 4 header lines, then token 4 of every line is the charge."""
+    from epnn_amd import labels
+    d = tmp_path / "out"
+    (d / "sub").mkdir(parents=True)
+    body = "header 1\nheader 2\nheader 3\nheader 4\n" + "".join(
+        f"{k} X 0.0 0.0 {q:.6f} 1.0 2.0\n" for k, q in enumerate([-0.25, 0.5, 0.125]))
+    (d / "a-mtp.txt").write_text(body)
+    (d / "sub" / "b-mtp.txt").write_text(body)
+    (d / "ignored.txt").write_text("nothing")
+    written = labels.horton_txt2npy(str(d))
+    assert sorted(os.path.relpath(w, d) for w in written) == ["a-mtp.npy", os.path.join("sub", "b-mtp.npy")]
+    for w in written:
+        q = np.load(w, allow_pickle=True)
+        assert q.dtype == np.float64 and np.array_equal(q, np.array([-0.25, 0.5, 0.125]))
