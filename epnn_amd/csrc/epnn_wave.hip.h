@@ -329,33 +329,39 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     const int fo = 4 * q;                                   // this lane's feature offset inside a 16-feature row block
 
     // G rows of every near pair for the pair MLP whose We is in gw (first e rows in ge0/ge1); rows >= glds go to HBM
-    auto gtiles = [&]() {
-#pragma unroll 1
-        for (int gt = 0; gt < ngt; ++gt) {
-            float en0[12], en1[12];
-            load_e(min(gt + 1, ngt - 1), en0, en1);
-            WAVE_FENCE();
-            const int s0 = gt * 32 + n16, s1 = s0 + 16;
-            f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
-            w16_mm<2, 12>(gw, ge0, d0);
-            // two separate predicated stores per target (LDS / HBM): merged into one pointer they become flat stores
-            if (s0 < min(np, glds)) { w16_st(Gl + s0 * EPNN_PST + fo, d0[0]); w16_st(Gl + s0 * EPNN_PST + 16 + fo, d0[1]); }
+    auto gtile = [&](int gt, const float (&e0)[12], const float (&e1)[12]) {
+        const int s0 = gt * 32 + n16, s1 = s0 + 16;
+        f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
+        w16_mm<2, 12>(gw, e0, d0);
+        // two separate predicated stores per target (LDS / HBM): merged into one pointer they become flat stores
+        if (s0 < min(np, glds)) { w16_st(Gl + s0 * EPNN_PST + fo, d0[0]); w16_st(Gl + s0 * EPNN_PST + 16 + fo, d0[1]); }
+        if (gover) {
+            asm volatile("" ::: "memory");
+            if (s0 >= glds && s0 < np) { w16_st(A.gx + (size_t)(p0 + s0) * 32 + fo, d0[0]); w16_st(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo, d0[1]); }
+        }
+        if (gt * 32 + 16 < np) {                            // the second 16 pairs of the tile exist
+            f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
+            w16_mm<2, 12>(gw, e1, d1);
+            if (s1 < min(np, glds)) { w16_st(Gl + s1 * EPNN_PST + fo, d1[0]); w16_st(Gl + s1 * EPNN_PST + 16 + fo, d1[1]); }
             if (gover) {
                 asm volatile("" ::: "memory");
-                if (s0 >= glds && s0 < np) { w16_st(A.gx + (size_t)(p0 + s0) * 32 + fo, d0[0]); w16_st(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo, d0[1]); }
+                if (s1 >= glds && s1 < np) { w16_st(A.gx + (size_t)(p0 + s1) * 32 + fo, d1[0]); w16_st(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo, d1[1]); }
             }
-            if (gt * 32 + 16 < np) {                        // the second 16 pairs of the tile exist
-                f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
-                w16_mm<2, 12>(gw, ge1, d1);
-                if (s1 < min(np, glds)) { w16_st(Gl + s1 * EPNN_PST + fo, d1[0]); w16_st(Gl + s1 * EPNN_PST + 16 + fo, d1[1]); }
-                if (gover) {
-                    asm volatile("" ::: "memory");
-                    if (s1 >= glds && s1 < np) { w16_st(A.gx + (size_t)(p0 + s1) * 32 + fo, d1[0]); w16_st(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo, d1[1]); }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 12; ++s) { ge0[s] = en0[s]; ge1[s] = en1[s]; }
         }
+    };
+    auto gtiles = [&]() {                                   // e rows of the next tile are fetched while this one runs
+        float en0[12], en1[12];
+        int gt = 0;
+#pragma unroll 1
+        for (; gt + 1 < ngt; gt += 2) {
+            load_e(gt + 1, en0, en1);
+            WAVE_FENCE();
+            gtile(gt, ge0, ge1);
+            load_e(min(gt + 2, ngt - 1), ge0, ge1);
+            WAVE_FENCE();
+            gtile(gt + 1, en0, en1);
+        }
+        if (gt < ngt) gtile(gt, ge0, ge1);
     };
     auto gprefetch = [&](int weoff) {
         W16_LD(gw, weoff, 2, 12);
@@ -450,21 +456,22 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                     auto slot0 = [&](int jp) -> int { return jp < n ? (int)pm[jp * 32 + n16] : 0xFFFF; };
                     auto slot1 = [&](int jp) -> int { return (two && jp < n) ? (int)pm[jp * 32 + col1] : 0xFFFF; };
                     auto tile = [&](const Ops &o_, float wt) {
-                        float z[8];
-                        f32x4 d[2];
+                        // both column blocks' inputs first, then all MFMA chains, then the sums: one pipeline drain per tile
+                        float z0[8], z1[8];
+                        f32x4 d0[2] = {b2v[0], b2v[1]}, d1[2] = {b2v[0], b2v[1]};
 #pragma unroll
-                        for (int s = 0; s < 8; ++s) z[s] = fmaxf((P0[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g0[s >> 2][s & 3], 0.f);
-                        d[0] = b2v[0]; d[1] = b2v[1];
-                        w16_mm<2, 8>(pb, z, d);
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) S0[rb] += wt * w16_relu(d[rb]);
+                        for (int s = 0; s < 8; ++s) z0[s] = fmaxf((P0[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g0[s >> 2][s & 3], 0.f);
                         if (two) {
 #pragma unroll
-                            for (int s = 0; s < 8; ++s) z[s] = fmaxf((P1[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g1[s >> 2][s & 3], 0.f);
-                            d[0] = b2v[0]; d[1] = b2v[1];
-                            w16_mm<2, 8>(pb, z, d);
+                            for (int s = 0; s < 8; ++s) z1[s] = fmaxf((P1[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g1[s >> 2][s & 3], 0.f);
+                        }
+                        w16_mm<2, 8>(pb, z0, d0);
+                        if (two) w16_mm<2, 8>(pb, z1, d1);
 #pragma unroll
-                            for (int rb = 0; rb < 2; ++rb) S1[rb] += wt * w16_relu(d[rb]);
+                        for (int rb = 0; rb < 2; ++rb) S0[rb] += wt * w16_relu(d0[rb]);
+                        if (two) {
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb) S1[rb] += wt * w16_relu(d1[rb]);
                         }
                     };
                     if (OVER) {          // rare (large or very dense molecules): no fetch-ahead
