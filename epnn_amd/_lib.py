@@ -79,8 +79,9 @@ def load():
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback for the EPNN hot path.")
     # Several handles (= HIP streams) keep batches in flight concurrently (engine.Pipeline).  The HIP runtime maps a
     # process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's): kernels of
-    # streams that share a queue serialise.  Ask for 8 unless the caller decided otherwise; read when HIP initialises.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # streams that share a queue serialise.  Ask for 16 unless the caller decided otherwise (six batches in flight, and an
+    # RCCL communicator in the same process takes queues of its own: with 8 the pipeline loses 15 %); read when HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:

@@ -277,7 +277,7 @@ class Pipeline:
     (8 per CU), so one batch of 1024 molecules fills half the machine and its largest molecules finish long after
     the smallest: the wavefronts of the next batches fill those slots.  A launch lasts as long as its largest molecule
     (~3x the mean under load), so about six batches in flight keep every slot busy; each needs its own hardware queue
-    (GPU_MAX_HW_QUEUES, raised to 8 in _lib.load(); with the runtime's default of 4 use depth 3).
+    (GPU_MAX_HW_QUEUES, raised to 16 in _lib.load(); with the runtime's default of 4 use depth 3).
     All handles carry the same weights.  Results of call k are complete after `sync()`."""
 
     def __init__(self, depth=6, **engine_kwargs):
