@@ -78,6 +78,103 @@ __global__ __launch_bounds__(256) void k_t_dense_dw(const float *X, const float 
         part[(size_t)slice * total + idx] = s;
     }
 }
+
+// ---- the same three products on v_mfma_f32_32x32x2_f32 (one 32x32 output tile per wavefront, four per workgroup).
+// Lane (c = lane & 31, hh = lane >> 5): A operand = A[row c][k = 2s + hh], B operand = B[k = 2s + hh][col c],
+// accumulator register r = D[row kappa(hh,r)][col c].  Every sum has a fixed order (bit-reproducible gradients).
+// forward: Y[r][o] = act(sum_k X[r][k] W[k][o] + b[o]);  tiles: rows x ceil(O/32)
+__global__ __launch_bounds__(256) void k_t_mm_fwd(const float *X, const float *W, const float *b, float *Y, int R, int K, int O,
+                                                   int relu, int ntile_o) {
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rt = tile / ntile_o, ot = tile - rt * ntile_o;
+    const int r0 = rt * 32, o0 = ot * 32;
+    if (r0 >= R) return;
+    const int row = min(r0 + c, R - 1), col = min(o0 + c, O - 1);
+    const float *xr = X + (size_t)row * K;
+    f32x16 acc = epnn_splat16(0.f);
+    const int steps = (K + 1) >> 1;
+#pragma unroll 8
+    for (int s = 0; s < steps; ++s) {
+        const int k = 2 * s + hh;
+        const float a = k < K ? xr[k] : 0.f;
+        const float w = k < K ? W[(size_t)k * O + col] : 0.f;
+        acc = epnn_mfma(a, w, acc);
+    }
+    if (o0 + c < O) {
+        const float bias = b[o0 + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = r0 + epnn_kappa(hh, r);
+            if (rr < R) {
+                const float v = acc[r] + bias;
+                Y[(size_t)rr * O + o0 + c] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
+// backward to the input: dX[r][k] = sum_o g[r][o] W[k][o],  g = dY * [Ypost > 0];  tiles: rows x ceil(K/32)
+__global__ __launch_bounds__(256) void k_t_mm_dx(const float *dY, const float *Ypost, const float *W, float *dX, int R, int K,
+                                                  int O, int ntile_k) {
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rt = tile / ntile_k, kt = tile - rt * ntile_k;
+    const int r0 = rt * 32, k0 = kt * 32;
+    if (r0 >= R) return;
+    const int row = min(r0 + c, R - 1), kk = min(k0 + c, K - 1);
+    f32x16 acc = epnn_splat16(0.f);
+    const int steps = (O + 1) >> 1;
+#pragma unroll 8
+    for (int s = 0; s < steps; ++s) {
+        const int o = 2 * s + hh;
+        float g = 0.f, w = 0.f;
+        if (o < O) {
+            g = dY[(size_t)row * O + o];
+            if (Ypost && !(Ypost[(size_t)row * O + o] > 0.f)) g = 0.f;
+            w = W[(size_t)kk * O + o];
+        }
+        acc = epnn_mfma(g, w, acc);
+    }
+    if (k0 + c < K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = r0 + epnn_kappa(hh, r);
+            if (rr < R) dX[(size_t)rr * K + k0 + c] = acc[r];
+        }
+    }
+}
+// weight gradient: part[slice][k][o] = sum_{r in slice} [X[r][:] | 1][k] g[r][o];  tiles: slices x ceil((K+1)/32) x ceil(O/32)
+__global__ __launch_bounds__(256) void k_t_mm_dw(const float *X, const float *dY, const float *Ypost, float *part, int R, int K,
+                                                  int O, int nslice, int ntile_k, int ntile_o) {
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slice = tile / (ntile_k * ntile_o), rem = tile - slice * (ntile_k * ntile_o);
+    const int kt = rem / ntile_o, ot = rem - kt * ntile_o;
+    if (slice >= nslice) return;
+    const int rlo = (int)((size_t)R * slice / nslice), rhi = (int)((size_t)R * (slice + 1) / nslice);
+    const int k0 = kt * 32, o0 = ot * 32;
+    const int krow = k0 + c, col = min(o0 + c, O - 1);      // A operand row = weight row k (k == K: the bias row)
+    f32x16 acc = epnn_splat16(0.f);
+#pragma unroll 4
+    for (int r2 = rlo; r2 < rhi; r2 += 2) {
+        const int r = r2 + hh;
+        float a = 0.f, g = 0.f;
+        if (r < rhi) {
+            a = krow < K ? X[(size_t)r * K + krow] : (krow == K ? 1.f : 0.f);
+            g = dY[(size_t)r * O + col];
+            if (Ypost && !(Ypost[(size_t)r * O + col] > 0.f)) g = 0.f;
+        }
+        acc = epnn_mfma(a, g, acc);
+    }
+    if (o0 + c < O) {
+        const int total = (K + 1) * O;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = k0 + epnn_kappa(hh, r);
+            if (kr <= K) part[(size_t)slice * total + (size_t)kr * O + o0 + c] = acc[r];
+        }
+    }
+}
 // grad[offW..] += sum_slices part (fixed order); bias row goes to offB
 __global__ __launch_bounds__(256) void k_t_dw_reduce(const float *part, float *grad, int offW, int offB, int K, int O, int nslice) {
     const int total = (K + 1) * O;
@@ -353,19 +450,33 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
     float *nm = P(o_nm), *wgt = P(o_wgt);
 
     auto dense = [&](const float *X, const TDense &d, float *Y, size_t rows, int relu) {
-        hipLaunchKernelGGL(k_t_dense, dim3(t_grid(rows * d.n_out)), dim3(256), 0, st, X, theta + d.offW, theta + d.offB, Y,
-                           (int)rows, d.n_in, d.n_out, relu);
+        if (d.n_out >= 16) {         // matrix pipe: one 32x32 output tile per wavefront
+            const int nto = (d.n_out + 31) / 32;
+            const size_t tiles = ((rows + 31) / 32) * nto;
+            hipLaunchKernelGGL(k_t_mm_fwd, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, X, theta + d.offW, theta + d.offB, Y,
+                               (int)rows, d.n_in, d.n_out, relu, nto);
+        } else {
+            hipLaunchKernelGGL(k_t_dense, dim3(t_grid(rows * d.n_out)), dim3(256), 0, st, X, theta + d.offW, theta + d.offB, Y,
+                               (int)rows, d.n_in, d.n_out, relu);
+        }
     };
     // backward of one Dense: dX (optional) and gradient accumulation
     auto dense_bwd = [&](const float *X, const float *dY, const float *Ypost, const TDense &d, float *dX, size_t rows) {
-        if (dX)
-            hipLaunchKernelGGL(k_t_dense_dx, dim3(t_grid(rows * d.n_in)), dim3(256), 0, st, dY, Ypost, theta + d.offW, dX,
-                               (int)rows, d.n_in, d.n_out);
+        if (dX) {
+            const int ntk = (d.n_in + 31) / 32;
+            const size_t tiles = ((rows + 31) / 32) * ntk;
+            hipLaunchKernelGGL(k_t_mm_dx, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, dY, Ypost, theta + d.offW, dX,
+                               (int)rows, d.n_in, d.n_out, ntk);
+        }
         // ~32 rows per slice: the pair-row GEMMs (B*N*N rows) spread over the whole GPU, the per-atom ones stay small
-        const int nsl = (int)std::min<size_t>(NSL, std::max<size_t>(1, rows / 32));
+        const int nsl = (int)std::min<size_t>(NSL, std::max<size_t>(1, rows / 64));
         const int tot = (d.n_in + 1) * d.n_out;
-        hipLaunchKernelGGL(k_t_dense_dw, dim3((tot + 255) / 256, nsl), dim3(256), 0, st, X, dY, Ypost, ts->part.as<float>(),
-                           (int)rows, d.n_in, d.n_out, nsl);
+        {
+            const int ntk = (d.n_in + 1 + 31) / 32, nto = (d.n_out + 31) / 32;
+            const size_t tiles = (size_t)nsl * ntk * nto;
+            hipLaunchKernelGGL(k_t_mm_dw, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, X, dY, Ypost, ts->part.as<float>(),
+                               (int)rows, d.n_in, d.n_out, nsl, ntk, nto);
+        }
         hipLaunchKernelGGL(k_t_dw_reduce, dim3((tot + 255) / 256), dim3(256), 0, st, ts->part.as<float>(), grad, d.offW,
                            d.offB, d.n_in, d.n_out, nsl);
     };
