@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_t_mm_fwd(const float *X, const float *W
     const float *xr = X + (size_t)row * K;
     f32x16 acc = epnn_splat16(0.f);
     const int steps = (K + 1) >> 1;
-#pragma unroll 8
+#pragma unroll 16
     for (int s = 0; s < steps; ++s) {
         const int k = 2 * s + hh;
         const float a = k < K ? xr[k] : 0.f;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_t_mm_dx(const float *dY, const float *Y
     const int row = min(r0 + c, R - 1), kk = min(k0 + c, K - 1);
     f32x16 acc = epnn_splat16(0.f);
     const int steps = (O + 1) >> 1;
-#pragma unroll 8
+#pragma unroll 16
     for (int s = 0; s < steps; ++s) {
         const int o = 2 * s + hh;
         float g = 0.f, w = 0.f;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_t_mm_dw(const float *X, const float *dY
     const int k0 = kt * 32, o0 = ot * 32;
     const int krow = k0 + c, col = min(o0 + c, O - 1);      // A operand row = weight row k (k == K: the bias row)
     f32x16 acc = epnn_splat16(0.f);
-#pragma unroll 4
+#pragma unroll 16
     for (int r2 = rlo; r2 < rhi; r2 += 2) {
         const int r = r2 + hh;
         float a = 0.f, g = 0.f;
@@ -468,7 +468,7 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
             hipLaunchKernelGGL(k_t_mm_dx, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, dY, Ypost, theta + d.offW, dX,
                                (int)rows, d.n_in, d.n_out, ntk);
         }
-        // ~32 rows per slice: the pair-row GEMMs (B*N*N rows) spread over the whole GPU, the per-atom ones stay small
+        // ~64 rows per slice: the pair-row GEMMs (B*N*N rows) spread over the whole GPU, the per-atom ones stay small
         const int nsl = (int)std::min<size_t>(NSL, std::max<size_t>(1, rows / 64));
         const int tot = (d.n_in + 1) * d.n_out;
         {
