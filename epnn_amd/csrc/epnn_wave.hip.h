@@ -154,9 +154,15 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     int nstamp = 0;
     (void)nstamp;
     WAVE_STAMP();
-    const bool two = n > 16;                                // the second column block holds atoms
-    const int col1 = 16 + n16;
-    const bool cat0 = n16 < n, cat1 = col1 < n;
+    // Column block 0 holds atoms 0..15.  Block 1 holds the m = n - 16 atoms beyond them, C = 16 / m COPIES of each (column
+    // n16 = atom 16 + n16 % m, copy n16 / m): every per-atom chain computes all 16 columns anyway, so the copies come for
+    // free, and the pair sweep gives each copy a different partner -- block 1 is done after (n + 1) / C tiles instead of n + 1.
+    const bool two = n > 16;
+    const int m1 = two ? n - 16 : 16, C1 = 16 / m1;
+    const int copy1 = n16 / m1;
+    const int col1 = 16 + n16 % m1;
+    const bool cat0 = n16 < n, cat1 = two && copy1 < C1;
+    const bool own1 = cat1 && copy1 == 0;                   // the copy that stores the atom's rows / results
 
     // ---- LDS layout of THIS molecule inside the wave's fixed budget.  The two stacks need different tables, and the G
     //      rows are recomputed by every step anyway, so each stack has its own layout behind the common part:
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 if (two) w16_mm<2, 12>(wh, hm1, U1);
             }
             if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
-            if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
+            if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
         }
         wave_sync_all();
         WAVE_STAMP();   // step-0 G tiles + projections
@@ -426,92 +432,164 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
             f32x4 S0[2] = {w16_splat(0.f), w16_splat(0.f)}, S1[2] = {w16_splat(0.f), w16_splat(0.f)};
             float u1s[2][8];
             {
-                // ---- partner tiles: tile jp holds partner jp of every atom; jp == n is the reference's zero-padded
-                //      partner (R = 0, G = 0, charge_gn.py:70), counted N - n times
+                // ---- partner tiles.  Partner index jp in [0, n]: atom jp, or (jp == n) the reference's zero-padded partner
+                //      (R = 0, G = 0, charge_gn.py:70), counted N - n times; beyond n nothing (weight 0).  Tile t gives block 0
+                //      partner t and copy k of block 1 partner t*C + k: block 1 is finished after nt1 tiles.
                 const float *zrow = Gl + glds * EPNN_PST;
+                const int nt0 = n + 1, nt1 = two ? (n + C1) / C1 : 0;
                 auto sweep = [&](auto over_tag) {
                     constexpr bool OVER = decltype(over_tag)::value;
-                    struct Ops { f32x4 r[2], g0[2], g1[2]; };
-                    auto load_ops = [&](int jp, int s0, int s1, Ops &o_) {
-                        const float *rrow = jp < n ? Rl + jp * EPNN_PST : zrow;
+                    struct Ops { f32x4 r[2], g[2]; float w; };
+                    auto grow = [&](int sl, f32x4 (&g)[2]) {
+                        const float *gp = Gl + min(sl, glds) * EPNN_PST;         // 0xFFFF / overflow -> the zero row
+                        g[0] = w16_ld(gp + fo);
+                        g[1] = w16_ld(gp + 16 + fo);
+                        if (OVER && sl >= glds && sl != 0xFFFF) {
+                            g[0] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + fo);
+                            g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo);
+                        }
+                    };
+                    // operands of tile t of block CB: partner row, G row of the lane's column, weight of the tile
+                    auto load_ops = [&](auto cb_tag, int t, Ops &o_) {
+                        constexpr int CB = decltype(cb_tag)::value;
+                        const int jp = CB == 0 ? t : t * C1 + copy1;
+                        const bool real = jp < n && (CB == 0 || cat1);
+                        const float *rrow = real ? Rl + jp * EPNN_PST : zrow;
                         o_.r[0] = w16_ld(rrow + fo);
                         o_.r[1] = w16_ld(rrow + 16 + fo);
-                        const float *g0 = Gl + min(s0, glds) * EPNN_PST;         // 0xFFFF / overflow -> the zero row
-                        o_.g0[0] = w16_ld(g0 + fo);
-                        o_.g0[1] = w16_ld(g0 + 16 + fo);
-                        if (OVER && s0 >= glds && s0 != 0xFFFF) {
-                            o_.g0[0] = w16_ld(A.gx + (size_t)(p0 + s0) * 32 + fo);
-                            o_.g0[1] = w16_ld(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo);
-                        }
-                        if (two) {
-                            const float *g1 = Gl + min(s1, glds) * EPNN_PST;
-                            o_.g1[0] = w16_ld(g1 + fo);
-                            o_.g1[1] = w16_ld(g1 + 16 + fo);
-                            if (OVER && s1 >= glds && s1 != 0xFFFF) {
-                                o_.g1[0] = w16_ld(A.gx + (size_t)(p0 + s1) * 32 + fo);
-                                o_.g1[1] = w16_ld(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo);
+                        grow(real ? (int)pm[jp * 32 + (CB == 0 ? n16 : col1)] : 0xFFFF, o_.g);
+                        o_.w = jp < n ? 1.f : (jp == n ? padw : 0.f);
+                    };
+                    auto tile = [&](const f32x4 (&Pc)[2], f32x4 (&Sc)[2], const Ops &o_) {
+                        float z[8];
+                        f32x4 d[2] = {b2v[0], b2v[1]};
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) z[s] = fmaxf((Pc[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g[s >> 2][s & 3], 0.f);
+                        w16_mm<2, 8>(pb, z, d);
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) Sc[rb] += o_.w * w16_relu(d[rb]);
+                    };
+                    // one block after the other; operands of tile t+1 are fetched while tile t is in the matrix pipe
+                    auto run = [&](auto cb_tag, int nt, const f32x4 (&Pc)[2], f32x4 (&Sc)[2], bool last_block) {
+                        if (OVER) {      // rare (large or very dense molecules): no fetch-ahead
+#pragma unroll 1
+                            for (int t = 0; t < nt; ++t) {
+                                if (last_block && t == nt - 1) { W16_LD(u1s, M.u1s, 2, 8); }
+                                Ops o_;
+                                load_ops(cb_tag, t, o_);
+                                tile(Pc, Sc, o_);
                             }
+                            return;
                         }
-                    };
-                    auto slot0 = [&](int jp) -> int { return jp < n ? (int)pm[jp * 32 + n16] : 0xFFFF; };
-                    auto slot1 = [&](int jp) -> int { return (two && jp < n) ? (int)pm[jp * 32 + col1] : 0xFFFF; };
-                    auto tile = [&](const Ops &o_, float wt) {
-                        // both column blocks' inputs first, then all MFMA chains, then the sums: one pipeline drain per tile
-                        float z0[8], z1[8];
-                        f32x4 d0[2] = {b2v[0], b2v[1]}, d1[2] = {b2v[0], b2v[1]};
-#pragma unroll
-                        for (int s = 0; s < 8; ++s) z0[s] = fmaxf((P0[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g0[s >> 2][s & 3], 0.f);
-                        if (two) {
-#pragma unroll
-                            for (int s = 0; s < 8; ++s) z1[s] = fmaxf((P1[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g1[s >> 2][s & 3], 0.f);
-                        }
-                        w16_mm<2, 8>(pb, z0, d0);
-                        if (two) w16_mm<2, 8>(pb, z1, d1);
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) S0[rb] += wt * w16_relu(d0[rb]);
-                        if (two) {
-#pragma unroll
-                            for (int rb = 0; rb < 2; ++rb) S1[rb] += wt * w16_relu(d1[rb]);
-                        }
-                    };
-                    if (OVER) {          // rare (large or very dense molecules): no fetch-ahead
-#pragma unroll 1
-                        for (int jp = 0; jp <= n; ++jp) {
-                            if (jp == n) { W16_LD(u1s, M.u1s, 2, 8); }
-                            Ops o_;
-                            load_ops(jp, slot0(jp), slot1(jp), o_);
-                            tile(o_, jp == n ? padw : 1.f);
-                        }
-                    } else {
                         Ops oa, ob;
-                        load_ops(0, slot0(0), slot1(0), oa);
-                        int sn0 = slot0(1), sn1 = slot1(1);
-                        int jp = 0;
+                        load_ops(cb_tag, 0, oa);
+                        int t = 0;
 #pragma unroll 1
-                        for (; jp + 2 <= n; jp += 2) {                         // tiles jp, jp+1: neither is the last one
-                            load_ops(jp + 1, sn0, sn1, ob);
-                            sn0 = slot0(jp + 2); sn1 = slot1(jp + 2);
+                        for (; t + 2 < nt; t += 2) {                           // tiles t, t+1: neither is the last one
+                            load_ops(cb_tag, t + 1, ob);
                             WAVE_FENCE();
-                            tile(oa, 1.f);
-                            load_ops(jp + 2, sn0, sn1, oa);
-                            sn0 = slot0(jp + 3); sn1 = slot1(jp + 3);
+                            tile(Pc, Sc, oa);
+                            load_ops(cb_tag, t + 2, oa);
                             WAVE_FENCE();
-                            tile(ob, 1.f);
+                            tile(Pc, Sc, ob);
                         }
-                        W16_LD(u1s, M.u1s, 2, 8);                             // first operand of the update MLP
-                        if (jp < n) {                                          // n odd: last partner, then the padded one
-                            load_ops(n, 0xFFFF, 0xFFFF, ob);
+                        if (last_block) { W16_LD(u1s, M.u1s, 2, 8); }         // first operand of the update MLP
+                        if (t + 1 < nt) {                                      // two tiles left
+                            load_ops(cb_tag, t + 1, ob);
                             WAVE_FENCE();
-                            tile(oa, 1.f);
-                            tile(ob, padw);
+                            tile(Pc, Sc, oa);
+                            tile(Pc, Sc, ob);
                         } else {
                             WAVE_FENCE();
-                            tile(oa, padw);                                    // oa holds tile n: zero rows
+                            tile(Pc, Sc, oa);
                         }
+                    };
+                    // molecules with 25+ atoms (one copy per block-1 atom): both blocks share the partner, one tile does both
+                    auto run_both = [&]() {
+                        struct Ops2 { f32x4 r[2], g0[2], g1[2]; };
+                        auto load2 = [&](int t, Ops2 &o_) {
+                            const bool real = t < n;
+                            const float *rrow = real ? Rl + t * EPNN_PST : zrow;
+                            o_.r[0] = w16_ld(rrow + fo);
+                            o_.r[1] = w16_ld(rrow + 16 + fo);
+                            grow(real ? (int)pm[t * 32 + n16] : 0xFFFF, o_.g0);
+                            grow(real && cat1 ? (int)pm[t * 32 + col1] : 0xFFFF, o_.g1);
+                        };
+                        auto tile2 = [&](int t, const Ops2 &o_) {
+                            float z0[8], z1[8];
+                            f32x4 d0[2] = {b2v[0], b2v[1]}, d1[2] = {b2v[0], b2v[1]};
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) {
+                                z0[s] = fmaxf((P0[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g0[s >> 2][s & 3], 0.f);
+                                z1[s] = fmaxf((P1[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g1[s >> 2][s & 3], 0.f);
+                            }
+                            w16_mm<2, 8>(pb, z0, d0);
+                            w16_mm<2, 8>(pb, z1, d1);
+                            const float w = t < n ? 1.f : padw;
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb) { S0[rb] += w * w16_relu(d0[rb]); S1[rb] += w * w16_relu(d1[rb]); }
+                        };
+                        if (OVER) {
+#pragma unroll 1
+                            for (int t = 0; t < nt0; ++t) {
+                                if (t == nt0 - 1) { W16_LD(u1s, M.u1s, 2, 8); }
+                                Ops2 o_;
+                                load2(t, o_);
+                                tile2(t, o_);
+                            }
+                            return;
+                        }
+                        Ops2 oa, ob;
+                        load2(0, oa);
+                        int t = 0;
+#pragma unroll 1
+                        for (; t + 2 < nt0; t += 2) {
+                            load2(t + 1, ob);
+                            WAVE_FENCE();
+                            tile2(t, oa);
+                            load2(t + 2, oa);
+                            WAVE_FENCE();
+                            tile2(t + 1, ob);
+                        }
+                        W16_LD(u1s, M.u1s, 2, 8);
+                        if (t + 1 < nt0) {
+                            load2(t + 1, ob);
+                            WAVE_FENCE();
+                            tile2(t, oa);
+                            tile2(t + 1, ob);
+                        } else {
+                            WAVE_FENCE();
+                            tile2(t, oa);
+                        }
+                    };
+                    if (two && C1 == 1) {
+                        run_both();
+                    } else {
+                        if (two) run(std::integral_constant<int, 1>{}, nt1, P1, S1, false);
+                        run(std::integral_constant<int, 0>{}, nt0, P0, S0, true);
                     }
                 };
                 if (gover) sweep(std::true_type{});
                 else sweep(std::false_type{});
+                if (two && C1 > 1) {
+                    // every copy of a block-1 atom holds the sum over its own partners: add the copies in a fixed order (all of
+                    // them end up with the same bits).  The G rows of this step are dead: their LDS words are the scratch.
+                    wave_sync_lds();
+                    float *scr = Gl;
+                    w16_st(scr + (n16 * 4 + q) * 8, S1[0]);
+                    w16_st(scr + (n16 * 4 + q) * 8 + 4, S1[1]);
+                    wave_sync_lds();
+                    f32x4 t0_ = w16_splat(0.f), t1_ = w16_splat(0.f);
+                    for (int k = 0; k < C1; ++k) {
+                        const int src = (n16 % m1) + m1 * k;
+                        t0_ += w16_ld(scr + (src * 4 + q) * 8);
+                        t1_ += w16_ld(scr + (src * 4 + q) * 8 + 4);
+                    }
+                    S1[0] = t0_;
+                    S1[1] = t1_;
+                    wave_sync_lds();
+                    if (lane < EPNN_PST) Gl[glds * EPNN_PST + lane] = 0.f;      // the scratch may have covered the zero row
+                }
             }
             if (t < 2) WAVE_STAMP();   // pair tiles
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
@@ -569,7 +647,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 w16_mm<2, 8 + EPNN_XS>(wb, in0, r0);
                 if (two) w16_mm<2, 8 + EPNN_XS>(wb, in1, r1);
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
-                if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
+                if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
                 vec2(X.g[t + 1].b2, b2v);
                 WAVE_FENCE();
@@ -604,7 +682,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 if (cat0) w16_st(A.h_out + (size_t)(a0 + n16) * EPNN_EDIM + 16 * rb + fo, hk0[rb]);
-                if (cat1) w16_st(A.h_out + (size_t)(a0 + col1) * EPNN_EDIM + 16 * rb + fo, hk1[rb]);
+                if (own1) w16_st(A.h_out + (size_t)(a0 + col1) * EPNN_EDIM + 16 * rb + fo, hk1[rb]);
             }
         }
     }
@@ -638,12 +716,12 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 w16_mm<2, EPNN_XS + 12>(wa, in0, d0);
                 if (two) w16_mm<2, EPNN_XS + 12>(wa, in1, d1);
                 if (cat0) { w16_st(Pl + n16 * EPNN_PST + fo, d0[0]); w16_st(Pl + n16 * EPNN_PST + 16 + fo, d0[1]); }
-                if (cat1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
+                if (own1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
                 d0[0] = w16_splat(0.f); d0[1] = w16_splat(0.f); d1[0] = w16_splat(0.f); d1[1] = w16_splat(0.f);
                 w16_mm<2, EPNN_XS + 12>(wb, in0, d0);
                 if (two) w16_mm<2, EPNN_XS + 12>(wb, in1, d1);
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
-                if (cat1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
+                if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
             }
             float pb[2][8];
             f32x4 b2v[2], w3[2];
@@ -749,7 +827,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         for (int s = 0; s < EPNN_XS; ++s)
             if (s == qs && q == ql) {
                 if (cat0) A.q_out[a0 + n16] = xq0[s];
-                if (cat1) A.q_out[a0 + col1] = xq1[s];
+                if (own1) A.q_out[a0 + col1] = xq1[s];
             }
     }
     if (FRONT && lane == 0) {
