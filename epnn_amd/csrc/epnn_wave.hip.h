@@ -471,16 +471,6 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                     };
                     // one block after the other; operands of tile t+1 are fetched while tile t is in the matrix pipe
                     auto run = [&](auto cb_tag, int nt, const f32x4 (&Pc)[2], f32x4 (&Sc)[2], bool last_block) {
-                        if (OVER) {      // rare (large or very dense molecules): no fetch-ahead
-#pragma unroll 1
-                            for (int t = 0; t < nt; ++t) {
-                                if (last_block && t == nt - 1) { W16_LD(u1s, M.u1s, 2, 8); }
-                                Ops o_;
-                                load_ops(cb_tag, t, o_);
-                                tile(Pc, Sc, o_);
-                            }
-                            return;
-                        }
                         Ops oa, ob;
                         load_ops(cb_tag, 0, oa);
                         int t = 0;
@@ -529,16 +519,6 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
 #pragma unroll
                             for (int rb = 0; rb < 2; ++rb) { S0[rb] += w * w16_relu(d0[rb]); S1[rb] += w * w16_relu(d1[rb]); }
                         };
-                        if (OVER) {
-#pragma unroll 1
-                            for (int t = 0; t < nt0; ++t) {
-                                if (t == nt0 - 1) { W16_LD(u1s, M.u1s, 2, 8); }
-                                Ops2 o_;
-                                load2(t, o_);
-                                tile2(t, o_);
-                            }
-                            return;
-                        }
                         Ops2 oa, ob;
                         load2(0, oa);
                         int t = 0;
