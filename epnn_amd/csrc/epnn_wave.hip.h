@@ -169,7 +169,8 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     //        common  eij [pairs] | R [n][PST]
     //        GNN     pair map [n][32] u16 | G rows ... | zero row        (the sweep reads every G row n times: all in LDS
     //                                                                     for molecules up to ~24 atoms)
-    //        EPN     P [n][PST] | transfer matrix [n][DST] | G rows ...  (G rows are read once per step: the rest from HBM)
+    //        EPN     P [n][PST] | transfer matrix [n][DST]              (its G term never leaves the registers: computed per
+    //                                                                     block of 16 pairs right where it is used)
     unsigned short *eij = reinterpret_cast<unsigned short *>(sm);     // [np]  li | lj << 8
     const int eij_n = FRONT ? n * (n - 1) / 2 : np;        // in-kernel front-end: np is not known yet, reserve every i<j pair
     const int o_r = EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
@@ -178,10 +179,10 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     unsigned short *pm = reinterpret_cast<unsigned short *>(sm + o_x);    // [j][32]  near-pair slot of (i, j), 0xFFFF = none
     float *Pl = sm + o_x;                                  // [n][PST]   P_i rows
     float *Dm = sm + o_x + n * EPNN_PST;                   // [n][DST]   weighted transfers: Dm[i][j] = what i receives from j
-    const int o_gg = o_x + ((n * 16 + 3) & ~3), o_ge = o_x + n * EPNN_PST + ((n * EPNN_DST + 3) & ~3);
-    const int grows_g = (A.lds_words - o_gg) / EPNN_PST - 1, grows_e = (A.lds_words - o_ge) / EPNN_PST;
-    float *Gl = sm + (GNN ? o_gg : o_ge);                  // G rows of the stack that is running; GNN: row glds is all zeros
-    int glds = min(np, GNN ? grows_g : grows_e);
+    const int o_gg = o_x + ((n * 16 + 3) & ~3);
+    const int grows_g = (A.lds_words - o_gg) / EPNN_PST - 1;
+    float *Gl = sm + o_gg;                                 // GNN: G rows [glds + 1][PST]; row glds is all zeros
+    int glds = min(np, grows_g);
     bool gover = np > glds;                                // some G rows live in HBM
     int ngt = (np + 31) >> 5;
 
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     // first G tiles: We and the first e rows are on their way while the LDS tables are built
     float gw[2][12], ge0[12], ge1[12];
     W16_LD(gw, GNN ? X.g[0].we : X.e[0].we, 2, 12);
-    if (!FRONT && ngt > 0) load_e(0, ge0, ge1);
+    if (GNN && !FRONT && ngt > 0) load_e(0, ge0, ge1);
     WAVE_FENCE();
 
     // ---- LDS init
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 }
                 vec2(M.bu2, bv);
                 if (!lastg) gprefetch(X.g[t + 1].we);
-                else if (Te > 0) gprefetch(X.e[0].we);
+                else if (Te > 0) { W16_LD(gw, X.e[0].we, 2, 12); }
                 WAVE_FENCE();
                 d0[0] = bv[0]; d0[1] = bv[1]; d1[0] = bv[0]; d1[1] = bv[1];
                 w16_feed(a0_, in0);
@@ -671,9 +672,6 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     // ================================================================== EPN steps (charge_gn.py:98-118)
     if (EPN) {
         wave_sync_lds();                                    // the GNN's tables are dead: switch to the EPN layout
-        Gl = sm + o_ge;
-        glds = min(np, grows_e);
-        gover = np > glds;
         for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
         wave_sync_lds();
         const int qs = (nx + 1) >> 2, ql = (nx + 1) & 3;    // step / lane group of xq that holds q
@@ -687,9 +685,6 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
 #pragma unroll
                 for (int s = 0; s < 12; ++s) { in0[EPNN_XS + s] = hk0[s >> 2][s & 3]; in1[EPNN_XS + s] = hk1[s >> 2][s & 3]; }
                 W16_LD(wa, M.wi, 2, EPNN_XS + 12);
-                WAVE_FENCE();
-                gtiles();
-                if (t < 2) WAVE_STAMP();   // EPN G tiles
                 W16_LD(wb, M.wj, 2, EPNN_XS + 12);
                 WAVE_FENCE();
                 f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)}, d1[2] = {w16_splat(0.f), w16_splat(0.f)};
@@ -712,10 +707,10 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
             if (t < 2) WAVE_STAMP();   // EPN P, R
             {
                 // one column per UNORDERED near pair, 16 pairs per column block.  Software pipeline: the pair record
-                // (indices in LDS, weights in HBM) is fetched two blocks ahead, the gathered P / R / G rows one block ahead
+                // (indices in LDS, weights in HBM) is fetched two blocks ahead, the gathered P / R rows and the e row one block ahead
                 const int nblk = (np + 15) >> 4;
                 struct Rec { int ij; float wi, wj; };
-                struct Rows { f32x4 g[2], pi_[2], rj_[2], pj_[2], ri_[2]; };
+                struct Rows { float e[12]; f32x4 pi_[2], rj_[2], pj_[2], ri_[2]; };
                 auto load_rec = [&](int blk, Rec &r_) {
                     const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
                     r_.ij = eij[sl];
@@ -725,8 +720,14 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 auto load_rows = [&](int blk, const Rec &r_, Rows &w_) {
                     const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
                     const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
-                    if (sl < glds) { w_.g[0] = w16_ld(Gl + sl * EPNN_PST + fo); w_.g[1] = w16_ld(Gl + sl * EPNN_PST + 16 + fo); }
-                    else { w_.g[0] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + fo); w_.g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo); }
+                    {   // e channels 12q..12q+11 of the lane's pair: the G term is computed here, it never goes through memory
+                        const float *er = A.pe + (size_t)(p0 + sl) * EPNN_EDIM + 12 * q;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const f32x4 v = w16_ld(er + 4 * k);
+                            w_.e[4 * k] = v[0]; w_.e[4 * k + 1] = v[1]; w_.e[4 * k + 2] = v[2]; w_.e[4 * k + 3] = v[3];
+                        }
+                    }
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
                         w_.pi_[rb] = w16_ld(Pl + li * EPNN_PST + 16 * rb + fo);
@@ -738,11 +739,13 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 auto block = [&](int blk, const Rec &r_, const Rows &w_) {
                     const bool valid = blk * 16 + n16 < np;
                     const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
+                    f32x4 g[2] = {w16_splat(0.f), w16_splat(0.f)};       // G = We^T e of the 16 pairs (charge_gn.py:105, e block)
+                    w16_mm<2, 12>(gw, w_.e, g);
                     float zu[8], zv[8];
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
-                        zu[s] = fmaxf((w_.g[s >> 2][s & 3] + w_.pi_[s >> 2][s & 3]) + w_.rj_[s >> 2][s & 3], 0.f);
-                        zv[s] = fmaxf((w_.g[s >> 2][s & 3] + w_.pj_[s >> 2][s & 3]) + w_.ri_[s >> 2][s & 3], 0.f);
+                        zu[s] = fmaxf((g[s >> 2][s & 3] + w_.pi_[s >> 2][s & 3]) + w_.rj_[s >> 2][s & 3], 0.f);
+                        zv[s] = fmaxf((g[s >> 2][s & 3] + w_.pj_[s >> 2][s & 3]) + w_.ri_[s >> 2][s & 3], 0.f);
                     }
                     f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
                     w16_mm<2, 8>(pb, zu, au);
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 }
             }
             wave_sync_lds();
-            if (t + 1 < Te) gprefetch(X.e[t + 1].we);     // on its way during the charge update
+            if (t + 1 < Te) { W16_LD(gw, X.e[t + 1].we, 2, 12); }     // on its way during the charge update
             WAVE_FENCE();
             if (t < 2) WAVE_STAMP();   // EPN pair tiles
             // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of the rows of its two atoms

@@ -23,7 +23,7 @@ eng.lib.epnn_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 eng.lib.epnn_debug_stamps(eng.h, buf.ctypes.data_as(C.c_void_p), buf.size)
 st = buf.reshape(B, 64)
 labels = ["init", "g0:G+proj", "g0:pairs", "g0:U1U2", "g0:Gtiles", "g0:proj", "g1:pairs", "g1:U1U2", "g1:Gtiles", "g1:proj",
-          "g2..4", "e0:G", "e0:PR", "e0:pairs", "e0:q", "e1:G", "e1:PR", "e1:pairs", "e1:q", "e2..4+out"]
+          "g2..4+h", "e0:PR", "e0:pairs", "e0:q", "e1:PR", "e1:pairs", "e1:q", "e2..4+out"]
 for blk in (0, B // 8, B // 2, B - 1):
     n = int(st[blk, 63] >> np.uint64(32)); npairs = int(st[blk, 63] & np.uint64(0xFFFFFFFF)); ns = int(st[blk, 62])
     d = np.diff(st[blk, :ns].astype(np.int64))
