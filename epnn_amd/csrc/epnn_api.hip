@@ -366,6 +366,8 @@ static int pack_weights(epnn_handle *h) {
             E.w3 = vec(32, [&](int k) { return (double)h->pas[t][2].W[k]; });
             E.wi = unfolded(W1, b1, 0);
             E.wj = unfolded(W1, nullptr, F);
+            E.wif = folded(W1, b1, 0);
+            E.wjf = folded(W1, nullptr, F);
         }
     }
     if (h->d_wpack.ensure(buf.size() * sizeof(float))) return 1;

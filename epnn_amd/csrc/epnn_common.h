@@ -77,7 +77,8 @@ struct WaveGnnPack {           // GNN step t
 };
 struct WaveEpnPack {           // EPN step t
     int we, w2, b2, w3;   // w3: [32]
-    int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features)
+    int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features): h given by the caller
+    int wif, wjf;         // [2][8+XS][64]   acc rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]: h = nm (Wu3^T u2 + bu3) of the GNN stack
 };
 struct WaveIndex {
     WaveGnnPack g[EPNN_MAXT];

@@ -380,13 +380,15 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         v[1] = w16_ld(wp + off + 16 + fo);
     };
 
+    // With both stacks in one launch the EPN takes h the way the GNN steps do, through nm*u2 of the last step and the
+    // folded matrices (K = 32 + xq instead of 48 + xq, h itself is then needed only when the caller asks for it).
+    constexpr bool FOLD = GNN && EPN;
+    f32x4 B0[2] = {w16_splat(0.f), w16_splat(0.f)}, B1[2] = {w16_splat(0.f), w16_splat(0.f)};     // nm*u2 of the two columns
     // ================================================================== GNN steps (charge_gn.py:60-74)
     if (GNN) {
-        f32x4 P0[2], P1[2], U0[2], U1[2], B0[2], B1[2];     // P, u1pre, nm*u2 of the two columns
+        f32x4 P0[2], P1[2], U0[2], U1[2];                   // P, u1pre of the two columns
         float pb[2][8];
         f32x4 b2v[2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) { B0[rb] = w16_splat(0.f); B1[rb] = w16_splat(0.f); }
         // ---- step 0: G rows, then P / R / u1pre from (xq | h)
         {
             float wa[2][EPNN_XS], wc[2][EPNN_XS];
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 if (t < 2) WAVE_STAMP();   // projections
             }
         }
-        {
+        if (!FOLD || A.h_out) {
             // h = node_mask * (Wu3^T u2 + bu3)  (charge_gn.py:73-74) after the last step, straight into the h registers
             float w[3][8], bin0[8], bin1[8];
             W16_LD(w, X.u3, 3, 8);
@@ -679,22 +681,30 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         for (int t = 0; t < Te; ++t) {
             const WaveEpnPack &M = X.e[t];
             {
-                float wa[2][EPNN_XS + 12], wb[2][EPNN_XS + 12], in0[EPNN_XS + 12], in1[EPNN_XS + 12];
+                constexpr int KS = FOLD ? 8 + EPNN_XS : EPNN_XS + 12;
+                float wa[2][KS], wb[2][KS], in0[KS], in1[KS];
+                if (FOLD) {
 #pragma unroll
-                for (int s = 0; s < EPNN_XS; ++s) { in0[s] = xq0[s]; in1[s] = xq1[s]; }
+                    for (int s = 0; s < 8; ++s) { in0[s] = B0[s >> 2][s & 3]; in1[s] = B1[s >> 2][s & 3]; }
 #pragma unroll
-                for (int s = 0; s < 12; ++s) { in0[EPNN_XS + s] = hk0[s >> 2][s & 3]; in1[EPNN_XS + s] = hk1[s >> 2][s & 3]; }
-                W16_LD(wa, M.wi, 2, EPNN_XS + 12);
-                W16_LD(wb, M.wj, 2, EPNN_XS + 12);
+                    for (int s = 0; s < EPNN_XS; ++s) { in0[8 + s] = xq0[s]; in1[8 + s] = xq1[s]; }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < EPNN_XS; ++s) { in0[s] = xq0[s]; in1[s] = xq1[s]; }
+#pragma unroll
+                    for (int s = 0; s < 12; ++s) { in0[EPNN_XS + s] = hk0[s >> 2][s & 3]; in1[EPNN_XS + s] = hk1[s >> 2][s & 3]; }
+                }
+                W16_LD(wa, FOLD ? M.wif : M.wi, 2, KS);
+                W16_LD(wb, FOLD ? M.wjf : M.wj, 2, KS);
                 WAVE_FENCE();
                 f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)}, d1[2] = {w16_splat(0.f), w16_splat(0.f)};
-                w16_mm<2, EPNN_XS + 12>(wa, in0, d0);
-                if (two) w16_mm<2, EPNN_XS + 12>(wa, in1, d1);
+                w16_mm<2, KS>(wa, in0, d0);
+                if (two) w16_mm<2, KS>(wa, in1, d1);
                 if (cat0) { w16_st(Pl + n16 * EPNN_PST + fo, d0[0]); w16_st(Pl + n16 * EPNN_PST + 16 + fo, d0[1]); }
                 if (own1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
                 d0[0] = w16_splat(0.f); d0[1] = w16_splat(0.f); d1[0] = w16_splat(0.f); d1[1] = w16_splat(0.f);
-                w16_mm<2, EPNN_XS + 12>(wb, in0, d0);
-                if (two) w16_mm<2, EPNN_XS + 12>(wb, in1, d1);
+                w16_mm<2, KS>(wb, in0, d0);
+                if (two) w16_mm<2, KS>(wb, in1, d1);
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
             }
