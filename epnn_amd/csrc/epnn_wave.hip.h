@@ -133,6 +133,20 @@ __device__ __forceinline__ void w16_mm(const float (&w)[NRB][S], const float (&i
 #pragma unroll
         for (int s = 0; s < S; ++s) d[rb] = w16_mfma(w[rb][s], in[s], d[rb]);
 }
+// same, but K step SKIP is left out when `skip` is set (the last xq step holds only zeros when nx + 3 <= 12)
+template <int NRB, int S, int SKIP>
+__device__ __forceinline__ void w16_mm_skip(const float (&w)[NRB][S], const float (&in)[S], f32x4 (&d)[NRB], bool skip) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s == SKIP) {
+                if (!skip) d[rb] = w16_mfma(w[rb][s], in[s], d[rb]);
+            } else {
+                d[rb] = w16_mfma(w[rb][s], in[s], d[rb]);
+            }
+        }
+}
 // an accumulator set [2 row blocks] of one column block as the next product's 8 input steps
 __device__ __forceinline__ void w16_feed(const f32x4 (&a)[2], float (&in)[8]) {
 #pragma unroll
@@ -150,6 +164,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     const int p0 = FRONT ? A.pbase[b] : A.row_off[a0];
     int np = FRONT ? 0 : A.row_off[a0 + n] - p0;
     const int nx = A.nx;
+    const bool xs3 = nx + 3 <= 4 * (EPNN_XS - 1);         // the last xq K step is empty
     const float *wp = A.wpack;
     int nstamp = 0;
     (void)nstamp;
@@ -402,9 +417,9 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
             f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); U0[rb] = w16_splat(0.f); U1[rb] = w16_splat(0.f); }
-            w16_mm<2, EPNN_XS>(wa, xq0, P0);
-            w16_mm<2, EPNN_XS>(wc, xq0, r0);
-            if (two) { w16_mm<2, EPNN_XS>(wa, xq1, P1); w16_mm<2, EPNN_XS>(wc, xq1, r1); }
+            w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq0, P0, xs3);
+            w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq0, r0, xs3);
+            if (two) { w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq1, P1, xs3); w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq1, r1, xs3); }
             if (have_h) {                                   // layer-level entry: h given by the caller
                 float wh[2][12], hin0[12], hin1[12], hm0[12], hm1[12];
 #pragma unroll
@@ -624,11 +639,11 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 WAVE_FENCE();
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); }
-                w16_mm<2, 8 + EPNN_XS>(wa, in0, P0);
-                if (two) w16_mm<2, 8 + EPNN_XS>(wa, in1, P1);
+                w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wa, in0, P0, xs3);
+                if (two) w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wa, in1, P1, xs3);
                 f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
-                w16_mm<2, 8 + EPNN_XS>(wb, in0, r0);
-                if (two) w16_mm<2, 8 + EPNN_XS>(wb, in1, r1);
+                w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wb, in0, r0, xs3);
+                if (two) w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wb, in1, r1, xs3);
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
@@ -682,6 +697,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
             const WaveEpnPack &M = X.e[t];
             {
                 constexpr int KS = FOLD ? 8 + EPNN_XS : EPNN_XS + 12;
+                constexpr int SK = FOLD ? 7 + EPNN_XS : EPNN_XS - 1;         // the last xq step
                 float wa[2][KS], wb[2][KS], in0[KS], in1[KS];
                 if (FOLD) {
 #pragma unroll
@@ -698,13 +714,13 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 W16_LD(wb, FOLD ? M.wjf : M.wj, 2, KS);
                 WAVE_FENCE();
                 f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)}, d1[2] = {w16_splat(0.f), w16_splat(0.f)};
-                w16_mm<2, KS>(wa, in0, d0);
-                if (two) w16_mm<2, KS>(wa, in1, d1);
+                w16_mm_skip<2, KS, SK>(wa, in0, d0, xs3);
+                if (two) w16_mm_skip<2, KS, SK>(wa, in1, d1, xs3);
                 if (cat0) { w16_st(Pl + n16 * EPNN_PST + fo, d0[0]); w16_st(Pl + n16 * EPNN_PST + 16 + fo, d0[1]); }
                 if (own1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
                 d0[0] = w16_splat(0.f); d0[1] = w16_splat(0.f); d1[0] = w16_splat(0.f); d1[1] = w16_splat(0.f);
-                w16_mm<2, KS>(wb, in0, d0);
-                if (two) w16_mm<2, KS>(wb, in1, d1);
+                w16_mm_skip<2, KS, SK>(wb, in0, d0, xs3);
+                if (two) w16_mm_skip<2, KS, SK>(wb, in1, d1, xs3);
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
             }
