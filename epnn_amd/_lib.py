@@ -62,6 +62,7 @@ SIGNATURES = {
     "epnn_timer_end": (C.c_int, [_vp, _fp]),
     "epnn_last_timing": (C.c_int, [_vp, _fp]),
     "epnn_timing_at": (C.c_int, [_vp, C.c_int, _fp]),
+    "epnn_edge_basis_residual": (C.c_double, [_vp]),
     "epnn_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "epnn_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
 }

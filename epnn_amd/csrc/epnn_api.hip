@@ -43,6 +43,8 @@ static void shape_layers(epnn_handle *h) {
     set(h->upd[2], H, h->cfg.h_dim);
 }
 
+static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, std::vector<double> &Bout);
+
 extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out) {
     if (!cfg || !out) EPNN_FAIL("epnn_create: null argument");
     if (cfg->h_dim != EPNN_EDIM || cfg->e_dim != EPNN_EDIM)
@@ -78,6 +80,7 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
     HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
     shape_layers(h);
+    h->edge_res = cfg->e_dim == EPNN_EDIM ? edge_basis(h->cfg, mu, h->edge_B) : 1.0;
     *out = h;
     return 0;
 }
@@ -88,7 +91,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pbase, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
-                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
+                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pe, &h->f_pw, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
@@ -108,6 +111,87 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ edge-feature basis
+// The 48 Gaussian edge features of a distance, e_k(D) = C(D) exp(-eta (D - mu_k)^2) (charge_gn.py:148-161), are 48 heavily
+// overlapping bumps of ONE variable: as vectors they stay in a 16-dimensional subspace to 5e-10 (relative to max e = 1)
+// for every D in [0, cutoff].  With B = the 16 leading right singular vectors of the family (orthonormal, 48 x 16),
+//   G = We^T e = (B^T We)^T (B^T e)   up to |We| * 5e-10,
+// i.e. far below the float32 rounding of e itself.  The fused kernel's own front-end (which produces e from coordinates,
+// so e IS of that family) projects every pair's e once and runs all 2T G products with K = 16 instead of 48.
+// One-sided Jacobi (Hestenes) SVD in float64: accurate also for the small singular directions.  Returns the residual
+// max |E - E B B^T| over the sampling grid.
+static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, std::vector<double> &Bout) {
+    const int K = cfg.e_dim, R = EPNN_ER, ND = 1025;
+    std::vector<double> E((size_t)ND * K), E0;
+    const double pi_d = 3.141592653589793, cut = (double)cfg.cutoff, eta = (double)cfg.eta;
+    for (int i = 0; i < ND; ++i) {
+        const double D = cut * (double)i / (double)(ND - 1);
+        double C = (cos(pi_d * D / cut) + 1.0) / 2.0;
+        if (D <= 0.0) C = 1.0;
+        if (D >= cut) C = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double d = D - mu[k];
+            E[(size_t)i * K + k] = C * exp(-eta * d * d);
+        }
+    }
+    E0 = E;
+    std::vector<double> V((size_t)K * K, 0.0);
+    for (int k = 0; k < K; ++k) V[(size_t)k * K + k] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < K; ++p)
+            for (int q = p + 1; q < K; ++q) {
+                double a = 0, b = 0, g = 0;
+                for (int i = 0; i < ND; ++i) {
+                    const double x = E[(size_t)i * K + p], y = E[(size_t)i * K + q];
+                    a += x * x; b += y * y; g += x * y;
+                }
+                if (a == 0.0 || b == 0.0 || fabs(g) <= 1e-15 * sqrt(a * b)) continue;
+                off = std::max(off, fabs(g) / sqrt(a * b));
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < ND; ++i) {
+                    const double x = E[(size_t)i * K + p], y = E[(size_t)i * K + q];
+                    E[(size_t)i * K + p] = c * x - sn * y;
+                    E[(size_t)i * K + q] = sn * x + c * y;
+                }
+                for (int i = 0; i < K; ++i) {
+                    const double x = V[(size_t)i * K + p], y = V[(size_t)i * K + q];
+                    V[(size_t)i * K + p] = c * x - sn * y;
+                    V[(size_t)i * K + q] = sn * x + c * y;
+                }
+            }
+        if (off < 1e-14) break;
+    }
+    std::vector<std::pair<double, int>> sv(K);
+    for (int k = 0; k < K; ++k) {
+        double a = 0;
+        for (int i = 0; i < ND; ++i) a += E[(size_t)i * K + k] * E[(size_t)i * K + k];
+        sv[k] = {sqrt(a), k};
+    }
+    std::sort(sv.begin(), sv.end(), [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x.first > y.first; });
+    Bout.assign((size_t)K * R, 0.0);
+    for (int r = 0; r < R; ++r)
+        for (int k = 0; k < K; ++k) Bout[(size_t)k * R + r] = V[(size_t)k * K + sv[r].second];
+    double res = 0.0;
+    std::vector<double> c(R);
+    for (int i = 0; i < ND; ++i) {
+        for (int r = 0; r < R; ++r) {
+            double a = 0;
+            for (int k = 0; k < K; ++k) a += E0[(size_t)i * K + k] * Bout[(size_t)k * R + r];
+            c[r] = a;
+        }
+        for (int k = 0; k < K; ++k) {
+            double a = 0;
+            for (int r = 0; r < R; ++r) a += c[r] * Bout[(size_t)k * R + r];
+            res = std::max(res, fabs(E0[(size_t)i * K + k] - a));
+        }
+    }
+    return res;
 }
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -300,9 +384,16 @@ static int pack_weights(epnn_handle *h) {
                 return xq_row(W1, b1, r0, 4 * (s - 8) + q, m, cb[m]);
             });
         };
-        auto pair_common = [&](HostDense (&mm)[3], int &we, int &w2, int &b2) {
+        const bool have_basis = (int)h->edge_B.size() == EPNN_EDIM * EPNN_ER;
+        auto pair_common = [&](HostDense (&mm)[3], int &we, int &we16, int &w2, int &b2) {
             const float *W1 = mm[0].W.data(), *W2 = mm[1].W.data(), *bb2 = mm[1].b.data();
             we = frag(2, 12, [&](int s, int q, int m) { return (double)W1[(size_t)(2 * F + 12 * q + s) * 32 + m]; });
+            we16 = frag(2, EPNN_ER / 4, [&](int s, int q, int m) -> double {      // (B^T We)[4q + s][m]
+                if (!have_basis) return 0.0;
+                double a = 0;
+                for (int ch = 0; ch < EPNN_EDIM; ++ch) a += h->edge_B[(size_t)ch * EPNN_ER + 4 * q + s] * (double)W1[(size_t)(2 * F + ch) * 32 + m];
+                return a;
+            });
             w2 = frag(2, 8, [&](int s, int q, int m) { return (double)W2[(size_t)accf(s, q) * 32 + m]; });
             b2 = vec(32, [&](int k) { return (double)bb2[k]; });
         };
@@ -325,7 +416,7 @@ static int pack_weights(epnn_handle *h) {
         const int off_bu2 = vec(32, [&](int k) { return (double)bu2[k]; });
         for (int t = 0; t < T; ++t) {
             WaveGnnPack &G = X.g[t];
-            pair_common(h->msg[t], G.we, G.w2, G.b2);
+            pair_common(h->msg[t], G.we, G.we16, G.w2, G.b2);
             const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
             std::vector<double> fold(32 * 32), cb3(32);
             for (int k = 0; k < 32; ++k)
@@ -359,9 +450,10 @@ static int pack_weights(epnn_handle *h) {
         X.u1h0 = frag(2, 12, [&](int s, int q, int m) { return (double)Wu1[(size_t)accf(s, q) * 32 + m]; });
         X.u3 = frag(3, 8, [&](int s, int q, int m) { return (double)Wu3[(size_t)accf(s, q) * EPNN_EDIM + m]; });
         X.bu3 = vec(48, [&](int k) { return (double)bu3[k]; });
+        X.bproj = frag(1, 12, [&](int s, int q, int m) { return have_basis ? h->edge_B[(size_t)(12 * q + s) * EPNN_ER + m] : 0.0; });
         for (int t = 0; t < T; ++t) {
             WaveEpnPack &E = X.e[t];
-            pair_common(h->pas[t], E.we, E.w2, E.b2);
+            pair_common(h->pas[t], E.we, E.we16, E.w2, E.b2);
             const float *W1 = h->pas[t][0].W.data(), *b1 = h->pas[t][0].b.data();
             E.w3 = vec(32, [&](int k) { return (double)h->pas[t][2].W[k]; });
             E.wi = unfolded(W1, b1, 0);
@@ -456,7 +548,8 @@ struct PairSource {     // where the fused / tiled kernels read atoms and pairs 
     const float *d_x = nullptr, *d_Q = nullptr, *d_hin = nullptr, *d_qin = nullptr, *d_nm = nullptr;
     float *d_q = nullptr, *d_hout = nullptr;
     int run_gnn = 1, run_epn = 1;
-    const float *d_xyz = nullptr;    // set: the wave kernel builds the pair list itself (no front-end kernels ran)
+    const float *d_xyz = nullptr;    // set: the wave kernel builds the pair lists of its molecules itself
+    int handoff = 0;                 // ... and its last wave hands status + pair count to the host (no other kernel ran)
 };
 
 static int launch_large(epnn_handle *h, const PairSource &S) {
@@ -477,9 +570,19 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.pi = h->d_pi.as<int>();
     A.pj = h->d_pj.as<int>();
     A.psym = h->d_psym.as<int>();
-    A.pe = h->d_pe.as<float>();
-    A.pwi = h->d_pwi.as<float>();
-    A.pwj = h->d_pwj.as<float>();
+    if (S.d_xyz) {      // in-kernel front-end: its own pair scratch, one slot per i<j pair of every small molecule
+        const size_t slots = (size_t)std::max(1, P.pair_slots);
+        if (h->f_pe.ensure(slots * EPNN_EDIM * 4) || h->f_pw.ensure(slots * 2 * 4) || h->s_pt.ensure(slots * EPNN_ER * 4)) return 1;
+        A.pe = h->f_pe.as<float>();
+        A.pwi = h->f_pw.as<float>();
+        A.pwj = h->f_pw.as<float>() + slots;
+        A.pt = h->s_pt.as<float>();
+    } else {
+        A.pe = h->d_pe.as<float>();
+        A.pwi = h->d_pwi.as<float>();
+        A.pwj = h->d_pwj.as<float>();
+    }
+    A.handoff = S.handoff;
     A.q_out = S.d_q;
     A.h_out = S.d_hout;
     A.h_in = S.d_hin;
@@ -490,7 +593,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.T = h->cfg.T;
     A.nx = h->cfg.nx;
     A.A = P.A;
-    if (h->s_gx.ensure((size_t)h->pcap * 32 * 4)) return 1;
+    if (h->s_gx.ensure((size_t)std::max(h->pcap, P.pair_slots) * 32 * 4)) return 1;
     A.gx = h->s_gx.as<float>();
     // worst case inside the budget: n = 32, every unordered pair + diagonal entries (528 records) and >= 1 G row
     const int lds = std::min(std::max(h->wave_lds, 16384), 65536) & ~15;
@@ -507,7 +610,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     {   // D < cutoff decided without the sqrt: cut2 = smallest double whose (correctly rounded, monotone) sqrt is >= cutoff
         double t = A.cutoff * A.cutoff;
         while (sqrt(t) >= A.cutoff) t = nextafter(t, 0.0);
-        while (sqrt(t) < A.cutoff) t = nextafter(t, INFINITY);
+        while (sqrt(t) < A.cutoff) t = nextafter(t, 1e300);
         A.cut2 = t;
     }
     A.tol = h->cfg.near_tol;
@@ -568,35 +671,36 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     if (pack_weights(h)) return 1;
     if (build_plan(h, B, N, offsets)) return 1;
     const Plan &P = h->plan;
-    // Batches of small molecules only: the wave kernel builds each molecule's pair list itself (slots for every i<j
-    // pair of the molecule, so nothing can overflow) and no front-end kernel runs.
-    const bool wave_front = h->opt_wave_front && P.large_list.empty() && !P.small_order.empty() && h->cfg.e_dim == EPNN_EDIM;
-    if (ensure_pairs(h, wave_front ? std::max(h->pcap, P.pair_slots)
-                                   : std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
-    // the in-kernel front-end keeps the control words zeroed itself (last wave) and writes status + pair count to the
-    // pinned host words: no memset kernel before and no copy kernels after the launch
-    if (!wave_front || !h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
-    h->ctl_clean = wave_front;
-    h->last_front = wave_front;
+    // Small molecules (fused kernel): the wavefront builds its molecule's pair list itself (slots for every i<j pair, so
+    // nothing can overflow; G products in the 16-dimensional edge basis, used only when it represents the features to
+    // 1e-8).  Which path a molecule takes does not depend on what else is in the batch.  With small molecules only no
+    // other kernel runs and the kernel's last wave also hands status + pair count to the host.
+    const bool front_small = h->opt_wave_front && !P.small_order.empty() && h->cfg.e_dim == EPNN_EDIM && h->edge_res < 1e-8;
+    const bool pure = front_small && P.large_list.empty();
+    if (!pure && ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
+    if (!pure || !h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    h->ctl_clean = pure;
+    h->last_front = pure;
     hipEvent_t *ev = nullptr;
     if (h->opt_profile > 0) {
         ev = h->evpool.data() + 4 * (h->ev_next % h->opt_profile);
         h->ev_next += 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
-    if (!wave_front && run_frontend_xyz(h, d_xyz)) return 1;
+    if (!pure && run_frontend_xyz(h, d_xyz)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[1], h->stream));
     PairSource S;
     S.d_x = d_x;
     S.d_Q = d_Q;
     S.d_q = d_q;
-    S.d_xyz = wave_front ? d_xyz : nullptr;
+    S.d_xyz = front_small ? d_xyz : nullptr;
+    S.handoff = pure;
     if (launch_small(h, S)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
     if (launch_large(h, S)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
     // status + pair count come back with the results
-    if (!wave_front) {
+    if (!pure) {
         HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
@@ -754,6 +858,7 @@ extern "C" int epnn_last_stats(epnn_handle *h, int64_t *out4) {
     memcpy(out4, h->stats, sizeof(h->stats));
     return 0;
 }
+extern "C" double epnn_edge_basis_residual(epnn_handle *h) { return h ? h->edge_res : 1.0; }
 extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     if (!h || !name) EPNN_FAIL("epnn_set_option: null argument");
     if (!strcmp(name, "profile")) {

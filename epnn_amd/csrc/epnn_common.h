@@ -62,9 +62,11 @@ struct WeightIndex {
 // 16rb' + 4q + r' ("acc" order).  Other K orders: "xq" feature 4s + q;  "e" channel 12q + s.
 // Fragment = [rb][step][64 lanes]: lane (q,m) holds W[in(step,q)][16rb + m].  Vectors are in natural feature order.
 #define EPNN_XS 4            // K-steps of the xq block: nx + 3 <= 16
+#define EPNN_ER 16           // dimension of the edge-feature subspace used by the fused kernel's own front-end
 #define EPNN_DST 33          // LDS row stride (floats) of the per-molecule charge-transfer matrix
 struct WaveGnnPack {           // GNN step t
     int we;               // [2][12][64]  e order       We_t
+    int we16;             // [2][4][64]   k = 4q + s    B^T We_t   (edge features in the 16-dimensional basis)
     int w2;               // [2][8][64]   acc order     W2_t
     int b2;               // [32]
     int u1s;              // [2][8][64]   acc order     W3_t Wu1_M
@@ -77,6 +79,7 @@ struct WaveGnnPack {           // GNN step t
 };
 struct WaveEpnPack {           // EPN step t
     int we, w2, b2, w3;   // w3: [32]
+    int we16;             // [2][4][64]   B^T We_t
     int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features): h given by the caller
     int wif, wjf;         // [2][8+XS][64]   acc rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]: h = nm (Wu3^T u2 + bu3) of the GNN stack
 };
@@ -87,6 +90,7 @@ struct WaveIndex {
     int u1h0;             // [2][12][64]     acc order over 48 features  Wu1_H
     int u3;               // [3][8][64]      acc order  Wu3 (48 outputs = 3 row blocks)
     int bu3;              // [48]
+    int bproj;            // [1][12][64]     e order  B (48 x 16): projection of a pair's edge features onto the basis
 };
 
 __host__ __device__ static inline int epnn_kappa(int hh, int r) { return 4 * hh + (r & 3) + 8 * (r >> 2); }

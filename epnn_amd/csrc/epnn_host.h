@@ -76,6 +76,8 @@ struct epnn_handle {
     bool weights_dirty = true;
     WeightIndex widx{};
     WaveIndex wvidx{};
+    std::vector<double> edge_B;       // [48][EPNN_ER] orthonormal basis of the edge-feature family (epnn_api.hip edge_basis)
+    double edge_res = 1.0;            // its residual max |e - B B^T e| over D in [0, cutoff]
     DevBuf d_wpack;
     DevBuf d_mu;
     // plan + workspace
@@ -86,7 +88,8 @@ struct epnn_handle {
     int pair_cap_per_atom = 16;
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
     // staging for the host-pointer entry points
-    DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_gx;
+    DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_gx, s_pt;
+    DevBuf f_pe, f_pw;                // pair scratch of the fused kernel's own front-end (e rows, near weights)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)

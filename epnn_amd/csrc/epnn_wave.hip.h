@@ -59,6 +59,8 @@ struct WaveArgs {
     double cutoff, eta;
     double cut2;           // smallest float64 t with sqrt(t) >= cutoff: D < cutoff  <=>  D*D (before the sqrt) < cut2
     float tol;
+    float *pt;             // [pcap][16] in-kernel front-end: the pairs' edge features in the 16-dimensional basis (B^T e)
+    int handoff;           // in-kernel front-end and nothing else runs: the last wave reports to host_status and re-zeroes `status`
     int *host_status;      // pinned host ints [0] status bits [1] near pairs of the batch: written by the last wave to finish
     unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][64] s_memtime values
 };
@@ -244,21 +246,33 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         }
     }
 
-    // e rows of G tile gt: lane (q, n16) takes channels 12q..12q+11 of pairs gt*32 + n16 and gt*32 + 16 + n16
-    auto load_e = [&](int gt, float (&e0)[12], float (&e1)[12]) {
-        const int s0 = gt * 32 + n16, s1 = s0 + 16;
-        const float *r0 = A.pe + (size_t)(p0 + (s0 < np ? s0 : 0)) * EPNN_EDIM + 12 * q;
-        const float *r1 = A.pe + (size_t)(p0 + (s1 < np ? s1 : 0)) * EPNN_EDIM + 12 * q;
+    // Edge operand of the G products.  Pair lists from outside carry arbitrary e rows: K = 48, lane (q, n16) takes channels
+    // 12q..12q+11 of its pair.  The in-kernel front-end knows its e rows are Gaussians of a distance, which live in a
+    // 16-dimensional subspace to 5e-10 (epnn_api.hip edge_basis): it projects every pair once (pt = B^T e) and all 2T
+    // G products run with K = 16, lane (q, n16) taking coefficients 4q..4q+3.
+    constexpr int KE = FRONT ? EPNN_ER / 4 : 12;
+    auto load_e1 = [&](int slot, float (&e)[KE]) {
+        const int sl = slot < np ? slot : 0;
+        if (FRONT) {
+            const f32x4 v = w16_ld(A.pt + (size_t)(p0 + sl) * EPNN_ER + 4 * q);
+            e[0] = v[0]; e[1] = v[1]; e[2] = v[2]; e[3] = v[3];
+        } else {
+            const float *r = A.pe + (size_t)(p0 + sl) * EPNN_EDIM + 12 * q;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const f32x4 v0 = w16_ld(r0 + 4 * k), v1 = w16_ld(r1 + 4 * k);
-            e0[4 * k] = v0[0]; e0[4 * k + 1] = v0[1]; e0[4 * k + 2] = v0[2]; e0[4 * k + 3] = v0[3];
-            e1[4 * k] = v1[0]; e1[4 * k + 1] = v1[1]; e1[4 * k + 2] = v1[2]; e1[4 * k + 3] = v1[3];
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 v = w16_ld(r + 4 * k);
+                e[(4 * k) % KE] = v[0]; e[(4 * k + 1) % KE] = v[1]; e[(4 * k + 2) % KE] = v[2]; e[(4 * k + 3) % KE] = v[3];
+            }
         }
     };
+    // e operands of G tile gt: pairs gt*32 + n16 and gt*32 + 16 + n16
+    auto load_e = [&](int gt, float (&e0)[KE], float (&e1)[KE]) {
+        load_e1(gt * 32 + n16, e0);
+        load_e1(gt * 32 + 16 + n16, e1);
+    };
     // first G tiles: We and the first e rows are on their way while the LDS tables are built
-    float gw[2][12], ge0[12], ge1[12];
-    W16_LD(gw, GNN ? X.g[0].we : X.e[0].we, 2, 12);
+    float gw[2][KE], ge0[KE], ge1[KE];
+    W16_LD(gw, FRONT ? X.g[0].we16 : (GNN ? X.g[0].we : X.e[0].we), 2, KE);
     if (GNN && !FRONT && ngt > 0) load_e(0, ge0, ge1);
     WAVE_FENCE();
 
@@ -327,6 +341,25 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
             }
         }
         wave_sync_all();
+        // ---- project the pairs' features onto the 16-dimensional basis: pt[pair] = B^T e[pair], 16 pairs per block
+        {
+            float bp[1][12];
+            W16_LD(bp, X.bproj, 1, 12);
+            for (int blk = 0; blk * 16 < np; ++blk) {
+                const int slot = blk * 16 + n16;
+                const float *r = A.pe + (size_t)(p0 + (slot < np ? slot : 0)) * EPNN_EDIM + 12 * q;
+                float ein[12];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const f32x4 v = w16_ld(r + 4 * k);
+                    ein[4 * k] = v[0]; ein[4 * k + 1] = v[1]; ein[4 * k + 2] = v[2]; ein[4 * k + 3] = v[3];
+                }
+                f32x4 d[1] = {w16_splat(0.f)};
+                w16_mm<1, 12>(bp, ein, d);                 // rows = coefficient 4q + r, column = pair
+                if (slot < np) w16_st(A.pt + (size_t)(p0 + slot) * EPNN_ER + 4 * q, d[0]);
+            }
+        }
+        wave_sync_all();
         if (ngt > 0) load_e(0, ge0, ge1);
     } else {
         if (GNN)
@@ -351,10 +384,10 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
     const int fo = 4 * q;                                   // this lane's feature offset inside a 16-feature row block
 
     // G rows of every near pair for the pair MLP whose We is in gw (first e rows in ge0/ge1); rows >= glds go to HBM
-    auto gtile = [&](int gt, const float (&e0)[12], const float (&e1)[12]) {
+    auto gtile = [&](int gt, const float (&e0)[KE], const float (&e1)[KE]) {
         const int s0 = gt * 32 + n16, s1 = s0 + 16;
         f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
-        w16_mm<2, 12>(gw, e0, d0);
+        w16_mm<2, KE>(gw, e0, d0);
         // two separate predicated stores per target (LDS / HBM): merged into one pointer they become flat stores
         if (s0 < min(np, glds)) { w16_st(Gl + s0 * EPNN_PST + fo, d0[0]); w16_st(Gl + s0 * EPNN_PST + 16 + fo, d0[1]); }
         if (gover) {
@@ -363,7 +396,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         }
         if (gt * 32 + 16 < np) {                            // the second 16 pairs of the tile exist
             f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
-            w16_mm<2, 12>(gw, e1, d1);
+            w16_mm<2, KE>(gw, e1, d1);
             if (s1 < min(np, glds)) { w16_st(Gl + s1 * EPNN_PST + fo, d1[0]); w16_st(Gl + s1 * EPNN_PST + 16 + fo, d1[1]); }
             if (gover) {
                 asm volatile("" ::: "memory");
@@ -372,7 +405,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         }
     };
     auto gtiles = [&]() {                                   // e rows of the next tile are fetched while this one runs
-        float en0[12], en1[12];
+        float en0[KE], en1[KE];
         int gt = 0;
 #pragma unroll 1
         for (; gt + 1 < ngt; gt += 2) {
@@ -386,7 +419,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         if (gt < ngt) gtile(gt, ge0, ge1);
     };
     auto gprefetch = [&](int weoff) {
-        W16_LD(gw, weoff, 2, 12);
+        W16_LD(gw, weoff, 2, KE);
         if (ngt > 0) load_e(0, ge0, ge1);
     };
     // 32-vector in natural feature order -> this lane's two groups of four
@@ -609,8 +642,8 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                     a1_[rb] = w16_relu(nm1 * (d1[rb] + Nf * cv[rb]) + bv[rb]);
                 }
                 vec2(M.bu2, bv);
-                if (!lastg) gprefetch(X.g[t + 1].we);
-                else if (Te > 0) { W16_LD(gw, X.e[0].we, 2, 12); }
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
+                else if (Te > 0) { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
                 WAVE_FENCE();
                 d0[0] = bv[0]; d0[1] = bv[1]; d1[0] = bv[0]; d1[1] = bv[1];
                 w16_feed(a0_, in0);
@@ -736,7 +769,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 // (indices in LDS, weights in HBM) is fetched two blocks ahead, the gathered P / R rows and the e row one block ahead
                 const int nblk = (np + 15) >> 4;
                 struct Rec { int ij; float wi, wj; };
-                struct Rows { float e[12]; f32x4 pi_[2], rj_[2], pj_[2], ri_[2]; };
+                struct Rows { float e[KE]; f32x4 pi_[2], rj_[2], pj_[2], ri_[2]; };
                 auto load_rec = [&](int blk, Rec &r_) {
                     const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
                     r_.ij = eij[sl];
@@ -746,14 +779,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 auto load_rows = [&](int blk, const Rec &r_, Rows &w_) {
                     const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
                     const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
-                    {   // e channels 12q..12q+11 of the lane's pair: the G term is computed here, it never goes through memory
-                        const float *er = A.pe + (size_t)(p0 + sl) * EPNN_EDIM + 12 * q;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const f32x4 v = w16_ld(er + 4 * k);
-                            w_.e[4 * k] = v[0]; w_.e[4 * k + 1] = v[1]; w_.e[4 * k + 2] = v[2]; w_.e[4 * k + 3] = v[3];
-                        }
-                    }
+                    load_e1(sl, w_.e);          // the G term is computed in the block, it never goes through memory
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
                         w_.pi_[rb] = w16_ld(Pl + li * EPNN_PST + 16 * rb + fo);
@@ -766,7 +792,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                     const bool valid = blk * 16 + n16 < np;
                     const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
                     f32x4 g[2] = {w16_splat(0.f), w16_splat(0.f)};       // G = We^T e of the 16 pairs (charge_gn.py:105, e block)
-                    w16_mm<2, 12>(gw, w_.e, g);
+                    w16_mm<2, KE>(gw, w_.e, g);
                     float zu[8], zv[8];
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
@@ -812,7 +838,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 }
             }
             wave_sync_lds();
-            if (t + 1 < Te) { W16_LD(gw, X.e[t + 1].we, 2, 12); }     // on its way during the charge update
+            if (t + 1 < Te) { W16_LD(gw, FRONT ? X.e[t + 1].we16 : X.e[t + 1].we, 2, KE); }     // on its way during the charge update
             WAVE_FENCE();
             if (t < 2) WAVE_STAMP();   // EPN pair tiles
             // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of the rows of its two atoms
@@ -839,7 +865,7 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
                 if (own1) A.q_out[a0 + col1] = xq1[s];
             }
     }
-    if (FRONT && lane == 0) {
+    if (FRONT && A.handoff && lane == 0) {
         // the last wave to finish hands status + pair count to the host and re-zeroes the control words
         atomicAdd(A.status + 1, np);
         __threadfence();

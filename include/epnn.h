@@ -136,6 +136,10 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * "pair_cap_per_atom" (initial capacity of the near-pair list of the tiled / dense paths), "wave_front" (1: batches of small
  * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
+/* The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features
+ * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative
+ * to max e = 1 (5e-10 for cutoff 3, eta 2); the basis is used only when this is below 1e-8. */
+double epnn_edge_basis_residual(epnn_handle *h);
 /* counters of the most recent forward: out[0]=near pairs, out[1]=molecules on the fused path,
  * out[2]=molecules on the tiled path, out[3]=pair-list regrows. */
 int epnn_last_stats(epnn_handle *h, int64_t *out4);
