@@ -272,3 +272,28 @@ def test_fused_kernel_edge_shapes_vs_oracle(gpu_engine_factory):
             assert err <= max(TOL, 4 * noise), (opts, k, n, err, noise)
             assert abs(float(q[off[k]:off[k + 1]].sum(dtype=np.float64)) - m[2]) < 2e-5
     print(f"edge shapes: {npairs} near pairs, float32 oracle noise {noise:.2e}")
+
+
+def test_edge_basis_residual_and_front_end_agreement(gpu_engine_factory, weights_decay, val_dir, val_names, val_gold):
+    """The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features.
+    The basis must reproduce the features to 1e-9 (relative to max e = 1), and charges must agree with the K = 48 path
+    (separate front-end kernels, exp per channel) far inside the parity tolerance."""
+    eng = gpu_engine_factory(nx=9, T=5)
+    res = float(eng.lib.epnn_edge_basis_residual(eng.h))
+    assert 0.0 < res < 1e-9, res
+    eng.set_weights(weights_decay)
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, val_names[:200])
+    sel = [i for i, m in enumerate(mols) if m[1].shape[0] <= 32]
+    ms = [mols[i] for i in sel]
+    off = np.zeros(len(ms) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([m[1].shape[0] for m in ms])
+    args = (off, np.concatenate([m[0] for m in ms]), np.concatenate([m[1] for m in ms]), np.array([m[2] for m in ms], dtype=np.float32))
+    q16 = eng.forward_xyz(*args, N=41)
+    eng48 = gpu_engine_factory(nx=9, T=5)
+    eng48.set_weights(weights_decay)
+    eng48.set_option("wave_front", 0)
+    q48 = eng48.forward_xyz(*args, N=41)
+    d = float(np.abs(q16 - q48).max())
+    worst = max(float(np.abs(q16[off[k]:off[k + 1]] - val_gold[i, :ms[k][1].shape[0]]).max()) for k, i in enumerate(sel))
+    print(f"edge basis residual {res:.2e}; K=16 vs K=48 charges {d:.2e}; vs stored TensorFlow outputs {worst:.2e}")
+    assert d < 3e-6 and worst <= TOL                      # float32 rounding of two different summations
