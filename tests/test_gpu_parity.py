@@ -297,3 +297,47 @@ def test_edge_basis_residual_and_front_end_agreement(gpu_engine_factory, weights
     worst = max(float(np.abs(q16[off[k]:off[k + 1]] - val_gold[i, :ms[k][1].shape[0]]).max()) for k, i in enumerate(sel))
     print(f"edge basis residual {res:.2e}; K=16 vs K=48 charges {d:.2e}; vs stored TensorFlow outputs {worst:.2e}")
     assert d < 3e-6 and worst <= TOL                      # float32 rounding of two different summations
+
+
+def test_fused_kernel_every_size_vs_oracle(gpu_engine_factory):
+    """Every molecule size 1..32 (the column-block / partner-copy layout of the fused kernel changes with n) at two
+    densities, random non-degenerate weights, nx = 10 (four xq K steps), float64 oracle; both front-ends."""
+    from epnn_amd import synth
+    nx, T, N = 10, 2, 34
+    w = random_weights(nx, T, seed=3, scale=0.35)
+    rng = np.random.default_rng(5)
+    names10 = ["H", "C", "N", "O", "F", "S", "Cl", "Br"]
+    mols = []
+    for n in range(1, 33):
+        for span_per_atom in (0.9, 2.2):
+            span = max(1.2, span_per_atom * n ** (1.0 / 3.0) * 1.6)
+            while True:
+                pts = rng.uniform(0, span, size=(n, 3))
+                d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 10
+                if d.min() > 0.7:
+                    break
+            sym = rng.choice(names10[:5], size=n)
+            x9 = synth.features(sym)
+            x = np.concatenate([x9, rng.uniform(0, 1, size=(n, nx - 9)).astype(np.float32)], axis=1)
+            mols.append((pts.astype(np.float32), x, float(rng.integers(-1, 2))))
+    off = np.zeros(len(mols) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([m[1].shape[0] for m in mols])
+    xyz, x = np.concatenate([m[0] for m in mols]), np.concatenate([m[1] for m in mols])
+    Q = np.array([m[2] for m in mols], dtype=np.float32)
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    for opts in ({}, {"wave_front": 0}):
+        eng = gpu_engine_factory(nx=nx, T=T)
+        eng.set_weights(w)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        q = eng.forward_xyz(off, xyz, x, Q, N=N)
+        worst, at = 0.0, -1
+        for k, m in enumerate(mols):
+            n = m[1].shape[0]
+            err = float(np.abs(q[off[k]:off[k + 1]] - ref[k][:n]).max())
+            if err > worst:
+                worst, at = err, n
+        print(f"sizes 1..32 {opts}: worst |dq| {worst:.2e} (n = {at}); float32 oracle noise {noise:.2e}")
+        assert worst <= max(TOL, 4 * noise), (opts, worst, at)
