@@ -345,18 +345,27 @@ __global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X)
         {
             float bp[1][12];
             W16_LD(bp, X.bproj, 1, 12);
-            for (int blk = 0; blk * 16 < np; ++blk) {
+            auto load48 = [&](int blk, float (&ein)[12]) {
                 const int slot = blk * 16 + n16;
                 const float *r = A.pe + (size_t)(p0 + (slot < np ? slot : 0)) * EPNN_EDIM + 12 * q;
-                float ein[12];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const f32x4 v = w16_ld(r + 4 * k);
                     ein[4 * k] = v[0]; ein[4 * k + 1] = v[1]; ein[4 * k + 2] = v[2]; ein[4 * k + 3] = v[3];
                 }
+            };
+            const int nb = (np + 15) >> 4;
+            float ea[12], eb[12];
+            if (nb > 0) load48(0, ea);
+            for (int blk = 0; blk < nb; ++blk) {               // the next block's rows are fetched while this one is projected
+                load48(min(blk + 1, nb - 1), eb);
+                WAVE_FENCE();
                 f32x4 d[1] = {w16_splat(0.f)};
-                w16_mm<1, 12>(bp, ein, d);                 // rows = coefficient 4q + r, column = pair
+                w16_mm<1, 12>(bp, ea, d);                   // rows = coefficient 4q + r, column = pair
+                const int slot = blk * 16 + n16;
                 if (slot < np) w16_st(A.pt + (size_t)(p0 + slot) * EPNN_ER + 4 * q, d[0]);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) ea[k] = eb[k];
             }
         }
         wave_sync_all();
