@@ -100,6 +100,9 @@ __device__ __forceinline__ double wave_dist2(const double *xs, int i, int j) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
+#ifndef EPNN_WAVES_PER_SIMD
+#define EPNN_WAVES_PER_SIMD 2     // register budget of the fused kernel: 2 -> 256 VGPRs (3 -> 168: measured slower)
+#endif
 // keep the loads issued above this point above it: the next chain's operands are fetched while the current chain runs
 #define WAVE_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -156,7 +159,7 @@ __device__ __forceinline__ void w16_feed(const f32x4 (&a)[2], float (&in)[8]) {
 }
 
 template <bool GNN, bool EPN, bool FRONT>
-__global__ __launch_bounds__(64, 2) void k_wave_forward(WaveArgs A, WaveIndex X) {
+__global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveArgs A, WaveIndex X) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, q = lane >> 4, n16 = lane & 15;
     const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
