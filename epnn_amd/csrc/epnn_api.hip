@@ -43,7 +43,7 @@ static void shape_layers(epnn_handle *h) {
     set(h->upd[2], H, h->cfg.h_dim);
 }
 
-static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, std::vector<double> &Bout);
+static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, std::vector<double> &Bout, std::vector<float> &tab);
 
 extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out) {
     if (!cfg || !out) EPNN_FAIL("epnn_create: null argument");
@@ -80,7 +80,14 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
     HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
     shape_layers(h);
-    h->edge_res = cfg->e_dim == EPNN_EDIM ? edge_basis(h->cfg, mu, h->edge_B) : 1.0;
+    {
+        std::vector<float> tab;
+        h->edge_res = cfg->e_dim == EPNN_EDIM ? edge_basis(h->cfg, mu, h->edge_B, tab) : 1.0;
+        if (!tab.empty()) {
+            if (h->d_etab.ensure(tab.size() * sizeof(float))) return 1;
+            HIPCHK(hipMemcpy(h->d_etab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     *out = h;
     return 0;
 }
@@ -91,7 +98,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pbase, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
-                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pe, &h->f_pw, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
+                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
@@ -123,7 +130,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
 // so e IS of that family) projects every pair's e once and runs all 2T G products with K = 16 instead of 48.
 // One-sided Jacobi (Hestenes) SVD in float64: accurate also for the small singular directions.  Returns the residual
 // max |E - E B B^T| over the sampling grid.
-static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, std::vector<double> &Bout) {
+static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, std::vector<double> &Bout, std::vector<float> &tab) {
     const int K = cfg.e_dim, R = EPNN_ER, ND = 1025;
     std::vector<double> E((size_t)ND * K), E0;
     const double pi_d = 3.141592653589793, cut = (double)cfg.cutoff, eta = (double)cfg.eta;
@@ -189,6 +196,41 @@ static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, 
             double a = 0;
             for (int r = 0; r < R; ++r) a += c[r] * Bout[(size_t)k * R + r];
             res = std::max(res, fabs(E0[(size_t)i * K + k] - a));
+        }
+    }
+    // table of the coordinates B^T e(D) for the kernel's cubic interpolation, and its error at off-grid distances
+    auto coords = [&](double D, double *out) {
+        double C = (cos(pi_d * D / cut) + 1.0) / 2.0;
+        if (D <= 0.0) C = 1.0;
+        if (D >= cut) C = 0.0;
+        for (int r = 0; r < R; ++r) out[r] = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double d = D - mu[k], e = C * exp(-eta * d * d);
+            for (int r = 0; r < R; ++r) out[r] += e * Bout[(size_t)k * R + r];
+        }
+    };
+    const int NT = EPNN_ETAB_N;
+    tab.assign((size_t)NT * R, 0.f);
+    std::vector<double> tabd((size_t)NT * R), row(R);
+    for (int i = 0; i < NT; ++i) {
+        coords(cut * (double)i / (double)(NT - 1), &tabd[(size_t)i * R]);
+        for (int r = 0; r < R; ++r) tab[(size_t)i * R + r] = (float)tabd[(size_t)i * R + r];
+    }
+    // interpolation error of the method (float64 nodes; the float32 storage of the nodes is the same 6e-8 relative
+    // rounding every float32 operand of the kernel has, like the reference's own float32 cast of e)
+    const double inv_h = (double)(NT - 1) / cut;
+    for (int t = 0; t < 20000; ++t) {
+        const double D = cut * ((double)t + 0.37) / 20000.0;
+        const double tt = D * inv_h;
+        const int i0 = std::min(std::max((int)tt - 1, 0), NT - 4);
+        const double u = tt - i0;
+        const double w[4] = {-(u - 1) * (u - 2) * (u - 3) / 6.0, u * (u - 2) * (u - 3) / 2.0, -u * (u - 1) * (u - 3) / 2.0,
+                             u * (u - 1) * (u - 2) / 6.0};
+        coords(D, row.data());
+        for (int r = 0; r < R; ++r) {
+            double a = 0;
+            for (int j = 0; j < 4; ++j) a += w[j] * tabd[(size_t)(i0 + j) * R + r];
+            res = std::max(res, fabs(a - row[r]));
         }
     }
     return res;
@@ -450,7 +492,6 @@ static int pack_weights(epnn_handle *h) {
         X.u1h0 = frag(2, 12, [&](int s, int q, int m) { return (double)Wu1[(size_t)accf(s, q) * 32 + m]; });
         X.u3 = frag(3, 8, [&](int s, int q, int m) { return (double)Wu3[(size_t)accf(s, q) * EPNN_EDIM + m]; });
         X.bu3 = vec(48, [&](int k) { return (double)bu3[k]; });
-        X.bproj = frag(1, 12, [&](int s, int q, int m) { return have_basis ? h->edge_B[(size_t)(12 * q + s) * EPNN_ER + m] : 0.0; });
         for (int t = 0; t < T; ++t) {
             WaveEpnPack &E = X.e[t];
             pair_common(h->pas[t], E.we, E.we16, E.w2, E.b2);
@@ -572,8 +613,8 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.psym = h->d_psym.as<int>();
     if (S.d_xyz) {      // in-kernel front-end: its own pair scratch, one slot per i<j pair of every small molecule
         const size_t slots = (size_t)std::max(1, P.pair_slots);
-        if (h->f_pe.ensure(slots * EPNN_EDIM * 4) || h->f_pw.ensure(slots * 2 * 4) || h->s_pt.ensure(slots * EPNN_ER * 4)) return 1;
-        A.pe = h->f_pe.as<float>();
+        if (h->f_pw.ensure(slots * 2 * 4) || h->s_pt.ensure(slots * EPNN_ER * 4)) return 1;
+        A.pe = nullptr;            // the 48-channel rows are never materialised on this path
         A.pwi = h->f_pw.as<float>();
         A.pwj = h->f_pw.as<float>() + slots;
         A.pt = h->s_pt.as<float>();
@@ -615,6 +656,19 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     }
     A.tol = h->cfg.near_tol;
     A.host_status = h->h_status;          // pinned, device-visible
+    A.etab = h->d_etab.as<float>();
+    A.tab_n = EPNN_ETAB_N;
+    A.tab_inv_h = (double)(EPNN_ETAB_N - 1) / A.cutoff;
+    if (h->dsafe < 0.0) {   // largest D up to which C(D) exp(-eta (dmu/2)^2) - a lower bound of max_k e_k, decreasing in D - stays above 2 tol
+        const double dmu = A.cutoff / (double)(EPNN_EDIM - 1), floor_g = exp(-A.eta * dmu * dmu / 4.0);
+        double lo = 0.0, hi = A.cutoff;
+        for (int it = 0; it < 60; ++it) {
+            const double m = 0.5 * (lo + hi), L = (cos(3.141592653589793 * m / A.cutoff) + 1.0) / 2.0 * floor_g;
+            if (L > 2.0 * (double)A.tol) lo = m; else hi = m;
+        }
+        h->dsafe = lo;
+    }
+    A.dsafe = h->dsafe;
     const dim3 grid((unsigned)P.small_order.size());
     const WaveIndex &X = h->wvidx;
     if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);

@@ -63,6 +63,7 @@ struct WeightIndex {
 // Fragment = [rb][step][64 lanes]: lane (q,m) holds W[in(step,q)][16rb + m].  Vectors are in natural feature order.
 #define EPNN_XS 4            // K-steps of the xq block: nx + 3 <= 16
 #define EPNN_ER 16           // dimension of the edge-feature subspace used by the fused kernel's own front-end
+#define EPNN_ETAB_N 2049     // grid points of the table of B^T e(D) over [0, cutoff]
 #define EPNN_DST 33          // LDS row stride (floats) of the per-molecule charge-transfer matrix
 struct WaveGnnPack {           // GNN step t
     int we;               // [2][12][64]  e order       We_t
@@ -90,7 +91,6 @@ struct WaveIndex {
     int u1h0;             // [2][12][64]     acc order over 48 features  Wu1_H
     int u3;               // [3][8][64]      acc order  Wu3 (48 outputs = 3 row blocks)
     int bu3;              // [48]
-    int bproj;            // [1][12][64]     e order  B (48 x 16): projection of a pair's edge features onto the basis
 };
 
 __host__ __device__ static inline int epnn_kappa(int hh, int r) { return 4 * hh + (r & 3) + 8 * (r >> 2); }

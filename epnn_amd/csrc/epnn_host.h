@@ -89,7 +89,8 @@ struct epnn_handle {
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
     // staging for the host-pointer entry points
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_gx, s_pt;
-    DevBuf f_pe, f_pw;                // pair scratch of the fused kernel's own front-end (e rows, near weights)
+    double dsafe = -1.0;              // distance up to which every pair is a near pair (computed at the first launch)
+    DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)

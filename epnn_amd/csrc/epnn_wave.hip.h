@@ -60,6 +60,9 @@ struct WaveArgs {
     double cut2;           // smallest float64 t with sqrt(t) >= cutoff: D < cutoff  <=>  D*D (before the sqrt) < cut2
     float tol;
     float *pt;             // [pcap][16] in-kernel front-end: the pairs' edge features in the 16-dimensional basis (B^T e)
+    const float *etab;     // [tab_n][16] B^T e(D) on the grid D = i / tab_inv_h, i = 0 .. tab_n - 1 (last point = cutoff)
+    double tab_inv_h, dsafe;
+    int tab_n;
     int handoff;           // in-kernel front-end and nothing else runs: the last wave reports to host_status and re-zeroes `status`
     int *host_status;      // pinned host ints [0] status bits [1] near pairs of the batch: written by the last wave to finish
     unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][64] s_memtime values
@@ -304,71 +307,44 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         gover = np > glds;
         ngt = (np + 31) >> 5;
         wave_sync_lds();
-        // ---- Gaussian edge features, one lane per pair: float64 recurrence over the evenly spaced mu_k (see epnn_wave.hip.h)
+        // ---- edge coefficients of every pair, one lane per pair: pt[pair] = B^T e(D), the 16 coordinates of the pair's Gaussian
+        //      features (charge_gn.py:148-161) in the edge basis.  They are smooth functions of the one variable D: cubic
+        //      Lagrange interpolation in a table of 4097 points over [0, cutoff] (built in float64 by epnn_create, error
+        //      < 1e-9, part of epnn_edge_basis_residual).  The near flag max_k e_k > tol (charge_gn.py:90-94) is 1 up to
+        //      dsafe (where a lower bound of max_k e_k is already > 2 tol) and evaluated exactly, float32 cast included, beyond it.
         const double pi_d = 3.141592653589793;
         const double mu0 = A.mu[0], dmu = (A.mu[EPNN_EDIM - 1] - A.mu[0]) / (double)(EPNN_EDIM - 1);
-        const double qq = exp(-2.0 * A.eta * dmu * dmu);
         for (int s0 = 0; s0 < np; s0 += 64) {
             if (s0 + lane < np) {
                 const int ij = eij[s0 + lane];
                 const double D = wave_dist(xs, ij & 0xFF, ij >> 8);
-                double C = (cos(pi_d * (D - 0.0) / A.cutoff) + 1.0) / 2.0;
-                if (D <= 0.0) C = 1.0;
-                int kb = min(EPNN_EDIM - 1, max(0, (int)((D - mu0) / dmu + 0.5)));
-                double best = 1e300;
-                int kbest = kb;
-                for (int k = max(0, kb - 1); k <= min(EPNN_EDIM - 1, kb + 1); ++k) {
-                    const double d = D - A.mu[k];
-                    if (d * d < best) { best = d * d; kbest = k; }
+                float w = 1.0f;
+                if (D > A.dsafe) {
+                    double C = (cos(pi_d * (D - 0.0) / A.cutoff) + 1.0) / 2.0;
+                    const int kb = min(EPNN_EDIM - 1, max(0, (int)((D - mu0) / dmu + 0.5)));
+                    double best = 1e300;
+                    for (int k = max(0, kb - 1); k <= min(EPNN_EDIM - 1, kb + 1); ++k) {
+                        const double d = D - A.mu[k];
+                        best = d * d < best ? d * d : best;
+                    }
+                    w = (float)(C * exp(-A.eta * best)) > A.tol ? 1.0f : 0.0f;
                 }
-                const double db = D - A.mu[kbest];
-                const float emax = (float)(C * exp(-A.eta * (db * db)));
-                const float w = emax > A.tol ? 1.0f : 0.0f;           // charge_gn.py:90-94
                 A.pwi[p0 + s0 + lane] = w;
                 A.pwj[p0 + s0 + lane] = w;
-                const double t0 = D - mu0;
-                double e = C * exp(-A.eta * (t0 * t0));
-                double rho = exp(A.eta * dmu * (2.0 * t0 - dmu));
-                float *erow = A.pe + (size_t)(p0 + s0 + lane) * EPNN_EDIM;
-#pragma unroll 1
-                for (int k4 = 0; k4 < EPNN_EDIM; k4 += 4) {
-                    f32x4 v;
+                const double tt = D * A.tab_inv_h;
+                const int i0 = min(max((int)tt - 1, 0), A.tab_n - 4);
+                const float u = (float)(tt - (double)i0);                    // position among the nodes i0 .. i0+3, normally in [1, 2)
+                const float um1 = u - 1.f, um2 = u - 2.f, um3 = u - 3.f;
+                const float w0 = -(um1 * um2 * um3) * (1.f / 6.f), w1 = (u * um2 * um3) * 0.5f;
+                const float w2 = -(u * um1 * um3) * 0.5f, w3 = (u * um1 * um2) * (1.f / 6.f);
+                const float *trow = A.etab + (size_t)i0 * EPNN_ER;
+                float *prow = A.pt + (size_t)(p0 + s0 + lane) * EPNN_ER;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        v[u] = (float)e;                               // charge_gn.py:160-161
-                        e *= rho;
-                        rho *= qq;
-                    }
-                    w16_st(erow + k4, v);
+                for (int g = 0; g < EPNN_ER / 4; ++g) {
+                    const f32x4 v = w0 * w16_ld(trow + 4 * g) + w1 * w16_ld(trow + EPNN_ER + 4 * g) +
+                                    w2 * w16_ld(trow + 2 * EPNN_ER + 4 * g) + w3 * w16_ld(trow + 3 * EPNN_ER + 4 * g);
+                    w16_st(prow + 4 * g, v);
                 }
-            }
-        }
-        wave_sync_all();
-        // ---- project the pairs' features onto the 16-dimensional basis: pt[pair] = B^T e[pair], 16 pairs per block
-        {
-            float bp[1][12];
-            W16_LD(bp, X.bproj, 1, 12);
-            auto load48 = [&](int blk, float (&ein)[12]) {
-                const int slot = blk * 16 + n16;
-                const float *r = A.pe + (size_t)(p0 + (slot < np ? slot : 0)) * EPNN_EDIM + 12 * q;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const f32x4 v = w16_ld(r + 4 * k);
-                    ein[4 * k] = v[0]; ein[4 * k + 1] = v[1]; ein[4 * k + 2] = v[2]; ein[4 * k + 3] = v[3];
-                }
-            };
-            const int nb = (np + 15) >> 4;
-            float ea[12], eb[12];
-            if (nb > 0) load48(0, ea);
-            for (int blk = 0; blk < nb; ++blk) {               // the next block's rows are fetched while this one is projected
-                load48(min(blk + 1, nb - 1), eb);
-                WAVE_FENCE();
-                f32x4 d[1] = {w16_splat(0.f)};
-                w16_mm<1, 12>(bp, ea, d);                   // rows = coefficient 4q + r, column = pair
-                const int slot = blk * 16 + n16;
-                if (slot < np) w16_st(A.pt + (size_t)(p0 + slot) * EPNN_ER + 4 * q, d[0]);
-#pragma unroll
-                for (int k = 0; k < 12; ++k) ea[k] = eb[k];
             }
         }
         wave_sync_all();
