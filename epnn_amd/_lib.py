@@ -38,6 +38,8 @@ SIGNATURES = {
     "epnn_weight_shape": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip]),
     "epnn_edges": (C.c_int, [_vp, C.c_int, _fp, _fp]),
     "epnn_forward_xyz": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp, _fp]),
+    "epnn_forward_xyz_begin": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp]),
+    "epnn_forward_xyz_end": (C.c_int, [_vp, _fp]),
     "epnn_forward_xyz_dev": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _vp, _vp, _vp, _vp]),
     "epnn_model_forward_dense": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_model_forward_dense_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -66,6 +66,7 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev_t0));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_ctl, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t1));
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_status), 4 * sizeof(int), hipHostMallocDefault));
     memset(h->h_status, 0, 4 * sizeof(int));
@@ -107,12 +108,18 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (h->train) {
         TrainState *ts = train_state(h);
         if (ts->comm) (void)ncclCommDestroy(ts->comm);
+        if (ts->gexec) (void)hipGraphExecDestroy(ts->gexec);
+        if (ts->graph) (void)hipGraphDestroy(ts->graph);
         for (DevBuf *b : {&ts->theta, &ts->grad, &ts->m, &ts->v, &ts->part, &ts->arena, &ts->loss}) b->release();
         delete ts;
         h->train = nullptr;
     }
     if (h->h_status) (void)hipHostFree(h->h_status);
     (void)hipEventDestroy(h->ev_t0);
+    if (h->ev_ctl) (void)hipEventDestroy(h->ev_ctl);
+    h->pin_ctl.release();
+    h->pin_in.release();
+    h->pin_out.release();
     (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->stream);
@@ -526,50 +533,62 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
     P.small_order.clear();
     P.large_list.clear();
     P.small_nmax = 0;
-    std::vector<int> molof(P.A);
+    // index arrays of the plan, written straight into page-locked memory and uploaded without waiting:
+    //   pbase [B] | moff [B+1] | order [B] | mflag [B] | molof [A]
+    if (h->ctl_uploading) {                         // the previous plan's upload must have run before its staging is reused
+        HIPCHK(hipEventSynchronize(h->ev_ctl));
+        h->ctl_uploading = false;
+    }
+    if (h->pin_ctl.ensure(((size_t)4 * B + 1 + P.A) * sizeof(int))) return 1;
+    int *c_pbase = h->pin_ctl.as<int>(), *c_moff = c_pbase + B, *c_order = c_moff + B + 1, *c_mflag = c_order + B,
+        *c_molof = c_mflag + B;
+    int count[EPNN_SMALL_NMAX + 2] = {0};
+    long long run = 0;
+    const bool wave_ok = h->cfg.nx + 3 <= 4 * EPNN_XS;       // the fused kernel's xq block holds nx + 3 inputs
     for (int b = 0; b < B; ++b) {
         const int n = offsets[b + 1] - offsets[b];
         if (n < 1) EPNN_FAIL("forward: molecule %d has %d atoms", b, n);
         if (n > N) EPNN_FAIL("forward: molecule %d has %d atoms but the padded size N is %d", b, n, N);
-        for (int a = offsets[b]; a < offsets[b + 1]; ++a) molof[a] = b;
-        const bool wave_ok = h->cfg.nx + 3 <= 4 * EPNN_XS;       // the fused kernel's xq block holds nx + 3 inputs
+        for (int a = offsets[b]; a < offsets[b + 1]; ++a) c_molof[a] = b;
         const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
+        c_mflag[b] = small ? 0 : 1;
         if (small) {
             P.small_order.push_back(b);
             P.small_nmax = std::max(P.small_nmax, n);
+            count[n] += 1;
         } else {
             P.large_list.push_back(b);
         }
+        // pair slots of the in-kernel front-end: every i<j pair of every molecule
+        c_pbase[b] = (int)run;
+        run += n <= EPNN_SMALL_NMAX ? (long long)n * (n - 1) / 2 : 0;
     }
-    {   // pair slots of the in-kernel front-end: every i<j pair of every molecule
-        std::vector<int> pbase(B);
-        long long run = 0;
-        for (int b = 0; b < B; ++b) {
-            const long long n = offsets[b + 1] - offsets[b];
-            pbase[b] = (int)run;
-            run += n <= EPNN_SMALL_NMAX ? n * (n - 1) / 2 : 0;
-        }
-        if (run > 0x7fffffffLL / 64) EPNN_FAIL("forward: batch too large (%lld pair slots)", run);
-        P.pair_slots = (int)run;
-        if (h->d_pbase.ensure((size_t)B * sizeof(int))) return 1;
-        HIPCHK(hipMemcpyAsync(h->d_pbase.p, pbase.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));        // pbase is a local
+    if (run > 0x7fffffffLL / 64) EPNN_FAIL("forward: batch too large (%lld pair slots)", run);
+    P.pair_slots = (int)run;
+    memcpy(c_moff, offsets, (size_t)(B + 1) * sizeof(int));
+    {   // largest molecules first (their wavefronts run longest), equal sizes in batch order: counting sort on n
+        int start[EPNN_SMALL_NMAX + 2], at = 0;
+        for (int n = EPNN_SMALL_NMAX; n >= 0; --n) { start[n] = at; at += count[n]; }
+        std::vector<int> sorted(P.small_order.size());
+        for (int b : P.small_order) sorted[start[offsets[b + 1] - offsets[b]]++] = b;
+        P.small_order.swap(sorted);
+        if (!P.small_order.empty()) memcpy(c_order, P.small_order.data(), P.small_order.size() * sizeof(int));
     }
-    std::stable_sort(P.small_order.begin(), P.small_order.end(), [&](int a, int b) {
-        return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
-    });
-    if (h->d_moff.ensure((B + 1) * sizeof(int)) || h->d_molof.ensure(std::max(1, P.A) * sizeof(int)) ||
+    if (h->d_pbase.ensure((size_t)B * sizeof(int)) || h->d_moff.ensure((B + 1) * sizeof(int)) ||
+        h->d_molof.ensure(std::max(1, P.A) * sizeof(int)) || h->l_mflag.ensure(std::max(1, P.B) * sizeof(int)) ||
         h->d_order.ensure(std::max<size_t>(1, P.small_order.size()) * sizeof(int)) ||
         h->d_rowcnt.ensure((P.A + 1) * sizeof(int)) || h->d_rowoff.ensure((P.A + 1) * sizeof(int)))
         return 1;
-    HIPCHK(hipMemcpyAsync(h->d_moff.p, offsets, (B + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_molof.p, molof.data(), P.A * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pbase.p, c_pbase, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_moff.p, c_moff, (size_t)(B + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->l_mflag.p, c_mflag, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_molof.p, c_molof, (size_t)P.A * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (!P.small_order.empty())
-        HIPCHK(hipMemcpyAsync(h->d_order.p, P.small_order.data(), P.small_order.size() * sizeof(int),
-                              hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));     // molof is a local
+        HIPCHK(hipMemcpyAsync(h->d_order.p, c_order, P.small_order.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_ctl, h->stream));
+    h->ctl_uploading = true;
     if (large_plan(h)) return 1;
     P.valid = true;
     return 0;
@@ -810,27 +829,62 @@ extern "C" int epnn_sync(epnn_handle *h) {
     return finish_forward(h);
 }
 
-extern "C" int epnn_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz,
-                                const float *x, const float *Q, float *q_out) {
-    if (!h || !offsets || !xyz || !x || !Q || !q_out) EPNN_FAIL("epnn_forward_xyz: null argument");
+// Host entry in two halves.  begin: the inputs are copied into the handle's page-locked staging (the caller may reuse
+// its arrays at once), uploads + kernel + download of the charges are queued, and the call returns without waiting for
+// the GPU.  end: waits and hands the charges over.  One forward per handle between begin and end; several handles
+// (engine.Pipeline) keep several batches in flight.
+extern "C" int epnn_forward_xyz_begin(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz,
+                                      const float *x, const float *Q) {
+    if (!h || !offsets || !xyz || !x || !Q) EPNN_FAIL("epnn_forward_xyz_begin: null argument");
     HIPCHK(hipSetDevice(h->device));
+    if (h->hostcall.active) EPNN_FAIL("epnn_forward_xyz_begin: collect the previous forward with epnn_forward_xyz_end first");
     if (B < 1) EPNN_FAIL("epnn_forward_xyz: empty batch");
     const int A = offsets[B];
     if (A < 1) EPNN_FAIL("epnn_forward_xyz: no atoms");
     const int nx = h->cfg.nx;
-    if (h->s_xyz.ensure((size_t)A * 3 * 4) || h->s_x.ensure((size_t)A * nx * 4) || h->s_Q.ensure((size_t)B * 4) ||
-        h->s_q.ensure((size_t)A * 4))
+    if (h->pending.active && finish_forward(h)) return 1;
+    const size_t n_xyz = (size_t)A * 3, n_x = (size_t)A * nx;
+    if (h->s_xyz.ensure(n_xyz * 4) || h->s_x.ensure(n_x * 4) || h->s_Q.ensure((size_t)B * 4) || h->s_q.ensure((size_t)A * 4) ||
+        h->pin_in.ensure((n_xyz + n_x + (size_t)B) * 4) || h->pin_out.ensure((size_t)A * 4))
         return 1;
-    HIPCHK(hipMemcpyAsync(h->s_xyz.p, xyz, (size_t)A * 3 * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->s_x.p, x, (size_t)A * nx * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->s_Q.p, Q, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    float *p_xyz = h->pin_in.as<float>(), *p_x = p_xyz + n_xyz, *p_Q = p_x + n_x;
+    memcpy(p_xyz, xyz, n_xyz * 4);
+    memcpy(p_x, x, n_x * 4);
+    memcpy(p_Q, Q, (size_t)B * 4);
+    HIPCHK(hipMemcpyAsync(h->s_xyz.p, p_xyz, n_xyz * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_x.p, p_x, n_x * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_Q.p, p_Q, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
     if (epnn_forward_xyz_dev(h, B, N, offsets, h->s_xyz.as<float>(), h->s_x.as<float>(), h->s_Q.as<float>(),
                              h->s_q.as<float>()))
         return 1;
-    if (finish_forward(h)) return 1;
-    HIPCHK(hipMemcpyAsync(q_out, h->s_q.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->hostcall.active = true;
+    h->hostcall.A = A;
+    h->hostcall.copied = !h->pending.active;        // nothing can overflow: the charges of this launch are final
+    if (h->hostcall.copied)
+        HIPCHK(hipMemcpyAsync(h->pin_out.p, h->s_q.p, (size_t)A * 4, hipMemcpyDeviceToHost, h->stream));
     return 0;
+}
+
+extern "C" int epnn_forward_xyz_end(epnn_handle *h, float *q_out) {
+    if (!h || !q_out) EPNN_FAIL("epnn_forward_xyz_end: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->hostcall.active) EPNN_FAIL("epnn_forward_xyz_end: no forward was begun on this handle");
+    h->hostcall.active = false;
+    if (finish_forward(h)) return 1;                 // waits; re-runs the forward if a pair list had to grow
+    const size_t bytes = (size_t)h->hostcall.A * 4;
+    if (!h->hostcall.copied) {
+        HIPCHK(hipMemcpyAsync(h->pin_out.p, h->s_q.p, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    memcpy(q_out, h->pin_out.p, bytes);
+    return 0;
+}
+
+extern "C" int epnn_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz,
+                                const float *x, const float *Q, float *q_out) {
+    if (!h || !offsets || !xyz || !x || !Q || !q_out) EPNN_FAIL("epnn_forward_xyz: null argument");
+    if (epnn_forward_xyz_begin(h, B, N, offsets, xyz, x, Q)) return 1;
+    return epnn_forward_xyz_end(h, q_out);
 }
 
 // ------------------------------------------------------------------------------------------------ edges
@@ -931,6 +985,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
+    else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -1254,8 +1309,32 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     if (!ts->ready) EPNN_FAIL("train step: call epnn_train_init first");
     if (ts->loss.ensure((size_t)B * 4 + (size_t)B * N * 4)) return 1;
     float *d_loss = ts->loss.as<float>(), *d_pred = d_loss + B;
-    HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));
-    if (train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss)) return 1;
+    if (h->opt_train_graph) {
+        // One molecule padded to N = 41 is ~2 Gflop spread over ~340 tiny launches: the step is launch-bound, so the
+        // launch sequence is recorded once per (B, N, buffer set) and replayed as one hipGraph.
+        if (train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, true)) return 1;
+        const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
+                                               d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p};
+        if (!ts->gexec || key != ts->gkey) {
+            if (ts->gexec) { (void)hipGraphExecDestroy(ts->gexec); ts->gexec = nullptr; }
+            if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
+            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            int bad = hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream) != hipSuccess;
+            bad = bad || train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss);
+            const hipError_t ec = hipStreamEndCapture(h->stream, &ts->graph);
+            if (bad || ec != hipSuccess) {
+                if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
+                if (!bad) EPNN_FAIL("train step: hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+                return 1;
+            }
+            HIPCHK(hipGraphInstantiate(&ts->gexec, ts->graph, nullptr, nullptr, 0));
+            ts->gkey = key;
+        }
+        HIPCHK(hipGraphLaunch(ts->gexec, h->stream));
+    } else {
+        HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));
+        if (train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss)) return 1;
+    }
     if (apply && train_apply(h)) return 1;
     if (pred_host) HIPCHK(hipMemcpyAsync(pred_host, d_pred, (size_t)B * N * 4, hipMemcpyDeviceToHost, h->stream));
     std::vector<float> lb(B);

@@ -49,6 +49,27 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+struct PinBuf {               // page-locked host memory: asynchronous copies really are asynchronous from / to it
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) HIPCHK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct HostDense {            // one Keras Dense: kernel [in][out], bias [out]
     int n_in = 0, n_out = 0;
     std::vector<float> W, b;
@@ -93,6 +114,7 @@ struct epnn_handle {
     DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
+    int opt_train_graph = 1;          // training: replay the step's launch sequence as a hipGraph (0: launch kernel by kernel)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     // large path workspace (epnn_large.hip.h)
@@ -103,6 +125,16 @@ struct epnn_handle {
     int opt_profile = 0, opt_force_path = 0;
     float timing[4] = {0, 0, 0, 0};
     int64_t stats[4] = {0, 0, 0, 0};
+    // page-locked staging: the plan's index arrays (reused once ev_ctl says the previous upload has run), and the
+    // inputs / charges of the asynchronous host entry (epnn_forward_xyz_begin / _end)
+    PinBuf pin_ctl, pin_in, pin_out;
+    hipEvent_t ev_ctl = nullptr;
+    bool ctl_uploading = false;
+    struct HostCall {
+        bool active = false;          // a begun forward has not been collected yet
+        bool copied = false;          // its charges are already on their way to pin_out
+        int A = 0;
+    } hostcall;
     // deferred overflow handling for the asynchronous entry point
     struct Pending {
         bool active = false;

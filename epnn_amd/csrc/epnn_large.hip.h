@@ -438,16 +438,14 @@ __global__ __launch_bounds__(256) void k_lg_export_q(LargeArgs L) {
 // ================================================================================================ host side
 struct LargePlanHost {
     std::vector<int4> atiles, stasks;
-    std::vector<int> stask_chunk, mflag;
+    std::vector<int> stask_chunk;
     int maxchunk = 0;
 };
 
 static int large_plan(epnn_handle *h) {
     Plan &P = h->plan;
     LargePlanHost lp;
-    lp.mflag.assign(P.B, 0);
     for (int b : P.large_list) {
-        lp.mflag[b] = 1;
         const int a0 = P.offsets[b], n = P.offsets[b + 1] - a0;
         const int first_tile = (int)lp.atiles.size();
         const int ntile = (n + 31) / 32, ngroup = (ntile + 3) / 4;
@@ -473,12 +471,7 @@ static int large_plan(epnn_handle *h) {
     h->l_natiles = (int)lp.atiles.size();
     h->l_nstasks = (int)lp.stasks.size();
     h->l_maxchunk = lp.maxchunk;
-    if (h->l_mflag.ensure(std::max(1, P.B) * sizeof(int))) return 1;
-    HIPCHK(hipMemcpyAsync(h->l_mflag.p, lp.mflag.data(), P.B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    if (P.large_list.empty()) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        return 0;
-    }
+    if (P.large_list.empty()) return 0;          // (the molecule flags travel with the plan's other index arrays)
     const size_t A = (size_t)P.A;
     if (h->l_tiles.ensure(lp.atiles.size() * sizeof(int4)) || h->l_stasks.ensure(lp.stasks.size() * sizeof(int4)) ||
         h->l_schunk.ensure(lp.stask_chunk.size() * sizeof(int)) || h->l_a.ensure(A * EPNN_AST * 4) ||

@@ -331,6 +331,10 @@ struct TrainState {
     bool dev_newer = false;                      // device masters are ahead of the host copies
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
+    // the ~340 launches of one forward + backward, captured once per (B, N, buffer set) and replayed as one hipGraph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    std::vector<const void *> gkey;
 };
 
 static TrainState *train_state(epnn_handle *h) {
@@ -417,7 +421,8 @@ static inline unsigned t_grid(size_t n) { return (unsigned)std::min<size_t>((n +
 // e [B][N][N][48], mask [B][N][N], x [B][N][nx], h0 [B][N][48], q0 [B][N], y [B][N] -> pred [B][N], loss [B];
 // gradients are ADDED into ts->grad (caller zeroes it).
 static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
-                         const float *d_h0, const float *d_q0, const float *d_y, float *d_pred, float *d_loss) {
+                         const float *d_h0, const float *d_q0, const float *d_y, float *d_pred, float *d_loss,
+                         bool size_only = false) {
     TrainState *ts = train_state(h);
     if (!ts->ready) EPNN_FAIL("training: call epnn_train_init first");
     const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, E = EPNN_EDIM, F = nx + H + 1, D = 2 * F + E;
@@ -445,6 +450,7 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
                  o_dU0 = sz((size_t)BN * 80), o_dU1 = sz((size_t)BN * 32), o_dU2 = sz((size_t)BN * 32), o_dh = sz((size_t)BN * H),
                  o_gh = sz((size_t)BN * H), o_gfeat = sz((size_t)BN * H), o_gq = sz(BN), o_dfN = sz(R), o_dfT = sz(R);
     if (ts->arena.ensure(need * 4)) return 1;
+    if (size_only) return 0;            // scratch is allocated: nothing below calls the allocator (graph capture)
     float *ar = ts->arena.as<float>();
     auto P = [&](size_t off) { return ar + off; };
     float *nm = P(o_nm), *wgt = P(o_wgt);

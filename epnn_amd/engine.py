@@ -121,6 +121,27 @@ class Engine:
         check(self.lib.epnn_forward_xyz(self.h, B, int(N), iptr(offsets), fptr(xyz), fptr(x), fptr(Q), fptr(out)), self.lib)
         return out
 
+    def forward_xyz_begin(self, offsets, xyz, x, Q, N):
+        """First half of forward_xyz: returns as soon as the work is queued (the arrays may be reused at once)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        xyz, x, Q = _f32(xyz), _f32(x), _f32(Q)
+        B = len(offsets) - 1
+        A = int(offsets[-1])
+        if xyz.shape != (A, 3) or x.shape != (A, self.nx) or Q.shape != (B,):
+            raise EpnnError(f"forward_xyz: shapes xyz {xyz.shape} x {x.shape} Q {Q.shape} do not match offsets (A={A}, B={B}, nx={self.nx})")
+        check(self.lib.epnn_forward_xyz_begin(self.h, B, int(N), iptr(offsets), fptr(xyz), fptr(x), fptr(Q)), self.lib)
+        self._begun = A
+
+    def forward_xyz_end(self):
+        """Second half: waits for the forward begun on this engine and returns its charges q (A,) float32."""
+        A = getattr(self, "_begun", None)
+        if A is None:
+            raise EpnnError("forward_xyz_end: no forward was begun on this engine")
+        self._begun = None
+        out = np.empty((A,), dtype=np.float32)
+        check(self.lib.epnn_forward_xyz_end(self.h, fptr(out)), self.lib)
+        return out
+
     def _dense_args(self, B, N, tensors, chans):
         out = []
         for t, ch in zip(tensors, chans):
@@ -296,6 +317,19 @@ class Pipeline:
         e = self.engines[self._next % len(self.engines)]
         self._next += 1
         return e
+
+    def map(self, batches, N):
+        """Charges of every batch of `batches` (an iterable of (offsets, xyz, x, Q) host arrays), in order, with up to
+        `depth` batches in flight: while the GPU works on some, the host stages the next and collects the oldest."""
+        busy = []                                   # engines with a begun forward, oldest first
+        for offsets, xyz, x, Q in batches:
+            e = self.lane()
+            if busy and busy[0] is e:
+                yield busy.pop(0).forward_xyz_end()
+            e.forward_xyz_begin(offsets, xyz, x, Q, N)
+            busy.append(e)
+        for e in busy:
+            yield e.forward_xyz_end()
 
     def sync(self):
         for e in self.engines:

@@ -71,6 +71,13 @@ int epnn_edges(epnn_handle *h, int n, const float *xyz, float *e_out);
  * (padded atoms are 0 in the reference output and are not stored).  Host pointers. */
 int epnn_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz, const float *x,
                      const float *Q, float *q_out);
+/* The same call in two halves (the loop of infer.py:62-76 with several batches in flight): _begin copies the host arrays
+ * into page-locked staging owned by the handle (the caller may reuse them at once), queues uploads, kernels and the
+ * download of the charges, and returns without waiting for the GPU; _end waits and writes q_out[A].  One forward per
+ * handle between _begin and _end; use several handles to overlap batches (epnn_amd.engine.Pipeline.map). */
+int epnn_forward_xyz_begin(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz, const float *x,
+                           const float *Q);
+int epnn_forward_xyz_end(epnn_handle *h, float *q_out);
 /* Same with device-resident xyz/x/Q/q_out (offsets stay on the host); asynchronous. */
 int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t *offsets, const float *d_xyz,
                          const float *d_x, const float *d_Q, float *d_q_out);
@@ -134,7 +141,8 @@ int epnn_last_timing(epnn_handle *h, float *out4);
 int epnn_timing_at(epnn_handle *h, int idx, float *out4);
 /* options: "profile" (0 = off, k > 0 = keep stage events of the last k forwards), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
  * "pair_cap_per_atom" (initial capacity of the near-pair list of the tiled / dense paths), "wave_front" (1: batches of small
- * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront). */
+ * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront),
+ * "train_graph" (1: a train step's launch sequence is captured once and replayed as a hipGraph, 0: kernel by kernel). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features
  * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative

@@ -341,3 +341,37 @@ def test_fused_kernel_every_size_vs_oracle(gpu_engine_factory):
                 worst, at = err, n
         print(f"sizes 1..32 {opts}: worst |dq| {worst:.2e} (n = {at}); float32 oracle noise {noise:.2e}")
         assert worst <= max(TOL, 4 * noise), (opts, worst, at)
+
+
+def test_pipeline_map_equals_one_call_at_a_time(weights_decay):
+    """Pipeline.map (epnn_forward_xyz_begin / _end on several handles, page-locked staging, plans uploaded without
+    waiting) returns, in order, bit-for-bit what forward_xyz returns for each batch - also when a batch contains a
+    system for the tiled path (the deferred pair-list regrow runs inside _end)."""
+    from epnn_amd import synth
+    from epnn_amd.engine import Engine, Pipeline
+    batches = [synth.qm9_like_batch(B=40 + 7 * s, seed=s) for s in range(7)]
+    N = max(b[4] for b in batches)
+    big = synth.qm9_like_batch(B=3, seed=99)
+    rng = np.random.default_rng(5)
+    nbig = 70                                         # one 70-atom chain: tiled path
+    xyz_big = np.cumsum(rng.normal(size=(nbig, 3)) * 0.8, axis=0).astype(np.float32)
+    x_big = np.tile(big[2][:1], (nbig, 1))
+    off = np.concatenate([big[0], [big[0][-1] + nbig]]).astype(np.int32)
+    mixed = (off, np.concatenate([big[1], xyz_big]), np.concatenate([big[2], x_big]), np.concatenate([big[3], [0.0]]).astype(np.float32))
+    stream = [b[:4] for b in batches[:3]] + [mixed] + [b[:4] for b in batches[3:]] + [batches[0][:4]]
+    Nall = max(N, nbig)
+    eng = Engine(nx=9, T=5)
+    eng.set_weights(weights_decay)
+    ref = [eng.forward_xyz(*b, Nall) for b in stream]
+    eng.close()
+    pipe = Pipeline(depth=3, nx=9, T=5)
+    pipe.set_weights(weights_decay)
+    got = list(pipe.map(stream, Nall))
+    pipe.close()
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    eng = Engine(nx=9, T=5)
+    with pytest.raises(Exception):
+        eng.forward_xyz_end()
+    eng.close()

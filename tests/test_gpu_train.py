@@ -85,6 +85,31 @@ def test_adam_trajectory_matches_oracle(gpu_engine_factory):
     assert np.abs(pred - ref).max() < 2e-5
 
 
+def test_graph_replay_equals_kernel_by_kernel(gpu_engine_factory):
+    """The train step replays its launch sequence as a hipGraph ("train_graph", default on): losses, predictions and the
+    weights after five Adam steps must be bit-identical to launching kernel by kernel."""
+    nx, T, N = 9, 2, 8
+    w = random_weights(nx, T, seed=3, scale=0.5)
+    batches = [_tiny_batch(nx, N, [7, 5], seed=s) for s in range(2)]
+    out = []
+    for graph in (1, 0):
+        eng = gpu_engine_factory(nx=nx, T=T)
+        eng.set_option("train_graph", graph)
+        eng.set_weights(w)
+        eng.train_init()
+        tr = []
+        for step in range(5):
+            h, e, x, q, mask, y = batches[step % 2]
+            p, l = eng.train_step_dense(h, e, x, q, mask, y, apply=True)
+            tr.append((p.copy(), l))
+        out.append((tr, eng.get_weights()))
+    (ta, wa), (tb, wb) = out
+    for (pa, la), (pb, lb) in zip(ta, tb):
+        assert la == lb and np.array_equal(pa, pb)
+    from oracle import epnn_oracle_train as ot
+    assert np.array_equal(ot.flatten(wa), ot.flatten(wb))
+
+
 def test_train_step_xyz_equals_dense(gpu_engine_factory, val_dir, val_names):
     from conftest import load_molecules
     from oracle import epnn_oracle as orc
