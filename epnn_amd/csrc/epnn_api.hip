@@ -986,6 +986,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
+    else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -1303,6 +1304,15 @@ extern "C" int epnn_train_apply(epnn_handle *h) {
 }
 
 // shared tail of the two train-step entry points: slot arrays are on the device
+// forward + backward of one batch: row-fused kernels when the padded size fits their LDS budget ("train_fused", default 1),
+// else (or with the option at 0) the layer-by-layer kernels
+static int train_fb(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x, const float *d_h0,
+                    const float *d_q0, const float *d_y, float *d_pred, float *d_loss, bool size_only = false) {
+    if (h->opt_train_fused && N <= EPNN_TF_NMAX)
+        return train_fwd_bwd_fused(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only);
+    return train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only);
+}
+
 static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
                             const float *d_h0, const float *d_q0, const float *d_y, float *pred_host, float *loss_host, int apply) {
     TrainState *ts = train_state(h);
@@ -1312,15 +1322,15 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     if (h->opt_train_graph) {
         // One molecule padded to N = 41 is ~2 Gflop spread over ~340 tiny launches: the step is launch-bound, so the
         // launch sequence is recorded once per (B, N, buffer set) and replayed as one hipGraph.
-        if (train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, true)) return 1;
-        const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
+        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, true)) return 1;
+        const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, (const void *)(size_t)h->opt_train_fused, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
                                                d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p};
         if (!ts->gexec || key != ts->gkey) {
             if (ts->gexec) { (void)hipGraphExecDestroy(ts->gexec); ts->gexec = nullptr; }
             if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
             HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
             int bad = hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream) != hipSuccess;
-            bad = bad || train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss);
+            bad = bad || train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss);
             const hipError_t ec = hipStreamEndCapture(h->stream, &ts->graph);
             if (bad || ec != hipSuccess) {
                 if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
@@ -1333,7 +1343,7 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
         HIPCHK(hipGraphLaunch(ts->gexec, h->stream));
     } else {
         HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));
-        if (train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss)) return 1;
+        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss)) return 1;
     }
     if (apply && train_apply(h)) return 1;
     if (pred_host) HIPCHK(hipMemcpyAsync(pred_host, d_pred, (size_t)B * N * 4, hipMemcpyDeviceToHost, h->stream));

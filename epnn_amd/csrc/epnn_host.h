@@ -114,6 +114,7 @@ struct epnn_handle {
     DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
+    int opt_train_fused = 1;          // training: row-fused pair-MLP kernels (0: the layer-by-layer kernels)
     int opt_train_graph = 1;          // training: replay the step's launch sequence as a hipGraph (0: launch kernel by kernel)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)

@@ -11,6 +11,7 @@
 // model.trainable_variables (charge_gn.py:371-374): update MLP, message MLPs t=0.., pass MLPs t=0..; kernel, bias.
 #pragma once
 #include "epnn_host.h"
+#include "epnn_train_fused.hip.h"
 
 struct TDense {            // one Dense inside the flat parameter vector
     int offW, offB, n_in, n_out;
@@ -335,6 +336,7 @@ struct TrainState {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     std::vector<const void *> gkey;
+    bool fused_attr = false;                     // dynamic LDS limit of the row-fused kernels raised
 };
 
 static TrainState *train_state(epnn_handle *h) {
@@ -561,6 +563,123 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
         hipLaunchKernelGGL(k_t_rows_bwd, dim3(t_grid((size_t)BN * F)), dim3(256), 0, st, P(o_dX), da, B, N, F, E, 0);
         hipLaunchKernelGGL(k_t_gh_prev, dim3(t_grid((size_t)BN * H)), dim3(256), 0, st, P(o_dU0), nm, da, gh, BN, nx, H, 32);
     }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The same forward + backward with the row-fused kernels of epnn_train_fused.hip.h (N <= EPNN_TF_NMAX): ~45 launches.
+static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
+                               const float *d_h0, const float *d_q0, const float *d_y, float *d_pred, float *d_loss,
+                               bool size_only = false) {
+    TrainState *ts = train_state(h);
+    if (!ts->ready) EPNN_FAIL("training: call epnn_train_init first");
+    const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, E = EPNN_EDIM, F = nx + H + 1, D = 2 * F + E, FS = F | 1;
+    const int BN = B * N;
+    const size_t R = (size_t)BN * N;
+    hipStream_t st = h->stream;
+    const float *theta = ts->theta.as<float>();
+    float *grad = ts->grad.as<float>();
+    const int Pm0 = D * 32 + 32 + 1024 + 32 + 32 * 32 + 32, Pm1 = D * 32 + 32 + 1024 + 32 + 32 + 1;
+    if (2 * T + 1 > EPNN_TF_MAXRED) EPNN_FAIL("training: T = %d exceeds the fused step's reduction table", T);
+    // ---- arena
+    size_t need = 0;
+    auto sz = [&](size_t n) { size_t o = need; need += (n + 63) & ~size_t(63); return o; };
+    struct GStep { size_t H1, H2, M, U0, U1, U2, hn; } gs[EPNN_MAXT];
+    struct EStep { size_t H1, H2, qn; } es[EPNN_MAXT];
+    const size_t o_nm = sz(BN), o_wgt = sz(R);
+    for (int t = 0; t < T; ++t)
+        gs[t] = {sz(R * 32), sz(R * 32), sz((size_t)BN * 32), sz((size_t)BN * 80), sz((size_t)BN * 32), sz((size_t)BN * 32), sz((size_t)BN * H)};
+    for (int t = 0; t < T; ++t) es[t] = {sz(2 * R * 32), sz(2 * R * 32), sz(BN)};
+    const size_t o_dz1 = sz(2 * R * 32), o_dU0 = sz((size_t)BN * 80), o_gh = sz((size_t)BN * H), o_gfeat = sz((size_t)BN * H), o_gq = sz(BN);
+    size_t o_pm[EPNN_MAXT], o_pp[EPNN_MAXT];
+    for (int t = 0; t < T; ++t) o_pm[t] = sz((size_t)BN * Pm0);
+    for (int t = 0; t < T; ++t) o_pp[t] = sz((size_t)BN * Pm1);
+    const size_t o_pu = sz((size_t)T * BN * EPNN_TF_PU);
+    if (ts->arena.ensure(need * 4)) return 1;
+    const size_t lds_fwd = ((size_t)N * FS + (size_t)N * 49 + (size_t)D * 32 + 4 * (size_t)N * 33 + 288) * 4;
+    const size_t lds_bwd = ((size_t)N * FS + (size_t)N * 49 + 8 * (size_t)N * 33 + 32 * 33 + 192 + N) * 4;
+    if (!ts->fused_attr) {
+        const int cap = 160 * 1024;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        ts->fused_attr = true;
+    }
+    if (size_only) return 0;            // scratch is allocated: nothing below calls the allocator (graph capture)
+    float *ar = ts->arena.as<float>();
+    auto P = [&](size_t off) { return ar + off; };
+    float *nm = P(o_nm), *wgt = P(o_wgt);
+    auto pair_args = [&](const TDense *mlp, const float *hh, const float *qq) {
+        TfPair A{};
+        A.x = d_x; A.h = hh; A.q = qq; A.e = d_e; A.theta = theta;
+        A.oW1 = mlp[0].offW; A.ob1 = mlp[0].offB; A.oW2 = mlp[1].offW; A.ob2 = mlp[1].offB; A.oW3 = mlp[2].offW; A.ob3 = mlp[2].offB;
+        A.N = N; A.nx = nx; A.wgt = wgt; A.nm = nm; A.dz1 = P(o_dz1);
+        return A;
+    };
+    auto upd_args = [&](int t, const float *hh) {
+        TfUpd U{};
+        U.h = hh; U.M = P(gs[t].M); U.nm = nm; U.theta = theta;
+        U.oW0 = ts->upd[0].offW; U.ob0 = ts->upd[0].offB; U.oW1 = ts->upd[1].offW; U.ob1 = ts->upd[1].offB;
+        U.oW2 = ts->upd[2].offW; U.ob2 = ts->upd[2].offB;
+        U.U0 = P(gs[t].U0); U.U1 = P(gs[t].U1); U.U2 = P(gs[t].U2); U.hn = P(gs[t].hn);
+        U.gh = P(o_gh); U.dU0 = P(o_dU0); U.part = P(o_pu) + (size_t)t * BN * EPNN_TF_PU;
+        return U;
+    };
+    hipLaunchKernelGGL(k_t_nodemask, dim3(t_grid(BN)), dim3(256), 0, st, d_mask, nm, B, N);
+    hipLaunchKernelGGL(k_t_wgt, dim3(t_grid(R)), dim3(256), 0, st, d_e, d_mask, wgt, (int)R, E, h->cfg.near_tol);
+    // ================================================================ forward: GNN (charge_gn.py:60-74)
+    const float *hcur = d_h0;
+    for (int t = 0; t < T; ++t) {
+        TfPair A = pair_args(ts->msg[t], hcur, d_q0);
+        A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
+        hipLaunchKernelGGL(k_tf_pair_fwd<0>, dim3(BN), dim3(256), lds_fwd, st, A);
+        hipLaunchKernelGGL(k_tf_update_fwd, dim3(BN), dim3(64), 0, st, upd_args(t, hcur));
+        hcur = P(gs[t].hn);
+    }
+    const float *feats = hcur;
+    // ================================================================ forward: EPN (charge_gn.py:98-118)
+    const float *qcur = d_q0;
+    for (int t = 0; t < T; ++t) {
+        TfPair A = pair_args(ts->pas[t], feats, qcur);
+        A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.qn = P(es[t].qn);
+        hipLaunchKernelGGL(k_tf_pair_fwd<1>, dim3(BN), dim3(256), lds_fwd, st, A);
+        qcur = P(es[t].qn);
+    }
+    HIPCHK(hipMemcpyAsync(d_pred, qcur, (size_t)BN * 4, hipMemcpyDeviceToDevice, st));
+    // ================================================================ loss (charge_gn.py:397-398)
+    float *gq = P(o_gq), *gfeat = P(o_gfeat), *gh = P(o_gh);
+    hipLaunchKernelGGL(k_t_loss, dim3(B), dim3(64), 0, st, d_y, qcur, gq, d_loss, N);
+    HIPCHK(hipMemsetAsync(gfeat, 0, (size_t)BN * H * 4, st));
+    // ================================================================ backward: EPN
+    for (int t = T - 1; t >= 0; --t) {
+        TfPair A = pair_args(ts->pas[t], feats, t ? P(es[t - 1].qn) : d_q0);
+        A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.gq = gq; A.part = P(o_pp[t]); A.gacc = gfeat;
+        hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(256), lds_bwd, st, A);
+        hipLaunchKernelGGL(k_tb_atoms<1>, dim3(BN), dim3(128), 0, st, A);
+    }
+    // ================================================================ backward: GNN
+    HIPCHK(hipMemcpyAsync(gh, gfeat, (size_t)BN * H * 4, hipMemcpyDeviceToDevice, st));
+    for (int t = T - 1; t >= 0; --t) {
+        const float *hin = t ? P(gs[t - 1].hn) : d_h0;
+        hipLaunchKernelGGL(k_tb_update_bwd, dim3(BN), dim3(64), 0, st, upd_args(t, hin));
+        TfPair A = pair_args(ts->msg[t], hin, d_q0);
+        A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.dU0 = P(o_dU0); A.part = P(o_pm[t]); A.gacc = gh;
+        hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(256), lds_bwd, st, A);
+        hipLaunchKernelGGL(k_tb_atoms<0>, dim3(BN), dim3(128), 0, st, A);
+    }
+    // ================================================================ gradient = sum of the workgroups' partials
+    TfReduce Rd{};
+    int maxlen = 0;
+    auto entry = [&](int theta_off, int len, int nblk, size_t part_off) {
+        Rd.theta_off[Rd.n] = theta_off; Rd.len[Rd.n] = len; Rd.nblk[Rd.n] = nblk; Rd.part_off[Rd.n] = part_off;
+        Rd.n += 1;
+        maxlen = std::max(maxlen, len);
+    };
+    entry(ts->upd[0].offW, EPNN_TF_PU, T * BN, o_pu);
+    for (int t = 0; t < T; ++t) entry(ts->msg[t][0].offW, Pm0, BN, o_pm[t]);
+    for (int t = 0; t < T; ++t) entry(ts->pas[t][0].offW, Pm1, BN, o_pp[t]);
+    hipLaunchKernelGGL(k_tb_wreduce, dim3((unsigned)((maxlen + 63) / 64), (unsigned)Rd.n), dim3(256), 0, st, Rd, ar, grad);
     HIPCHK(hipGetLastError());
     return 0;
 }

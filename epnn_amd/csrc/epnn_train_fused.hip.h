@@ -1,0 +1,464 @@
+// Training step, fused along the pair rows (reference charge_gn.py:393-402; forward :56-75 and :87-119).
+//
+// One molecule padded to N = 41 is 1681 pair rows and ~2 Gflop per step: every kernel of the layer-by-layer path
+// (epnn_train.hip.h) is a short dependent chain on a few dozen wavefronts and lasts ~9 us whatever it computes (kernel
+// trace in DESIGN.md section 6b).  Here ONE workgroup owns atom i of a molecule and runs the whole pair MLP over its N
+// partner rows -- both orders of the pair for the pass network -- with the rows [a_i | a_j | e_ij] (charge_gn.py:62-66,
+// 101-108) assembled in LDS instead of HBM; the backward kernel does the same and leaves one block of weight-gradient
+// partials per workgroup, summed in a fixed order by one launch at the end of the step.  ~45 launches instead of ~340.
+// The work per launch is far too small for the matrix pipe to matter (latency-bound): plain FMA code, LDS-resident rows.
+// All sums have a fixed order: gradients are bit-reproducible.
+#pragma once
+#include "epnn_host.h"
+
+#define EPNN_TF_NMAX 96          // LDS of the backward kernel: 372 N + 2 k floats
+#define EPNN_TF_JM 6             // partner rows per thread and pass of the layer-1 loop (8 row groups x 6 = 48 rows)
+
+struct TfPair {                  // one sweep of a pair MLP (message network of GNN step t / pass network of EPN step t)
+    const float *x, *h, *q;      // the step's per-atom inputs: x [BN][nx], h [BN][48], q [BN]   (a = [x | h | q])
+    const float *e;              // [R][48]
+    const float *theta;          // flat parameters; the MLP's six tensors start at these offsets
+    int oW1, ob1, oW2, ob2, oW3, ob3;
+    float *H1, *H2;              // post-activation hidden layers [dir][R][32] (dir 1 = rows [a_j | a_i | e_ij], pass network only)
+    float *M;                    // message network: summed messages [BN][32]         (charge_gn.py:70)
+    const float *wgt;            // pass network: mask * is_near [R]                   (charge_gn.py:90-94,116)
+    float *qn;                   // pass network: q + sum_j 0.5 (f_ij - f_ji) wgt [BN] (charge_gn.py:116-118)
+    int N, nx;
+    // backward
+    const float *dU0, *nm;       // message network: gradient of the update MLP's input [BN][80], node mask [BN]
+    float *gq;                   // pass network: gradient of the loss w.r.t. the step's output charges [BN]
+    float *dz1;                  // gradient at the first layer's pre-activation [dir][R][32]
+    float *part;                 // weight-gradient partials [BN][Pm], Pm = D*32 + 32 + 1024 + 32 + 32*O + O (parameter order)
+    float *gacc;                 // atoms kernel: pass network gfeat [BN][48] (+=), message network gh [BN][48] (=)
+};
+
+// ---------------------------------------------------------------------------------------------- forward, pair MLP
+// MODE 0: message network (out_dim 32, summed over ALL N partners); MODE 1: pass network (out_dim 1, both orders).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
+    extern __shared__ __attribute__((aligned(16))) float tf_sm[];
+    const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
+    const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
+    const int tid = threadIdx.x, o = tid & 31, g = tid >> 5;
+    constexpr int ND = MODE ? 2 : 1;
+    float *As = tf_sm;                        // [N][FS]   a_j of every atom of the molecule
+    float *Es = As + N * FS;                  // [N][49]   e_ij of this atom's rows
+    float *W1s = Es + N * 49;                 // [D][32]
+    float *H1s = W1s + D * 32;                // [ND][N][33]
+    float *H2s = H1s + ND * N * 33;           // [ND][N][33]
+    float *red = H2s + ND * N * 33;           // [8][32] + [32]  /  [2][N]
+    const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
+    const size_t dstride = (size_t)gridDim.x * N * 32;
+    for (int idx = tid; idx < N * F; idx += 256) {
+        const int j = idx / F, k = idx - j * F;
+        const size_t at = a0 + j;
+        As[j * FS + k] = k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
+    }
+    for (int idx = tid; idx < N * 48; idx += 256) {
+        const int j = idx / 48, k = idx - j * 48;
+        Es[j * 49 + k] = A.e[rowbase * 48 + idx];
+    }
+    for (int idx = tid; idx < D * 32; idx += 256) W1s[idx] = A.theta[A.oW1 + idx];
+    __syncthreads();
+    // ---- layer 1: z1 = b1 + a_i W1[0:F] + a_j W1[F:2F] + e_ij W1[2F:]   (the a_i term once per thread, not per row)
+    const float b1 = A.theta[A.ob1 + o];
+    const float *ai = As + i * FS;
+    float pa = b1, ra = 0.f;
+    for (int k = 0; k < F; ++k) {
+        pa = fmaf(ai[k], W1s[k * 32 + o], pa);
+        if (MODE) ra = fmaf(ai[k], W1s[(F + k) * 32 + o], ra);
+    }
+    for (int jb = 0; jb < N; jb += 8 * EPNN_TF_JM) {
+        float accR[EPNN_TF_JM], accG[EPNN_TF_JM], accP[EPNN_TF_JM];
+        int jr[EPNN_TF_JM];
+#pragma unroll
+        for (int m = 0; m < EPNN_TF_JM; ++m) {
+            jr[m] = min(jb + g + 8 * m, N - 1);
+            accR[m] = accG[m] = accP[m] = 0.f;
+        }
+        for (int k = 0; k < F; ++k) {
+            const float wR = W1s[(F + k) * 32 + o], wP = MODE ? W1s[k * 32 + o] : 0.f;
+#pragma unroll
+            for (int m = 0; m < EPNN_TF_JM; ++m) {
+                const float a = As[jr[m] * FS + k];
+                accR[m] = fmaf(a, wR, accR[m]);
+                if (MODE) accP[m] = fmaf(a, wP, accP[m]);
+            }
+        }
+        for (int k = 0; k < 48; ++k) {
+            const float wG = W1s[(2 * F + k) * 32 + o];
+#pragma unroll
+            for (int m = 0; m < EPNN_TF_JM; ++m) accG[m] = fmaf(Es[jr[m] * 49 + k], wG, accG[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < EPNN_TF_JM; ++m) {
+            const int j = jb + g + 8 * m;
+            if (j < N) {
+                const float h1 = fmaxf((pa + accR[m]) + accG[m], 0.f);
+                H1s[j * 33 + o] = h1;
+                A.H1[(rowbase + j) * 32 + o] = h1;
+                if (MODE) {
+                    const float h1t = fmaxf(((b1 + accP[m]) + ra) + accG[m], 0.f);
+                    H1s[(N + j) * 33 + o] = h1t;
+                    A.H1[dstride + (rowbase + j) * 32 + o] = h1t;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2
+    {
+        float w2[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) w2[k] = A.theta[A.oW2 + k * 32 + o];
+        const float b2 = A.theta[A.ob2 + o];
+        for (int d = 0; d < ND; ++d)
+            for (int j = g; j < N; j += 8) {
+                const float *hr = H1s + (d * N + j) * 33;
+                float z = b2;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) z = fmaf(hr[k], w2[k], z);
+                const float h2 = fmaxf(z, 0.f);
+                H2s[(d * N + j) * 33 + o] = h2;
+                A.H2[d * dstride + (rowbase + j) * 32 + o] = h2;
+            }
+    }
+    __syncthreads();
+    // ---- layer 3 (linear) and the reduction over partners
+    if (MODE == 0) {
+        // sum_j (H2_j W3 + b3) = (sum_j H2_j) W3 + N b3: column sums in a fixed order, then one 32x32 product
+        float cs = 0.f;
+        for (int j = g; j < N; j += 8) cs += H2s[j * 33 + o];
+        red[g * 32 + o] = cs;
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.f;
+            for (int gg = 0; gg < 8; ++gg) s += red[gg * 32 + tid];
+            red[256 + tid] = s;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float mo = (float)N * A.theta[A.ob3 + tid];
+            for (int k = 0; k < 32; ++k) mo = fmaf(red[256 + k], A.theta[A.oW3 + k * 32 + tid], mo);
+            A.M[(size_t)bi * 32 + tid] = mo;
+        }
+    } else {
+        float *fs = red;                      // [2][N]
+        for (int idx = tid; idx < 2 * N; idx += 256) {
+            const float *hr = H2s + idx * 33;
+            float f = A.theta[A.ob3];
+            for (int k = 0; k < 32; ++k) f = fmaf(hr[k], A.theta[A.oW3 + k], f);
+            fs[idx] = f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * A.wgt[rowbase + j];
+            A.qn[bi] = A.q[bi] + s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward, pair MLP
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tb_pair_bwd(TfPair A) {
+    extern __shared__ __attribute__((aligned(16))) float tf_sm[];
+    const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
+    const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
+    const int tid = threadIdx.x, o = tid & 31, g = tid >> 5;
+    constexpr int ND = MODE ? 2 : 1;
+    constexpr int O = MODE ? 1 : 32;
+    float *As = tf_sm;                        // [N][FS]
+    float *Es = As + N * FS;                  // [N][49]
+    float *H1s = Es + N * 49;                 // [ND][N][33]
+    float *H2s = H1s + ND * N * 33;
+    float *D1s = H2s + ND * N * 33;           // gradient at z1
+    float *D2s = D1s + ND * N * 33;           // gradient at z2
+    float *W2s = D2s + ND * N * 33;           // [32][33]
+    float *vec = W2s + 32 * 33;               // dms [32] | vs [32] | s1 [2][32] | sb2 [32] | c2 / dw3 [32] | df [N]
+    float *dms = vec, *vs = vec + 32, *s1 = vec + 64, *sb2 = vec + 128, *c2 = vec + 160, *dfs = vec + 192;
+    const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
+    const size_t dstride = (size_t)gridDim.x * N * 32;
+    for (int idx = tid; idx < N * F; idx += 256) {
+        const int j = idx / F, k = idx - j * F;
+        const size_t at = a0 + j;
+        As[j * FS + k] = k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
+    }
+    for (int idx = tid; idx < N * 48; idx += 256) {
+        const int j = idx / 48, k = idx - j * 48;
+        Es[j * 49 + k] = A.e[rowbase * 48 + idx];
+    }
+    for (int d = 0; d < ND; ++d)
+        for (int idx = tid; idx < N * 32; idx += 256) {
+            const int j = idx >> 5, k = idx & 31;
+            H1s[(d * N + j) * 33 + k] = A.H1[d * dstride + rowbase * 32 + idx];
+            H2s[(d * N + j) * 33 + k] = A.H2[d * dstride + rowbase * 32 + idx];
+        }
+    for (int idx = tid; idx < 1024; idx += 256) W2s[(idx >> 5) * 33 + (idx & 31)] = A.theta[A.oW2 + idx];
+    if (MODE == 0) {
+        if (tid < 32) dms[tid] = A.dU0[(size_t)bi * 80 + 48 + tid] * A.nm[bi];     // dM_i: the same for every partner row
+    } else {
+        const float gqi = 0.5f * A.gq[bi];
+        for (int j = tid; j < N; j += 256) dfs[j] = gqi * A.wgt[rowbase + j];      // df_ij; the swapped row gets -df_ij
+    }
+    __syncthreads();
+    // ---- gradient at z2 = [H2 > 0] * (dOut W3^T)
+    if (MODE == 0) {
+        if (tid < 32) {
+            float v = 0.f;
+            for (int oo = 0; oo < 32; ++oo) v = fmaf(dms[oo], A.theta[A.oW3 + tid * 32 + oo], v);
+            vs[tid] = v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * 32; idx += 256) {
+            const int j = idx >> 5, k = idx & 31;
+            D2s[j * 33 + k] = H2s[j * 33 + k] > 0.f ? vs[k] : 0.f;
+        }
+    } else {
+        const float w3 = A.theta[A.oW3 + o];
+        for (int d = 0; d < 2; ++d)
+            for (int j = g; j < N; j += 8) {
+                const float df = d ? -dfs[j] : dfs[j];
+                D2s[(d * N + j) * 33 + o] = H2s[(d * N + j) * 33 + o] > 0.f ? df * w3 : 0.f;
+            }
+    }
+    __syncthreads();
+    // ---- gradient at z1 = [H1 > 0] * (dz2 W2^T); thread = (k = o, row group g)
+    {
+        float w2row[32];
+#pragma unroll
+        for (int oo = 0; oo < 32; ++oo) w2row[oo] = W2s[o * 33 + oo];
+        for (int d = 0; d < ND; ++d)
+            for (int j = g; j < N; j += 8) {
+                const float *dr = D2s + (d * N + j) * 33;
+                float s = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < 32; ++oo) s = fmaf(dr[oo], w2row[oo], s);
+                const float v = H1s[(d * N + j) * 33 + o] > 0.f ? s : 0.f;
+                D1s[(d * N + j) * 33 + o] = v;
+                A.dz1[d * dstride + (rowbase + j) * 32 + o] = v;
+            }
+    }
+    __syncthreads();
+    // ---- column sums (fixed order over j)
+    if (tid < 32 * ND) {                      // s1[d][o] = sum_j dz1
+        const int d = tid >> 5;
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += D1s[(d * N + j) * 33 + o];
+        s1[d * 32 + o] = s;
+    } else if (tid >= 64 && tid < 96) {       // sb2[o] = sum_d sum_j dz2
+        float s = 0.f;
+        for (int d = 0; d < ND; ++d)
+            for (int j = 0; j < N; ++j) s += D2s[(d * N + j) * 33 + o];
+        sb2[o] = s;
+    } else if (tid >= 96 && tid < 128) {      // message: c2[k] = sum_j H2; pass: dw3[k] = sum_d sum_j H2 * df
+        float s = 0.f;
+        if (MODE == 0) {
+            for (int j = 0; j < N; ++j) s += H2s[j * 33 + o];
+        } else {
+            for (int j = 0; j < N; ++j) s = fmaf(H2s[j * 33 + o], dfs[j], s);
+            for (int j = 0; j < N; ++j) s = fmaf(H2s[(N + j) * 33 + o], -dfs[j], s);
+        }
+        c2[o] = s;
+    }
+    __syncthreads();
+    // ---- weight-gradient partials of this workgroup, in parameter order: W1 [D][32] | b1 | W2 [32][32] | b2 | W3 [32][O] | b3
+    const int Pm = D * 32 + 32 + 1024 + 32 + 32 * O + O;
+    float *P = A.part + (size_t)bi * Pm;
+    const float *ai = As + i * FS;
+    for (int k = g; k < D; k += 8) {
+        float v;
+        if (k < F) {                          // first block of the row: a_i (rows as listed) / a_j (swapped rows)
+            v = ai[k] * s1[o];
+            if (MODE) {
+                float s = 0.f;
+                for (int j = 0; j < N; ++j) s = fmaf(As[j * FS + k], D1s[(N + j) * 33 + o], s);
+                v += s;
+            }
+        } else if (k < 2 * F) {               // second block: a_j / a_i
+            const int kk = k - F;
+            float s = 0.f;
+            for (int j = 0; j < N; ++j) s = fmaf(As[j * FS + kk], D1s[j * 33 + o], s);
+            v = s;
+            if (MODE) v += ai[kk] * s1[32 + o];
+        } else {                              // edge block: the same e_ij in both orders
+            const int kk = k - 2 * F;
+            float s = 0.f;
+            for (int j = 0; j < N; ++j) s = fmaf(Es[j * 49 + kk], D1s[j * 33 + o] + (MODE ? D1s[(N + j) * 33 + o] : 0.f), s);
+            v = s;
+        }
+        P[k * 32 + o] = v;
+    }
+    float *Pb1 = P + D * 32, *PW2 = Pb1 + 32, *Pb2 = PW2 + 1024, *PW3 = Pb2 + 32, *Pb3 = PW3 + 32 * O;
+    if (tid < 32) {
+        Pb1[tid] = s1[tid] + (MODE ? s1[32 + tid] : 0.f);
+        Pb2[tid] = sb2[tid];
+    }
+    for (int k = g; k < 32; k += 8) {         // dW2[k][o] = sum_d sum_j H1[j][k] dz2[j][o]
+        float s = 0.f;
+        for (int d = 0; d < ND; ++d)
+            for (int j = 0; j < N; ++j) s = fmaf(H1s[(d * N + j) * 33 + k], D2s[(d * N + j) * 33 + o], s);
+        PW2[k * 32 + o] = s;
+    }
+    if (MODE == 0) {
+        for (int k = g; k < 32; k += 8) PW3[k * 32 + o] = c2[k] * dms[o];
+        if (tid < 32) Pb3[tid] = (float)N * dms[tid];
+    } else {
+        if (tid < 32) PW3[tid] = c2[tid];
+        if (tid == 0) Pb3[0] = 0.f;           // sum over the rows of df and of -df, each in the same order: exactly 0
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward, to the atoms
+// da_a = (row / column sums of dz1 in which atom a is the first block of the row) W1[0:F]^T + (... second block) W1[F:2F]^T;
+// only the h and q parts of a = [x | h | q] carry gradient.  Pass network: gfeat += da_h, gq += da_q.  Message network:
+// gh = dU0[:, :48] * nm + da_h  (the gradient w.r.t. the previous step's h; q is the frozen initial charge there).
+template <int MODE>
+__global__ __launch_bounds__(128) void k_tb_atoms(TfPair A) {
+    __shared__ float sh[4][32];
+    const int N = A.N, nx = A.nx, F = nx + 49;
+    const int bi = blockIdx.x, b = bi / N, ia = bi - b * N;
+    const int tid = threadIdx.x, o = tid & 31, which = tid >> 5;
+    const size_t dstride = (size_t)gridDim.x * N * 32;
+    const size_t rows = (size_t)bi * N, mol = (size_t)b * N;
+    float s = 0.f;
+    if (which == 0) {                         // listed rows (a, j): a is the first block
+        for (int j = 0; j < N; ++j) s += A.dz1[(rows + j) * 32 + o];
+    } else if (which == 1) {                  // listed rows (i, a): a is the second block
+        for (int i = 0; i < N; ++i) s += A.dz1[((mol + i) * N + ia) * 32 + o];
+    } else if (MODE == 1 && which == 2) {     // swapped rows (i, a) = [a_a | a_i | e]: a is the first block
+        for (int i = 0; i < N; ++i) s += A.dz1[dstride + ((mol + i) * N + ia) * 32 + o];
+    } else if (MODE == 1) {                   // swapped rows (a, j) = [a_j | a_a | e]: a is the second block
+        for (int j = 0; j < N; ++j) s += A.dz1[dstride + (rows + j) * 32 + o];
+    }
+    sh[which][o] = s;
+    __syncthreads();
+    const int k = nx + tid;                   // h part: k in [nx, nx+48), q part: k = nx + 48
+    if (k < F) {
+        float da = 0.f;
+        for (int oo = 0; oo < 32; ++oo) {
+            const float sP = sh[0][oo] + sh[2][oo], sR = sh[1][oo] + sh[3][oo];
+            da = fmaf(sP, A.theta[A.oW1 + k * 32 + oo], da);
+            da = fmaf(sR, A.theta[A.oW1 + (F + k) * 32 + oo], da);
+        }
+        if (MODE == 1) {
+            if (tid < 48) A.gacc[(size_t)bi * 48 + tid] += da;
+            else A.gq[bi] += da;
+        } else if (tid < 48) {
+            A.gacc[(size_t)bi * 48 + tid] = A.dU0[(size_t)bi * 80 + tid] * A.nm[bi] + da;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- update MLP
+struct TfUpd {
+    const float *h, *M, *nm, *theta;          // h [BN][48] (input of the step), M [BN][32]
+    int oW0, ob0, oW1, ob1, oW2, ob2;
+    float *U0, *U1, *U2, *hn;                 // [BN][80], [BN][32], [BN][32], [BN][48] = update(...) * nm   (charge_gn.py:71-74)
+    const float *gh;                          // backward: gradient w.r.t. hn [BN][48]
+    float *dU0;                               // [BN][80]
+    float *part;                              // [BN][Pu], Pu = 80*32 + 32 + 32*32 + 32 + 32*48 + 48
+};
+#define EPNN_TF_PU (80 * 32 + 32 + 32 * 32 + 32 + 32 * 48 + 48)
+
+__global__ __launch_bounds__(64) void k_tf_update_fwd(TfUpd U) {
+    __shared__ float u0[80], u1[32], u2[32];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const float nm = U.nm[a];
+    for (int k = tid; k < 80; k += 64) {
+        const float v = (k < 48 ? U.h[(size_t)a * 48 + k] : U.M[(size_t)a * 32 + (k - 48)]) * nm;
+        u0[k] = v;
+        U.U0[(size_t)a * 80 + k] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float z = U.theta[U.ob0 + tid];
+        for (int k = 0; k < 80; ++k) z = fmaf(u0[k], U.theta[U.oW0 + k * 32 + tid], z);
+        z = fmaxf(z, 0.f);
+        u1[tid] = z;
+        U.U1[(size_t)a * 32 + tid] = z;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float z = U.theta[U.ob1 + tid];
+        for (int k = 0; k < 32; ++k) z = fmaf(u1[k], U.theta[U.oW1 + k * 32 + tid], z);
+        z = fmaxf(z, 0.f);
+        u2[tid] = z;
+        U.U2[(size_t)a * 32 + tid] = z;
+    }
+    __syncthreads();
+    if (tid < 48) {
+        float z = U.theta[U.ob2 + tid];
+        for (int k = 0; k < 32; ++k) z = fmaf(u2[k], U.theta[U.oW2 + k * 48 + tid], z);
+        U.hn[(size_t)a * 48 + tid] = z * nm;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tb_update_bwd(TfUpd U) {
+    __shared__ float u0[80], u1[32], u2[32], dh[48], du2[32], du1[32];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const float nm = U.nm[a];
+    for (int k = tid; k < 80; k += 64) u0[k] = U.U0[(size_t)a * 80 + k];
+    if (tid < 32) {
+        u1[tid] = U.U1[(size_t)a * 32 + tid];
+        u2[tid] = U.U2[(size_t)a * 32 + tid];
+    }
+    if (tid < 48) dh[tid] = U.gh[(size_t)a * 48 + tid] * nm;
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f;
+        for (int oo = 0; oo < 48; ++oo) s = fmaf(dh[oo], U.theta[U.oW2 + tid * 48 + oo], s);
+        du2[tid] = u2[tid] > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f;
+        for (int oo = 0; oo < 32; ++oo) s = fmaf(du2[oo], U.theta[U.oW1 + tid * 32 + oo], s);
+        du1[tid] = u1[tid] > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < 80; k += 64) {
+        float s = 0.f;
+        for (int oo = 0; oo < 32; ++oo) s = fmaf(du1[oo], U.theta[U.oW0 + k * 32 + oo], s);
+        U.dU0[(size_t)a * 80 + k] = s;
+    }
+    // weight-gradient partials of this atom (rank one per layer), parameter order
+    float *P = U.part + (size_t)a * EPNN_TF_PU;
+    for (int idx = tid; idx < 80 * 32; idx += 64) P[idx] = u0[idx >> 5] * du1[idx & 31];
+    P += 80 * 32;
+    if (tid < 32) P[tid] = du1[tid];
+    P += 32;
+    for (int idx = tid; idx < 32 * 32; idx += 64) P[idx] = u1[idx >> 5] * du2[idx & 31];
+    P += 32 * 32;
+    if (tid < 32) P[tid] = du2[tid];
+    P += 32;
+    for (int idx = tid; idx < 32 * 48; idx += 64) P[idx] = u2[idx / 48] * dh[idx % 48];
+    P += 32 * 48;
+    if (tid < 48) P[tid] = dh[tid];
+}
+
+// ---------------------------------------------------------------------------------------------- gradient = sum of partials
+#define EPNN_TF_MAXRED 24
+struct TfReduce {
+    int n;
+    int theta_off[EPNN_TF_MAXRED], len[EPNN_TF_MAXRED], nblk[EPNN_TF_MAXRED];
+    size_t part_off[EPNN_TF_MAXRED];
+};
+// grad[theta_off + idx] += sum_blk part[part_off + blk * len + idx]: four quarter sums (one per wavefront), combined in order
+__global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *part, float *grad) {
+    __shared__ float sh[4][64];
+    const int en = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int len = T.len[en], idx = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= len) return;
+    const int nblk = T.nblk[en];
+    const int lo = (int)((long long)nblk * w / 4), hi = (int)((long long)nblk * (w + 1) / 4);
+    float s = 0.f;
+    if (idx < len) {
+        const float *p = part + T.part_off[en] + idx;
+#pragma unroll 8
+        for (int blk = lo; blk < hi; ++blk) s += p[(size_t)blk * len];
+    }
+    sh[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && idx < len) grad[T.theta_off[en] + idx] += ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+}

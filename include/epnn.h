@@ -142,7 +142,9 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
 /* options: "profile" (0 = off, k > 0 = keep stage events of the last k forwards), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
  * "pair_cap_per_atom" (initial capacity of the near-pair list of the tiled / dense paths), "wave_front" (1: batches of small
  * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront),
- * "train_graph" (1: a train step's launch sequence is captured once and replayed as a hipGraph, 0: kernel by kernel). */
+ * "train_graph" (1: a train step's launch sequence is captured once and replayed as a hipGraph, 0: kernel by kernel),
+ * "train_fused" (1: one workgroup per atom runs a whole pair MLP over its rows, forward and backward; 0: one launch per
+ * Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS budget of 96 atoms). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features
  * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative

@@ -14,8 +14,9 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("nx,T,N,ns", [(9, 2, 8, [6, 8]), (10, 3, 12, [12, 5, 9])])
-def test_gradients_match_oracle(gpu_engine_factory, nx, T, N, ns):
+def test_gradients_match_oracle(gpu_engine_factory, nx, T, N, ns, fused):
     """Gradient of sum (y-p)^2 over a small batch: float32 HIP kernels vs the finite-difference-checked float64
     oracle, per parameter tensor, plus the structural zero (last pass bias)."""
     from oracle import epnn_oracle_train as ot
@@ -23,6 +24,7 @@ def test_gradients_match_oracle(gpu_engine_factory, nx, T, N, ns):
     h, e, x, q, mask, y = _tiny_batch(nx, N, ns, seed=2)
     loss_ref, pred_ref, g_ref = ot.loss_and_grads(h, e, x, q, mask, y, w)
     eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_option("train_fused", fused)       # 1: one workgroup per atom and pair MLP; 0: one launch per Dense layer
     eng.set_weights(w)
     eng.train_init()
     pred, loss = eng.train_step_dense(h, e, x, q, mask, y, apply=False)
@@ -44,7 +46,7 @@ def test_gradients_match_oracle(gpu_engine_factory, nx, T, N, ns):
                 else:
                     assert np.all(g[sl] == 0)
                 pos += arr.size
-    print(f"nx={nx} T={T} N={N}: worst per-tensor relative gradient error {worst:.2e}; loss {loss:.6f} vs {loss_ref:.6f}")
+    print(f"fused={fused} nx={nx} T={T} N={N}: worst per-tensor relative gradient error {worst:.2e}; loss {loss:.6f} vs {loss_ref:.6f}")
     assert worst < 2e-4
     # weights untouched with apply=False
     w2 = eng.get_weights()
@@ -108,6 +110,42 @@ def test_graph_replay_equals_kernel_by_kernel(gpu_engine_factory):
         assert la == lb and np.array_equal(pa, pb)
     from oracle import epnn_oracle_train as ot
     assert np.array_equal(ot.flatten(wa), ot.flatten(wb))
+
+
+def test_fused_step_equals_layer_by_layer_at_full_size(gpu_engine_factory, val_dir, val_names, weights_decay):
+    """configs[2] shape (N = 41, T = 5, shipped checkpoint, real molecules): the row-fused kernels and the layer-by-layer
+    kernels are two implementations of the same literal algorithm; predictions, loss and every gradient tensor agree
+    to float32 rounding."""
+    from conftest import load_molecules
+    names = [nm for nm in val_names if nm.startswith("dsgdb9nsd")][:4]
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, names, 9)
+    rng = np.random.default_rng(1)
+    y = (rng.normal(size=int(offsets[-1])) * 0.2).astype(np.float32)
+    res = []
+    for fused in (1, 0):
+        eng = gpu_engine_factory(nx=9, T=5)
+        eng.set_option("train_fused", fused)
+        eng.set_weights(weights_decay)
+        eng.train_init()
+        q, loss = eng.train_step_xyz(offsets, xyz, x, Q, y, 41, apply=False)
+        res.append((q, loss, eng.get_gradients().astype(np.float64)))
+    (qa, la, ga), (qb, lb, gb) = res
+    assert np.abs(qa - qb).max() < 2e-6
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(lb))
+    pos = 0
+    worst = 0.0
+    for m in [weights_decay["upd"]] + weights_decay["msg"] + weights_decay["pas"]:
+        for W, b in m:
+            for arr in (W, b):
+                sl = slice(pos, pos + arr.size)
+                scale = np.abs(gb[sl]).max()
+                if scale > 0:
+                    worst = max(worst, np.abs(ga[sl] - gb[sl]).max() / scale)
+                else:
+                    assert np.all(ga[sl] == 0)
+                pos += arr.size
+    print(f"fused vs layer-by-layer at N=41, T=5: worst per-tensor relative gradient difference {worst:.2e}")
+    assert worst < 1e-4
 
 
 def test_train_step_xyz_equals_dense(gpu_engine_factory, val_dir, val_names):

@@ -17,12 +17,13 @@ def batch(k):
     ms = mols[k * B:(k + 1) * B]; ys = labels[k * B:(k + 1) * B]
     off = np.zeros(len(ms) + 1, np.int32); off[1:] = np.cumsum([len(m[1]) for m in ms])
     return off, np.concatenate([m[0] for m in ms]), np.concatenate([m[1] for m in ms]), np.array([m[2] for m in ms], np.float32), np.concatenate(ys)
-for graph in (1, 0):
+for fused, graph in ((1, 1), (1, 0), (0, 0)):
+    eng.set_option("train_fused", fused)
     eng.set_option("train_graph", graph)
     for k in range(2): eng.train_step_xyz(*batch(k), 41)
     t0 = time.perf_counter(); nst = min(20, 64 // B); tot = 0.0
     for k in range(nst):
         q, loss = eng.train_step_xyz(*batch(k), 41); tot += loss
     dt = (time.perf_counter() - t0) / nst
-    print(f"train step ({'hipGraph replay' if graph else 'kernel by kernel'}): B={B} molecule(s) per step, N=41: {dt*1e3:.2f} ms/step "
+    print(f"train step ({'row-fused' if fused else 'layer by layer'}, {'hipGraph replay' if graph else 'kernel by kernel'}): B={B} molecule(s) per step, N=41: {dt*1e3:.2f} ms/step "
           f"({1/dt:.1f} steps/s, {B/dt:.1f} molecules/s); mean loss {tot/nst:.4f}")
