@@ -12,7 +12,10 @@
 #include "epnn_host.h"
 
 #define EPNN_TF_NMAX 96          // LDS of the backward kernel: 372 N + 2 k floats
-#define EPNN_TF_JM 6             // partner rows per thread and pass of the layer-1 loop (8 row groups x 6 = 48 rows)
+#define EPNN_TF_NT 512           // threads of a pair workgroup: 16 row groups x 32 outputs
+#define EPNN_TF_NG (EPNN_TF_NT / 32)
+#define EPNN_TF_JM 3             // partner rows per thread and pass of the layer-1 loop (16 row groups x 3 = 48 rows)
+#define EPNN_TF_KT 4             // weight rows per thread and pass of the dW1 loops
 
 struct TfPair {                  // one sweep of a pair MLP (message network of GNN step t / pass network of EPN step t)
     const float *x, *h, *q;      // the step's per-atom inputs: x [BN][nx], h [BN][48], q [BN]   (a = [x | h | q])
@@ -35,7 +38,7 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
 // ---------------------------------------------------------------------------------------------- forward, pair MLP
 // MODE 0: message network (out_dim 32, summed over ALL N partners); MODE 1: pass network (out_dim 1, both orders).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
+__global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
     const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
     const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
@@ -46,19 +49,19 @@ __global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
     float *W1s = Es + N * 49;                 // [D][32]
     float *H1s = W1s + D * 32;                // [ND][N][33]
     float *H2s = H1s + ND * N * 33;           // [ND][N][33]
-    float *red = H2s + ND * N * 33;           // [8][32] + [32]  /  [2][N]
+    float *red = H2s + ND * N * 33;           // [NG][32] + [32]  /  [2][N]
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
-    for (int idx = tid; idx < N * F; idx += 256) {
+    for (int idx = tid; idx < N * F; idx += EPNN_TF_NT) {
         const int j = idx / F, k = idx - j * F;
         const size_t at = a0 + j;
         As[j * FS + k] = k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
     }
-    for (int idx = tid; idx < N * 48; idx += 256) {
+    for (int idx = tid; idx < N * 48; idx += EPNN_TF_NT) {
         const int j = idx / 48, k = idx - j * 48;
         Es[j * 49 + k] = A.e[rowbase * 48 + idx];
     }
-    for (int idx = tid; idx < D * 32; idx += 256) W1s[idx] = A.theta[A.oW1 + idx];
+    for (int idx = tid; idx < D * 32; idx += EPNN_TF_NT) W1s[idx] = A.theta[A.oW1 + idx];
     __syncthreads();
     // ---- layer 1: z1 = b1 + a_i W1[0:F] + a_j W1[F:2F] + e_ij W1[2F:]   (the a_i term once per thread, not per row)
     const float b1 = A.theta[A.ob1 + o];
@@ -68,12 +71,12 @@ __global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
         pa = fmaf(ai[k], W1s[k * 32 + o], pa);
         if (MODE) ra = fmaf(ai[k], W1s[(F + k) * 32 + o], ra);
     }
-    for (int jb = 0; jb < N; jb += 8 * EPNN_TF_JM) {
+    for (int jb = 0; jb < N; jb += EPNN_TF_NG * EPNN_TF_JM) {
         float accR[EPNN_TF_JM], accG[EPNN_TF_JM], accP[EPNN_TF_JM];
         int jr[EPNN_TF_JM];
 #pragma unroll
         for (int m = 0; m < EPNN_TF_JM; ++m) {
-            jr[m] = min(jb + g + 8 * m, N - 1);
+            jr[m] = min(jb + g + EPNN_TF_NG * m, N - 1);
             accR[m] = accG[m] = accP[m] = 0.f;
         }
         for (int k = 0; k < F; ++k) {
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
         }
 #pragma unroll
         for (int m = 0; m < EPNN_TF_JM; ++m) {
-            const int j = jb + g + 8 * m;
+            const int j = jb + g + EPNN_TF_NG * m;
             if (j < N) {
                 const float h1 = fmaxf((pa + accR[m]) + accG[m], 0.f);
                 H1s[j * 33 + o] = h1;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
         for (int k = 0; k < 32; ++k) w2[k] = A.theta[A.oW2 + k * 32 + o];
         const float b2 = A.theta[A.ob2 + o];
         for (int d = 0; d < ND; ++d)
-            for (int j = g; j < N; j += 8) {
+            for (int j = g; j < N; j += EPNN_TF_NG) {
                 const float *hr = H1s + (d * N + j) * 33;
                 float z = b2;
 #pragma unroll
@@ -126,25 +129,25 @@ __global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
     __syncthreads();
     // ---- layer 3 (linear) and the reduction over partners
     if (MODE == 0) {
-        // sum_j (H2_j W3 + b3) = (sum_j H2_j) W3 + N b3: column sums in a fixed order, then one 32x32 product
+        // sum_j (H2_j W3 + b3) = (sum_j H2_j) W3 + N b3: column sums in a fixed order (row groups, then the groups in order), then one 32x32 product
         float cs = 0.f;
-        for (int j = g; j < N; j += 8) cs += H2s[j * 33 + o];
+        for (int j = g; j < N; j += EPNN_TF_NG) cs += H2s[j * 33 + o];
         red[g * 32 + o] = cs;
         __syncthreads();
         if (tid < 32) {
             float s = 0.f;
-            for (int gg = 0; gg < 8; ++gg) s += red[gg * 32 + tid];
-            red[256 + tid] = s;
+            for (int gg = 0; gg < EPNN_TF_NG; ++gg) s += red[gg * 32 + tid];
+            red[EPNN_TF_NG * 32 + tid] = s;
         }
         __syncthreads();
         if (tid < 32) {
             float mo = (float)N * A.theta[A.ob3 + tid];
-            for (int k = 0; k < 32; ++k) mo = fmaf(red[256 + k], A.theta[A.oW3 + k * 32 + tid], mo);
+            for (int k = 0; k < 32; ++k) mo = fmaf(red[EPNN_TF_NG * 32 + k], A.theta[A.oW3 + k * 32 + tid], mo);
             A.M[(size_t)bi * 32 + tid] = mo;
         }
     } else {
         float *fs = red;                      // [2][N]
-        for (int idx = tid; idx < 2 * N; idx += 256) {
+        for (int idx = tid; idx < 2 * N; idx += EPNN_TF_NT) {
             const float *hr = H2s + idx * 33;
             float f = A.theta[A.ob3];
             for (int k = 0; k < 32; ++k) f = fmaf(hr[k], A.theta[A.oW3 + k], f);
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void k_tf_pair_fwd(TfPair A) {
 
 // ---------------------------------------------------------------------------------------------- backward, pair MLP
 template <int MODE>
-__global__ __launch_bounds__(256) void k_tb_pair_bwd(TfPair A) {
+__global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
     const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
     const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
@@ -179,27 +182,27 @@ __global__ __launch_bounds__(256) void k_tb_pair_bwd(TfPair A) {
     float *dms = vec, *vs = vec + 32, *s1 = vec + 64, *sb2 = vec + 128, *c2 = vec + 160, *dfs = vec + 192;
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
-    for (int idx = tid; idx < N * F; idx += 256) {
+    for (int idx = tid; idx < N * F; idx += EPNN_TF_NT) {
         const int j = idx / F, k = idx - j * F;
         const size_t at = a0 + j;
         As[j * FS + k] = k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
     }
-    for (int idx = tid; idx < N * 48; idx += 256) {
+    for (int idx = tid; idx < N * 48; idx += EPNN_TF_NT) {
         const int j = idx / 48, k = idx - j * 48;
         Es[j * 49 + k] = A.e[rowbase * 48 + idx];
     }
     for (int d = 0; d < ND; ++d)
-        for (int idx = tid; idx < N * 32; idx += 256) {
+        for (int idx = tid; idx < N * 32; idx += EPNN_TF_NT) {
             const int j = idx >> 5, k = idx & 31;
             H1s[(d * N + j) * 33 + k] = A.H1[d * dstride + rowbase * 32 + idx];
             H2s[(d * N + j) * 33 + k] = A.H2[d * dstride + rowbase * 32 + idx];
         }
-    for (int idx = tid; idx < 1024; idx += 256) W2s[(idx >> 5) * 33 + (idx & 31)] = A.theta[A.oW2 + idx];
+    for (int idx = tid; idx < 1024; idx += EPNN_TF_NT) W2s[(idx >> 5) * 33 + (idx & 31)] = A.theta[A.oW2 + idx];
     if (MODE == 0) {
         if (tid < 32) dms[tid] = A.dU0[(size_t)bi * 80 + 48 + tid] * A.nm[bi];     // dM_i: the same for every partner row
     } else {
         const float gqi = 0.5f * A.gq[bi];
-        for (int j = tid; j < N; j += 256) dfs[j] = gqi * A.wgt[rowbase + j];      // df_ij; the swapped row gets -df_ij
+        for (int j = tid; j < N; j += EPNN_TF_NT) dfs[j] = gqi * A.wgt[rowbase + j];      // df_ij; the swapped row gets -df_ij
     }
     __syncthreads();
     // ---- gradient at z2 = [H2 > 0] * (dOut W3^T)
@@ -210,14 +213,14 @@ __global__ __launch_bounds__(256) void k_tb_pair_bwd(TfPair A) {
             vs[tid] = v;
         }
         __syncthreads();
-        for (int idx = tid; idx < N * 32; idx += 256) {
+        for (int idx = tid; idx < N * 32; idx += EPNN_TF_NT) {
             const int j = idx >> 5, k = idx & 31;
             D2s[j * 33 + k] = H2s[j * 33 + k] > 0.f ? vs[k] : 0.f;
         }
     } else {
         const float w3 = A.theta[A.oW3 + o];
         for (int d = 0; d < 2; ++d)
-            for (int j = g; j < N; j += 8) {
+            for (int j = g; j < N; j += EPNN_TF_NG) {
                 const float df = d ? -dfs[j] : dfs[j];
                 D2s[(d * N + j) * 33 + o] = H2s[(d * N + j) * 33 + o] > 0.f ? df * w3 : 0.f;
             }
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void k_tb_pair_bwd(TfPair A) {
 #pragma unroll
         for (int oo = 0; oo < 32; ++oo) w2row[oo] = W2s[o * 33 + oo];
         for (int d = 0; d < ND; ++d)
-            for (int j = g; j < N; j += 8) {
+            for (int j = g; j < N; j += EPNN_TF_NG) {
                 const float *dr = D2s + (d * N + j) * 33;
                 float s = 0.f;
 #pragma unroll
@@ -266,42 +269,58 @@ __global__ __launch_bounds__(256) void k_tb_pair_bwd(TfPair A) {
     const int Pm = D * 32 + 32 + 1024 + 32 + 32 * O + O;
     float *P = A.part + (size_t)bi * Pm;
     const float *ai = As + i * FS;
-    for (int k = g; k < D; k += 8) {
-        float v;
-        if (k < F) {                          // first block of the row: a_i (rows as listed) / a_j (swapped rows)
-            v = ai[k] * s1[o];
-            if (MODE) {
-                float s = 0.f;
-                for (int j = 0; j < N; ++j) s = fmaf(As[j * FS + k], D1s[(N + j) * 33 + o], s);
-                v += s;
+    // dW1[k][o] = sum over the rows of X[row][k] dz1[row][o].  The a_i block of a row is the same for every row of the
+    // workgroup (a_i x column sum); the partner block a_j feeds both orders of the pair from ONE read; KT weight rows per
+    // thread share the reads of dz1.
+    for (int k0 = g * EPNN_TF_KT; k0 < F; k0 += EPNN_TF_NG * EPNN_TF_KT) {
+        float accA[EPNN_TF_KT], accB[EPNN_TF_KT];
+#pragma unroll
+        for (int kk = 0; kk < EPNN_TF_KT; ++kk) accA[kk] = accB[kk] = 0.f;
+#pragma unroll 2
+        for (int j = 0; j < N; ++j) {
+            const float dN = D1s[j * 33 + o], dT = MODE ? D1s[(N + j) * 33 + o] : 0.f;
+#pragma unroll
+            for (int kk = 0; kk < EPNN_TF_KT; ++kk) {
+                const float a = As[j * FS + min(k0 + kk, F - 1)];
+                accB[kk] = fmaf(a, dN, accB[kk]);              // second block of the listed rows
+                if (MODE) accA[kk] = fmaf(a, dT, accA[kk]);    // first block of the swapped rows
             }
-        } else if (k < 2 * F) {               // second block: a_j / a_i
-            const int kk = k - F;
-            float s = 0.f;
-            for (int j = 0; j < N; ++j) s = fmaf(As[j * FS + kk], D1s[j * 33 + o], s);
-            v = s;
-            if (MODE) v += ai[kk] * s1[32 + o];
-        } else {                              // edge block: the same e_ij in both orders
-            const int kk = k - 2 * F;
-            float s = 0.f;
-            for (int j = 0; j < N; ++j) s = fmaf(Es[j * 49 + kk], D1s[j * 33 + o] + (MODE ? D1s[(N + j) * 33 + o] : 0.f), s);
-            v = s;
         }
-        P[k * 32 + o] = v;
+#pragma unroll
+        for (int kk = 0; kk < EPNN_TF_KT; ++kk) {
+            const int k = k0 + kk;
+            if (k < F) {
+                P[k * 32 + o] = ai[k] * s1[o] + accA[kk];
+                P[(F + k) * 32 + o] = accB[kk] + (MODE ? ai[k] * s1[32 + o] : 0.f);
+            }
+        }
+    }
+    for (int k0 = g * EPNN_TF_KT; k0 < 48; k0 += EPNN_TF_NG * EPNN_TF_KT) {      // edge block: the same e_ij in both orders
+        float acc[EPNN_TF_KT];
+#pragma unroll
+        for (int kk = 0; kk < EPNN_TF_KT; ++kk) acc[kk] = 0.f;
+#pragma unroll 2
+        for (int j = 0; j < N; ++j) {
+            const float dS = D1s[j * 33 + o] + (MODE ? D1s[(N + j) * 33 + o] : 0.f);
+#pragma unroll
+            for (int kk = 0; kk < EPNN_TF_KT; ++kk) acc[kk] = fmaf(Es[j * 49 + k0 + kk], dS, acc[kk]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < EPNN_TF_KT; ++kk) P[(2 * F + k0 + kk) * 32 + o] = acc[kk];
     }
     float *Pb1 = P + D * 32, *PW2 = Pb1 + 32, *Pb2 = PW2 + 1024, *PW3 = Pb2 + 32, *Pb3 = PW3 + 32 * O;
     if (tid < 32) {
         Pb1[tid] = s1[tid] + (MODE ? s1[32 + tid] : 0.f);
         Pb2[tid] = sb2[tid];
     }
-    for (int k = g; k < 32; k += 8) {         // dW2[k][o] = sum_d sum_j H1[j][k] dz2[j][o]
+    for (int k = g; k < 32; k += EPNN_TF_NG) {         // dW2[k][o] = sum_d sum_j H1[j][k] dz2[j][o]
         float s = 0.f;
         for (int d = 0; d < ND; ++d)
             for (int j = 0; j < N; ++j) s = fmaf(H1s[(d * N + j) * 33 + k], D2s[(d * N + j) * 33 + o], s);
         PW2[k * 32 + o] = s;
     }
     if (MODE == 0) {
-        for (int k = g; k < 32; k += 8) PW3[k * 32 + o] = c2[k] * dms[o];
+        for (int k = g; k < 32; k += EPNN_TF_NG) PW3[k * 32 + o] = c2[k] * dms[o];
         if (tid < 32) Pb3[tid] = (float)N * dms[tid];
     } else {
         if (tid < 32) PW3[tid] = c2[tid];
@@ -322,14 +341,21 @@ __global__ __launch_bounds__(128) void k_tb_atoms(TfPair A) {
     const size_t dstride = (size_t)gridDim.x * N * 32;
     const size_t rows = (size_t)bi * N, mol = (size_t)b * N;
     float s = 0.f;
-    if (which == 0) {                         // listed rows (a, j): a is the first block
-        for (int j = 0; j < N; ++j) s += A.dz1[(rows + j) * 32 + o];
-    } else if (which == 1) {                  // listed rows (i, a): a is the second block
-        for (int i = 0; i < N; ++i) s += A.dz1[((mol + i) * N + ia) * 32 + o];
-    } else if (MODE == 1 && which == 2) {     // swapped rows (i, a) = [a_a | a_i | e]: a is the first block
-        for (int i = 0; i < N; ++i) s += A.dz1[dstride + ((mol + i) * N + ia) * 32 + o];
-    } else if (MODE == 1) {                   // swapped rows (a, j) = [a_j | a_a | e]: a is the second block
-        for (int j = 0; j < N; ++j) s += A.dz1[dstride + (rows + j) * 32 + o];
+    // which 0: listed rows (a, j), a is the first block;  1: listed rows (i, a), a is the second block;
+    //       2: swapped rows (i, a) = [a_a | a_i | e], first block;  3: swapped rows (a, j) = [a_j | a_a | e], second block
+    if (which < 2 || MODE == 1) {
+        const bool byrow = which == 0 || which == 3;
+        const float *p = A.dz1 + (which >= 2 ? dstride : 0) + (byrow ? rows * 32 : (mol * N + ia) * 32) + o;
+        const size_t step = byrow ? 32 : (size_t)N * 32;
+        int t = 0;
+        for (; t + 8 <= N; t += 8) {          // eight loads in flight, summed in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(t + u) * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; t < N; ++t) s += p[(size_t)t * step];
     }
     sh[which][o] = s;
     __syncthreads();
