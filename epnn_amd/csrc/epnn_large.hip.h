@@ -186,45 +186,68 @@ __global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int
 }
 
 // ------------------------------------------------------------------------------------------------ all-pairs sweep
-// workgroup = up to 4 atom tiles (one per wave) x one j-chunk of the same molecule; R_j staged in LDS
+// workgroup = up to 4 atom tiles (one per wave) x one j-chunk of the same molecule; R_j staged in LDS.
+// v_mfma_f32_16x16x4_f32 in the fused kernel's layout (epnn_wave.hip.h): lane (q, n16) owns atoms n16 and 16 + n16 of
+// the tile and features 16 rb + 4 q + r of each; tile j = "partner j of every atom", S accumulates in registers.  The
+// co-resident wavefronts' VALU work (two adds and two max per feature and pair) overlaps this MFMA shape better than
+// 32x32x2 (tools/micro/mfma_covalu.hip), which is what bounds the sweep.  W2 / b2 come from the fused kernel's pack.
 #define EPNN_LG_JC 64
-__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, PairMlpPack M) {
+__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2off) {
     __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
     const int4 tk = L.stasks[blockIdx.x];            // first atile, #atiles, j_lo, j_hi (global atom indices)
     const int chunk = L.stask_chunk[blockIdx.x];
     const bool active = wave < tk.y;
     const int4 tl = L.atiles[tk.x + (active ? wave : 0)];
     const float *wp = L.wpack;
-    float pr[16], w2[16];
-    epnn_ld16(L.P + (size_t)(tl.x + (c < tl.y ? c : 0)) * 32 + hh * 16, pr);
+    const bool two = tl.y > 16;                      // the tile's second column block holds atoms
+    // P and R rows are stored in the operand order of the 32x32x2 kernels (k_lg_proj): position 16 hh + r holds feature
+    // kappa(hh, r) = 8 (r >> 2) + 4 hh + (r & 3), so this lane's features 16 rb + 4 q .. + 3 sit together at po + 8 rb
+    const int po = 16 * (q & 1) + 4 * (q >> 1);
+    const int c0 = n16 < tl.y ? n16 : 0, c1 = 16 + n16 < tl.y ? 16 + n16 : 0;
+    f32x4 P0[2], P1[2], S0[2], S1[2], b2v[2];
+    float pb[2][8];
+    W16_LD(pb, w2off, 2, 8);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
-    const f32x16 cb2 = epnn_splat16(wp[M.b2 + c]);
-    f32x16 sum = epnn_splat16(0.f);
+    for (int rb = 0; rb < 2; ++rb) {
+        P0[rb] = w16_ld(L.P + (size_t)(tl.x + c0) * 32 + po + 8 * rb);
+        P1[rb] = w16_ld(L.P + (size_t)(tl.x + c1) * 32 + po + 8 * rb);
+        b2v[rb] = w16_ld(wp + b2off + 16 * rb + fo);
+        S0[rb] = w16_splat(0.f);
+        S1[rb] = w16_splat(0.f);
+    }
+    auto block = [&](const f32x4 (&Pc)[2], f32x4 (&Sc)[2], const f32x4 (&r)[2]) {
+        const f32x4 za = w16_relu(Pc[0] + r[0]), zb = w16_relu(Pc[1] + r[1]);
+        const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+        f32x4 d[2] = {b2v[0], b2v[1]};
+        w16_mm<2, 8>(pb, z, d);
+        Sc[0] += w16_relu(d[0]);
+        Sc[1] += w16_relu(d[1]);
+    };
     for (int j0 = tk.z; j0 < tk.w; j0 += EPNN_LG_JC) {
         const int nj = min(EPNN_LG_JC, tk.w - j0);
         __syncthreads();
         for (int i = tid; i < nj * 32; i += 256) Rs[i] = L.R[(size_t)j0 * 32 + i];
         __syncthreads();
-        if (active)
+        if (active) {
+            f32x4 ra[2] = {w16_ld(Rs + po), w16_ld(Rs + po + 8)};
 #pragma unroll 2
             for (int j = 0; j < nj; ++j) {
-                float rj[16];
-                epnn_ld16(Rs + j * 32 + hh * 16, rj);
-                f32x16 acc = cb2;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc = epnn_mfma(fmaxf(pr[s] + rj[s], 0.f), w2[s], acc);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum[r] += fmaxf(acc[r], 0.f);
+                const float *nr = Rs + min(j + 1, nj - 1) * 32 + po;      // the next partner's row while this one is in the pipe
+                const f32x4 rn[2] = {w16_ld(nr), w16_ld(nr + 8)};
+                block(P0, S0, ra);
+                if (two) block(P1, S1, ra);
+                ra[0] = rn[0];
+                ra[1] = rn[1];
             }
+        }
     }
     if (!active) return;
     float *dst = L.S0 + ((size_t)chunk * L.A) * 32;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = epnn_kappa(hh, r);
-        if (row < tl.y) dst[(size_t)(tl.x + row) * 32 + c] = sum[r];
+    for (int rb = 0; rb < 2; ++rb) {
+        if (n16 < tl.y) w16_st(dst + (size_t)(tl.x + n16) * 32 + 16 * rb + fo, S0[rb]);
+        if (16 + n16 < tl.y) w16_st(dst + (size_t)(tl.x + 16 + n16) * 32 + 16 * rb + fo, S1[rb]);
     }
 }
 
@@ -549,7 +572,7 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     hipLaunchKernelGGL(k_lg_dn_sort, dim3(gAt), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
     for (int t = 0; t < (run_gnn ? L.T : 0); ++t) {
         hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[t], 1);
-        hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->widx.msg[t]);
+        hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
         hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
         hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
         hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk, h->l_sfin.as<float>());

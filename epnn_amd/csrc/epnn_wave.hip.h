@@ -500,10 +500,10 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                         o_.w = jp < n ? 1.f : (jp == n ? padw : 0.f);
                     };
                     auto tile = [&](const f32x4 (&Pc)[2], f32x4 (&Sc)[2], const Ops &o_) {
-                        float z[8];
+                        // four-wide adds (v_pk_add_f32): every VALU instruction here competes with the matrix pipe's issue
+                        const f32x4 za = w16_relu((Pc[0] + o_.r[0]) + o_.g[0]), zb = w16_relu((Pc[1] + o_.r[1]) + o_.g[1]);
+                        const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
                         f32x4 d[2] = {b2v[0], b2v[1]};
-#pragma unroll
-                        for (int s = 0; s < 8; ++s) z[s] = fmaxf((Pc[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g[s >> 2][s & 3], 0.f);
                         w16_mm<2, 8>(pb, z, d);
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb) Sc[rb] += o_.w * w16_relu(d[rb]);
@@ -545,13 +545,11 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                             grow(real && cat1 ? (int)pm[t * 32 + col1] : 0xFFFF, o_.g1);
                         };
                         auto tile2 = [&](int t, const Ops2 &o_) {
-                            float z0[8], z1[8];
+                            const f32x4 za0 = w16_relu((P0[0] + o_.r[0]) + o_.g0[0]), zb0 = w16_relu((P0[1] + o_.r[1]) + o_.g0[1]);
+                            const f32x4 za1 = w16_relu((P1[0] + o_.r[0]) + o_.g1[0]), zb1 = w16_relu((P1[1] + o_.r[1]) + o_.g1[1]);
+                            const float z0[8] = {za0[0], za0[1], za0[2], za0[3], zb0[0], zb0[1], zb0[2], zb0[3]};
+                            const float z1[8] = {za1[0], za1[1], za1[2], za1[3], zb1[0], zb1[1], zb1[2], zb1[3]};
                             f32x4 d0[2] = {b2v[0], b2v[1]}, d1[2] = {b2v[0], b2v[1]};
-#pragma unroll
-                            for (int s = 0; s < 8; ++s) {
-                                z0[s] = fmaxf((P0[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g0[s >> 2][s & 3], 0.f);
-                                z1[s] = fmaxf((P1[s >> 2][s & 3] + o_.r[s >> 2][s & 3]) + o_.g1[s >> 2][s & 3], 0.f);
-                            }
                             w16_mm<2, 8>(pb, z0, d0);
                             w16_mm<2, 8>(pb, z1, d1);
                             const float w = t < n ? 1.f : padw;
@@ -781,20 +779,20 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
                     f32x4 g[2] = {w16_splat(0.f), w16_splat(0.f)};       // G = We^T e of the 16 pairs (charge_gn.py:105, e block)
                     w16_mm<2, KE>(gw, w_.e, g);
-                    float zu[8], zv[8];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        zu[s] = fmaxf((g[s >> 2][s & 3] + w_.pi_[s >> 2][s & 3]) + w_.rj_[s >> 2][s & 3], 0.f);
-                        zv[s] = fmaxf((g[s >> 2][s & 3] + w_.pj_[s >> 2][s & 3]) + w_.ri_[s >> 2][s & 3], 0.f);
-                    }
+                    const f32x4 ua = w16_relu((g[0] + w_.pi_[0]) + w_.rj_[0]), ub = w16_relu((g[1] + w_.pi_[1]) + w_.rj_[1]);
+                    const f32x4 va = w16_relu((g[0] + w_.pj_[0]) + w_.ri_[0]), vb = w16_relu((g[1] + w_.pj_[1]) + w_.ri_[1]);
+                    const float zu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
+                    const float zv[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
                     f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
                     w16_mm<2, 8>(pb, zu, au);
                     w16_mm<2, 8>(pb, zv, av);
                     float fd = 0.f;                                    // w3 . (relu(u) - relu(v)) over this lane's 8 features
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const f32x4 t = w16_relu(au[rb]) - w16_relu(av[rb]);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) fd = fmaf(w3[rb][r], fmaxf(au[rb][r], 0.f) - fmaxf(av[rb][r], 0.f), fd);
+                        for (int r = 0; r < 4; ++r) fd = fmaf(w3[rb][r], t[r], fd);
+                    }
                     const float d = 0.5f * w16_sumq(fd);               // charge_gn.py:116; all lanes take part
                     // entries with weight 0 are never written (they stay 0): a one-sided entry (j,i) of the dense
                     // front-end must not clear what the entry (i,j) wrote
