@@ -89,6 +89,19 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
             HIPCHK(hipMemcpy(h->d_etab.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
+    {   // dsafe: largest D up to which a lower bound of max_k e_k stays above 2 tol (every pair closer than that is a near
+        // pair, charge_gn.py:90-94).  Bound: C(D), decreasing in D, times the Gaussian at the largest possible distance
+        // `gap` from D to its nearest mu_k (half the widest spacing; mu_0 itself for D below it).
+        double gap = std::max(mu[0], stop - mu[cfg->e_dim - 1]);
+        for (int k = 0; k + 1 < cfg->e_dim; ++k) gap = std::max(gap, 0.5 * (mu[k + 1] - mu[k]));
+        const double floor_g = exp(-(double)cfg->eta * gap * gap);
+        double lo = 0.0, hi = stop;
+        for (int it = 0; it < 60; ++it) {
+            const double m = 0.5 * (lo + hi), L = (cos(3.141592653589793 * m / stop) + 1.0) / 2.0 * floor_g;
+            if (L > 2.0 * (double)cfg->near_tol) lo = m; else hi = m;
+        }
+        h->dsafe = lo;
+    }
     *out = h;
     return 0;
 }
@@ -678,15 +691,6 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.etab = h->d_etab.as<float>();
     A.tab_n = EPNN_ETAB_N;
     A.tab_inv_h = (double)(EPNN_ETAB_N - 1) / A.cutoff;
-    if (h->dsafe < 0.0) {   // largest D up to which C(D) exp(-eta (dmu/2)^2) - a lower bound of max_k e_k, decreasing in D - stays above 2 tol
-        const double dmu = A.cutoff / (double)(EPNN_EDIM - 1), floor_g = exp(-A.eta * dmu * dmu / 4.0);
-        double lo = 0.0, hi = A.cutoff;
-        for (int it = 0; it < 60; ++it) {
-            const double m = 0.5 * (lo + hi), L = (cos(3.141592653589793 * m / A.cutoff) + 1.0) / 2.0 * floor_g;
-            if (L > 2.0 * (double)A.tol) lo = m; else hi = m;
-        }
-        h->dsafe = lo;
-    }
     A.dsafe = h->dsafe;
     const dim3 grid((unsigned)P.small_order.size());
     const WaveIndex &X = h->wvidx;

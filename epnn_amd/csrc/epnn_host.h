@@ -110,7 +110,7 @@ struct epnn_handle {
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
     // staging for the host-pointer entry points
     DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_gx, s_pt;
-    double dsafe = -1.0;              // distance up to which every pair is a near pair (computed at the first launch)
+    double dsafe = 0.0;               // distance up to which every pair is a near pair (epnn_create)
     DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)

@@ -81,10 +81,11 @@ def parse_xyz(path, nx=9):
     return np.array(xyz, dtype=np.float32), np.array(x, dtype=np.float32), Q
 
 
-def dense_inputs(xyz, x, Q, N, h_dim=48, e_dim=48):
-    """reference charge_gn.py:331-364 for one molecule: the five (N,N,.) tensors make_model consumes."""
+def dense_inputs(xyz, x, Q, N, h_dim=48, e_dim=48, cutoff=3.0, eta=2.0):
+    """reference charge_gn.py:331-364 for one molecule: the five (N,N,.) tensors make_model consumes.  (cutoff / eta
+    are the reference's constants 3 and 2, charge_gn.py:148-161; parameters here because the C ABI's config has them.)"""
     n = x.shape[0]
-    e, _ = get_init_edges(xyz, num=e_dim)
+    e, _ = get_init_edges(xyz, num=e_dim, cutoff=cutoff, eta=eta)
     x_p = np.zeros((N, N, x.shape[1]))
     h_p = np.zeros((N, N, h_dim))
     q_p = np.zeros((N, N, 1))
@@ -213,10 +214,10 @@ def model_forward(h_inp, e_inp, x_inp, q_inp, mask_inp, weights, dtype=np.float3
     return epn_layer(feats, e_inp, x, q, mask, weights["pas"], dtype, row_block)                 # :387
 
 
-def forward_xyz(xyz, x, Q, weights, N=None, dtype=np.float32, row_block=64):
+def forward_xyz(xyz, x, Q, weights, N=None, dtype=np.float32, row_block=64, cutoff=3.0, eta=2.0):
     """Featurise one molecule like gen_padded_init_state and run the model; returns (N,) charges."""
     n = x.shape[0]
     N = n if N is None else N
-    h_p, e_p, x_p, q_p, mask = dense_inputs(xyz, x, Q, N)
+    h_p, e_p, x_p, q_p, mask = dense_inputs(xyz, x, Q, N, cutoff=cutoff, eta=eta)
     out = model_forward(h_p[None], e_p[None], x_p[None], q_p[None], mask[None], weights, dtype, row_block)
     return out[0, :, 0]

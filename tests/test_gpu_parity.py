@@ -375,3 +375,27 @@ def test_pipeline_map_equals_one_call_at_a_time(weights_decay):
     with pytest.raises(Exception):
         eng.forward_xyz_end()
     eng.close()
+
+
+@pytest.mark.parametrize("cutoff,eta", [(2.5, 4.0), (3.4, 1.2)])
+def test_other_edge_constants_vs_oracle(gpu_engine_factory, val_dir, val_names, cutoff, eta):
+    """The C ABI's config carries cutoff and eta (the reference hard-codes 3 and 2, charge_gn.py:148-161).  The fused
+    kernel derives everything that depends on them at epnn_create -- edge basis, its interpolation table, the distance
+    up to which every pair is a near pair -- so other values must work the same (or, when 16 basis vectors do not reach
+    1e-8, fall back to the 48-channel front-end by themselves): both front-end settings vs the float64 oracle."""
+    from oracle import epnn_oracle as orc
+    nx, T, N = 9, 3, 33
+    w = random_weights(nx, T, seed=17, scale=0.35)
+    names = [nm for nm in val_names if nm.startswith("dsgdb9nsd")][:20]
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, names, nx)
+    ref = [orc.forward_xyz(m[0], m[1], m[2], w, N=N, dtype=np.float64, cutoff=cutoff, eta=eta) for m in mols]
+    for front in (1, 0):
+        eng = gpu_engine_factory(nx=nx, T=T, cutoff=cutoff, eta=eta)
+        res = float(eng.lib.epnn_edge_basis_residual(eng.h))   # >= 1e-8 (narrower Gaussians): the kernel's own front-end is not used
+        eng.set_weights(w)
+        eng.set_option("wave_front", front)
+        q = eng.forward_xyz(offsets, xyz, x, Q, N=N)
+        assert eng.last_stats()[1] == len(mols)
+        worst = max(np.abs(q[offsets[k]:offsets[k + 1]] - ref[k][:m[1].shape[0]]).max() for k, m in enumerate(mols))
+        print(f"cutoff {cutoff} eta {eta} front-end {front}: worst |dq| {worst:.2e}, edge basis residual {res:.1e}")
+        assert worst <= TOL
