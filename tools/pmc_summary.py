@@ -4,9 +4,11 @@
         gpurun_out/r1c_fetch gpurun_out/r1c_write gpurun_out/r1c_sq [--merge old.json]
 
 Per-launch means per kernel.  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  MI355X_MICROARCH.md (HBM
-section) says gfx950's FETCH_SIZE under-counts wide coalesced streams by 2x; the kernels here read 16-byte gathers of
-pair rows and 4-byte weight fragments, so the counter is NOT doubled and is an uncalibrated lower bound (noted in the
-output).  bench.py reads `dominant[<kernel>]["hbm_bytes_per_launch"]` for its roofline.traffic field.
+section): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced read and other access widths must
+be calibrated.  tools/micro/fetch_calib.hip does that for the fused kernel's own patterns (16-byte pieces of scattered
+64-byte pair rows; one dword per lane of contiguous weight fragments; 512 MiB read once): FETCH_SIZE reads 0.506 /
+0.500 / 0.500 of the bytes, WRITE_SIZE exactly 1.000 (profiles/r01_fetch_calibration.txt).  So FETCH_SIZE is doubled,
+WRITE_SIZE taken as is.  bench.py reads `dominant[<kernel>]["hbm_bytes_per_launch"]` for its roofline.traffic field.
 """
 import argparse
 import glob
@@ -50,7 +52,7 @@ def main():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             ent["FETCH_SIZE_KiB"] = v["FETCH_SIZE"]
             ent["WRITE_SIZE_KiB"] = v["WRITE_SIZE"]
-            ent["hbm_bytes_per_launch"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+            ent["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "SQ_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs (GUI/8 = kernel cycles); MFMA busy cycles are summed over the
             # 1024 SIMDs: busy share of SIMD-cycles = busy / (GUI/8 * 1024)
@@ -59,8 +61,9 @@ def main():
         dominant[k] = ent
     out = {"source": a.source or "rocprofv3 --pmc (separate passes); MI355X; per-launch means",
            "workload": a.workload,
-           "note": "FETCH_SIZE not doubled: 16-B gathers and 4-B weight fragments, not wide coalesced streams "
-                   "(MI355X_MICROARCH.md HBM section); uncalibrated lower bound for this access pattern",
+           "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): gfx950's FETCH_SIZE reads 1/2 of the "
+                   "bytes (MI355X_MICROARCH.md HBM section), calibrated for this kernel's access patterns with "
+                   "tools/micro/fetch_calib.hip (profiles/r01_fetch_calibration.txt)",
            "dominant": dominant, "kernels": kernels}
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
