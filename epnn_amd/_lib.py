@@ -37,6 +37,7 @@ SIGNATURES = {
     "epnn_get_weights": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "epnn_weight_shape": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip]),
     "epnn_edges": (C.c_int, [_vp, C.c_int, _fp, _fp]),
+    "epnn_edges_ex": (C.c_int, [_vp, C.c_int, _fp, C.c_int, C.c_double, C.c_double, _fp, C.POINTER(C.c_double)]),
     "epnn_forward_xyz": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp, _fp]),
     "epnn_forward_xyz_begin": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp]),
     "epnn_forward_xyz_end": (C.c_int, [_vp, _fp]),

@@ -189,16 +189,11 @@ def get_init_edges(xyz, molecular_splits, num=32, cutoff=3.0, eta=2.0):
     if molecular_splits.ndim == 1 and molecular_splits.shape != (0,):
         raise ValueError("get_init_edges: the reference calls exit() for 1-D non-empty molecular_splits (charge_gn.py:134-145)")
     xyz = np.asarray(xyz)
-    mu = np.linspace(0.1, cutoff, num=num)
-    x64 = xyz.astype(np.float64)
-    d = x64[:, None, :] - x64[None, :, :]
-    D = np.sqrt((d * d).sum(-1))
-    C = (np.cos(np.pi * (D - 0.0) / cutoff) + 1.0) / 2.0
-    C[D >= cutoff] = 0.0
-    C[D <= 0.0] = 1.0
-    np.fill_diagonal(C, 0.0)
-    e = C[:, :, None] * np.exp(-eta * (D[:, :, None] - mu[None, None, :]) ** 2)
-    return np.array(e, dtype=np.float32), np.tile(C[:, :, None], [1, 1, num])
+    if xyz.ndim != 2 or xyz.shape[1] != 3 or xyz.shape[0] < 1:
+        raise ValueError(f"get_init_edges: xyz must be (n, 3), got {xyz.shape}")
+    # distances in float64 from the float32-rounded coordinates, cosine cutoff, Gaussians, float32 cast: k_edges_dense
+    e, C = _scratch_engine().edges_ex(xyz, num, cutoff, eta)
+    return e, np.tile(C[:, :, None], [1, 1, num])
 
 
 def read_xyz(filename, n_elems=None):

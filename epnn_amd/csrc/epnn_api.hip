@@ -892,19 +892,45 @@ extern "C" int epnn_forward_xyz(epnn_handle *h, int B, int N, const int32_t *off
 }
 
 // ------------------------------------------------------------------------------------------------ edges
+static int edges_impl(epnn_handle *h, int n, const float *xyz, int num, double cutoff, double eta, const double *d_mu,
+                      float *e_out, double *c_out) {
+    const size_t total = (size_t)n * n * num, nn = (size_t)n * n;
+    if (h->s_xyz.ensure((size_t)n * 3 * 4) || h->s_misc.ensure(total * 4 + (c_out ? nn * 8 + 8 : 0))) return 1;
+    double *d_c = c_out ? reinterpret_cast<double *>(h->s_misc.as<char>() + ((total * 4 + 7) & ~size_t(7))) : nullptr;
+    HIPCHK(hipMemcpyAsync(h->s_xyz.p, xyz, (size_t)n * 3 * 4, hipMemcpyHostToDevice, h->stream));
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_edges_dense, dim3(grid), dim3(256), 0, h->stream, h->s_xyz.as<float>(), n, num, cutoff, eta, d_mu,
+                       h->s_misc.as<float>(), d_c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e_out, h->s_misc.p, total * 4, hipMemcpyDeviceToHost, h->stream));
+    if (c_out) HIPCHK(hipMemcpyAsync(c_out, d_c, nn * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int epnn_edges(epnn_handle *h, int n, const float *xyz, float *e_out) {
     if (!h || !xyz || !e_out || n < 1) EPNN_FAIL("epnn_edges: bad argument");
     HIPCHK(hipSetDevice(h->device));
-    const size_t total = (size_t)n * n * h->cfg.e_dim;
-    if (h->s_xyz.ensure((size_t)n * 3 * 4) || h->s_misc.ensure(total * 4)) return 1;
-    HIPCHK(hipMemcpyAsync(h->s_xyz.p, xyz, (size_t)n * 3 * 4, hipMemcpyHostToDevice, h->stream));
-    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_edges_dense, dim3(grid), dim3(256), 0, h->stream, h->s_xyz.as<float>(), n, h->cfg.e_dim,
-                       (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->s_misc.as<float>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(e_out, h->s_misc.p, total * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
+    if (h->pending.active && finish_forward(h)) return 1;
+    return edges_impl(h, n, xyz, h->cfg.e_dim, (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), e_out, nullptr);
+}
+
+// get_init_edges with the reference's own parameters (charge_gn.py:122: num, and the constants 3.0 / 2.0 of :148-161 as
+// arguments): any number of channels, plus the cutoff weights C[n][n] (float64) the reference returns tiled.
+extern "C" int epnn_edges_ex(epnn_handle *h, int n, const float *xyz, int num, double cutoff, double eta, float *e_out,
+                             double *c_out) {
+    if (!h || !xyz || !e_out || n < 1 || num < 2 || !(cutoff > 0.1)) EPNN_FAIL("epnn_edges_ex: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    // mu = np.linspace(0.1, cutoff, num): arange(num)*step + start, last element forced to stop
+    std::vector<double> mu(num);
+    const double step = (cutoff - 0.1) / (double)(num - 1);
+    for (int k = 0; k < num; ++k) mu[k] = (double)k * step + 0.1;
+    mu[num - 1] = cutoff;
+    if (h->s_gx.ensure((size_t)num * sizeof(double))) return 1;
+    HIPCHK(hipMemcpyAsync(h->s_gx.p, mu.data(), (size_t)num * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));      // mu is a local
+    return edges_impl(h, n, xyz, num, cutoff, eta, h->s_gx.as<double>(), e_out, c_out);
 }
 
 // ------------------------------------------------------------------------------------------------ plumbing

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
 
 // epnn_edges: dense (n,n,e_dim) tensor exactly like get_init_edges, one thread per (i,j,ch)
 __global__ __launch_bounds__(256) void k_edges_dense(const float *xyz, int n, int e_dim, double cutoff, double eta,
-                                                     const double *mu, float *e_out) {
+                                                     const double *mu, float *e_out, double *c_out) {
     const size_t total = (size_t)n * n * e_dim;
     const double pi_d = 3.141592653589793;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -176,5 +176,6 @@ __global__ __launch_bounds__(256) void k_edges_dense(const float *xyz, int n, in
         if (i == j) C = 0.0;
         const double d = D - mu[ch];
         e_out[idx] = (float)(C * exp(-eta * (d * d)));
+        if (c_out && ch == 0) c_out[pr] = C;                  // the cutoff weights the reference returns tiled (charge_gn.py:163)
     }
 }

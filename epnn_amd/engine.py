@@ -109,6 +109,16 @@ class Engine:
         check(self.lib.epnn_edges(self.h, n, fptr(xyz), fptr(out)), self.lib)
         return out
 
+    def edges_ex(self, xyz, num, cutoff=3.0, eta=2.0):
+        """get_init_edges with its own parameters: (e float32 (n,n,num), C float64 (n,n)) from the device kernel."""
+        xyz = _f32(xyz)
+        n = xyz.shape[0]
+        e = np.empty((n, n, int(num)), dtype=np.float32)
+        c = np.empty((n, n), dtype=np.float64)
+        check(self.lib.epnn_edges_ex(self.h, n, fptr(xyz), int(num), float(cutoff), float(eta), fptr(e),
+                                     c.ctypes.data_as(C.POINTER(C.c_double))), self.lib)
+        return e, c
+
     def forward_xyz(self, offsets, xyz, x, Q, N):
         """Flat batch: offsets (B+1,), xyz (A,3), x (A,nx), Q (B,) -> q (A,) float32."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)

@@ -64,6 +64,10 @@ int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, int32_t *n_in
 
 /* get_init_edges (charge_gn.py:122-163): xyz[n][3] float32 -> e[n][n][e_dim] float32, host pointers. */
 int epnn_edges(epnn_handle *h, int n, const float *xyz, float *e_out);
+/* The same with the reference function's own parameters: num channels (charge_gn.py:122; mu = linspace(0.1, cutoff, num)),
+ * cutoff and eta (the constants 3.0 and 2.0 of charge_gn.py:148-161), and, when c_out is not NULL, the cutoff weights
+ * C[n][n] (float64) that get_init_edges returns tiled over the channels (charge_gn.py:163). */
+int epnn_edges_ex(epnn_handle *h, int n, const float *xyz, int num, double cutoff, double eta, float *e_out, double *c_out);
 
 /* Compact entry == gen_padded_init_state featurisation (charge_gn.py:292-366) + model([h,e,x,q,mask])
  * (charge_gn.py:369-391, infer.py:32-35) without materialising the dense (N,N,.) tensors:
