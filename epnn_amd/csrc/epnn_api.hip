@@ -111,7 +111,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
-                      &h->d_status, &h->d_bsum, &h->d_pbase, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
+                      &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->l_mflag, &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
@@ -547,14 +547,15 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
     P.large_list.clear();
     P.small_nmax = 0;
     // index arrays of the plan, written straight into page-locked memory and uploaded without waiting:
-    //   pbase [B] | moff [B+1] | order [B] | mflag [B] | molof [A]
+    //   wblk [B] int4 | moff [B+1] | mflag [B] | molof [A]
     if (h->ctl_uploading) {                         // the previous plan's upload must have run before its staging is reused
         HIPCHK(hipEventSynchronize(h->ev_ctl));
         h->ctl_uploading = false;
     }
-    if (h->pin_ctl.ensure(((size_t)4 * B + 1 + P.A) * sizeof(int))) return 1;
-    int *c_pbase = h->pin_ctl.as<int>(), *c_moff = c_pbase + B, *c_order = c_moff + B + 1, *c_mflag = c_order + B,
-        *c_molof = c_mflag + B;
+    if (h->pin_ctl.ensure(((size_t)6 * B + 1 + P.A) * sizeof(int))) return 1;
+    int4 *c_wblk = h->pin_ctl.as<int4>();
+    int *c_moff = h->pin_ctl.as<int>() + 4 * (size_t)B, *c_mflag = c_moff + B + 1, *c_molof = c_mflag + B;
+    std::vector<int> pbase(B);
     int count[EPNN_SMALL_NMAX + 2] = {0};
     long long run = 0;
     const bool wave_ok = h->cfg.nx + 3 <= 4 * EPNN_XS;       // the fused kernel's xq block holds nx + 3 inputs
@@ -575,7 +576,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
             P.large_list.push_back(b);
         }
         // pair slots of the in-kernel front-end: every i<j pair of every molecule
-        c_pbase[b] = (int)run;
+        pbase[b] = (int)run;
         run += n <= EPNN_SMALL_NMAX ? (long long)n * (n - 1) / 2 : 0;
     }
     if (run > 0x7fffffffLL / 64) EPNN_FAIL("forward: batch too large (%lld pair slots)", run);
@@ -587,19 +588,21 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
         std::vector<int> sorted(P.small_order.size());
         for (int b : P.small_order) sorted[start[offsets[b + 1] - offsets[b]]++] = b;
         P.small_order.swap(sorted);
-        if (!P.small_order.empty()) memcpy(c_order, P.small_order.data(), P.small_order.size() * sizeof(int));
+        for (size_t k = 0; k < P.small_order.size(); ++k) {
+            const int b = P.small_order[k];
+            c_wblk[k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
+        }
     }
-    if (h->d_pbase.ensure((size_t)B * sizeof(int)) || h->d_moff.ensure((B + 1) * sizeof(int)) ||
+    if (h->d_moff.ensure((B + 1) * sizeof(int)) ||
         h->d_molof.ensure(std::max(1, P.A) * sizeof(int)) || h->l_mflag.ensure(std::max(1, P.B) * sizeof(int)) ||
-        h->d_order.ensure(std::max<size_t>(1, P.small_order.size()) * sizeof(int)) ||
+        h->d_order.ensure(std::max<size_t>(1, P.small_order.size()) * sizeof(int4)) ||
         h->d_rowcnt.ensure((P.A + 1) * sizeof(int)) || h->d_rowoff.ensure((P.A + 1) * sizeof(int)))
         return 1;
-    HIPCHK(hipMemcpyAsync(h->d_pbase.p, c_pbase, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_moff.p, c_moff, (size_t)(B + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->l_mflag.p, c_mflag, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_molof.p, c_molof, (size_t)P.A * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (!P.small_order.empty())
-        HIPCHK(hipMemcpyAsync(h->d_order.p, c_order, P.small_order.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_order.p, c_wblk, P.small_order.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev_ctl, h->stream));
     h->ctl_uploading = true;
     if (large_plan(h)) return 1;
@@ -637,8 +640,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.wpack = h->d_wpack.as<float>();
     A.xin = S.d_x;
     A.Q = S.d_Q;
-    A.moff = h->d_moff.as<int>();
-    A.order = h->d_order.as<int>();
+    A.wblk = h->d_order.as<int4>();
     A.row_off = h->d_rowoff.as<int>();
     A.pi = h->d_pi.as<int>();
     A.pj = h->d_pj.as<int>();
@@ -676,7 +678,6 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.stamps = h->l_nm.as<unsigned long long>();
 #endif
     A.xyz = S.d_xyz;
-    A.pbase = h->d_pbase.as<int>();
     A.mu = h->d_mu.as<double>();
     A.cutoff = (double)h->cfg.cutoff;
     A.eta = (double)h->cfg.eta;

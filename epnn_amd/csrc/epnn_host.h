@@ -103,7 +103,7 @@ struct epnn_handle {
     DevBuf d_mu;
     // plan + workspace
     Plan plan;
-    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status, d_bsum, d_pbase;
+    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status, d_bsum;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     int pcap = 0;
     int pair_cap_per_atom = 16;

@@ -38,8 +38,8 @@ struct WaveArgs {
     const float *wpack;
     const float *xin;      // [A][nx]
     const float *Q;        // [B]
-    const int *moff;       // [B+1]
-    const int *order;      // molecules of this launch (largest first)
+    const int4 *wblk;      // per wavefront of this launch (largest molecule first): molecule b, first atom, atoms, first pair slot of the
+                           // in-kernel front-end (sum of n(n-1)/2 over the molecules before b)
     const int *row_off;    // [A+1]
     const int *pi, *pj, *psym;
     float *pe, *pwi, *pwj;  // written by the kernel itself with the in-kernel front-end, read-only otherwise
@@ -54,7 +54,6 @@ struct WaveArgs {
     int lds_words;         // LDS budget of one wave (floats)
     // in-kernel front-end (FRONT): the wave builds its molecule's near-pair list itself (get_init_edges, charge_gn.py:122-163)
     const float *xyz;      // [A][3]
-    const int *pbase;      // [B] first pair slot of molecule b: sum of n(n-1)/2 over the molecules before it
     const double *mu;      // [48]
     double cutoff, eta;
     double cut2;           // smallest float64 t with sqrt(t) >= cutoff: D < cutoff  <=>  D*D (before the sqrt) < cut2
@@ -167,9 +166,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     const int lane = threadIdx.x, q = lane >> 4, n16 = lane & 15;
     const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
     if (!FRONT && (*A.status & EPNN_ST_PAIR_OVERFLOW)) return;
-    const int b = A.order[blockIdx.x];
-    const int a0 = A.moff[b], n = A.moff[b + 1] - a0;
-    const int p0 = FRONT ? A.pbase[b] : A.row_off[a0];
+    const int4 wb = A.wblk[blockIdx.x];                   // molecule, first atom, atoms, first pair slot: ONE load, not a chain of three
+    const int b = wb.x, a0 = wb.y, n = wb.z;
+    const int p0 = FRONT ? wb.w : A.row_off[a0];
     int np = FRONT ? 0 : A.row_off[a0 + n] - p0;
     const int nx = A.nx;
     const bool xs3 = nx + 3 <= 4 * (EPNN_XS - 1);         // the last xq K step is empty
