@@ -231,7 +231,6 @@ __global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2
         __syncthreads();
         if (active) {
             f32x4 ra[2] = {w16_ld(Rs + po), w16_ld(Rs + po + 8)};
-#pragma unroll 2
             for (int j = 0; j < nj; ++j) {
                 const float *nr = Rs + min(j + 1, nj - 1) * 32 + po;      // the next partner's row while this one is in the pipe
                 const f32x4 rn[2] = {w16_ld(nr), w16_ld(nr + 8)};

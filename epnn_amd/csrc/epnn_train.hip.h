@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void k_t_mm_fwd(const float *X, const float *W
     const float *xr = X + (size_t)row * K;
     f32x16 acc = epnn_splat16(0.f);
     const int steps = (K + 1) >> 1;
-#pragma unroll 16
     for (int s = 0; s < steps; ++s) {
         const int k = 2 * s + hh;
         const float a = k < K ? xr[k] : 0.f;
@@ -125,7 +124,6 @@ __global__ __launch_bounds__(256) void k_t_mm_dx(const float *dY, const float *Y
     const int row = min(r0 + c, R - 1), kk = min(k0 + c, K - 1);
     f32x16 acc = epnn_splat16(0.f);
     const int steps = (O + 1) >> 1;
-#pragma unroll 16
     for (int s = 0; s < steps; ++s) {
         const int o = 2 * s + hh;
         float g = 0.f, w = 0.f;
@@ -156,7 +154,6 @@ __global__ __launch_bounds__(256) void k_t_mm_dw(const float *X, const float *dY
     const int k0 = kt * 32, o0 = ot * 32;
     const int krow = k0 + c, col = min(o0 + c, O - 1);      // A operand row = weight row k (k == K: the bias row)
     f32x16 acc = epnn_splat16(0.f);
-#pragma unroll 16
     for (int r2 = rlo; r2 < rhi; r2 += 2) {
         const int r = r2 + hh;
         float a = 0.f, g = 0.f;
