@@ -110,7 +110,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
+    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_mu_ex, &h->d_moff, &h->d_molof, &h->d_order, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
@@ -928,10 +928,10 @@ extern "C" int epnn_edges_ex(epnn_handle *h, int n, const float *xyz, int num, d
     const double step = (cutoff - 0.1) / (double)(num - 1);
     for (int k = 0; k < num; ++k) mu[k] = (double)k * step + 0.1;
     mu[num - 1] = cutoff;
-    if (h->s_gx.ensure((size_t)num * sizeof(double))) return 1;
-    HIPCHK(hipMemcpyAsync(h->s_gx.p, mu.data(), (size_t)num * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->d_mu_ex.ensure((size_t)num * sizeof(double))) return 1;
+    HIPCHK(hipMemcpyAsync(h->d_mu_ex.p, mu.data(), (size_t)num * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));      // mu is a local
-    return edges_impl(h, n, xyz, num, cutoff, eta, h->s_gx.as<double>(), e_out, c_out);
+    return edges_impl(h, n, xyz, num, cutoff, eta, h->d_mu_ex.as<double>(), e_out, c_out);
 }
 
 // ------------------------------------------------------------------------------------------------ plumbing

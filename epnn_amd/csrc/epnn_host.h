@@ -103,6 +103,7 @@ struct epnn_handle {
     DevBuf d_mu;
     // plan + workspace
     Plan plan;
+    DevBuf d_mu_ex;                   // Gaussian centres of an epnn_edges_ex call with its own num / cutoff
     DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status, d_bsum;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     int pcap = 0;
