@@ -337,11 +337,51 @@ __global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin) {
     const int n = L.moff[tl.z + 1] - L.moff[tl.z];
     const int nchunk = tl.w;
     float s = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) s += L.S0[((size_t)ch * L.A + at) * 32 + o];
-    for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) s += L.corr[((size_t)p * 2 + 0) * 32 + o];
-    for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
-        const int p = L.dn_ent[e];
-        if (L.psym[p]) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
+    {   // eight loads in flight, added in chunk order (the order of the sum is part of the result)
+        const float *src = L.S0 + (size_t)at * 32 + o;
+        const size_t step = (size_t)L.A * 32;
+        int ch = 0;
+        for (; ch + 8 <= nchunk; ch += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(ch + u) * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; ch < nchunk; ++ch) s += src[(size_t)ch * step];
+    }
+    {
+        const int p0 = L.row_off[at], p1 = L.row_off[at + 1];
+        int p = p0;
+        for (; p + 4 <= p1; p += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = L.corr[((size_t)(p + u) * 2 + 0) * 32 + o];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; p < p1; ++p) s += L.corr[((size_t)p * 2 + 0) * 32 + o];
+    }
+    {   // the pairs in which this atom is the second one: entry -> pair -> correction, four chains in flight
+        const int e0 = L.dn_off[at], e1 = L.dn_off[at + 1];
+        int e = e0;
+        for (; e + 4 <= e1; e += 4) {
+            int pp[4], sy[4];
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pp[u] = L.dn_ent[e + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sy[u] = L.psym[pp[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = L.corr[((size_t)pp[u] * 2 + 1) * 32 + o];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sy[u]) s += v[u];
+        }
+        for (; e < e1; ++e) {
+            const int p = L.dn_ent[e];
+            if (L.psym[p]) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
+        }
     }
     s += (float)(L.N - n) * L.zp[(size_t)at * 32 + o];
     Sfin[(size_t)at * 32 + o] = s;
@@ -354,14 +394,29 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
     const int t0 = blockIdx.x * 4;
     const int np = L.row_off[L.A];
     if (np > L.pcap) return;
-    for (int idx = tid; idx < 4 * 32 * 32; idx += 256) {
-        const int o = idx & 31, a = (idx >> 5) & 31, w = idx >> 10;
-        float s = 0.f;
-        if (t0 + w < L.natiles) {
-            const int4 tl = L.atiles[t0 + w];
-            if (a < tl.y) s = Sfin[(size_t)(tl.x + a) * 32 + o];
+    // every weight fragment of the three layers is requested before anything else: the kernel has natiles/4 workgroups and
+    // is pure latency, so the 88 loads travel while S is staged instead of one by one in front of their MFMAs
+    const float *wp = L.wpack;
+    float w1[40], w2[16], w3[32];
+#pragma unroll
+    for (int s = 0; s < 40; ++s) w1[s] = wp[U.u1F + s * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w2[s] = wp[U.u2F + s * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) w3[s] = wp[U.u3F + s * 64 + lane];
+    {   // stage S of the workgroup's four tiles: the tile descriptors first, then all sixteen loads of a thread in flight
+        int4 tls[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tls[w] = t0 + w < L.natiles ? L.atiles[t0 + w] : make_int4(0, 0, 0, 0);
+        const int o = tid & 31, a8 = tid >> 5;
+        float v[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int w = it >> 2, a = a8 + 8 * (it & 3);
+            v[it] = a < tls[w].y ? Sfin[(size_t)(tls[w].x + a) * 32 + o] : 0.f;
         }
-        Ss[(w * 32 + a) * EPNN_SST + o] = s;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) Ss[((it >> 2) * 32 + a8 + 8 * (it & 3)) * EPNN_SST + o] = v[it];
     }
     (void)maxchunk;
     __syncthreads();
@@ -369,7 +424,6 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
     const int4 tl = L.atiles[t0 + wave];
     const bool live = c < tl.y;
     const int at = tl.x + (live ? c : 0);
-    const float *wp = L.wpack;
     const int nx = L.nx;
     const int u0 = (nx - hh + 1) >> 1;
     const float *arow = L.a_eo + (size_t)at * EPNN_AST + hh * 32 + u0;
@@ -386,9 +440,9 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = Nf * cb[r];
 #pragma unroll
-    for (int s = 0; s < 24; ++s) acc = epnn_mfma(wp[U.u1F + s * 64 + lane], hv[s], acc);
+    for (int s = 0; s < 24; ++s) acc = epnn_mfma(w1[s], hv[s], acc);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = epnn_mfma(wp[U.u1F + (24 + s) * 64 + lane], sv[s], acc);
+    for (int s = 0; s < 16; ++s) acc = epnn_mfma(w1[24 + s], sv[s], acc);
     float u1[16], b2v[16];
     // node_mask (charge_gn.py:59,72,74): 1 for every real atom unless the dense front-end supplies one
     const float nmc = L.nm_in ? L.nm_in[at] : 1.f;
@@ -398,7 +452,7 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b2v[r];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = epnn_mfma(wp[U.u2F + s * 64 + lane], u1[s], acc);
+    for (int s = 0; s < 16; ++s) acc = epnn_mfma(w2[s], u1[s], acc);
     float u2[16], b3a[16], b3b[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) u2[r] = fmaxf(acc[r], 0.f);
@@ -409,8 +463,8 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
     for (int r = 0; r < 16; ++r) { o0[r] = b3a[r]; o1[r] = b3b[r]; }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        o0 = epnn_mfma(wp[U.u3F + s * 64 + lane], u2[s], o0);
-        o1 = epnn_mfma(wp[U.u3F + (16 + s) * 64 + lane], u2[s], o1);
+        o0 = epnn_mfma(w3[s], u2[s], o0);
+        o1 = epnn_mfma(w3[16 + s], u2[s], o1);
     }
     if (live) {
         float *dst = L.a_eo + (size_t)at * EPNN_AST;
