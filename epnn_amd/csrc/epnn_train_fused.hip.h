@@ -35,6 +35,26 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     float *gacc;                 // atoms kernel: pass network gfeat [BN][48] (+=), message network gh [BN][48] (=)
 };
 
+// Staging loops: `total` elements, element idx loaded by ld(idx) and placed by st(idx, value).  Four loads of a thread are
+// in flight before the first store (a plain loop would wait for every load in front of its LDS write: the loop trip
+// counts are run-time values, the compiler does not overlap the iterations).
+template <typename LD, typename ST>
+__device__ __forceinline__ void tf_stage(int total, int tid, LD &&ld, ST &&st) {
+    for (int base = 0; base < total; base += 4 * EPNN_TF_NT) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * EPNN_TF_NT + tid;
+            v[u] = idx < total ? ld(idx) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * EPNN_TF_NT + tid;
+            if (idx < total) st(idx, v[u]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- forward, pair MLP
 // MODE 0: message network (out_dim 32, summed over ALL N partners); MODE 1: pass network (out_dim 1, both orders).
 template <int MODE>
@@ -52,16 +72,16 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A) {
     float *red = H2s + ND * N * 33;           // [NG][32] + [32]  /  [2][N]
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
-    for (int idx = tid; idx < N * F; idx += EPNN_TF_NT) {
-        const int j = idx / F, k = idx - j * F;
-        const size_t at = a0 + j;
-        As[j * FS + k] = k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
-    }
-    for (int idx = tid; idx < N * 48; idx += EPNN_TF_NT) {
-        const int j = idx / 48, k = idx - j * 48;
-        Es[j * 49 + k] = A.e[rowbase * 48 + idx];
-    }
-    for (int idx = tid; idx < D * 32; idx += EPNN_TF_NT) W1s[idx] = A.theta[A.oW1 + idx];
+    tf_stage(N * F, tid,
+             [&](int idx) {
+                 const int j = idx / F, k = idx - j * F;
+                 const size_t at = a0 + j;
+                 return k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
+             },
+             [&](int idx, float v) { const int j = idx / F; As[j * FS + (idx - j * F)] = v; });
+    tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
+             [&](int idx, float v) { const int j = idx / 48; Es[j * 49 + (idx - j * 48)] = v; });
+    tf_stage(D * 32, tid, [&](int idx) { return A.theta[A.oW1 + idx]; }, [&](int idx, float v) { W1s[idx] = v; });
     __syncthreads();
     // ---- layer 1: z1 = b1 + a_i W1[0:F] + a_j W1[F:2F] + e_ij W1[2F:]   (the a_i term once per thread, not per row)
     const float b1 = A.theta[A.ob1 + o];
@@ -182,22 +202,22 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A) {
     float *dms = vec, *vs = vec + 32, *s1 = vec + 64, *sb2 = vec + 128, *c2 = vec + 160, *dfs = vec + 192;
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
-    for (int idx = tid; idx < N * F; idx += EPNN_TF_NT) {
-        const int j = idx / F, k = idx - j * F;
-        const size_t at = a0 + j;
-        As[j * FS + k] = k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
+    tf_stage(N * F, tid,
+             [&](int idx) {
+                 const int j = idx / F, k = idx - j * F;
+                 const size_t at = a0 + j;
+                 return k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
+             },
+             [&](int idx, float v) { const int j = idx / F; As[j * FS + (idx - j * F)] = v; });
+    tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
+             [&](int idx, float v) { const int j = idx / 48; Es[j * 49 + (idx - j * 48)] = v; });
+    for (int d = 0; d < ND; ++d) {
+        tf_stage(N * 32, tid, [&](int idx) { return A.H1[d * dstride + rowbase * 32 + idx]; },
+                 [&](int idx, float v) { H1s[(d * N + (idx >> 5)) * 33 + (idx & 31)] = v; });
+        tf_stage(N * 32, tid, [&](int idx) { return A.H2[d * dstride + rowbase * 32 + idx]; },
+                 [&](int idx, float v) { H2s[(d * N + (idx >> 5)) * 33 + (idx & 31)] = v; });
     }
-    for (int idx = tid; idx < N * 48; idx += EPNN_TF_NT) {
-        const int j = idx / 48, k = idx - j * 48;
-        Es[j * 49 + k] = A.e[rowbase * 48 + idx];
-    }
-    for (int d = 0; d < ND; ++d)
-        for (int idx = tid; idx < N * 32; idx += EPNN_TF_NT) {
-            const int j = idx >> 5, k = idx & 31;
-            H1s[(d * N + j) * 33 + k] = A.H1[d * dstride + rowbase * 32 + idx];
-            H2s[(d * N + j) * 33 + k] = A.H2[d * dstride + rowbase * 32 + idx];
-        }
-    for (int idx = tid; idx < 1024; idx += EPNN_TF_NT) W2s[(idx >> 5) * 33 + (idx & 31)] = A.theta[A.oW2 + idx];
+    tf_stage(1024, tid, [&](int idx) { return A.theta[A.oW2 + idx]; }, [&](int idx, float v) { W2s[(idx >> 5) * 33 + (idx & 31)] = v; });
     if (MODE == 0) {
         if (tid < 32) dms[tid] = A.dU0[(size_t)bi * 80 + 48 + tid] * A.nm[bi];     // dM_i: the same for every partner row
     } else {
