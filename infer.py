@@ -59,18 +59,13 @@ def main(argv=None):
     test_preds = []
     timeC = timeD = time.time()
     for i in range(len(x)):
-        hb = np.array(np.expand_dims(h[i], axis=0))
-        eb = np.array(np.expand_dims(e[i], axis=0))
-        xb = np.array(np.expand_dims(x[i], axis=0))
-        qb = np.array(np.expand_dims(q[i], axis=0))
-        yb = np.array(np.expand_dims(y[i], axis=0))
-        maskb = np.array(np.expand_dims(mask[i], axis=0))
+        # one system per call, batch axis of length 1 (infer.py:62-69)
+        hb, eb, xb, qb, yb, maskb = (np.asarray(t[i])[None] for t in (h, e, x, q, y, mask))
         timeC = time.time()
-        for j in range(repeats):
-            inf_1 = time.time()
+        for _ in range(repeats):
+            t_call = time.time()
             test_preds.append(test_step(model, hb, eb, xb, qb, yb, maskb))
-            inf_2 = time.time()
-            print(inf_2 - inf_1)
+            print(time.time() - t_call)                       # the reference prints every call's seconds (infer.py:74)
         timeD = time.time()
     np.save(args.out, np.array(test_preds))
 
