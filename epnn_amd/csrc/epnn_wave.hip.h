@@ -126,10 +126,15 @@ __device__ __forceinline__ float w16_sumq(float v) {
 __device__ __forceinline__ f32x4 w16_ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void w16_st(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
-// fragment loads: [nrb][stride][64 lanes], steps s0 .. s0+cnt-1 of every row block
+// fragment loads: [nrb][stride][64 lanes], steps s0 .. s0+cnt-1 of every row block.  One address per row block, the steps
+// as immediate offsets of the load (256 bytes apart, at most 16 of them: inside the 4 KB immediate range).  With the step
+// inside the index every load beyond that range cost three VALU instructions of address arithmetic -- and f32 MFMA and
+// VALU share the SIMD's issue cycles.
 #define W16_LDX(dst, off, nrb, cnt, stride, s0)                                                   \
-    _Pragma("unroll") for (int rb_ = 0; rb_ < (nrb); ++rb_) _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[rb_][s_] = \
-        wp[(off) + (rb_ * (stride) + (s0) + s_) * 64 + lane]
+    _Pragma("unroll") for (int rb_ = 0; rb_ < (nrb); ++rb_) {                                     \
+        const float *fp_ = wp + (size_t)(unsigned)((off) + (rb_ * (stride) + (s0)) * 64 + lane);  \
+        _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[rb_][s_] = fp_[s_ * 64];        \
+    }
 #define W16_LD(dst, off, nrb, steps) W16_LDX(dst, off, nrb, steps, steps, 0)
 
 // D[rb][CB] += sum_s W[rb][s] * in[s]  for one column block (dependent chain of S MFMAs per row block)
