@@ -179,3 +179,35 @@ def test_infer_entry_point(tmp_path):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_error_behaviour_at_the_boundary(weights_decay):
+    """Bad calls come back as EpnnError with the C side's message (epnn_last_error), never as a crash or a silent
+    result; the handle stays usable afterwards."""
+    from epnn_amd import synth
+    from epnn_amd._lib import EpnnError
+    from epnn_amd.engine import Engine
+    eng = Engine(nx=9, T=5)
+    eng.set_weights(weights_decay)
+    offsets, xyz, x, Q, N = synth.qm9_like_batch(B=8, seed=3)
+    good = eng.forward_xyz(offsets, xyz, x, Q, N)
+    with pytest.raises(EpnnError, match="padded size"):
+        eng.forward_xyz(offsets, xyz, x, Q, 5)                      # a molecule does not fit N
+    bad = offsets.copy()
+    bad[0] = 1
+    with pytest.raises(EpnnError):
+        eng.forward_xyz(bad, xyz, x, Q, N)                          # offsets must start at 0
+    with pytest.raises(EpnnError, match="shapes"):
+        eng.forward_xyz(offsets, xyz[:-1], x, Q, N)                 # arrays do not match the offsets
+    with pytest.raises(EpnnError, match="unknown option"):
+        eng.set_option("no_such_option", 1)
+    eng.forward_xyz_begin(offsets, xyz, x, Q, N)
+    with pytest.raises(EpnnError, match="collect the previous forward"):
+        eng.forward_xyz_begin(offsets, xyz, x, Q, N)                # one forward per handle between begin and end
+    assert np.array_equal(eng.forward_xyz_end(), good)
+    with pytest.raises(EpnnError):
+        eng.train_step_xyz(offsets, xyz, x, Q, np.zeros(int(offsets[-1]), np.float32), N)    # train_init not called
+    assert np.array_equal(eng.forward_xyz(offsets, xyz, x, Q, N), good)                     # still usable
+    eng.close()
+    with pytest.raises(EpnnError):
+        Engine(nx=9, T=5, h_dim=32)                                 # the kernels are built for h_dim == e_dim == 48
