@@ -104,7 +104,11 @@ struct epnn_handle {
     // plan + workspace
     Plan plan;
     DevBuf d_mu_ex;                   // Gaussian centres of an epnn_edges_ex call with its own num / cutoff
-    DevBuf d_moff, d_molof, d_order, d_rowcnt, d_rowoff, d_status, d_bsum;
+    DevBuf d_ctl;                     // the plan's index arrays, one upload: wblk [B] int4 | moff [B+1] | mflag [B] | molof [A]
+    int4 *p_wblk = nullptr;
+    int *p_moff = nullptr, *p_mflag = nullptr, *p_molof = nullptr;
+    DevBuf d_moff;                    // molecule offsets of a train step (epnn_train_step_xyz)
+    DevBuf d_rowcnt, d_rowoff, d_status, d_bsum;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     int pcap = 0;
     int pair_cap_per_atom = 16;
@@ -121,7 +125,7 @@ struct epnn_handle {
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
-    DevBuf l_mflag, l_stasks, l_schunk, l_sfin;
+    DevBuf l_stasks, l_schunk, l_sfin;
     int l_natiles = 0, l_nstasks = 0, l_maxchunk = 0;
     // options / stats
     int opt_profile = 0, opt_force_path = 0;
@@ -134,7 +138,6 @@ struct epnn_handle {
     bool ctl_uploading = false;
     struct HostCall {
         bool active = false;          // a begun forward has not been collected yet
-        bool copied = false;          // its charges are already on their way to pin_out
         int A = 0;
     } hostcall;
     // deferred overflow handling for the asynchronous entry point

@@ -577,9 +577,9 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.N = P.N;
     L.A = P.A;
     L.B = P.B;
-    L.moff = h->d_moff.as<int>();
-    L.mol_of = h->d_molof.as<int>();
-    L.mflag = h->l_mflag.as<int>();
+    L.moff = h->p_moff;
+    L.mol_of = h->p_molof;
+    L.mflag = h->p_mflag;
     L.xin = d_x;
     L.Q = d_Q;
     L.h_in = d_hin;
