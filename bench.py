@@ -52,8 +52,8 @@ def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)     # 400 x 0.13 ms: long enough for the fill / drain of the
-    ap.add_argument("--warmup", type=int, default=24)     # six-deep pipeline (~0.6 ms each) not to weigh on the rate
+    ap.add_argument("--steps", type=int, default=4000)    # 4000 x 0.09 ms = 0.35 s: the fill / drain of the six-deep pipeline
+    ap.add_argument("--warmup", type=int, default=24)     # (~0.6 ms each) and the barrier do not weigh on the rate
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight per GPU (handles/streams used round robin)")
@@ -127,14 +127,15 @@ def main():
         step(k)
     barrier()
     dt = time.perf_counter() - t0
-    # Kernel durations for the roofline: the SAME K steps again, right after the timed region, this time with
+    # Kernel durations for the roofline: the same steps again (up to 600), right after the timed region, this time with
     # hipEvents recorded around every stage on the stream the kernels run on (four event records per forward cost
     # ~20 us of host time per step, which would otherwise be charged to `value`).
-    pipe.set_option("profile", args.steps)
-    for k in range(args.steps):
+    prof_steps = min(args.steps, 600)            # enough launches for a stable mean; four hipEvents are kept per forward
+    pipe.set_option("profile", prof_steps)
+    for k in range(prof_steps):
         step(k)
     pipe.sync()
-    per_lane = [sum(1 for k in range(args.steps) if k % len(lanes) == l) for l in range(len(lanes))]
+    per_lane = [sum(1 for k in range(prof_steps) if k % len(lanes) == l) for l in range(len(lanes))]
     # ms per forward: front-end kernels (none: the fused kernel builds its pair lists itself), fused kernel, tiled kernels, total
     stage = np.array([lanes[l][0].timing_at(i) for l in range(len(lanes)) for i in range(per_lane[l])])
     pipe.set_option("profile", 0)
