@@ -332,14 +332,21 @@ class Pipeline:
         """Charges of every batch of `batches` (an iterable of (offsets, xyz, x, Q) host arrays), in order, with up to
         `depth` batches in flight: while the GPU works on some, the host stages the next and collects the oldest."""
         busy = []                                   # engines with a begun forward, oldest first
-        for offsets, xyz, x, Q in batches:
-            e = self.lane()
-            if busy and busy[0] is e:
+        try:
+            for offsets, xyz, x, Q in batches:
+                e = self.lane()
+                if busy and busy[0] is e:
+                    yield busy.pop(0).forward_xyz_end()
+                e.forward_xyz_begin(offsets, xyz, x, Q, N)
+                busy.append(e)
+            while busy:
                 yield busy.pop(0).forward_xyz_end()
-            e.forward_xyz_begin(offsets, xyz, x, Q, N)
-            busy.append(e)
-        for e in busy:
-            yield e.forward_xyz_end()
+        finally:
+            for e in busy:                          # abandoned half way (error, or the caller stopped iterating): collect
+                try:                                # what is in flight so that the engines can be used again
+                    e.forward_xyz_end()
+                except EpnnError:
+                    pass
 
     def sync(self):
         for e in self.engines:

@@ -371,6 +371,15 @@ def test_pipeline_map_equals_one_call_at_a_time(weights_decay):
     assert len(got) == len(ref)
     for a, b in zip(got, ref):
         assert a.shape == b.shape and np.array_equal(a, b)
+    # a caller that stops iterating half way leaves no forward behind: the pipeline can be used again at once
+    pipe = Pipeline(depth=3, nx=9, T=5)
+    pipe.set_weights(weights_decay)
+    it = pipe.map(stream, Nall)
+    first = next(it)
+    it.close()
+    again = list(pipe.map(stream[:2], Nall))
+    pipe.close()
+    assert np.array_equal(first, ref[0]) and np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
     eng = Engine(nx=9, T=5)
     with pytest.raises(Exception):
         eng.forward_xyz_end()
