@@ -27,6 +27,9 @@ _ip = C.POINTER(C.c_int32)
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/epnn.h declares
+# int exchange(void *ctx, float *d_rows, int row_len, int n_rows, int row_lo, int row_hi)   (epnn_set_partition)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
+
 SIGNATURES = {
     "epnn_last_error": (C.c_char_p, []),
     "epnn_version": (C.c_int, []),
@@ -41,6 +44,7 @@ SIGNATURES = {
     "epnn_forward_xyz": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp, _fp]),
     "epnn_forward_xyz_begin": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp]),
     "epnn_forward_xyz_end": (C.c_int, [_vp, _fp]),
+    "epnn_set_partition": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "epnn_forward_xyz_dev": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _vp, _vp, _vp, _vp]),
     "epnn_model_forward_dense": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_model_forward_dense_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -828,6 +828,22 @@ extern "C" int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t 
     return 0;
 }
 
+// Row-block partition of a SINGLE large system over `world` processes: the all-pairs sweep -- all of
+// the cost of the tiled path -- is split by atom tiles; after every GNN step `exchange` must complete the rows of S this
+// process did not compute (it is called with the device pointer, the row length, the number of rows and this process's
+// own row range, on a synchronised stream; epnn_memcpy_d2h / _h2d move rows).  Everything else is computed by every
+// process, so all of them end with all the charges.  world = 1 switches the partition off.
+extern "C" int epnn_set_partition(epnn_handle *h, int rank, int world, epnn_exchange_fn exchange, void *ctx) {
+    if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) EPNN_FAIL("epnn_set_partition: bad argument");
+    if (h->pending.active && finish_forward(h)) return 1;
+    h->part_rank = rank;
+    h->part_world = world;
+    h->part_exchange = exchange;
+    h->part_ctx = ctx;
+    h->plan.valid = false;
+    return 0;
+}
+
 extern "C" int epnn_sync(epnn_handle *h) {
     if (!h) EPNN_FAIL("epnn_sync: null handle");
     HIPCHK(hipSetDevice(h->device));

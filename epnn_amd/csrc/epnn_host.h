@@ -126,6 +126,12 @@ struct epnn_handle {
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
     DevBuf l_stasks, l_schunk, l_sfin;
+    // row-block partition of the all-pairs sweep over `part_world` processes (epnn_set_partition): this one runs the tile
+    // groups [part_g0, part_g1) = atoms [part_row_lo, part_row_hi) and the callback completes S after every GNN step
+    int part_rank = 0, part_world = 1;
+    int part_row_lo = 0, part_row_hi = 0;
+    epnn_exchange_fn part_exchange = nullptr;
+    void *part_ctx = nullptr;
     int l_natiles = 0, l_nstasks = 0, l_maxchunk = 0;
     // options / stats
     int opt_profile = 0, opt_force_path = 0;

@@ -521,6 +521,16 @@ struct LargePlanHost {
 static int large_plan(epnn_handle *h) {
     Plan &P = h->plan;
     LargePlanHost lp;
+    // row-block partition (epnn_set_partition): the tile groups of all tiled molecules, in atom order, are dealt out in
+    // contiguous ranges; everything else of the plan -- tiles, j-chunks -- is the same on every process, so the partial
+    // sums of an atom are the same numbers in the same order whoever computes them
+    int total_groups = 0;
+    for (int b : P.large_list) total_groups += ((P.offsets[b + 1] - P.offsets[b] + 31) / 32 + 3) / 4;
+    const int g_own0 = (int)((long long)total_groups * h->part_rank / h->part_world);
+    const int g_own1 = (int)((long long)total_groups * (h->part_rank + 1) / h->part_world);
+    int gidx = 0;
+    h->part_row_lo = P.A;
+    h->part_row_hi = 0;
     for (int b : P.large_list) {
         const int a0 = P.offsets[b], n = P.offsets[b + 1] - a0;
         const int first_tile = (int)lp.atiles.size();
@@ -537,13 +547,18 @@ static int large_plan(epnn_handle *h) {
         nchunk = (n + clen - 1) / clen;
         for (int i0 = 0; i0 < n; i0 += 32) lp.atiles.push_back(make_int4(a0 + i0, std::min(32, n - i0), b, nchunk));
         lp.maxchunk = std::max(lp.maxchunk, nchunk);
-        for (int tg = 0; tg < ntile; tg += 4)
+        for (int tg = 0; tg < ntile; tg += 4, ++gidx) {
+            if (gidx < g_own0 || gidx >= g_own1) continue;
+            h->part_row_lo = std::min(h->part_row_lo, a0 + tg * 32);
+            h->part_row_hi = std::max(h->part_row_hi, a0 + std::min(n, (tg + 4) * 32));
             for (int ch = 0; ch < nchunk; ++ch) {
                 lp.stasks.push_back(make_int4(first_tile + tg, std::min(4, ntile - tg), a0 + ch * clen,
                                               a0 + std::min(n, (ch + 1) * clen)));
                 lp.stask_chunk.push_back(ch);
             }
+        }
     }
+    if (h->part_row_hi < h->part_row_lo) h->part_row_lo = h->part_row_hi = 0;        // no group of its own
     h->l_natiles = (int)lp.atiles.size();
     h->l_nstasks = (int)lp.stasks.size();
     h->l_maxchunk = lp.maxchunk;
@@ -556,8 +571,10 @@ static int large_plan(epnn_handle *h) {
         h->l_cnt.ensure((A + 1) * sizeof(int)) || h->l_sfin.ensure(A * 32 * 4))
         return 1;
     HIPCHK(hipMemcpyAsync(h->l_tiles.p, lp.atiles.data(), lp.atiles.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->l_stasks.p, lp.stasks.data(), lp.stasks.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->l_schunk.p, lp.stask_chunk.data(), lp.stask_chunk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!lp.stasks.empty()) {
+        HIPCHK(hipMemcpyAsync(h->l_stasks.p, lp.stasks.data(), lp.stasks.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->l_schunk.p, lp.stask_chunk.data(), lp.stask_chunk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -625,9 +642,19 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     hipLaunchKernelGGL(k_lg_dn_sort, dim3(gAt), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
     for (int t = 0; t < (run_gnn ? L.T : 0); ++t) {
         hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[t], 1);
-        hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
+        if (L.nstasks > 0)
+            hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
         hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
         hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
+        if (h->part_world > 1) {
+            // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms): the caller's
+            // exchange fills them in; everything after this point is computed by every process for every atom
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            if (!h->part_exchange) EPNN_FAIL("forward: a partition is set but no exchange function");
+            if (h->part_exchange(h->part_ctx, h->l_sfin.as<float>(), 32, P.A, h->part_row_lo, h->part_row_hi))
+                EPNN_FAIL("forward: the partition's exchange function reported an error");
+        }
         hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk, h->l_sfin.as<float>());
     }
     if (d_hout) hipLaunchKernelGGL(k_lg_export_h, dim3(gA), dim3(256), 0, st, L);

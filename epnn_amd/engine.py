@@ -267,6 +267,43 @@ class Engine:
         arr = np.ascontiguousarray(arr)
         return DeviceArray(self, arr.nbytes).upload(arr)
 
+    def set_partition(self, rank, world, exchange=None):
+        """One large system on `world` processes: this engine computes the all-pairs sums of its own
+        rows of atoms and `exchange(d_rows_ptr, row_len, n_rows, row_lo, row_hi) -> None` completes the others' after
+        every GNN step (shard.make_row_exchange builds one on torch.distributed).  world = 1 switches it off."""
+        if world > 1:
+            if exchange is None:
+                raise EpnnError("set_partition: an exchange function is needed for world > 1")
+
+            def _cb(ctx, d_rows, row_len, n_rows, row_lo, row_hi):
+                try:
+                    exchange(d_rows, row_len, n_rows, row_lo, row_hi)
+                    return 0
+                except Exception as exc:                    # an exception must not cross the C frames
+                    self._exchange_error = exc
+                    return 1
+
+            self._exchange_cb = _lib.EXCHANGE_FN(_cb)       # keep the thunk alive as long as the handle uses it
+            fn = C.cast(self._exchange_cb, C.c_void_p)
+        else:
+            self._exchange_cb = None
+            fn = None
+        check(self.lib.epnn_set_partition(self.h, int(rank), int(world), fn, None), self.lib)
+
+    def copy_rows_to_host(self, d_ptr, row_len, row_lo, row_hi):
+        """rows [row_lo, row_hi) of a device array [..][row_len] float32 -> NumPy (used by exchange functions)."""
+        out = np.empty((row_hi - row_lo, row_len), dtype=np.float32)
+        if out.size:
+            check(self.lib.epnn_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(d_ptr + 4 * row_len * row_lo),
+                                           out.nbytes), self.lib)
+        return out
+
+    def copy_rows_to_device(self, d_ptr, row_len, row_lo, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.size:
+            check(self.lib.epnn_memcpy_h2d(self.h, C.c_void_p(d_ptr + 4 * row_len * row_lo), rows.ctypes.data_as(C.c_void_p),
+                                           rows.nbytes), self.lib)
+
     def forward_xyz_dev(self, offsets, d_xyz, d_x, d_Q, d_q, N):
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         check(self.lib.epnn_forward_xyz_dev(self.h, len(offsets) - 1, int(N), iptr(offsets), d_xyz.ptr, d_x.ptr,

@@ -67,6 +67,38 @@ def forward_sharded(compute, offsets, xyz, x, Q, N, rank=0, world=1, dist=None):
     return out
 
 
+# --------------------------------------------------------------------------------------------- one large system
+def make_row_exchange(engine, dist, rank, world):
+    """Exchange function for Engine.set_partition: all-gather of the rows of S every process owns, through
+    torch.distributed (host-staged, so it runs on gloo and on nccl alike; the rows of one GNN step of a 100 000-atom
+    system are 12.8 MB).  Every process calls it at the same points of the forward (after each GNN step)."""
+    import torch
+    known = {}                                   # (n_rows, row_lo, row_hi) -> every process's row range (fixed per plan)
+
+    def exchange(d_rows, row_len, n_rows, row_lo, row_hi):
+        mine = engine.copy_rows_to_host(d_rows, row_len, row_lo, row_hi)
+        key = (int(n_rows), int(row_lo), int(row_hi))
+        if key not in known:
+            ranges = [None] * world
+            dist.all_gather_object(ranges, (int(row_lo), int(row_hi)))
+            known.clear()
+            known[key] = ranges
+        ranges = known[key]
+        width = max(hi - lo for lo, hi in ranges)
+        send = torch.zeros((max(width, 1), row_len), dtype=torch.float32)
+        send[:mine.shape[0]] = torch.from_numpy(mine)
+        on_gpu = dist.get_backend() == "nccl"
+        if on_gpu:
+            send = send.cuda()
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(recv, send)
+        for r, (lo, hi) in enumerate(ranges):
+            if r != rank and hi > lo:
+                engine.copy_rows_to_device(d_rows, row_len, lo, recv[r][:hi - lo].cpu().numpy())
+
+    return exchange
+
+
 # --------------------------------------------------------------------------------------------- data-parallel training
 def dp_step_molecules(order, world, step):
     """Molecules of optimizer step `step` when `world` ranks each take one molecule (train.py): rank r gets

@@ -82,6 +82,14 @@ int epnn_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const
 int epnn_forward_xyz_begin(epnn_handle *h, int B, int N, const int32_t *offsets, const float *xyz, const float *x,
                            const float *Q);
 int epnn_forward_xyz_end(epnn_handle *h, float *q_out);
+/* One large system on several GPUs (one process each, same inputs everywhere): the all-pairs sum of GNN_layer
+ * (charge_gn.py:70), which is all of the cost of a system with thousands of atoms, is split by rows of atoms.  After every
+ * GNN step the library calls `exchange(ctx, d_rows, row_len, n_rows, row_lo, row_hi)`: d_rows is a device array
+ * [n_rows][row_len] float of which this process has filled rows row_lo..row_hi-1; the function must fill in the rows the
+ * other processes own (an all-gather; epnn_memcpy_d2h / epnn_memcpy_h2d move rows) and return 0.  Molecules of at most 32
+ * atoms are not partitioned.  Results are bit-identical to the unpartitioned run. */
+typedef int (*epnn_exchange_fn)(void *ctx, float *d_rows, int row_len, int n_rows, int row_lo, int row_hi);
+int epnn_set_partition(epnn_handle *h, int rank, int world, epnn_exchange_fn exchange, void *ctx);
 /* Same with device-resident xyz/x/Q/q_out (offsets stay on the host); asynchronous. */
 int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t *offsets, const float *d_xyz,
                          const float *d_x, const float *d_Q, float *d_q_out);

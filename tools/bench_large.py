@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Large-system timings (BASELINE.json configs[3] and [4]): the 2220-atom protein and a synthetic box.
-    python tools/bench_large.py protein | box100k | box<N>k
+    python tools/bench_large.py protein | box100k | box<N>k [steps]
+One system on several GPUs (row-block partition of the all-pairs sweep):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_large.py box100k
 """
 import os, sys, time
 import numpy as np
@@ -13,8 +15,20 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "protein"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     w = checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights"))
-    eng = Engine(nx=9, T=5)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from epnn_amd import shard
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        ndev = torch.cuda.device_count()
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # the exchange is host-staged
+    eng = Engine(nx=9, T=5, device=device)
     eng.set_weights(w)
+    if world > 1:
+        eng.set_partition(rank, world, shard.make_row_exchange(eng, dist, rank, world))
     if what == "protein":
         xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(ROOT, "tests/golden/protein/6qlp_capped.xyz"), 9)
         offsets = np.array([0, len(x)], dtype=np.int32)
@@ -40,7 +54,8 @@ def main():
     stats = eng.last_stats()
     q = dq.download((A,))
     flops = synth.algorithmic_flops([A], int(stats[0]))
-    print(f"{what}: {A} atoms, {stats[0]} near pairs; {dt*1e3:.3f} ms/forward wall, device stages front/fused/tiled/total ms = {np.round(st,3)}; "
+    if rank == 0:
+      print((f"[{world} processes, rows of atoms partitioned] " if world > 1 else "") + f"{what}: {A} atoms, {stats[0]} near pairs; {dt*1e3:.3f} ms/forward wall, device stages front/fused/tiled/total ms = {np.round(st,3)}; "
           f"{A/dt:.3e} atoms/s; algorithmic {flops/1e9:.1f} Gflop -> {flops/(st[3]*1e-3)/1e12:.1f} TFLOP/s; sum q = {q.sum(dtype=np.float64):.6f}", flush=True)
     eng.close()
 
