@@ -220,3 +220,34 @@ def test_train_script_and_mirror(tmp_path, golden_dir):
     assert np.abs(after - before).max() > 0                          # weights moved, inference sees them
     tv = model.trainable_variables
     assert len(tv) == 66 and sum(v.size for v in tv) == 74037
+
+
+@pytest.mark.parametrize("N,ns", [(50, [50, 33]), (96, [96]), (97, [60])])
+def test_fused_step_at_larger_padded_sizes(gpu_engine_factory, N, ns):
+    """Padded sizes beyond one pass of the fused kernels' row loops (48 rows per pass), their LDS limit N = 96, and the
+    fallback to the layer-by-layer kernels above it: both settings of "train_fused" give the same loss and gradients."""
+    nx, T = 9, 2
+    w = random_weights(nx, T, seed=11, scale=0.4)
+    h, e, x, q, mask, y = _tiny_batch(nx, N, ns, seed=4)
+    res = []
+    for fused in (1, 0):
+        eng = gpu_engine_factory(nx=nx, T=T)
+        eng.set_option("train_fused", fused)
+        eng.set_weights(w)
+        eng.train_init()
+        pred, loss = eng.train_step_dense(h, e, x, q, mask, y, apply=False)
+        res.append((pred, loss, eng.get_gradients().astype(np.float64)))
+    (pa, la, ga), (pb, lb, gb) = res
+    assert np.abs(pa - pb).max() < 5e-6
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(lb))
+    pos, worst = 0, 0.0
+    for m in [w["upd"]] + w["msg"] + w["pas"]:
+        for W, b in m:
+            for arr in (W, b):
+                sl = slice(pos, pos + arr.size)
+                scale = np.abs(gb[sl]).max()
+                if scale > 0:
+                    worst = max(worst, np.abs(ga[sl] - gb[sl]).max() / scale)
+                pos += arr.size
+    print(f"N={N}: fused vs layer-by-layer worst per-tensor relative gradient difference {worst:.2e}")
+    assert worst < 1e-4
