@@ -211,3 +211,46 @@ def test_error_behaviour_at_the_boundary(weights_decay):
     eng.close()
     with pytest.raises(EpnnError):
         Engine(nx=9, T=5, h_dim=32)                                 # the kernels are built for h_dim == e_dim == 48
+
+
+def test_layer_calls_on_a_system_for_the_tiled_kernels():
+    """GNN_layer.call / EPN_layer.call / the model on dense inputs of a 50-atom system next to a 20-atom one, padded to 56:
+    the larger one runs on the tiled kernels (n > 32), with h, q and the node mask coming from the caller."""
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    nx, T, N = 9, 2, 56
+    rng = np.random.default_rng(7)
+    mols = []
+    for n in (50, 20):
+        xyz = (rng.normal(size=(n, 3)) * 2.6).astype(np.float32)
+        x = np.zeros((n, nx), np.float32)
+        x[np.arange(n), rng.integers(1, nx, size=n)] = 1
+        x[:, 0] = rng.integers(1, 10, size=n)
+        mols.append(orc.dense_inputs(xyz, x, np.float32(1.0), N))
+    h, e, x, q, mask = (np.stack([m[k] for m in mols]) for k in range(5))
+    w = random_weights(nx, T, seed=21, scale=0.35)
+    hx, xx, qx, m4 = orc.model_reduce(h, x, q, mask)
+    hx = (rng.normal(size=hx.shape) * 0.2 * (xx[..., :1] != 0)).astype(np.float32)
+    qx = (qx + 0.05 * rng.normal(size=qx.shape) * (xx[..., :1] != 0)).astype(np.float32)
+    gnn = charge_gn.GNN_layer(charge_gn.MLP_layer, charge_gn.MLP_layer([32, 32], out_dim=48), T)
+    for t in range(T):
+        gnn.message_fns[t].set_weights(w["msg"][t])
+    gnn.update_fn.set_weights(w["upd"])
+    h_gpu = gnn.call(hx, e, xx, qx, m4)
+    h_ref = orc.gnn_layer(hx, e, xx, qx, m4, w["msg"], w["upd"], dtype=np.float64)
+    h_r32 = orc.gnn_layer(hx, e, xx, qx, m4, w["msg"], w["upd"], dtype=np.float32)
+    assert np.abs(h_gpu - h_ref).max() <= max(TOL, 3 * np.abs(h_r32 - h_ref).max())
+    epn = charge_gn.EPN_layer(charge_gn.MLP_layer, T=T)
+    for t in range(T):
+        epn.pass_fns[t].set_weights(w["pas"][t])
+    q_gpu = epn.call(h_ref.astype(np.float32), e, xx, qx, m4)
+    q_ref = orc.epn_layer(h_ref.astype(np.float32), e, xx, qx, m4, w["pas"], dtype=np.float64)
+    q_r32 = orc.epn_layer(h_ref.astype(np.float32), e, xx, qx, m4, w["pas"], dtype=np.float32)
+    assert np.abs(q_gpu - q_ref).max() <= max(TOL, 3 * np.abs(q_r32 - q_ref).max())
+    assert np.abs(q_gpu.sum(axis=(1, 2)) - qx.sum(axis=(1, 2))).max() < 5e-6
+    model = charge_gn.make_model([32, 32], 48, T, nx, N)
+    model.set_weights_dict(w)
+    p_gpu = model([h, e, x, q, mask])
+    p_ref = orc.model_forward(h, e, x, q, mask, w, np.float64)
+    p_r32 = orc.model_forward(h, e, x, q, mask, w, np.float32)
+    assert np.abs(p_gpu - p_ref).max() <= max(TOL, 3 * np.abs(p_r32 - p_ref).max())
