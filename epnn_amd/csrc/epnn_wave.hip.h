@@ -446,21 +446,20 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq0, r0, xs3);
             if (two) { w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq1, P1, xs3); w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq1, r1, xs3); }
             if (have_h) {                                   // layer-level entry: h given by the caller
-                float wh[2][12], hin0[12], hin1[12], hm0[12], hm1[12];
+                float wh[2][12], hin0[12], hin1[12];
 #pragma unroll
-                for (int s = 0; s < 12; ++s) {
-                    hin0[s] = hk0[s >> 2][s & 3]; hin1[s] = hk1[s >> 2][s & 3];
-                    hm0[s] = nm0 * hin0[s]; hm1[s] = nm1 * hin1[s];    // masked_input = [h, m] * node_mask (charge_gn.py:72)
-                }
+                for (int s = 0; s < 12; ++s) { hin0[s] = hk0[s >> 2][s & 3]; hin1[s] = hk1[s >> 2][s & 3]; }
                 W16_LDX(wh, X.wi0, 2, 12, EPNN_XS + 12, EPNN_XS);
                 w16_mm<2, 12>(wh, hin0, P0);
                 if (two) w16_mm<2, 12>(wh, hin1, P1);
                 W16_LDX(wh, X.wj0, 2, 12, EPNN_XS + 12, EPNN_XS);
                 w16_mm<2, 12>(wh, hin0, r0);
                 if (two) w16_mm<2, 12>(wh, hin1, r1);
+                // the h block of the update MLP's first layer; masked_input = [h, m] * node_mask (charge_gn.py:72): the mask
+                // multiplies the whole pre-activation where the summed messages join it (once: it may be fractional)
                 W16_LD(wh, X.u1h0, 2, 12);
-                w16_mm<2, 12>(wh, hm0, U0);
-                if (two) w16_mm<2, 12>(wh, hm1, U1);
+                w16_mm<2, 12>(wh, hin0, U0);
+                if (two) w16_mm<2, 12>(wh, hin1, U1);
             }
             if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
             if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }

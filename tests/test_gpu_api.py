@@ -254,3 +254,35 @@ def test_layer_calls_on_a_system_for_the_tiled_kernels():
     p_ref = orc.model_forward(h, e, x, q, mask, w, np.float64)
     p_r32 = orc.model_forward(h, e, x, q, mask, w, np.float32)
     assert np.abs(p_gpu - p_ref).max() <= max(TOL, 3 * np.abs(p_r32 - p_ref).max())
+
+
+def test_fractional_node_mask():
+    """node_mask = clip(sum_i mask[i, j], 0, 1) (charge_gn.py:59) is fractional when an atom's mask column sums to less than
+    1 -- tiny systems with fractional masks.  It multiplies the update MLP's input and its output once each (:72, :74).
+    (Found by tests/fuzz_dense.py: the h block of the first step used to be masked twice.)"""
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    nx, T = 9, 2
+    rng = np.random.default_rng(2)
+    w = random_weights(nx, T, seed=13, scale=0.35)
+    e = (rng.random((2, 3, 3, 48)) * 0.3).astype(np.float32)
+    mask = np.zeros((2, 3, 3, 1), np.float32)
+    mask[0, :2, :2, 0] = [[1.0, 0.5], [1.0, 0.0]]             # node masks 1, 0.5 (and 0 for the padded third atom)
+    mask[1, :, :, 0] = [[0.5, 0.0, 0.5], [0.0, 0.0, 0.0], [0.0, 0.5, 0.0]]       # node masks 0.5, 0.5, 0.5
+    e[0, 2] = 0
+    e[0, :, 2] = 0
+    x = np.zeros((2, 3, nx), np.float32)
+    x[:, :, 0] = [[7, 1, 0], [6, 8, 1]]
+    x[0, :2, 4] = 1
+    x[1, :, 2] = 1
+    h = (rng.normal(size=(2, 3, 48)) * 0.2).astype(np.float32)
+    h[0, 2] = 0
+    q = (rng.normal(size=(2, 3, 1)) * 0.1).astype(np.float32)
+    q[0, 2] = 0
+    gnn = charge_gn.GNN_layer(charge_gn.MLP_layer, charge_gn.MLP_layer([32, 32], out_dim=48), T)
+    for t in range(T):
+        gnn.message_fns[t].set_weights(w["msg"][t])
+    gnn.update_fn.set_weights(w["upd"])
+    h_gpu = gnn.call(h, e, x, q, mask)
+    h_ref = orc.gnn_layer(h, e, x, q, mask, w["msg"], w["upd"], dtype=np.float64)
+    assert np.abs(h_gpu - h_ref).max() < 2e-6, np.abs(h_gpu - h_ref).max()
