@@ -1,0 +1,40 @@
+"""Randomised check of the literal make_model call (epnn_model_forward_dense: the (B,N,N,.) tensors and their reductions,
+charge_gn.py:382-384) on arbitrary inputs -- tiled like the featuriser's or not, rank-3 or rank-4 mask -- against the float64
+oracle (not collected by pytest; run by hand on a GPU box).  Round 1: 1867 cases, worst error 6 % of the tolerance."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import random_weights
+from epnn_amd import charge_gn
+from oracle import epnn_oracle as orc
+from fuzz_dense import random_case
+rng = np.random.default_rng(21)
+t0 = time.time(); n = 0; worst = 0
+while time.time() - t0 < 150:
+    T, h, e, x, q, mask = random_case(rng)
+    B, N = e.shape[:2]
+    w = random_weights(9, T, seed=int(rng.integers(1 << 30)), scale=0.35)
+    # literal make_model inputs: (B,N,N,.) tensors, NOT necessarily tiled: random per-pair values times the mask
+    mode = int(rng.integers(0, 3))
+    if mode == 0:      # tiled like gen_padded_init_state (row j*n+k of the tiled per-atom array is atom k)
+        h_inp = np.broadcast_to(h[:, None, :, :], (B, N, N, 48)) * (mask > 0)
+        x_inp = np.broadcast_to(x[:, None, :, :], (B, N, N, 9)) * (mask > 0)
+        q_inp = np.broadcast_to(q[:, None, :, :], (B, N, N, 1)) * (mask > 0)
+    else:              # arbitrary
+        h_inp = (rng.normal(size=(B, N, N, 48)) * 0.2).astype(np.float32) * (rng.random((B, N, N, 1)) < 0.7)
+        x_inp = np.broadcast_to(x[:, None, :, :], (B, N, N, 9)) * (rng.random((B, N, N, 1)) < 0.8)
+        q_inp = (rng.normal(size=(B, N, N, 1)) * 0.1).astype(np.float32)
+    h_inp, x_inp, q_inp = (np.ascontiguousarray(t, dtype=np.float32) for t in (h_inp, x_inp, q_inp))
+    m_inp = mask if mode < 2 else mask[..., 0]          # rank-3 mask is accepted like Keras does
+    model = charge_gn.make_model([32, 32], 48, T, 9, N)
+    model.set_weights_dict(w)
+    p = model([h_inp, e, x_inp, q_inp, m_inp])
+    ref = orc.model_forward(h_inp, e, x_inp, q_inp, m_inp, w, np.float64)
+    r32 = orc.model_forward(h_inp, e, x_inp, q_inp, m_inp, w, np.float32)
+    err = np.abs(p - ref).max() / max(1e-5, 3 * np.abs(r32 - ref).max())
+    worst = max(worst, err)
+    if err > 1:
+        print("FAIL", dict(T=T, B=B, N=N, mode=mode, err=float(err))); sys.exit(1)
+    n += 1
+print(f"model fuzz ok: {n} cases, worst err / tolerance {worst:.3f}")
