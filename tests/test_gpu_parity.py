@@ -427,12 +427,14 @@ xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(ROOT, "tests/golden/protein/6qlp_
 gold = np.load(os.path.join(ROOT, "tests/golden/protein/preds.npy")).astype(np.float32).ravel()
 cases.append((checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights")), 5,
               np.array([0, len(x)], np.int32), xyz, x, np.array([Q], np.float32), len(x), gold))
-# (b) random non-degenerate weights (the all-pairs sums matter), a 700-atom box next to small molecules
+# (b) random non-degenerate weights (the all-pairs sums matter): a 700-atom box, small molecules, a 300-atom box -- the
+#     ranges of tile groups dealt out to the processes cross the boundaries between the tiled molecules
 offs, bxyz, bx, bQ, bN = synth.box_system(n_atoms=700, seed=3)
+_, cxyz, cx, cQ, _ = synth.box_system(n_atoms=300, seed=4)
 so, sxyz, sx, sQ, sN = synth.qm9_like_batch(B=5, seed=1)
-off = np.concatenate([so, so[-1] + offs[1:]]).astype(np.int32)
-cases.append((random_weights(9, 3, seed=5, scale=0.35), 3, off, np.concatenate([sxyz, bxyz]), np.concatenate([sx, bx]),
-              np.concatenate([sQ, bQ]).astype(np.float32), 700, None))
+off = np.concatenate([[0, 700], 700 + so[1:], [700 + so[-1] + 300]]).astype(np.int32)
+cases.append((random_weights(9, 3, seed=5, scale=0.35), 3, off, np.concatenate([bxyz, sxyz, cxyz]), np.concatenate([bx, sx, cx]),
+              np.concatenate([bQ, sQ, cQ]).astype(np.float32), 700, None))
 for w, T, off, xyz, x, Q, N, gold in cases:
     eng = Engine(nx=9, T=T)
     eng.set_weights(w)
