@@ -28,25 +28,48 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
-    """The oracle (literal dense float32 restatement of charge_gn.py, one molecule per call like infer.py:62-76)
-    timed on this host on a bounded sample of the same workload (~12 s of CPU work)."""
+def _cpu_worker(args):
+    """One CPU-baseline worker: the oracle on its share of the molecules, one molecule per call, for `budget_s` seconds."""
+    mols, weights, N, budget_s = args
     from oracle import epnn_oracle as orc
-    B = len(offsets) - 1
-    threads = os.cpu_count() or 1
-    done_atoms = 0
-    done_mols = 0
+    orc.forward_xyz(*mols[0], weights, N=N, dtype=np.float32)           # first call outside the clock (imports, BLAS start-up)
+    atoms = calls = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        b = done_mols % B
-        lo, hi = offsets[b], offsets[b + 1]
-        orc.forward_xyz(xyz[lo:hi], x[lo:hi], Q[b], weights, N=N, dtype=np.float32)
-        done_atoms += hi - lo
-        done_mols += 1
-    dt = time.perf_counter() - t0
-    return {"value": done_atoms / dt, "unit": "atoms/s", "cores": threads, "kind": "port",
-            "sample": f"{done_mols} molecule calls ({done_atoms} atoms) cycling through the same batch, padded to N={N}, "
-                      f"one molecule per call like infer.py, NumPy float32 + multithreaded BLAS, {dt:.1f} s"}
+        xyz, x, Q = mols[calls % len(mols)]
+        orc.forward_xyz(xyz, x, Q, weights, N=N, dtype=np.float32)
+        atoms += x.shape[0]
+        calls += 1
+    return atoms, calls, time.perf_counter() - t0
+
+
+def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
+    """The oracle (literal dense float32 restatement of charge_gn.py, one molecule per call like infer.py:62-76) timed on
+    this host on a bounded sample of the same workload: `workers` single-threaded processes (spawned: nothing of this
+    process's GPU state is inherited), each cycling through its share of the batch for ~12 s."""
+    import multiprocessing as mp
+    B = len(offsets) - 1
+    workers = max(1, min(16, os.cpu_count() or 1))
+    shares = [[(xyz[offsets[b]:offsets[b + 1]], x[offsets[b]:offsets[b + 1]], Q[b]) for b in range(w, B, workers)]
+              for w in range(workers)]
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"                                             # inherited by the spawned workers
+    try:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            res = pool.map(_cpu_worker, [(sh, weights, N, budget_s) for sh in shares])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    atoms = sum(r[0] for r in res)
+    calls = sum(r[1] for r in res)
+    dt = max(r[2] for r in res)
+    return {"value": atoms / dt, "unit": "atoms/s", "cores": workers, "kind": "port",
+            "sample": f"{calls} molecule calls ({atoms} atoms) of the same batch, padded to N={N}, one molecule per call like "
+                      f"infer.py, NumPy float32, {workers} single-threaded worker processes, {dt:.1f} s each"}
 
 
 def main():
