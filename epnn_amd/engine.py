@@ -279,8 +279,9 @@ class Engine:
                 try:
                     exchange(d_rows, row_len, n_rows, row_lo, row_hi)
                     return 0
-                except Exception as exc:                    # an exception must not cross the C frames
-                    self._exchange_error = exc
+                except Exception:                           # an exception must not cross the C frames: report it here,
+                    import traceback                        # the forward then fails with the library's own message
+                    traceback.print_exc()
                     return 1
 
             self._exchange_cb = _lib.EXCHANGE_FN(_cb)       # keep the thunk alive as long as the handle uses it
