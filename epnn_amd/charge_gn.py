@@ -348,6 +348,17 @@ class EPNNModel(_Stack):
         """Compact entry: flat atom arrays instead of dense tensors; N defaults to the model's natom."""
         return self._eng().forward_xyz(offsets, xyz, x, Q, self.natom if N is None else N)
 
+    def predict_xyz_stream(self, batches, N=None, depth=6):
+        """Charges of every (offsets, xyz, x, Q) batch of `batches`, in order, with `depth` batches in flight on the GPU
+        (engine.Pipeline.map: the loop of infer.py:62-76 at the throughput of the compact entry)."""
+        from .engine import Pipeline
+        pipe = Pipeline(depth=depth, nx=self.n_elems, T=self.T, device=_DEVICE)
+        try:
+            pipe.set_weights(self.weights_dict())
+            yield from pipe.map(batches, self.natom if N is None else N)
+        finally:
+            pipe.close()
+
     def engine(self):
         return self._eng()
 

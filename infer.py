@@ -85,6 +85,13 @@ def main(argv=None):
             n = mols[i][1].shape[0]
             worst = max(worst, float(np.abs(qf[offsets[i]:offsets[i + 1]] - test_preds[i * repeats][0, :n, 0]).max()))
         print(f"batched compact entry: {len(mols)} molecules in {t1-t0:.6f} s, max |dq| vs per-molecule calls {worst:.2e}")
+        # the same through the pipeline that keeps several batches in flight (here: one molecule per batch)
+        singles = [(np.array([0, m[1].shape[0]], dtype=np.int32), m[0], m[1], np.array([m[2]], dtype=np.float32)) for m in mols]
+        t0 = time.time()
+        streamed = list(model.predict_xyz_stream(singles))
+        t1 = time.time()
+        worst = max(float(np.abs(streamed[i] - qf[offsets[i]:offsets[i + 1]]).max()) for i in range(len(mols)))
+        print(f"pipelined compact entry: {len(mols)} calls in {t1-t0:.6f} s (incl. creating the pipeline), max |dq| vs the batch {worst:.2e}")
     return np.array(test_preds), names
 
 

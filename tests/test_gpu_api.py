@@ -172,6 +172,8 @@ def test_infer_entry_point(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "avg inference time:" in out.stdout and "avg feature time:" in out.stdout
     assert os.path.exists(tmp_path / "test_names.npy")
+    piped = [l for l in out.stdout.splitlines() if l.startswith("pipelined compact entry")][0]
+    assert float(piped.rsplit(" ", 1)[1]) == 0.0            # bit-identical to the one-call batch
     line = [l for l in out.stdout.splitlines() if l.startswith("batched compact entry")][0]
     assert float(line.rsplit(" ", 1)[1]) <= 2e-6
 
