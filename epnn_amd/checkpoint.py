@@ -299,62 +299,168 @@ def _build_block(items, restart_interval=16) -> bytes:
     return bytes(buf)
 
 
-def _object_graph_proto(var_keys):
-    """Minimal ``TrackableObjectGraph``: a root node whose children are one node per variable.
+def keras_object_graph(T: int, n_plain_layers: int = 14) -> bytes:
+    """The ``TrackableObjectGraph`` proto Keras writes for the reference's ``make_model`` (``charge_gn.py:369-391``).
 
-    TensorFlow's loader matches by object-graph traversal; a Keras model restoring this file needs the
-    real Keras graph, so ``save_weights`` here copies the graph string of the checkpoint the weights were
-    loaded from when there is one (``graph_bytes``), and falls back to this flat graph otherwise.
+    TensorFlow restores by walking this graph, so a file without the real layout cannot be loaded by the reference's
+    ``model.load_weights`` (``infer.py:57``).  The layout is fully determined by the model's Python object tree:
+    node ids are handed out in breadth-first order of discovery from the Model; a node lists its children as
+    (node_id, local_name) and a variable lists one attribute (VARIABLE_VALUE, Keras variable name, checkpoint key).
+
+      root: ``layer-0 .. layer-13`` (the five Inputs and the TF-op layers of ``:382-384``; no weights, no children),
+            ``layer_with_weights-0`` = ``layer-14`` = the GNN_layer, ``layer_with_weights-1`` = ``layer-15`` = the EPN_layer
+      GNN_layer (``:48-54``): ``message_fns`` (list 0..T-1), ``update_fn``, ``message_fn`` (the attribute set at ``:61``: the
+            SAME object as list element T-1)              EPN_layer (``:80-85``): ``pass_fns``, ``pass_fn`` (``:99``)
+      MLP_layer (``:31-39``): ``nodes`` (plain list, no children), ``layer_set`` (list 0..2 of Dense: ``kernel``, ``bias``)
+
+    Keras variable names follow creation order in ``make_model`` (``:371-374``): ``dense .. dense_2`` update MLP,
+    then the T message MLPs, then the T pass MLPs.  Checked byte for byte against the graph strings of all three shipped
+    checkpoints (``tests/test_checkpoint.py``).
     """
-    nodes = []
-    root_children = b""
-    for n, key in enumerate(var_keys):
-        child = _proto_field(1, 0, n + 1) + _proto_field(2, 2, key.encode())
-        root_children += _proto_field(1, 2, child)
-    nodes.append(root_children)
-    for key in var_keys:
-        attr = (_proto_field(1, 2, b"VARIABLE_VALUE") + _proto_field(2, 2, key.encode())
-                + _proto_field(3, 2, (key + _SUFFIX).encode()))
-        nodes.append(_proto_field(2, 2, attr))
-    return b"".join(_proto_field(1, 2, nd) for nd in nodes)
+    class Obj:
+        def __init__(self):
+            self.children = []        # (local_name, Obj)
+            self.attr = None          # (full_name, checkpoint_key)
+
+    dense_counter = [0]
+
+    def mlp():
+        m = Obj()
+        m.children.append(("nodes", Obj()))
+        ls = Obj()
+        for l in range(3):
+            d = Obj()
+            stem = "dense" if dense_counter[0] == 0 else f"dense_{dense_counter[0]}"
+            dense_counter[0] += 1
+            for kind in ("kernel", "bias"):
+                v = Obj()
+                v.attr = f"{stem}/{kind}"
+                d.children.append((kind, v))
+            ls.children.append((str(l), d))
+        m.children.append(("layer_set", ls))
+        return m
+
+    upd = mlp()
+    msgs = [mlp() for _ in range(T)]
+    pas = [mlp() for _ in range(T)]
+    gnn, epn = Obj(), Obj()
+    lst = Obj()
+    lst.children = [(str(t), msgs[t]) for t in range(T)]
+    gnn.children = [("message_fns", lst), ("update_fn", upd), ("message_fn", msgs[T - 1])]
+    lst = Obj()
+    lst.children = [(str(t), pas[t]) for t in range(T)]
+    epn.children = [("pass_fns", lst), ("pass_fn", pas[T - 1])]
+    root = Obj()
+    root.children = [(f"layer-{k}", Obj()) for k in range(n_plain_layers)]
+    root.children += [("layer_with_weights-0", gnn), (f"layer-{n_plain_layers}", gnn),
+                      ("layer_with_weights-1", epn), (f"layer-{n_plain_layers + 1}", epn)]
+
+    # breadth-first numbering; the checkpoint key of a variable is the path by which it was FIRST reached
+    ids, order, path = {id(root): 0}, [root], {id(root): ""}
+    head = 0
+    while head < len(order):
+        o = order[head]
+        head += 1
+        for name, c in o.children:
+            if id(c) not in ids:
+                ids[id(c)] = len(order)
+                order.append(c)
+                path[id(c)] = (path[id(o)] + "/" + name) if path[id(o)] else name
+    out = b""
+    for o in order:
+        nd = b""
+        for name, c in o.children:
+            nd += _proto_field(1, 2, _proto_field(1, 0, ids[id(c)]) + _proto_field(2, 2, name.encode()))
+        if o.attr is not None:
+            nd += _proto_field(2, 2, _proto_field(1, 2, b"VARIABLE_VALUE") + _proto_field(2, 2, o.attr.encode())
+                               + _proto_field(3, 2, (path[id(o)] + _SUFFIX).encode()))
+        out += _proto_field(1, 2, nd)
+    return out
 
 
-def read_object_graph(prefix: str):
-    """Raw bytes of the ``_CHECKPOINTABLE_OBJECT_GRAPH`` string tensor, or None."""
-    num_shards, entries = read_index(prefix, verify=False)
+def object_graph_keys(graph_bytes: bytes):
+    """Checkpoint keys of the variables in a ``TrackableObjectGraph``, in node order (= TensorFlow's save order)."""
+    keys = []
+    for fno, _, node in _parse_proto(graph_bytes):
+        if fno != 1:
+            continue
+        for f2, _, val in _parse_proto(node):
+            if f2 == 2:
+                for f3, _, v3 in _parse_proto(val):
+                    if f3 == 3:
+                        keys.append(v3.decode())
+    return keys
+
+
+def _string_tensor(payload: bytes):
+    """Bytes and entry checksum of a scalar string tensor the way TensorFlow's ``WriteStringTensor`` lays it out:
+    ``varint length | u32 masked crc32c of the length as uint32 LE | bytes``; the entry's crc32c runs over the uint32
+    length, then the 4 checksum bytes, then the payload."""
+    ln = struct.pack("<I", len(payload))
+    crc = crc32c(ln)
+    len_ck = struct.pack("<I", _mask(crc))
+    crc = crc32c(payload, crc32c(len_ck, crc))
+    return _put_varint(len(payload)) + len_ck + payload, _mask(crc)
+
+
+def _read_string_tensor(raw: bytes, stored_crc, verify: bool, what: str) -> bytes:
+    ln, pos = _get_varint(raw, 0)
+    len_ck = raw[pos:pos + 4]
+    payload = raw[pos + 4:pos + 4 + ln]
+    if len(payload) != ln or pos + 4 + ln != len(raw):
+        raise ValueError(f"{what}: string tensor truncated")
+    if verify:
+        crc = crc32c(struct.pack("<I", ln))
+        if struct.pack("<I", _mask(crc)) != len_ck:
+            raise ValueError(f"{what}: string length checksum mismatch")
+        if stored_crc is not None and _mask(crc32c(payload, crc32c(len_ck, crc))) != stored_crc:
+            raise ValueError(f"{what}: checksum mismatch")
+    return payload
+
+
+def read_object_graph(prefix: str, verify: bool = True):
+    """Raw bytes of the ``_CHECKPOINTABLE_OBJECT_GRAPH`` string tensor (both of its checksums verified), or None."""
+    num_shards, entries = read_index(prefix, verify)
     ent = entries.get(_GRAPH_KEY)
     if ent is None:
         return None
     with open(f"{prefix}.data-{ent['shard_id']:05d}-of-{num_shards:05d}", "rb") as f:
         f.seek(ent["offset"])
         raw = f.read(ent["size"])
-    ln, pos = _get_varint(raw, 0)
-    return raw[pos + 4:pos + 4 + ln]
+    return _read_string_tensor(raw, ent["crc32c"], verify, _GRAPH_KEY)
 
 
-def write_bundle(prefix: str, tensors, graph_bytes: bytes | None = None):
-    """Write ``tensors`` (mapping key -> float32 array, keys WITHOUT the attribute suffix are accepted)
-    as a single-shard tensor bundle ``<prefix>.index`` + ``<prefix>.data-00000-of-00001``."""
+def _short_successor(key: bytes) -> bytes:
+    """LevelDB ``BytewiseComparator::FindShortSuccessor``: the index block's separator after the last data block."""
+    for i, b in enumerate(key):
+        if b != 0xFF:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
+def write_bundle(prefix: str, tensors, graph_bytes: bytes):
+    """Write ``tensors`` (mapping key -> float32 array, keys WITHOUT the attribute suffix are accepted) and the object
+    graph as a single-shard tensor bundle ``<prefix>.index`` + ``<prefix>.data-00000-of-00001`` -- byte for byte what
+    ``model.save_weights`` (``charge_gn.py:462``) writes for the same values: tensor bytes in the object graph's
+    variable order with the graph string last, index entries in key order (restart interval 16), empty metaindex."""
     items = {}
     for key, arr in tensors.items():
         k = key if key.endswith(_SUFFIX) else key + _SUFFIX
         items[k] = np.ascontiguousarray(arr, dtype="<f4")
-    if graph_bytes is None:
-        graph_bytes = _object_graph_proto([k[:-len(_SUFFIX)] for k in sorted(items)])
+    order = [k for k in object_graph_keys(graph_bytes) if k in items]
+    missing = sorted(set(items) - set(order))
+    if missing:
+        raise ValueError(f"tensors without a node in the object graph (TensorFlow could not restore them): {missing[:3]}")
     data = bytearray()
     entries = []
-    # string tensor: varint length, 4-byte masked crc of the lengths, then the bytes
-    lens = _put_varint(len(graph_bytes))
-    sraw = lens + struct.pack("<I", _mask(crc32c(lens))) + graph_bytes
-    # TF's entry crc for string tensors covers lengths-as-u32 + bytes; readers here skip it, TF checks it
-    scrc = _mask(crc32c(graph_bytes, crc32c(struct.pack("<I", len(graph_bytes)))))
-    entries.append((_GRAPH_KEY.encode(), _entry_proto(_DT_STRING, [], 0, 0, len(sraw), scrc)))
-    data += sraw
-    for k in sorted(items):
+    for k in order:
         raw = items[k].tobytes()
         entries.append((k.encode(), _entry_proto(_DT_FLOAT, list(items[k].shape), 0, len(data), len(raw),
                                                  _mask(crc32c(raw)))))
         data += raw
+    sraw, scrc = _string_tensor(graph_bytes)
+    entries.append((_GRAPH_KEY.encode(), _entry_proto(_DT_STRING, [], 0, len(data), len(sraw), scrc)))
+    data += sraw
     entries.sort(key=lambda kv: kv[0])
     header = _proto_field(1, 0, 1) + _proto_field(3, 2, _proto_field(1, 0, 1))  # num_shards=1, version.producer=1
     block = _build_block([(b"", header)] + entries)
@@ -370,8 +476,7 @@ def write_bundle(prefix: str, tensors, graph_bytes: bytes | None = None):
 
     doff, dsize = emit(block)
     moff, msize = emit(_build_block([]))
-    last_key = entries[-1][0] if entries else b""
-    ioff, isize = emit(_build_block([(last_key + b"\x00", _put_varint(doff) + _put_varint(dsize))]))
+    ioff, isize = emit(_build_block([(_short_successor(entries[-1][0]), _put_varint(doff) + _put_varint(dsize))]))
     footer = _put_varint(moff) + _put_varint(msize) + _put_varint(ioff) + _put_varint(isize)
     footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
     out.extend(footer)
@@ -415,5 +520,5 @@ def save_epnn_weights(prefix: str, weights, graph_bytes: bytes | None = None):
     for l in range(3):
         tensors[keys[("upd", 0, l, "kernel")]] = weights["upd"][l][0]
         tensors[keys[("upd", 0, l, "bias")]] = weights["upd"][l][1]
-    # the reference's files list message_fns/4 and message_fn as the same node; one copy is enough to reload
-    write_bundle(prefix, tensors, graph_bytes)
+    # message_fns/T-1 and message_fn are the same node of the object graph: one tensor, stored under message_fn
+    write_bundle(prefix, tensors, graph_bytes if graph_bytes is not None else keras_object_graph(T))

@@ -54,6 +54,63 @@ def test_write_read_round_trip(tmp_path):
     assert ck.read_object_graph(str(tmp_path / "ck" / "w")) == graph
 
 
+def test_rewrite_of_reference_checkpoint_is_byte_identical(tmp_path):
+    """The only pin available without TensorFlow: re-writing the reference's single-shard checkpoint
+    (models/model_weights, written by charge_gn.py:462) from its decoded tensors reproduces BOTH files byte for byte --
+    tensor order in the data file, string-tensor layout and its two checksums, index block, footer."""
+    from epnn_amd import checkpoint as ck
+    src = os.path.join(MODELS, "model_weights")
+    w = ck.load_epnn_weights(src)
+    for graph in (ck.read_object_graph(src), None):          # the stored graph string, and the generated one
+        dst = str(tmp_path / ("a" if graph else "b") / "model_weights")
+        ck.save_epnn_weights(dst, w, graph)
+        for suf in (".index", ".data-00000-of-00001"):
+            with open(src + suf, "rb") as f, open(dst + suf, "rb") as g:
+                assert f.read() == g.read(), suf
+
+
+@pytest.mark.parametrize("name,T", [("decay_model_weights", 5), ("model_weights", 5), ("model2_weights", 3)])
+def test_generated_object_graph_equals_the_stored_one(name, T):
+    """keras_object_graph(T) is the graph string Keras wrote into every shipped checkpoint (read_object_graph verifies
+    the string tensor's length checksum and entry checksum on the way)."""
+    from epnn_amd import checkpoint as ck
+    stored = ck.read_object_graph(os.path.join(MODELS, name))
+    assert ck.keras_object_graph(T) == stored
+    keys = ck.object_graph_keys(stored)
+    assert len(keys) == 6 * (2 * T + 1)
+    assert keys[0] == "layer_with_weights-0/update_fn/layer_set/0/kernel/.ATTRIBUTES/VARIABLE_VALUE"
+
+
+def test_string_tensor_checksums_follow_tensorflow(tmp_path):
+    """Known answers from the reference's own file: length checksum 904473428 and entry crc 4144287813 of
+    models/model_weights' _CHECKPOINTABLE_OBJECT_GRAPH; a flipped payload bit or length checksum is refused."""
+    import struct
+    from epnn_amd import checkpoint as ck
+    src = os.path.join(MODELS, "model_weights")
+    graph = ck.read_object_graph(src)
+    raw, crc = ck._string_tensor(graph)
+    assert struct.unpack("<I", raw[2:6])[0] == 904473428 and crc == 4144287813
+    _, entries = ck.read_index(src)
+    assert entries["_CHECKPOINTABLE_OBJECT_GRAPH"]["crc32c"] == crc
+    for f in os.listdir(MODELS):
+        if f.startswith("model_weights"):
+            shutil.copy(os.path.join(MODELS, f), tmp_path / f)
+    data = tmp_path / "model_weights.data-00000-of-00001"
+    good = data.read_bytes()
+    for pos in (298708 + 3, 298708 + 100):                   # inside the length checksum / inside the payload
+        bad = bytearray(good)
+        bad[pos] ^= 0x10
+        data.write_bytes(bytes(bad))
+        with pytest.raises(ValueError, match="checksum"):
+            ck.read_object_graph(str(tmp_path / "model_weights"))
+
+
+def test_tensor_without_graph_node_is_refused(tmp_path):
+    from epnn_amd import checkpoint as ck
+    with pytest.raises(ValueError, match="object graph"):
+        ck.write_bundle(str(tmp_path / "x"), {"not/in/graph": np.zeros(3, np.float32)}, ck.keras_object_graph(2))
+
+
 def test_corruption_is_detected(tmp_path):
     from epnn_amd import checkpoint as ck
     for f in os.listdir(MODELS):
