@@ -47,21 +47,48 @@ def get_init_edges(xyz, num=48, cutoff=3.0, eta=2.0, row_block=256):
     ``xyz`` is float32 (charge_gn.py:330); SciPy's distance_matrix promotes it to float64 (:124)."""
     xyz = np.asarray(xyz, dtype=np.float32).astype(np.float64)
     n = xyz.shape[0]
-    mu = np.linspace(0.1, cutoff, num=num)
     e = np.empty((n, n, num), dtype=np.float32)
     Call = np.empty((n, n), dtype=np.float64)
     for i0 in range(0, n, row_block):
-        d = xyz[i0:i0 + row_block, None, :] - xyz[None, :, :]
-        D = np.sqrt((d * d).sum(-1))                                   # scipy minkowski_distance p=2
-        C = (np.cos(np.pi * (D - 0.0) / cutoff) + 1.0) / 2.0            # :148
-        C[D >= cutoff] = 0.0                                            # :150
-        C[D <= 0.0] = 1.0                                               # :151
-        idx = np.arange(i0, min(n, i0 + row_block))
-        C[idx - i0, idx] = 0.0                                          # :152 fill_diagonal
-        e[i0:i0 + row_block] = (C[:, :, None] * np.exp(-eta * (D[:, :, None] - mu[None, None, :]) ** 2)
-                                ).astype(np.float32)                    # :160-161
-        Call[i0:i0 + row_block] = C
+        e[i0:i0 + row_block], Call[i0:i0 + row_block] = _edge_rows(xyz, i0, min(n, i0 + row_block), num, cutoff, eta)
     return e, Call
+
+
+def _edge_rows(xyz64, i0, i1, num, cutoff, eta):
+    """Rows i0..i1-1 of get_init_edges' output (the same operations on a block of rows)."""
+    mu = np.linspace(0.1, cutoff, num=num)                              # :123
+    d = xyz64[i0:i1, None, :] - xyz64[None, :, :]
+    D = np.sqrt((d * d).sum(-1))                                        # :124 scipy minkowski_distance p=2
+    C = (np.cos(np.pi * (D - 0.0) / cutoff) + 1.0) / 2.0                # :148
+    C[D >= cutoff] = 0.0                                                # :150
+    C[D <= 0.0] = 1.0                                                   # :151
+    idx = np.arange(i0, i1)
+    C[idx - i0, idx] = 0.0                                              # :152 fill_diagonal
+    e = (C[:, :, None] * np.exp(-eta * (D[:, :, None] - mu[None, None, :]) ** 2)).astype(np.float32)   # :160-161
+    return e, C
+
+
+class EdgeRows:
+    """The (1, n, n, num) edge tensor of ONE unpadded system, produced a block of rows at a time (for systems whose
+    dense tensor does not fit: 4096 atoms = 3.2 GB in float32).  gnn_layer / epn_layer accept it in place of `e`."""
+
+    def __init__(self, xyz, num=48, cutoff=3.0, eta=2.0):
+        self.xyz = np.asarray(xyz, dtype=np.float32).astype(np.float64)
+        self.num, self.cutoff, self.eta = num, cutoff, eta
+        self.shape = (1, self.xyz.shape[0], self.xyz.shape[0], num)
+        self._blocks = {}                  # float32 blocks are kept (the 15 sweeps of a forward ask for the same ones)
+
+    def rows(self, i0, i1):
+        key = (i0, min(i1, self.shape[1]))
+        if key not in self._blocks:
+            self._blocks[key] = _edge_rows(self.xyz, key[0], key[1], self.num, self.cutoff, self.eta)[0][None]
+        return self._blocks[key]
+
+
+def _e_rows(e, i0, i1, dtype):
+    """Rows i0..i1-1 (axis 1) of the edge tensor: float32 values, and the same cast to the working dtype."""
+    e32 = e.rows(i0, i1) if isinstance(e, EdgeRows) else np.asarray(e[:, i0:i1], dtype=np.float32)
+    return e32, e32.astype(dtype, copy=False)
 
 
 def parse_xyz(path, nx=9):
@@ -134,7 +161,7 @@ def _cast_layers(layers, dtype):
 
 def gnn_layer(h, e, x, q, mask, msg, upd, dtype=np.float32, row_block=64):
     """reference charge_gn.py:56-75 (GNN_layer.call).  h (B,N,H) e (B,N,N,E) x (B,N,nx) q (B,N,1) mask (B,N,N,1)."""
-    h, e, x, q, mask = (np.asarray(a, dtype=dtype) for a in (h, e, x, q, mask))
+    h, x, q, mask = (np.asarray(a, dtype=dtype) for a in (h, x, q, mask))
     B, N = e.shape[0], e.shape[1]
     node_mask = np.clip(mask.sum(axis=1), 0, 1)                         # :59  (B,N,1)
     upd = _cast_layers(upd, dtype)
@@ -147,7 +174,7 @@ def gnn_layer(h, e, x, q, mask, msg, upd, dtype=np.float32, row_block=64):
             nb = ai.shape[1]
             inp_i = np.broadcast_to(ai[:, :, None, :], (B, nb, N, a.shape[-1]))      # :63
             inp_j = np.broadcast_to(a[:, None, :, :], (B, nb, N, a.shape[-1]))       # :64
-            inp_ij = np.concatenate([inp_i, inp_j, e[:, i0:i0 + row_block]], axis=-1)  # :65
+            inp_ij = np.concatenate([inp_i, inp_j, _e_rows(e, i0, i0 + row_block, dtype)[1]], axis=-1)  # :65
             pm = mlp(inp_ij.reshape(-1, inp_ij.shape[-1]), layers)                    # :66-68
             messages[:, i0:i0 + row_block] = pm.reshape(B, nb, N, -1).sum(axis=2)     # :69-70 (ALL j)
         upd_in = np.concatenate([h, messages], axis=2) * node_mask      # :71-72
@@ -157,11 +184,8 @@ def gnn_layer(h, e, x, q, mask, msg, upd, dtype=np.float32, row_block=64):
 
 def epn_layer(h, e, x, q, mask, pas, dtype=np.float32, row_block=64, return_transfer=False):
     """reference charge_gn.py:87-119 (EPN_layer.call)."""
-    e32 = np.asarray(e, dtype=np.float32)
     tol = np.float32(1e-5)
-    largest = np.clip(e32, tol, np.float32(1e5)).max(axis=-1)           # :90-92 (float32 compare)
-    is_near = (largest != tol).astype(dtype)                            # :93-94
-    h, e, x, q, mask = (np.asarray(a, dtype=dtype) for a in (h, e, x, q, mask))
+    h, x, q, mask = (np.asarray(a, dtype=dtype) for a in (h, x, q, mask))
     B, N = e.shape[0], e.shape[1]
     pad = mask.max(axis=-1)                                             # :116 reduce_max(mask, -1)
     transfers = []
@@ -174,13 +198,15 @@ def epn_layer(h, e, x, q, mask, pas, dtype=np.float32, row_block=64, return_tran
             nb = ai.shape[1]
             inp_i = np.broadcast_to(ai[:, :, None, :], (B, nb, N, a.shape[-1]))
             inp_j = np.broadcast_to(a[:, None, :, :], (B, nb, N, a.shape[-1]))
-            eb = e[:, i0:i0 + row_block]
+            e32, eb = _e_rows(e, i0, i0 + row_block, dtype)
+            largest = np.clip(e32, tol, np.float32(1e5)).max(axis=-1)   # :90-92 (float32 compare)
+            is_near = (largest != tol).astype(dtype)                    # :93-94
             f_ij = mlp(np.concatenate([inp_i, inp_j, eb], axis=-1).reshape(-1, 2 * a.shape[-1] + eb.shape[-1]),
                        layers).reshape(B, nb, N)                        # :104,107,110,113
             f_ji = mlp(np.concatenate([inp_j, inp_i, eb], axis=-1).reshape(-1, 2 * a.shape[-1] + eb.shape[-1]),
                        layers).reshape(B, nb, N)                        # :105,108,111,114
             anti[:, i0:i0 + row_block] = (dtype(0.5) * (f_ij - f_ji) * pad[:, i0:i0 + row_block]
-                                          * is_near[:, i0:i0 + row_block])          # :116
+                                          * is_near)                             # :116
         q = q + anti.sum(axis=2)[..., None]                             # :118
         transfers.append(anti)
     if return_transfer:
@@ -221,3 +247,19 @@ def forward_xyz(xyz, x, Q, weights, N=None, dtype=np.float32, row_block=64, cuto
     h_p, e_p, x_p, q_p, mask = dense_inputs(xyz, x, Q, N, cutoff=cutoff, eta=eta)
     out = model_forward(h_p[None], e_p[None], x_p[None], q_p[None], mask[None], weights, dtype, row_block)
     return out[0, :, 0]
+
+
+def forward_xyz_large(xyz, x, Q, weights, dtype=np.float64, row_block=64, cutoff=3.0, eta=2.0):
+    """forward_xyz for one UNPADDED system (N = n) too large for its dense (n,n,.) inputs: the per-atom x, h = 0 and
+    q = Q/n are what make_model's reductions (:382-384) return for gen_padded_init_state's tiled arrays (:335-338), the
+    mask is all ones, and the edge tensor is produced a block of rows at a time.  Same layer functions, same operations
+    per block; equality with forward_xyz on small systems is a CPU test."""
+    x = np.asarray(x, dtype=np.float32)
+    n = x.shape[0]
+    h = np.zeros((1, n, 48), dtype=dtype)
+    q = np.full((1, n, 1), np.float32(np.float32(Q) / np.float32(n)), dtype=dtype)     # :337 float32 / int
+    mask = np.ones((1, n, 1, 1), dtype=dtype)              # sum over axis 1 / max over the last axis are all it is used for
+    e = EdgeRows(xyz, 48, cutoff, eta)
+    xx = x[None].astype(dtype)
+    feats = gnn_layer(h, e, xx, q, mask, weights["msg"], weights["upd"], dtype, row_block)
+    return epn_layer(feats, e, xx, q, mask, weights["pas"], dtype, row_block)[0, :, 0]

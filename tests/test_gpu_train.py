@@ -53,6 +53,58 @@ def test_gradients_match_oracle(gpu_engine_factory, nx, T, N, ns, fused):
     assert np.array_equal(w2["msg"][0][0][0], w["msg"][0][0][0])
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("which", ["decay_model_weights", "random"])
+def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, val_dir, val_names, golden_dir, weights_decay, which, fused):
+    """BASELINE.json configs[2] shape: N = 41, T = 5, real molecules of the reference's `mixed` set (a QM9 molecule, an SSI
+    dimer, the largest system of the validation split) with their stored MBIS labels, through the entry train.py uses
+    (train_step_xyz).  Gradient of sum (y-p)^2 (charge_gn.py:397-398) per parameter tensor vs the float64 oracle, with the
+    shipped checkpoint (collapsed GNN: its message / update tensors get exactly zero gradient in both) and with random
+    non-degenerate weights, for both train-step implementations."""
+    from conftest import load_molecules
+    from oracle import epnn_oracle as orc
+    from oracle import epnn_oracle_train as ot
+    nx, T, N = 9, 5, 41
+    w = weights_decay if which == "decay_model_weights" else random_weights(nx, T, seed=9, scale=0.4)
+    labs = np.load(os.path.join(golden_dir, "test_lab_charges.npy"))
+    sizes = [orc.parse_xyz(os.path.join(val_dir, nm + ".xyz"), nx)[1].shape[0] for nm in val_names]
+    pick = [next(i for i, nm in enumerate(val_names) if nm.startswith("dsgdb9nsd")),
+            next(i for i, nm in enumerate(val_names) if nm.startswith("SSI")), int(np.argmax(sizes))]
+    assert sizes[pick[2]] == 38                              # the split's largest; the directory maximum 41 is a training file
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, [val_names[i] for i in pick], nx)
+    y = np.concatenate([labs[i, :sizes[i]] for i in pick]).astype(np.float32)
+    dense = [orc.dense_inputs(m[0], m[1], m[2], N) for m in mols]
+    h, e, xd, q, mask = (np.stack([d[k] for d in dense]) for k in range(5))
+    yd = np.zeros((len(mols), N, 1))
+    for b, i in enumerate(pick):
+        yd[b, :sizes[i], 0] = labs[i, :sizes[i]]
+    loss_ref, pred_ref, g_ref = ot.loss_and_grads(h, e, xd, q, mask, yd, w)
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_option("train_fused", fused)
+    eng.set_weights(w)
+    eng.train_init()
+    qq, loss = eng.train_step_xyz(offsets, xyz, x, Q, y, N, apply=False)
+    for b in range(len(mols)):
+        assert np.abs(qq[offsets[b]:offsets[b + 1]] - pred_ref[b, :sizes[pick[b]], 0]).max() < 2e-5
+    assert abs(loss - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    g, gr = eng.get_gradients().astype(np.float64), ot.flatten(g_ref)
+    pos, worst, zero_tensors = 0, 0.0, 0
+    for m in [w["upd"]] + w["msg"] + w["pas"]:
+        for W, b in m:
+            for arr in (W, b):
+                sl = slice(pos, pos + arr.size)
+                scale = np.abs(gr[sl]).max()
+                if scale > 0:
+                    worst = max(worst, np.abs(g[sl] - gr[sl]).max() / scale)
+                else:
+                    zero_tensors += 1
+                    assert np.all(g[sl] == 0)
+                pos += arr.size
+    print(f"{which} fused={fused} N=41 T=5: worst per-tensor relative gradient error {worst:.2e}; {zero_tensors} tensors with zero "
+          f"gradient; loss {loss:.6f} vs {loss_ref:.6f}")
+    assert worst < 2e-4
+
+
 def test_adam_trajectory_matches_oracle(gpu_engine_factory):
     """Ten optimizer steps (one small batch per step, like charge_gn.py:443-451) vs the oracle's Adam in float64."""
     from oracle import epnn_oracle_train as ot
