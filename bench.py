@@ -5,15 +5,30 @@
 
 One "step" = one forward of the whole hot path (near-pair construction + T GNN steps + T EPN steps) over one
 batch of 1024 synthetic QM9-like molecules padded to N=29, inputs (coordinates, atom features, total charges)
-already resident in HBM, charges left in HBM.  With N > 1 ranks (torch.distributed.run, one rank per GPU) every
-rank runs its own batch of 1024 molecules (weak scaling, molecules are independent: no data-path collective);
-the only communication is the barrier and the MAX over ranks of the timed interval.
+already resident in HBM, charges left in HBM.  With N > 1 ranks (one per GPU) every rank runs its own batch of 1024
+molecules (weak scaling, molecules are independent: no data-path collective); the only communication is the barrier
+and the MAX over ranks of the timed interval.
 
-Prints ONE JSON line on rank 0.
+Launch forms for N > 1: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment), or plain `python bench.py --gpus N ...`: this process then starts the N
+rank processes itself, as fresh children, before it makes any GPU call of its own (it never makes one), relays rank 0's
+JSON line and exits with the first non-zero exit code.  With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks
+share devices and the timing exchange runs over gloo.
+
+Prints ONE JSON line on rank 0.  Besides the contract's fields:
+  roofline.*          dominant kernel k_wave_forward; `frac` is ALGORITHMIC flops of the launches per second of
+                      the timed region / f32 MFMA peak; `pipe_frac` the same with the flops the kernel really executes
+                      (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); `single_launch` = a launch with the GPU to itself
+                      (65536 molecules, depth 1: flops / hipEvent duration IS its fraction, reproducible from
+                      profiles/r02_big_launch_kernel_stats.csv)
+  host_to_host        the same forward from host arrays to host arrays (Pipeline.map, a DIFFERENT batch every call)
+  cpu_baseline        the oracle (CPU restatement of the reference's algorithm, not TensorFlow) on this host's cores
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,9 +40,21 @@ if ROOT not in sys.path:
 # before anything (torch included) initialises HIP in this process: one hardware queue per batch in flight (epnn_amd/_lib.py)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
+KNAME = "k_wave_forward<true,true,true>"
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
 
 
+def kernel_source_sha():
+    """Identity of the fused kernel's source: PMC figures recorded for another revision are not quoted."""
+    hsh = hashlib.sha256()
+    for f in ("epnn_wave.hip.h", "epnn_common.h"):
+        with open(os.path.join(ROOT, "epnn_amd", "csrc", f), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_worker(args):
     """One CPU-baseline worker: the oracle on its share of the molecules, one molecule per call, for `budget_s` seconds."""
     mols, weights, N, budget_s = args
@@ -43,13 +70,26 @@ def _cpu_worker(args):
     return atoms, calls, time.perf_counter() - t0
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
     """The oracle (literal dense float32 restatement of charge_gn.py, one molecule per call like infer.py:62-76) timed on
-    this host on a bounded sample of the same workload: `workers` single-threaded processes (spawned: nothing of this
-    process's GPU state is inherited), each cycling through its share of the batch for ~12 s."""
+    this host on a bounded sample of the same workload: one single-threaded worker process per usable core (spawned:
+    nothing of this process's GPU state is inherited), each cycling through its share of the batch for ~12 s."""
     import multiprocessing as mp
     B = len(offsets) - 1
-    workers = max(1, min(16, os.cpu_count() or 1))
+    workers = min(usable_cores(), B, 256)
     shares = [[(xyz[offsets[b]:offsets[b + 1]], x[offsets[b]:offsets[b + 1]], Q[b]) for b in range(w, B, workers)]
               for w in range(workers)]
     saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
@@ -67,11 +107,90 @@ def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
     atoms = sum(r[0] for r in res)
     calls = sum(r[1] for r in res)
     dt = max(r[2] for r in res)
-    return {"value": atoms / dt, "unit": "atoms/s", "cores": workers, "kind": "port",
+    return {"value": atoms / dt, "unit": "atoms/s", "cores": workers, "cores_total": os.cpu_count(), "kind": "port",
+            "what": "CPU restatement of the reference algorithm (oracle/epnn_oracle.py, NumPy float32), not TensorFlow",
             "sample": f"{calls} molecule calls ({atoms} atoms) of the same batch, padded to N={N}, one molecule per call like "
-                      f"infer.py, NumPy float32, {workers} single-threaded worker processes, {dt:.1f} s each"}
+                      f"infer.py, {workers} single-threaded worker processes (one per usable core of {os.cpu_count()}), {dt:.1f} s each"}
 
 
+# ------------------------------------------------------------------------------------------------ launcher (N > 1, no torchrun)
+def launch_ranks(argv, n):
+    """Start the n rank processes as fresh children of this (GPU-free) process; relay rank 0's output."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    return bad[0] if bad else 0
+
+
+# ------------------------------------------------------------------------------------------------ PMC passes (opt-in)
+def collect_pmc(args):
+    """`--pmc`: rocprofv3 counter passes of this same workload, each its own child run (kernel-trace only next to --pmc),
+    started before this process touches the GPU.  FETCH_SIZE / WRITE_SIZE at the bench's depth (HBM bytes per launch,
+    gfx950 correction: FETCH_SIZE x 2, MI355X_MICROARCH.md), the SQ counters at depth 1 (a launch alone).  Writes PMC_JSON."""
+    import glob
+    import pandas as pd
+    base = os.path.join(ROOT, "gpurun_out", "pmc_r02")
+    passes = [("fetch", "FETCH_SIZE", args.depth), ("write", "WRITE_SIZE", args.depth),
+              ("mops", "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE", 1),
+              ("lds", "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY", 1)]
+    vals = {}
+    for name, counters, depth in passes:
+        d = os.path.join(base, name)
+        cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "12", "--warmup", "6", "--no-cpu-baseline", "--no-extras", "--depth", str(depth), "--molecules", str(args.molecules)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        rc = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd="/tmp")
+        if rc.returncode != 0:
+            print(f"[bench --pmc] pass {name} failed: {rc.stderr[-400:]}", file=sys.stderr)
+            continue
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            df = pd.read_csv(f)
+            df = df[df.Kernel_Name.str.contains("k_wave_forward")]
+            for c, g in df.groupby("Counter_Name"):
+                vals[c] = float(g.Counter_Value.mean())
+                vals["launches_" + c] = int(len(g))
+    out = {"workload": f"qm9_like_b{args.molecules}_N29", "kernel": KNAME, "kernel_source_sha": kernel_source_sha(),
+           "command": "python bench.py --pmc  (child passes: rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 12 "
+                      "--warmup 6 --no-cpu-baseline --no-extras --depth D; FETCH_SIZE / WRITE_SIZE at the bench depth, SQ_* at depth 1)",
+           "counters_per_launch": vals}
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        # rocprofv3 reports KiB; gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes (x2), WRITE_SIZE is exact
+        out["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32" in vals:
+        out["executed_gflop_per_launch"] = vals["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0 / 1e9
+    if "SQ_LDS_BANK_CONFLICT" in vals and vals.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_frac"] = vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and vals.get("GRBM_GUI_ACTIVE"):
+        out["mfma_busy_frac_one_launch_alone"] = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (vals["GRBM_GUI_ACTIVE"] * 128.0)
+    with open(PMC_JSON, "w") as f:
+        json.dump(out, f, indent=1)
+    return out
+
+
+def committed_pmc(workload):
+    try:
+        with open(PMC_JSON) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == workload and pmc.get("kernel_source_sha") == kernel_source_sha():
+            return pmc
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ one rank
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,21 +198,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)     # (~0.6 ms each) and the barrier do not weigh on the rate
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-launch and host-to-host measurements")
+    ap.add_argument("--pmc", action="store_true", help="first run the rocprofv3 counter passes of this workload (writes profiles/r02_pmc_bench.json)")
     ap.add_argument("--depth", type=int, default=6, help="batches in flight per GPU (handles/streams used round robin)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if args.pmc and world == 1:
+        collect_pmc(args)
 
     dist = None
     torch = None
     device = local_rank
+    backend = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -113,6 +237,7 @@ def main():
             device = local_rank % max(1, ndev)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             sync_dev = torch.device("cpu")
+        backend = dist.get_backend()
 
     from epnn_amd import checkpoint, synth
     from epnn_amd.engine import Pipeline
@@ -164,45 +289,96 @@ def main():
     pipe.set_option("profile", 0)
 
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=sync_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_max = float(tt.item())
-        at = torch.tensor([float(A)], dtype=torch.float64, device=sync_dev)
-        dist.all_reduce(at, op=dist.ReduceOp.SUM)
-        atoms_total = float(at.item())
+        mine = torch.tensor([dt, float(A)], dtype=torch.float64, device=sync_dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [(float(t[0]), float(t[1])) for t in every]
+        dt_max = max(d for d, _ in per_rank)
+        atoms_total = sum(a for _, a in per_rank)
     else:
+        per_rank = [(dt, float(A))]
         dt_max, atoms_total = dt, float(A)
 
     eng, d_q = lanes[0][0], lanes[0][4]
     q = d_q.download((A,))
     stats = eng.last_stats()
-    # sanity inside the bench: charges finite and every molecule's total charge conserved
+    # sanity inside the bench: charges finite and every molecule's total charge conserved (the batch itself is compared
+    # with the float64 oracle in tests/test_gpu_parity.py::test_bench_batch_vs_oracle)
     assert np.isfinite(q).all()
     sums = np.add.reduceat(q.astype(np.float64), offsets[:-1])
     assert np.abs(sums - Q).max() < 1e-4, np.abs(sums - Q).max()
+    ns = np.diff(offsets)
+    flops = synth.algorithmic_flops(ns, int(stats[0]))
+
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        # (1) a launch with the GPU to itself: 64 copies of the batch in ONE launch (65536 molecules), one handle, hipEvents
+        #     around each launch: algorithmic flops / duration is that kernel's rate with nothing else on the machine
+        rep = max(1, 65536 // B)
+        big_off = np.concatenate([[0]] + [offsets[1:] + r * A for r in range(rep)]).astype(np.int32)
+        e0 = pipe.engines[0]
+        big = [e0.to_device(np.tile(a, (rep,) + (1,) * (a.ndim - 1))) for a in (xyz, x, Q)]
+        big_q = e0.alloc(A * rep * 4)
+        for _ in range(2):
+            e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
+        e0.sync()
+        nbig = 10
+        e0.set_option("profile", nbig)
+        for _ in range(nbig):
+            e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
+        e0.sync()
+        big_ms = float(np.mean([e0.timing_at(i)[1] for i in range(nbig)]))
+        e0.set_option("profile", 0)
+        qb = big_q.download((A * rep,))
+        assert np.array_equal(qb[:A], q) and np.array_equal(qb[-A:], q)          # batch composition does not change the bits
+        for d in big + [big_q]:
+            d.free()
+        extras["single_launch"] = {"molecules": B * rep, "launches": nbig, "kernel_ms_avg": big_ms,
+                                   "algorithmic_gflop_per_launch": flops * rep / 1e9,
+                                   "achieved": flops * rep / (big_ms * 1e-3) / 1e12,
+                                   "frac": flops * rep / (big_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                   "atoms_per_s": A * rep / (big_ms * 1e-3)}
+        # (2) host to host: Pipeline.map on host arrays, a different batch every call (new plan, PCIe both ways)
+        batches = [synth.qm9_like_batch(B=B, seed=1000 + s, N=29)[:4] for s in range(8)]
+        ncall = 240
+        stream = [batches[k % len(batches)] for k in range(ncall)]
+        for _ in pipe.map(stream[:2 * len(lanes)], N):
+            pass
+        t1 = time.perf_counter()
+        h_atoms = sum(qq.shape[0] for qq in pipe.map(stream, N))
+        h_dt = time.perf_counter() - t1
+        extras["host_to_host"] = {"value": h_atoms / h_dt, "unit": "atoms/s", "ms_per_batch": h_dt / ncall * 1e3, "calls": ncall,
+                                  "what": "Pipeline.map (epnn_forward_xyz_begin/_end): host xyz/x/Q -> host q, a different "
+                                          f"batch of {B} molecules every call, {len(lanes)} in flight; PCIe inclusive, not `value`"}
 
     if rank == 0:
-        ns = np.diff(offsets)
-        flops = synth.algorithmic_flops(ns, int(stats[0]))
-        kname = "k_wave_forward<true,true,true>"
         k_ms = float(stage[:, 1].mean())                   # duration of one launch (hipEvents on its stream)
         step_ms = dt_max / args.steps * 1e3
-        # `depth` launches of the SAME kernel share the GPU (one batch is 1024 wavefronts, the machine holds 2048), so
+        # `depth` launches of the SAME kernel share the GPU (one batch is ~1024 wavefronts, the machine holds 2048), so
         # the duration of one launch measures the share of the machine it got, not the kernel's rate.  achieved =
         # algorithmic flops of a launch / the time the machine spends per launch (= duration / launches in flight).
         in_flight = max(1.0, k_ms / step_ms)
         achieved = flops / (k_ms / in_flight * 1e-3) / 1e12
-        per_launch = flops / (k_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-        # command (FETCH_SIZE / WRITE_SIZE in separate passes, profiles/r01_pmc_bench.json); null for other shapes
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("workload") == f"qm9_like_b{B}_N{N}":
-                traffic = pmc["dominant"][kname]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        workload = f"qm9_like_b{B}_N{N}"
+        pmc = committed_pmc(workload)
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        executed = pmc.get("executed_gflop_per_launch") if pmc else None
+        roof = {"bound": "mfma", "kernel": KNAME, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
+                "traffic_source": (pmc["command"] + f"; kernel source {pmc['kernel_source_sha']}; profiles/r02_pmc_bench.json") if pmc else None,
+                "algorithmic_gflop_per_launch": flops / 1e9,
+                "executed_gflop_per_launch": executed,
+                "pipe_frac": (executed * 1e9 / (k_ms / in_flight * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if executed else None,
+                "kernel_ms_avg": k_ms, "launches_in_flight": in_flight,
+                "frac_of_one_launch_sharing_the_gpu": flops / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "note": "frac = algorithmic flops per launch / (kernel_ms_avg / launches_in_flight) / peak = flops x launches / "
+                        "wall time of the timed region: `launches_in_flight` launches of this kernel share the GPU, so flops / "
+                        "kernel_ms_avg alone (frac_of_one_launch_sharing_the_gpu, what a rocprofv3 --stats average of THIS command "
+                        "gives) is one launch's share of the machine; single_launch is the same kernel with the GPU to itself; "
+                        "pipe_frac counts the MFMA flops the kernel executes (PMC) instead of the algorithmic ones",
+                "device_ms_per_forward_avg": float(stage[:, 3].mean())}
+        if "single_launch" in extras:
+            roof["single_launch"] = extras["single_launch"]
         out = {
             "metric": "atoms/sec (inference), QM9-sized batch",
             "value": atoms_total * args.steps / dt_max,
@@ -216,20 +392,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"qm9_like_b{B}_N{N}", "molecules_per_gpu": B, "atoms_per_gpu": A, "N": N,
-                       "near_pairs_per_gpu": int(stats[0]), "entry": "epnn_forward_xyz_dev (coordinates in HBM)",
+            "config": {"workload": workload, "molecules_per_gpu": B, "atoms_per_gpu": A, "N": N,
+                       "pairs_under_cutoff_per_gpu": int(stats[0]), "entry": "epnn_forward_xyz_dev (coordinates in HBM)",
                        "weights": "decay_model_weights", "parallelism": f"molecule-sharded x{world}",
                        "batches_in_flight_per_gpu": len(lanes)},
-            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
-                         "algorithmic_gflop_per_launch": flops / 1e9, "kernel_ms_avg": k_ms,
-                         "launches_in_flight": in_flight, "tflops_of_one_launch_sharing_the_gpu": per_launch,
-                         "note": "kernel_ms_avg = hipEvent duration of one launch while `launches_in_flight` launches of "
-                                 "the same kernel share the GPU; achieved = algorithmic flops per launch / "
-                                 "(kernel_ms_avg / launches_in_flight) = flops x launches / wall time of the timed region",
-                         "device_ms_per_forward_avg": float(stage[:, 3].mean())},
+            "roofline": roof,
         }
+        if world > 1:
+            out["ranks"] = {"world_size": world, "timing_backend": backend,
+                            "atoms_per_s_per_rank": [a * args.steps / d for d, a in per_rank]}
+        if "host_to_host" in extras:
+            out["host_to_host"] = extras["host_to_host"]
         if not args.no_cpu_baseline and world == 1:         # the reported CPU baseline belongs to the N=1 line only
             out["cpu_baseline"] = cpu_baseline(offsets, xyz, x, Q, N, weights)
         print(json.dumps(out), flush=True)

@@ -162,7 +162,8 @@ int epnn_set_option(epnn_handle *h, const char *name, int value);
  * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative
  * to max e = 1 (5e-10 for cutoff 3, eta 2); the basis is used only when this is below 1e-8. */
 double epnn_edge_basis_residual(epnn_handle *h);
-/* counters of the most recent forward: out[0]=near pairs, out[1]=molecules on the fused path,
+/* counters of the most recent forward: out[0]=listed pairs (unordered, D < cutoff; the is_near test of charge_gn.py:90-94
+ * enters as the pairs' weights), out[1]=molecules on the fused path,
  * out[2]=molecules on the tiled path, out[3]=pair-list regrows. */
 int epnn_last_stats(epnn_handle *h, int64_t *out4);
 

@@ -523,10 +523,11 @@ def box100k():
 
 def test_box_100k_full_size_properties(gpu_engine_factory, weights_decay, box100k):
     """BASELINE.json configs[4] at FULL size (100 000 atoms, seed 0; 0.9 s on the tiled kernels) through properties that
-    do not need an O(n^2) oracle: charges finite, total charge conserved (Q = 0), the number of near pairs the device
-    front-end found equals a host count (every pair under the cutoff from a k-d tree, then the reference's own
-    `is_near` test on its float32 edge features, charge_gn.py:90-94,148-161), and the charges of atoms far from each
-    other in the list agree with a second run bit for bit."""
+    do not need an O(n^2) oracle: charges finite, total charge conserved (Q = 0), the pair list the device
+    front-end built has exactly the pairs a host count finds under the cutoff (k-d tree candidates, then the reference's
+    own float64 distance and compare, charge_gn.py:124,150; how many of them also pass `is_near`, :90-94, is printed --
+    that test enters the kernels as the pairs' weights and is covered by the oracle / golden comparisons), and a second
+    run gives the same bits."""
     from scipy.spatial import cKDTree
     offsets, xyz, x, Q, N = box100k
     eng = gpu_engine_factory(nx=9, T=5)
@@ -539,15 +540,16 @@ def test_box_100k_full_size_properties(gpu_engine_factory, weights_decay, box100
     x64 = xyz.astype(np.float64)
     pr = cKDTree(x64).query_pairs(3.0 + 1e-9, output_type="ndarray")
     d = x64[pr[:, 1]] - x64[pr[:, 0]]
-    D = np.sqrt((d * d).sum(-1))
+    D = np.sqrt((d * d).sum(-1))                     # charge_gn.py:124 on float32 coordinates promoted to float64
+    listed = int((D < 3.0).sum())                    # charge_gn.py:150: C = 0 from D >= cutoff on
     mu = np.linspace(0.1, 3.0, 48)
     C = (np.cos(np.pi * D / 3.0) + 1.0) / 2.0
     C[D >= 3.0] = 0.0
     emax = (C[:, None] * np.exp(-2.0 * (D[:, None] - mu[None]) ** 2)).astype(np.float32).max(axis=1)
-    near = int((emax > np.float32(1e-5)).sum())
-    print(f"100k box: {len(pr)} pairs under 3 A, {near} near pairs on the host, {st[0]} on the device; sum q {q.sum(dtype=np.float64):.2e}; "
-          f"|q| up to {np.abs(q).max():.3f}")
-    assert near == st[0]
+    near = int((emax > np.float32(1e-5)).sum())      # charge_gn.py:90-94; the device carries it as the pairs' weights
+    print(f"100k box: {listed} pairs under the cutoff on the host, {st[0]} listed on the device ({near} of them pass is_near); "
+          f"sum q {q.sum(dtype=np.float64):.2e}; |q| up to {np.abs(q).max():.3f}")
+    assert listed == st[0]
     assert np.array_equal(eng.forward_xyz(offsets, xyz, x, Q, N=N), q)
 
 
@@ -572,9 +574,8 @@ def test_box_subbox_4096_vs_oracle(gpu_engine_factory, box100k):
     q = eng.forward_xyz(off, xyz, x, np.array([1.0], np.float32), N=n)
     st = eng.last_stats()
     assert st[2] == 1 and 8.0 < 2.0 * st[0] / n < 13.0
-    ref = orc.forward_xyz_large(xyz, x, np.float32(1.0), w, dtype=np.float64, row_block=64)
-    ref32 = orc.forward_xyz_large(xyz, x, np.float32(1.0), w, dtype=np.float32, row_block=64)
-    err, noise = np.abs(q - ref).max(), np.abs(ref32 - ref).max()
-    print(f"sub-box 4096 atoms: |dq| {err:.3e}; float32 oracle noise {noise:.3e}; |q| up to {np.abs(ref).max():.3f}; sum q {q.sum(dtype=np.float64):.6f}")
-    assert err <= max(TOL, 3 * noise)
+    ref = orc.forward_xyz_large(xyz, x, np.float32(1.0), w, dtype=np.float64, row_block=64)     # ~2.5 min of host time
+    err = np.abs(q - ref).max()
+    print(f"sub-box 4096 atoms: |dq| {err:.3e}; |q| up to {np.abs(ref).max():.3f}; sum q {q.sum(dtype=np.float64):.6f}")
+    assert err <= TOL
     assert abs(float(q.sum(dtype=np.float64)) - 1.0) < 1e-4
