@@ -113,27 +113,6 @@ def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
                       f"infer.py, {workers} single-threaded worker processes (one per usable core of {os.cpu_count()}), {dt:.1f} s each"}
 
 
-# ------------------------------------------------------------------------------------------------ launcher (N > 1, no torchrun)
-def launch_ranks(argv, n):
-    """Start the n rank processes as fresh children of this (GPU-free) process; relay rank 0's output."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    return bad[0] if bad else 0
-
-
 # ------------------------------------------------------------------------------------------------ PMC passes (opt-in)
 def collect_pmc(args):
     """`--pmc`: rocprofv3 counter passes of this same workload, each its own child run (kernel-trace only next to --pmc),
@@ -205,7 +184,9 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
+        # no launcher: start the rank processes from here, before this process makes any GPU call (it never makes one)
+        from epnn_amd.rendezvous import launch_ranks
+        sys.exit(launch_ranks(__file__, sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

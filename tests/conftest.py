@@ -30,6 +30,20 @@ def val_dir(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def train_dir(tmp_path_factory):
+    """The 3480 training xyz + label files of the reference's recorded split (tests/golden/mixed_train.tar.gz)."""
+    d = tmp_path_factory.mktemp("mixed_train")
+    with tarfile.open(os.path.join(GOLDEN, "mixed_train.tar.gz")) as tf:
+        tf.extractall(d)
+    return os.path.join(str(d), "mixed_train")
+
+
+@pytest.fixture(scope="session")
+def train_names():
+    return [str(n) for n in np.load(os.path.join(GOLDEN, "train_names.npy"), allow_pickle=True)]
+
+
+@pytest.fixture(scope="session")
 def val_names():
     return [str(n) for n in np.load(os.path.join(GOLDEN, "val_names.npy"), allow_pickle=True)]
 

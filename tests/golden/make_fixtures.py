@@ -7,6 +7,7 @@ What it copies (data files, not source):
   * models/<ckpt>.{index,data-*}            the reference's three TF tensor-bundle checkpoints
   * tests/golden/test_pred_charges.npy ...   stored TF predictions for the 871-system validation split
   * tests/golden/mixed_val.tar.gz            the 871 validation xyz files (+ label .npy) out of data/mixed.tar.gz
+  * tests/golden/mixed_train.tar.gz          the 3480 training xyz files (+ label .npy) of the recorded split (train_names.npy)
   * tests/golden/protein/                    6qlp_capped.xyz + preds.npy out of data/protein.tar.gz
   * tests/golden/qm9_small/                  four small xyz files (+ labels) for the infer.py plumbing test
 What it computes with the reference's own NumPy/SciPy featuriser (charge_gn.get_init_edges /
@@ -89,6 +90,19 @@ def main():
                     if stem in SMALL:
                         with open(os.path.join(small_dir, stem + ".npy"), "wb") as f:
                             f.write(lblob)
+
+    # the recorded training split (models/model_systems/train_names.npy; charge_gn.py:431-434): BASELINE.json configs[2]'s data
+    tnames = set(str(n) for n in np.load(os.path.join(ms, "train_names.npy"), allow_pickle=True))
+    with tarfile.open(os.path.join(REF, "data", "mixed.tar.gz")) as src, \
+            tarfile.open(os.path.join(HERE, "mixed_train.tar.gz"), "w:gz", compresslevel=9) as dst:
+        members = {m.name: m for m in src.getmembers() if m.isfile()}
+        for name in sorted(members):
+            base = os.path.basename(name)
+            if base[:-4] in tnames and (base.endswith(".xyz") or (base.endswith(".npy") and not base.endswith("splits.npy"))):
+                blob = src.extractfile(members[name]).read()
+                ti = tarfile.TarInfo("mixed_train/" + base)
+                ti.size = len(blob)
+                dst.addfile(ti, io.BytesIO(blob))
 
     pdir = os.path.join(HERE, "protein")
     os.makedirs(pdir, exist_ok=True)

@@ -251,7 +251,7 @@ def test_train_script_and_mirror(tmp_path, golden_dir):
     from conftest import ROOT
     out = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), os.path.join(golden_dir, "qm9_small"), "--epochs", "2",
                           "--n-elems", "9", "--init", os.path.join(ROOT, "models", "decay_model_weights"), "--out", str(tmp_path / "w")],
-                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)          # arrays go to the cwd like the reference's
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("Epoch")]
     assert len(lines) == 2 and "Test Acc" in lines[0]
@@ -303,3 +303,92 @@ def test_fused_step_at_larger_padded_sizes(gpu_engine_factory, N, ns):
                 pos += arr.size
     print(f"N={N}: fused vs layer-by-layer worst per-tensor relative gradient difference {worst:.2e}")
     assert worst < 1e-4
+
+
+def _merged_split_dir(tmp_path, train_dir, val_dir):
+    """One directory with the training and the validation files, like the reference's data/mixed/ (symlinks)."""
+    d = tmp_path / "mixed"
+    d.mkdir()
+    for src in (train_dir, val_dir):
+        for f in os.listdir(src):
+            os.symlink(os.path.join(src, f), d / f)
+    return str(d)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_train_script_on_the_recorded_split(tmp_path, golden_dir, train_dir, val_dir, train_names, world):
+    """train.py --names on the reference's recorded split (BASELINE.json configs[2]; models/model_systems/train_names.npy,
+    val_names.npy), N = 41: six optimizer steps from the shipped checkpoint, at world size 1 and with two rank processes
+    started by `--gpus 2` (they share this box's one GPU, so the gradient sum goes through the host; one GPU per rank
+    uses the RCCL all-reduce).  Row k of train_pred_charges / train_lab_charges must belong to training molecule k of
+    the recorded order -- whichever rank computed it: the labels are that molecule's, the prediction has exactly its
+    atoms and sums to its total charge.  The validation arrays cover all 871 systems in the recorded order."""
+    import subprocess, sys
+    from conftest import ROOT
+    from epnn_amd import charge_gn
+    data = _merged_split_dir(tmp_path, train_dir, val_dir)
+    steps = 6
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), data, "--epochs", "1", "--n-elems", "9", "--init",
+           os.path.join(ROOT, "models", "decay_model_weights"), "--out", str(tmp_path / "ck" / "w"), "--outdir", str(tmp_path / "arr"),
+           "--names", os.path.join(golden_dir, "train_names.npy"), os.path.join(golden_dir, "val_names.npy"), "--max-steps", str(steps)]
+    if world > 1:
+        cmd += ["--gpus", str(world)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert len([l for l in res.stdout.splitlines() if l.startswith("Epoch 0, Loss:")]) == 1
+    arr = tmp_path / "arr"
+    assert [str(n) for n in np.load(arr / "train_names.npy", allow_pickle=True)] == train_names
+    pred, lab = np.load(arr / "train_pred_charges.npy"), np.load(arr / "train_lab_charges.npy")
+    assert pred.shape == lab.shape == (steps * world, 41)
+    for k in range(steps * world):
+        xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(train_dir, train_names[k] + ".xyz"), 9)
+        y = np.load(os.path.join(train_dir, train_names[k] + ".npy")).ravel()
+        n = len(y)
+        assert np.array_equal(lab[k, :n], y.astype(np.float32)) and np.all(lab[k, n:] == 0)
+        assert np.all(pred[k, :n] != 0) and np.all(pred[k, n:] == 0)
+        assert abs(float(pred[k].sum(dtype=np.float64)) - float(Q)) < 1e-4
+        assert np.abs(pred[k, :n] - y).max() < 0.5                   # a trained model: predictions are near the labels
+    vp, vl = np.load(arr / "test_pred_charges.npy"), np.load(arr / "test_lab_charges.npy")
+    gold_lab = np.load(os.path.join(golden_dir, "test_lab_charges.npy"))
+    assert vp.shape == vl.shape == (871, 41)
+    assert np.abs(vl - gold_lab).max() < 1e-6                        # the reference's own stored validation labels, same order
+    gold_pred = np.load(os.path.join(golden_dir, "test_pred_charges.npy"))
+    assert np.abs(vp - gold_pred).max() < 0.05                       # six Adam steps away from the checkpoint that wrote them
+    from epnn_amd import checkpoint
+    assert len(checkpoint.load_epnn_weights(str(tmp_path / "ck" / "w"))["msg"]) == 5
+
+
+def test_loss_curve_on_the_recorded_split_matches_oracle(gpu_engine_factory, train_dir, train_names, weights_decay):
+    """configs[2] numerics over a trajectory: 50 optimizer steps (one molecule per step, charge_gn.py:443-451) from
+    decay_model_weights on the first 50 molecules of the recorded training split, N = 41 -- the per-step losses follow
+    the float64 oracle's (its own Adam on its own gradients)."""
+    from conftest import load_molecules
+    from oracle import epnn_oracle as orc
+    from oracle import epnn_oracle_train as ot
+    nx, N, steps = 9, 41, 50
+    mols, offsets, xyz, x, Q = load_molecules(train_dir, train_names[:steps], nx)
+    ys = [np.load(os.path.join(train_dir, nm + ".npy")).ravel().astype(np.float32) for nm in train_names[:steps]]
+    eng = gpu_engine_factory(nx=nx, T=5)
+    eng.set_weights(weights_decay)
+    eng.train_init()
+    theta = ot.flatten(weights_decay)
+    opt = ot.Adam(theta.size)
+    losses, ref = [], []
+    for s in range(steps):
+        xyz_s, x_s, Q_s = mols[s]
+        n = x_s.shape[0]
+        _, l = eng.train_step_xyz(np.array([0, n], np.int32), xyz_s, x_s, np.array([Q_s], np.float32), ys[s], N, apply=True)
+        losses.append(l)
+        h, e, xd, q, mask = (a[None] for a in orc.dense_inputs(xyz_s, x_s, Q_s, N))
+        yd = np.zeros((1, N, 1))
+        yd[0, :n, 0] = ys[s]
+        lr, _, g = ot.loss_and_grads(h, e, xd, q, mask, yd, ot.unflatten(theta, weights_decay))
+        theta = opt.step(theta, ot.flatten(g))
+        ref.append(lr)
+    losses, ref = np.array(losses), np.array(ref)
+    rel = np.abs(losses - ref) / np.maximum(ref, 1e-6)
+    print(f"50 steps on the recorded split: loss {ref[0]:.5f} .. {ref[-1]:.5f}; worst relative loss difference {rel.max():.2e} "
+          f"(step {int(rel.argmax())}); sum of losses {losses.sum():.5f} vs {ref.sum():.5f}")
+    assert rel[0] < 1e-4                                             # step 0: same weights, forward parity
+    assert rel.max() < 2e-2 and abs(losses.sum() - ref.sum()) < 2e-3 * ref.sum()

@@ -1,15 +1,19 @@
 """Training entry point, same flow as the reference's ``charge_gn.py`` ``__main__`` block (charge_gn.py:412-471):
-read a directory of .xyz (+ .npy labels), 80/20 split with random_state=42, EPOCHS passes of one optimizer step per
-training molecule, validation pass, save_weights on the best validation MAE, dump names / predictions / labels, print
-the reference's epoch line.  Arithmetic on the MI355X through ``epnn_amd`` (no TensorFlow).
+read a directory of .xyz (+ .npy labels), 80/20 split with random_state=42 (or the reference's RECORDED split, ``--names``),
+EPOCHS passes of one optimizer step per training molecule, validation pass, save_weights on the best validation MAE,
+dump names / predictions / labels, print the reference's epoch line.  Arithmetic on the MI355X through ``epnn_amd``
+(no TensorFlow, no torch).
 
-Data parallel (BASELINE.json configs[2]): launch with
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py data/mixed/ ...
-Each optimizer step then takes WORLD_SIZE consecutive training molecules, one per GPU; the gradients are summed with
-one RCCL all-reduce of the flat 296 KB gradient (the reference is single-device batch 1, so trajectories are only
-comparable at world size 1).
+Data parallel (BASELINE.json configs[2]): ``python train.py DIR --gpus 8`` starts one rank process per GPU itself (fresh
+children, before this process makes any GPU call; ``python -m torch.distributed.run --nproc-per-node 8 train.py DIR`` works
+as well).  Each optimizer step then takes WORLD_SIZE consecutive training molecules, one per rank; the gradients are
+summed with ONE RCCL all-reduce of the flat 296 KB gradient on the GPU (the 128-byte RCCL id travels over
+``epnn_amd.rendezvous``), then every rank takes the same Adam step.  The reference is single-device batch 1, so
+trajectories are comparable only at world size 1.  With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks
+share devices, RCCL cannot join two ranks of one device, and the gradient sum goes through the host instead.
 
     python train.py xyz_dir/ [--epochs E] [--n-elems 10] [--init PREFIX] [--out models/model_weights] [--limit M]
+                             [--names train_names.npy val_names.npy] [--gpus N] [--max-steps S] [--outdir DIR]
 """
 import argparse
 import os
@@ -30,25 +34,47 @@ def main(argv=None):
     ap.add_argument("--init", default=None, help="checkpoint prefix to start from (default: Glorot init)")
     ap.add_argument("--out", default="models/model_weights")      # charge_gn.py:462
     ap.add_argument("--limit", type=int, default=0, help="use only the first M molecules (smoke runs)")
+    ap.add_argument("--names", nargs=2, metavar=("TRAIN_NPY", "VAL_NPY"), default=None,
+                    help="the recorded split (models/model_systems/train_names.npy val_names.npy, charge_gn.py:433-434) "
+                         "instead of a fresh train_test_split; only the named molecules are read")
+    ap.add_argument("--gpus", type=int, default=0, help="start this many rank processes (one per GPU)")
+    ap.add_argument("--max-steps", type=int, default=0, help="optimizer steps per epoch (0: the whole training split)")
+    ap.add_argument("--outdir", default=".", help="where the names / predictions / labels arrays go (the reference: cwd)")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from epnn_amd.rendezvous import launch_ranks
+        sys.exit(launch_ranks(__file__, sys.argv[1:] if argv is None else argv, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)     # only carries the 128-byte RCCL id
 
-    from sklearn.model_selection import train_test_split
-    from epnn_amd import charge_gn, shard
+    from epnn_amd import _lib, charge_gn, shard
     from epnn_amd.engine import Engine
+
+    rdzv = None
+    if world > 1:
+        from epnn_amd.rendezvous import Rendezvous
+        rdzv = Rendezvous(rank, world)
+        ndev = _lib.load().epnn_device_count()
+        if ndev < 1:
+            raise SystemExit("train.py: no HIP device visible")
+        # one GPU per rank; ranks beyond the device count share (charge_gn reads LOCAL_RANK when the module is imported,
+        # so the device is fixed here before the first engine exists)
+        charge_gn._DEVICE = int(os.environ.get("LOCAL_RANK", str(rank))) % ndev
+        rccl = ndev >= world
 
     h_dim, e_dim, layers, T = 48, 48, [32, 32], 5                  # charge_gn.py:413-417
     path = args.path if args.path.endswith("/") else args.path + "/"
-    files = sorted(f for f in os.listdir(path) if f.endswith(".xyz"))
-    if args.limit:
-        files = files[:args.limit]
+    if args.names:
+        tr = [str(n) for n in np.load(args.names[0], allow_pickle=True)]
+        va = [str(n) for n in np.load(args.names[1], allow_pickle=True)]
+        if args.limit:
+            tr, va = tr[:args.limit], va[:max(1, args.limit // 4)]
+        files = [n + ".xyz" for n in tr + va]
+    else:
+        files = sorted(f for f in os.listdir(path) if f.endswith(".xyz"))
+        if args.limit:
+            files = files[:args.limit]
     mols, labels, names = [], [], []
     for f in files:
         xyz, x, Q, nlines = charge_gn.read_xyz(path + f, args.n_elems)
@@ -58,69 +84,94 @@ def main(argv=None):
         labels.append(y)
         names.append(f[:-4])
     N = max(len(y) for y in labels)                                 # the directory maximum (charge_gn.py:340)
-    idx = np.arange(len(mols))
-    it, ie = train_test_split(idx, test_size=0.2, random_state=42)  # charge_gn.py:431
+    if args.names:
+        it, ie = np.arange(len(tr)), np.arange(len(tr), len(tr) + len(va))
+    else:
+        from sklearn.model_selection import train_test_split
+        it, ie = train_test_split(np.arange(len(mols)), test_size=0.2, random_state=42)     # charge_gn.py:431
+    os.makedirs(args.outdir, exist_ok=True)
+    out = lambda f: os.path.join(args.outdir, f)
     if rank == 0:
-        np.save("train_names.npy", np.array([names[i] for i in it]), allow_pickle=True)
-        np.save("val_names.npy", np.array([names[i] for i in ie]), allow_pickle=True)
+        np.save(out("train_names.npy"), np.array([names[i] for i in it]), allow_pickle=True)    # charge_gn.py:433-434
+        np.save(out("val_names.npy"), np.array([names[i] for i in ie]), allow_pickle=True)
 
     model = charge_gn.make_model(layers, h_dim, T, args.n_elems, N)
     if args.init:
         model.load_weights(args.init)
+    elif world > 1:
+        model.set_weights_dict(rdzv.broadcast(model.weights_dict() if rank == 0 else None, name="init"))   # same start everywhere
     eng = model.engine()
     opt = charge_gn.Adam()
     opt.bind(model)
-    if world > 1:
-        ids = [Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0], rank, world)
+    if world > 1 and rccl:
+        eng.comm_init(rdzv.broadcast(Engine.comm_unique_id() if rank == 0 else None, name="rccl_id"), rank, world)
 
-    def one(i):
-        xyz, x, Q = mols[i]
-        return (np.array([0, len(x)], np.int32), xyz, x, np.array([Q], np.float32), labels[i])
+    def padded(v):
+        p = np.zeros(N, np.float32)
+        p[:len(v)] = v
+        return p
+
+    def batch_of(idx):
+        """flat batch (offsets, xyz, x, Q) of the molecules `idx`"""
+        off = np.zeros(len(idx) + 1, np.int32)
+        off[1:] = np.cumsum([len(mols[i][1]) for i in idx])
+        return (off, np.concatenate([mols[i][0] for i in idx]), np.concatenate([mols[i][1] for i in idx]),
+                np.array([mols[i][2] for i in idx], np.float32))
 
     train_loss, train_acc = charge_gn.Mean("train_loss"), charge_gn.MeanAbsoluteError("train_acc")
     test_loss, test_acc = charge_gn.Mean("test_loss"), charge_gn.MeanAbsoluteError("test_acc")
     best = np.inf
+    nsteps = len(it) // world
+    if args.max_steps:
+        nsteps = min(nsteps, args.max_steps)
+    my_val = [int(i) for i in ie[rank::world]]                      # validation molecules are independent: sharded
     for epoch in range(args.epochs):
         for m in (train_loss, train_acc, test_loss, test_acc):
             m.reset_states()
-        train_preds, test_preds = [], []
-        nsteps = len(it) // world
+        train_rows = []                                             # (position in `it`, prediction padded to N) of this rank
         for s in range(nsteps):
+            pos = s * world + rank
             i = shard.dp_step_molecules(it, world, s)[rank]
-            off, xyz, x, Q, y = one(i)
-            q, _ = eng.train_step_xyz(off, xyz, x, Q, y, N, apply=True)
-            pad = np.zeros(N, np.float32)
-            pad[:len(q)] = q
-            ypad = np.zeros(N, np.float32)
-            ypad[:len(y)] = y
-            train_loss((ypad - pad) ** 2)
-            train_acc(pad, ypad)
-            train_preds.append(pad)
-        for i in ie:
-            off, xyz, x, Q, y = one(int(i))
-            q = eng.forward_xyz(off, xyz, x, Q, N)
-            pad = np.zeros(N, np.float32)
-            pad[:len(q)] = q
-            ypad = np.zeros(N, np.float32)
-            ypad[:len(y)] = y
-            test_loss((ypad - pad) ** 2)
-            test_acc(pad, ypad)
-            test_preds.append(pad)
-        if test_acc.result() < best and rank == 0:
+            off, xyz, x, Q = batch_of([i])
+            if world > 1 and not rccl:
+                q, _ = eng.train_step_xyz(off, xyz, x, Q, labels[i], N, apply=False)
+                g = rdzv.all_gather(eng.get_gradients(), name="grad")
+                eng.set_gradients(np.sum(np.stack(g).astype(np.float64), axis=0).astype(np.float32))      # rank order: same bits everywhere
+                eng.train_apply()
+            else:
+                q, _ = eng.train_step_xyz(off, xyz, x, Q, labels[i], N, apply=True)       # all-reduce (RCCL) + Adam on the device
+            train_rows.append((pos, padded(q)))
+            train_loss((padded(labels[i]) - padded(q)) ** 2)                               # charge_gn.py:400-401
+            train_acc(padded(q), padded(labels[i]))
+        val_rows = []
+        if my_val:
+            off, xyz, x, Q = batch_of(my_val)
+            qv = eng.forward_xyz(off, xyz, x, Q, N)                 # the validation pass (charge_gn.py:453-459) as ONE batch
+            for k, i in enumerate(my_val):
+                p = padded(qv[off[k]:off[k + 1]])
+                val_rows.append((rank + k * world, p))
+                test_loss((padded(labels[i]) - p) ** 2)
+                test_acc(p, padded(labels[i]))
+        if world > 1:
+            parts = rdzv.all_gather((train_rows, val_rows, [(m._sum, m._n) for m in (train_loss, train_acc, test_loss, test_acc)]), name="epoch")
+            train_rows = sorted((r for p in parts for r in p[0]), key=lambda r: r[0])
+            val_rows = sorted((r for p in parts for r in p[1]), key=lambda r: r[0])
+            for k, m in enumerate((train_loss, train_acc, test_loss, test_acc)):
+                m._sum, m._n = sum(p[2][k][0] for p in parts), sum(p[2][k][1] for p in parts)
+        if test_acc.result() < best:                                # every rank holds the same metrics: same decision
             best = test_acc.result()
-            model.save_weights(args.out)
-            np.save("train_pred_charges.npy", np.array(train_preds))
-            np.save("train_lab_charges.npy", np.array([np.pad(labels[i], (0, N - len(labels[i]))) for i in it[:len(train_preds)]]))
-            np.save("test_pred_charges.npy", np.array(test_preds))
-            np.save("test_lab_charges.npy", np.array([np.pad(labels[i], (0, N - len(labels[i]))) for i in ie]))
+            if rank == 0:
+                model.save_weights(args.out)                                                            # charge_gn.py:462
+                np.save(out("train_pred_charges.npy"), np.array([p for _, p in train_rows]))             # charge_gn.py:465-468
+                np.save(out("train_lab_charges.npy"), np.array([padded(labels[it[pos]]) for pos, _ in train_rows]))
+                np.save(out("test_pred_charges.npy"), np.array([p for _, p in val_rows]))
+                np.save(out("test_lab_charges.npy"), np.array([padded(labels[ie[pos]]) for pos, _ in val_rows]))
         if rank == 0:
             template = 'Epoch {}, Loss: {}, Acc: {}, Test Loss: {}, Test Acc: {}'
             print(template.format(epoch, train_loss.result(), train_acc.result(), test_loss.result(), test_acc.result()), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.barrier("end")
+        rdzv.close()
 
 
 if __name__ == "__main__":
