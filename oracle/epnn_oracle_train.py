@@ -17,25 +17,31 @@ import numpy as np
 from . import epnn_oracle as orc
 
 
+_KINK_SHIFT = 0.0     # see loss_and_grads(kink_shift=...)
+
+
 def _mlp_fwd(rows, layers):
-    """Returns output and the list of layer inputs / post-activations needed by the backward."""
-    acts = [rows]
+    """Returns output and the layer inputs / pre-activations needed by the backward."""
+    acts, pres = [rows], [None]
     x = rows
     for W, b in layers[:-1]:
-        x = np.maximum(x @ W + b, 0)
+        z = x @ W + b
+        x = np.maximum(z, 0)
         acts.append(x)
+        pres.append(z)
     W, b = layers[-1]
-    return x @ W + b, acts
+    return x @ W + b, (acts, pres)
 
 
-def _mlp_bwd(dout, acts, layers):
+def _mlp_bwd(dout, tape, layers):
     """dout: gradient wrt the MLP output.  Returns (d rows, [(dW, db)] per layer)."""
+    acts, pres = tape
     grads = [None] * len(layers)
     W, b = layers[-1]
     grads[-1] = (acts[-1].T @ dout, dout.sum(0))
     d = dout @ W.T
     for l in range(len(layers) - 2, -1, -1):
-        d = d * (acts[l + 1] > 0)
+        d = d * (pres[l + 1] > _KINK_SHIFT)            # relu'(z) = [z > 0]; shifted only to bracket float32 kink decisions
         W, b = layers[l]
         grads[l] = (acts[l].T @ d, d.sum(0))
         d = d @ W.T
@@ -57,10 +63,24 @@ def _acc(dst, src):
         dst[k] = (dst[k][0] + dW, dst[k][1] + db)
 
 
-def loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype=np.float64):
+def loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype=np.float64, kink_shift=0.0):
     """Batch of B molecules (dense make_model inputs).  Returns (loss_sum, predictions (B,N,1), grads dict);
     loss_sum = sum over molecules and atoms of (y - p)^2, i.e. what tape.gradient differentiates when the B
-    molecules' gradients are summed (data-parallel training: one molecule per rank, all-reduce sum)."""
+    molecules' gradients are summed (data-parallel training: one molecule per rank, all-reduce sum).
+
+    kink_shift: the backward takes relu'(z) = [z > kink_shift] (forward unchanged).  The gradient of a ReLU network is
+    discontinuous where a pre-activation crosses 0; a float32 implementation whose z differs from the float64 one by its
+    rounding (~1e-6 here) may land on the other side.  Evaluating with kink_shift = +tau and -tau brackets every such
+    decision: where no |z| < tau exists both equal the kink_shift = 0 gradient exactly."""
+    global _KINK_SHIFT
+    _KINK_SHIFT = float(kink_shift)
+    try:
+        return _loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype)
+    finally:
+        _KINK_SHIFT = 0.0
+
+
+def _loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype):
     w = _cast(weights, dtype)
     f32 = [np.asarray(t, dtype=np.float32) for t in (h_inp, e_inp, x_inp, q_inp, mask_inp)]
     h0, x, q0, mask = orc.model_reduce(f32[0], f32[2], f32[3], f32[4], dtype)

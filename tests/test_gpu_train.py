@@ -79,6 +79,13 @@ def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, val_dir, va
     for b, i in enumerate(pick):
         yd[b, :sizes[i], 0] = labs[i, :sizes[i]]
     loss_ref, pred_ref, g_ref = ot.loss_and_grads(h, e, xd, q, mask, yd, w)
+    # ReLU kinks: the gradient jumps where a pre-activation crosses 0, and a float32 evaluation of a |z| < ~1e-6 may land
+    # on either side (the SSI dimer has one in the last pass network with the shipped weights: z = 2.9e-7; the two train-step
+    # implementations, which add the first layer's terms in different orders, then differ from each other by 1e-2 in that
+    # layer's bias gradient).  The oracle brackets every such decision: relu'(z) = [z > +tau] and [z > -tau].
+    tau = 2e-5
+    g_lo = ot.flatten(ot.loss_and_grads(h, e, xd, q, mask, yd, w, kink_shift=+tau)[2])
+    g_hi = ot.flatten(ot.loss_and_grads(h, e, xd, q, mask, yd, w, kink_shift=-tau)[2])
     eng = gpu_engine_factory(nx=nx, T=T)
     eng.set_option("train_fused", fused)
     eng.set_weights(w)
@@ -88,20 +95,25 @@ def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, val_dir, va
         assert np.abs(qq[offsets[b]:offsets[b + 1]] - pred_ref[b, :sizes[pick[b]], 0]).max() < 2e-5
     assert abs(loss - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
     g, gr = eng.get_gradients().astype(np.float64), ot.flatten(g_ref)
-    pos, worst, zero_tensors = 0, 0.0, 0
+    lo, hi = np.minimum(np.minimum(g_lo, g_hi), gr), np.maximum(np.maximum(g_lo, g_hi), gr)
+    pos, worst, zero_tensors, kinked = 0, 0.0, 0, 0
     for m in [w["upd"]] + w["msg"] + w["pas"]:
         for W, b in m:
             for arr in (W, b):
                 sl = slice(pos, pos + arr.size)
                 scale = np.abs(gr[sl]).max()
                 if scale > 0:
-                    worst = max(worst, np.abs(g[sl] - gr[sl]).max() / scale)
+                    # distance from the interval the kink decisions span (an exact match needs none of them)
+                    band = hi[sl] - lo[sl]
+                    out = np.maximum(np.maximum(lo[sl] - band - g[sl], g[sl] - hi[sl] - band), 0.0)
+                    kinked += int(band.max() > 1e-6 * scale)
+                    worst = max(worst, out.max() / scale)
                 else:
                     zero_tensors += 1
                     assert np.all(g[sl] == 0)
                 pos += arr.size
     print(f"{which} fused={fused} N=41 T=5: worst per-tensor relative gradient error {worst:.2e}; {zero_tensors} tensors with zero "
-          f"gradient; loss {loss:.6f} vs {loss_ref:.6f}")
+          f"gradient, {kinked} touched by a ReLU kink within {tau}; loss {loss:.6f} vs {loss_ref:.6f}")
     assert worst < 2e-4
 
 
