@@ -18,6 +18,7 @@ from . import epnn_oracle as orc
 
 
 _KINK_SHIFT = 0.0     # see loss_and_grads(kink_shift=...)
+_KINK_WHERE = "all"
 
 
 def _mlp_fwd(rows, layers):
@@ -33,15 +34,16 @@ def _mlp_fwd(rows, layers):
     return x @ W + b, (acts, pres)
 
 
-def _mlp_bwd(dout, tape, layers):
+def _mlp_bwd(dout, tape, layers, where="gnn"):
     """dout: gradient wrt the MLP output.  Returns (d rows, [(dW, db)] per layer)."""
     acts, pres = tape
+    shift = _KINK_SHIFT if _KINK_WHERE in ("all", where) else 0.0
     grads = [None] * len(layers)
     W, b = layers[-1]
     grads[-1] = (acts[-1].T @ dout, dout.sum(0))
     d = dout @ W.T
     for l in range(len(layers) - 2, -1, -1):
-        d = d * (pres[l + 1] > _KINK_SHIFT)            # relu'(z) = [z > 0]; shifted only to bracket float32 kink decisions
+        d = d * (pres[l + 1] > shift)                  # relu'(z) = [z > 0]; shifted only to bracket float32 kink decisions
         W, b = layers[l]
         grads[l] = (acts[l].T @ d, d.sum(0))
         d = d @ W.T
@@ -63,7 +65,7 @@ def _acc(dst, src):
         dst[k] = (dst[k][0] + dW, dst[k][1] + db)
 
 
-def loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype=np.float64, kink_shift=0.0):
+def loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype=np.float64, kink_shift=0.0, kink_where="all"):
     """Batch of B molecules (dense make_model inputs).  Returns (loss_sum, predictions (B,N,1), grads dict);
     loss_sum = sum over molecules and atoms of (y - p)^2, i.e. what tape.gradient differentiates when the B
     molecules' gradients are summed (data-parallel training: one molecule per rank, all-reduce sum).
@@ -71,13 +73,15 @@ def loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype=np.fl
     kink_shift: the backward takes relu'(z) = [z > kink_shift] (forward unchanged).  The gradient of a ReLU network is
     discontinuous where a pre-activation crosses 0; a float32 implementation whose z differs from the float64 one by its
     rounding (~1e-6 here) may land on the other side.  Evaluating with kink_shift = +tau and -tau brackets every such
-    decision: where no |z| < tau exists both equal the kink_shift = 0 gradient exactly."""
-    global _KINK_SHIFT
-    _KINK_SHIFT = float(kink_shift)
+    decision: where no |z| < tau exists both equal the kink_shift = 0 gradient exactly.  kink_where restricts the shift to
+    the GNN's networks ("gnn"), to the pass network's rows [a_i|a_j|e] ("listed") or to its rows [a_j|a_i|e] ("swapped"):
+    every pair is evaluated once in each of the two row sets, an implementation may flip one and not the other."""
+    global _KINK_SHIFT, _KINK_WHERE
+    _KINK_SHIFT, _KINK_WHERE = float(kink_shift), kink_where
     try:
         return _loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype)
     finally:
-        _KINK_SHIFT = 0.0
+        _KINK_SHIFT, _KINK_WHERE = 0.0, "all"
 
 
 def _loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype):
@@ -133,8 +137,8 @@ def _loss_and_grads(h_inp, e_inp, x_inp, q_inp, mask_inp, y, weights, dtype):
         ganti = np.broadcast_to(gq, (B, N, N)) * wgt                        # d q_i / d anti_ij = 1
         dN = (0.5 * ganti).reshape(-1, 1)
         dT = (-0.5 * ganti).reshape(-1, 1)
-        dXN, gN = _mlp_bwd(dN, actsN, w["pas"][t])
-        dXT, gT = _mlp_bwd(dT, actsT, w["pas"][t])
+        dXN, gN = _mlp_bwd(dN, actsN, w["pas"][t], "listed")
+        dXT, gT = _mlp_bwd(dT, actsT, w["pas"][t], "swapped")
         _acc(g["pas"][t], gN)
         _acc(g["pas"][t], gT)
         dXN = dXN.reshape(B, N, N, -1)

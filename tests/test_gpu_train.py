@@ -53,23 +53,16 @@ def test_gradients_match_oracle(gpu_engine_factory, nx, T, N, ns, fused):
     assert np.array_equal(w2["msg"][0][0][0], w["msg"][0][0][0])
 
 
-@pytest.mark.parametrize("fused", [1, 0])
-@pytest.mark.parametrize("which", ["decay_model_weights", "random"])
-def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, val_dir, val_names, golden_dir, weights_decay, which, fused):
-    """BASELINE.json configs[2] shape: N = 41, T = 5, real molecules of the reference's `mixed` set (a QM9 molecule, an SSI
-    dimer, the largest system of the validation split) with their stored MBIS labels, through the entry train.py uses
-    (train_step_xyz).  Gradient of sum (y-p)^2 (charge_gn.py:397-398) per parameter tensor vs the float64 oracle, with the
-    shipped checkpoint (collapsed GNN: its message / update tensors get exactly zero gradient in both) and with random
-    non-degenerate weights, for both train-step implementations."""
+@pytest.fixture(scope="module")
+def config3_case(val_dir, val_names, golden_dir, weights_decay):
+    """Inputs and float64 / float32 oracle gradients of the config-3 gradient test (shared by the two implementations)."""
     from conftest import load_molecules
     from oracle import epnn_oracle as orc
     from oracle import epnn_oracle_train as ot
     nx, T, N = 9, 5, 41
-    w = weights_decay if which == "decay_model_weights" else random_weights(nx, T, seed=9, scale=0.4)
     labs = np.load(os.path.join(golden_dir, "test_lab_charges.npy"))
     sizes = [orc.parse_xyz(os.path.join(val_dir, nm + ".xyz"), nx)[1].shape[0] for nm in val_names]
-    pick = [next(i for i, nm in enumerate(val_names) if nm.startswith("dsgdb9nsd")),
-            next(i for i, nm in enumerate(val_names) if nm.startswith("SSI")), int(np.argmax(sizes))]
+    pick = [val_names.index("dsgdb9nsd_081300"), val_names.index("SSI-081ILE-085ARG-1-dimer"), int(np.argmax(sizes))]
     assert sizes[pick[2]] == 38                              # the split's largest; the directory maximum 41 is a training file
     mols, offsets, xyz, x, Q = load_molecules(val_dir, [val_names[i] for i in pick], nx)
     y = np.concatenate([labs[i, :sizes[i]] for i in pick]).astype(np.float32)
@@ -78,43 +71,73 @@ def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, val_dir, va
     yd = np.zeros((len(mols), N, 1))
     for b, i in enumerate(pick):
         yd[b, :sizes[i], 0] = labs[i, :sizes[i]]
-    loss_ref, pred_ref, g_ref = ot.loss_and_grads(h, e, xd, q, mask, yd, w)
-    # ReLU kinks: the gradient jumps where a pre-activation crosses 0, and a float32 evaluation of a |z| < ~1e-6 may land
-    # on either side (the SSI dimer has one in the last pass network with the shipped weights: z = 2.9e-7; the two train-step
-    # implementations, which add the first layer's terms in different orders, then differ from each other by 1e-2 in that
-    # layer's bias gradient).  The oracle brackets every such decision: relu'(z) = [z > +tau] and [z > -tau].
-    tau = 2e-5
-    g_lo = ot.flatten(ot.loss_and_grads(h, e, xd, q, mask, yd, w, kink_shift=+tau)[2])
-    g_hi = ot.flatten(ot.loss_and_grads(h, e, xd, q, mask, yd, w, kink_shift=-tau)[2])
+    out = {"batch": (offsets, xyz, x, Q, y), "sizes": [sizes[i] for i in pick], "N": N}
+    # ReLU kinks.  The gradient jumps where a pre-activation crosses 0, and a float32 evaluation of a tiny |z| may land on
+    # either side -- every row of the pass network is evaluated twice (as [a_i|a_j|e] of atom i and as the swapped row of
+    # atom j), each in its own summation order.  With the shipped weights SSI-001ASN-030MET-1-dimer has z = 2.9e-7 in the
+    # last pass network: the two train-step implementations then differ by 1e-2 in that layer's bias gradient, the float64
+    # value lies between.  The oracle brackets such decisions (relu'(z) = [z > +tau] / [z > -tau], separately for the GNN's
+    # rows and for each of the pass network's two row sets).  The molecules are chosen so that the shipped weights have no
+    # such decision within tau = 2e-5 (|z| reaches ~90 there; asserted).  With random weights (|z| = O(1), tau = 2e-6) the
+    # 2.4 M pre-activations of a forward always include a few: their bracket widens the tolerance of the tensors they touch.
+    for which, w, tau in (("decay_model_weights", weights_decay, 2e-5), ("random", random_weights(nx, T, seed=13, scale=0.4), 2e-6)):
+        loss_ref, pred_ref, g_ref = ot.loss_and_grads(h, e, xd, q, mask, yd, w)
+        gr = ot.flatten(g_ref)
+        g32 = ot.flatten(ot.loss_and_grads(h, e, xd, q, mask, yd, w, dtype=np.float32)[2]).astype(np.float64)
+        band = np.zeros_like(gr)
+        for where in ("gnn", "listed", "swapped"):
+            g_lo = ot.flatten(ot.loss_and_grads(h, e, xd, q, mask, yd, w, kink_shift=+tau, kink_where=where)[2])
+            g_hi = ot.flatten(ot.loss_and_grads(h, e, xd, q, mask, yd, w, kink_shift=-tau, kink_where=where)[2])
+            band += np.abs(g_hi - g_lo)
+        if which == "decay_model_weights":
+            assert band.max() == 0.0
+        out[which] = (w, loss_ref, pred_ref, gr, g32, band)
+    return out
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("which", ["decay_model_weights", "random"])
+def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, config3_case, which, fused):
+    """BASELINE.json configs[2] shape: N = 41, T = 5, real molecules of the reference's `mixed` set (a QM9 molecule, a
+    charged SSI dimer, the largest system of the validation split) with their stored MBIS labels, through the entry
+    train.py uses (train_step_xyz).  Gradient of sum (y-p)^2 (charge_gn.py:397-398) per parameter tensor vs the float64
+    oracle, with the shipped checkpoint (collapsed GNN: its message / update tensors get exactly zero gradient in both)
+    and with random non-degenerate weights, for both train-step implementations.  Tolerance per tensor: 2e-4 of its
+    largest entry, or 4x the float32 noise of the reference algorithm itself (the float32 oracle against the float64
+    one) where that is larger: with a trained model the residuals y - p are ~1e-3, so the float32 rounding of p alone
+    (3e-7) moves every gradient by ~3e-4 of its size."""
+    nx, T, N = 9, 5, config3_case["N"]
+    offsets, xyz, x, Q, y = config3_case["batch"]
+    w, loss_ref, pred_ref, gr, g32, band = config3_case[which]
     eng = gpu_engine_factory(nx=nx, T=T)
     eng.set_option("train_fused", fused)
     eng.set_weights(w)
     eng.train_init()
     qq, loss = eng.train_step_xyz(offsets, xyz, x, Q, y, N, apply=False)
-    for b in range(len(mols)):
-        assert np.abs(qq[offsets[b]:offsets[b + 1]] - pred_ref[b, :sizes[pick[b]], 0]).max() < 2e-5
+    for b, n in enumerate(config3_case["sizes"]):
+        assert np.abs(qq[offsets[b]:offsets[b + 1]] - pred_ref[b, :n, 0]).max() < 2e-5
     assert abs(loss - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
-    g, gr = eng.get_gradients().astype(np.float64), ot.flatten(g_ref)
-    lo, hi = np.minimum(np.minimum(g_lo, g_hi), gr), np.maximum(np.maximum(g_lo, g_hi), gr)
-    pos, worst, zero_tensors, kinked = 0, 0.0, 0, 0
+    g = eng.get_gradients().astype(np.float64)
+    pos, worst, worst_noise, zero_tensors, kinked = 0, 0.0, 0.0, 0, 0
     for m in [w["upd"]] + w["msg"] + w["pas"]:
         for W, b in m:
             for arr in (W, b):
                 sl = slice(pos, pos + arr.size)
                 scale = np.abs(gr[sl]).max()
                 if scale > 0:
-                    # distance from the interval the kink decisions span (an exact match needs none of them)
-                    band = hi[sl] - lo[sl]
-                    out = np.maximum(np.maximum(lo[sl] - band - g[sl], g[sl] - hi[sl] - band), 0.0)
-                    kinked += int(band.max() > 1e-6 * scale)
-                    worst = max(worst, out.max() / scale)
+                    noise = np.abs(g32[sl] - gr[sl]).max() / scale
+                    kink = band[sl].max() / scale                          # 0 for every tensor with the shipped weights
+                    err = np.abs(g[sl] - gr[sl]).max() / scale
+                    kinked += kink > 0
+                    if kink == 0:
+                        worst, worst_noise = max(worst, err), max(worst_noise, noise)
+                    assert err <= max(2e-4, 4 * noise) + 2 * kink, (err, noise, kink)
                 else:
                     zero_tensors += 1
                     assert np.all(g[sl] == 0)
                 pos += arr.size
-    print(f"{which} fused={fused} N=41 T=5: worst per-tensor relative gradient error {worst:.2e}; {zero_tensors} tensors with zero "
-          f"gradient, {kinked} touched by a ReLU kink within {tau}; loss {loss:.6f} vs {loss_ref:.6f}")
-    assert worst < 2e-4
+    print(f"{which} fused={fused} N=41 T=5: worst per-tensor relative gradient error {worst:.2e} (float32 oracle: {worst_noise:.2e}) over the "
+          f"tensors no ReLU kink touches; {kinked} touched, {zero_tensors} with zero gradient; loss {loss:.6f} vs {loss_ref:.6f}")
 
 
 def test_adam_trajectory_matches_oracle(gpu_engine_factory):
