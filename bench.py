@@ -127,7 +127,7 @@ def collect_pmc(args):
     vals = {}
     for name, counters, depth in passes:
         d = os.path.join(base, name)
-        cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+        cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--steps", "12", "--warmup", "6", "--no-cpu-baseline", "--no-extras", "--depth", str(depth), "--molecules", str(args.molecules)]
         env = dict(os.environ, TMPDIR="/tmp")
         rc = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, cwd="/tmp")
@@ -179,10 +179,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-launch and host-to-host measurements")
     ap.add_argument("--pmc", action="store_true", help="first run the rocprofv3 counter passes of this workload (writes profiles/r02_pmc_bench.json)")
-    ap.add_argument("--depth", type=int, default=6, help="batches in flight per GPU (handles/streams used round robin)")
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight per GPU (handles/streams used round robin); 0 = by run "
+                    "length: 6 for long runs (best steady state), for short ones the divisor of --steps among 5, 4, 6 -- the last "
+                    "round of launches then fills every lane (a launch takes ~0.3 ms whatever shares the GPU with it, so a short run "
+                    "that ends with two of six lanes busy pays for it: K = 20 runs at 184 M atoms/s five deep, 175 M six deep)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
     args = ap.parse_args()
 
+    if args.depth <= 0:
+        args.depth = 6 if args.steps >= 200 else next((d for d in (5, 4, 6) if args.steps % d == 0), 6)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the rank processes from here, before this process makes any GPU call (it never makes one)
         from epnn_amd.rendezvous import launch_ranks

@@ -658,6 +658,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         A.pwj = h->d_pwj.as<float>();
     }
     A.handoff = S.handoff;
+    A.prio_n = h->opt_wave_prio;
     A.q_out = S.d_q;
     A.h_out = S.d_hout;
     A.h_in = S.d_hin;
@@ -1028,6 +1029,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
+    else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);

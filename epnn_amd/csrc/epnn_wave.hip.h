@@ -62,6 +62,7 @@ struct WaveArgs {
     const float *etab;     // [tab_n][16] B^T e(D) on the grid D = i / tab_inv_h, i = 0 .. tab_n - 1 (last point = cutoff)
     double tab_inv_h, dsafe;
     int tab_n;
+    int prio_n;            // molecules with at least this many atoms run at raised wave priority (0: off), see k_wave_forward
     int handoff;           // in-kernel front-end and nothing else runs: the last wave reports to host_status and re-zeroes `status`
     int *host_status;      // pinned host ints [0] status bits [1] near pairs of the batch: written by the last wave to finish
     unsigned long long *stamps;   // diagnostic build only (-DEPNN_STAMPS): [block][64] s_memtime values
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     if (!FRONT && (*A.status & EPNN_ST_PAIR_OVERFLOW)) return;
     const int4 wb = A.wblk[blockIdx.x];                   // molecule, first atom, atoms, first pair slot: ONE load, not a chain of three
     const int b = wb.x, a0 = wb.y, n = wb.z;
+    // A launch lasts as long as its largest molecules (a 29-atom one takes 3.5x the mean), and the end of a run is their
+    // latency.  The largest ones therefore run at raised priority: beside a smaller molecule on the same SIMD they win the
+    // issue arbitration and run at nearly the speed they would have alone; the total work of the SIMD is unchanged.
+    if (A.prio_n > 0 && n >= A.prio_n) __builtin_amdgcn_s_setprio(3);
     const int p0 = FRONT ? wb.w : A.row_off[a0];
     int np = FRONT ? 0 : A.row_off[a0 + n] - p0;
     const int nx = A.nx;
