@@ -1030,6 +1030,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
+    else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);

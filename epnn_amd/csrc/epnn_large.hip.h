@@ -82,6 +82,10 @@ __global__ __launch_bounds__(256) void k_lg_init(LargeArgs L) {
 }
 
 // ------------------------------------------------------------------------------------------------ "down" lists
+// entry = pair slot; the top bit marks a one-sided entry (an arbitrary dense e / mask may list (i,j) without (j,i)): such an
+// entry carries the EPN weight pwj but no GNN correction for its second atom
+#define EPNN_DN_ONESIDED ((int)0x80000000)
+#define EPNN_DN_SLOT 0x7fffffff
 __global__ __launch_bounds__(256) void k_lg_dn_count(LargeArgs L) {
     const int np = L.row_off[L.A];
     if (np > L.pcap) return;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void k_lg_dn_fill(LargeArgs L, int *dn_ent_w) 
         if (L.psym[p] || L.pwj[p] != 0.f) {
             const int j = L.pj[p];
             const int pos = atomicAdd(&L.dn_cnt[j], 1);
-            dn_ent_w[L.dn_off[j] + pos] = p;
+            dn_ent_w[L.dn_off[j] + pos] = p | (L.psym[p] ? 0 : EPNN_DN_ONESIDED);     // flag: no GNN correction through this entry
         }
 }
 // order every atom's list by pair slot so that sums over it have a fixed order
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void k_lg_dn_sort(LargeArgs L, int *dn_ent_w) 
         for (int a = lo + 1; a < hi; ++a) {
             const int v = dn_ent_w[a];
             int b = a - 1;
-            while (b >= lo && dn_ent_w[b] > v) {
+            while (b >= lo && (dn_ent_w[b] & EPNN_DN_SLOT) > (v & EPNN_DN_SLOT)) {
                 dn_ent_w[b + 1] = dn_ent_w[b];
                 --b;
             }
@@ -147,15 +151,15 @@ __global__ __launch_bounds__(256) void k_lg_dn_sort(LargeArgs L, int *dn_ent_w) 
 }
 
 // ------------------------------------------------------------------------------------------------ projection
-// one wave per 32-atom tile
-__global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int with_zp) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
-    const int it = blockIdx.x * 4 + wave;
-    if (it >= L.natiles) return;
-    const int4 tl = L.atiles[it];
+// one wave per 32-atom tile; `arow` = this lane's half (hh) of its atom's even/odd feature row (global a_eo or an LDS image).
+// WHAT: 3 = P, R (and zp) by this wave; 1 = P (and zp) only; 2 = R only (the tail kernel gives the halves to two waves).
+// `wA` = the wave's weight fragments (Wi for WHAT & 1, else Wj), already in registers when PRE.
+template <int WHAT, bool PRE>
+__device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPack &M, int with_zp, const int4 tl, const float *arow, int lane,
+                                             const float (&wA)[EPNN_KA]) {
+    const int c = lane & 31, hh = lane >> 5;
     const int at = tl.x + (c < tl.y ? c : 0);
     const float *wp = L.wpack;
-    const float *arow = L.a_eo + (size_t)at * EPNN_AST + hh * 32;
     float bv[32];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -165,14 +169,14 @@ __global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int
     f32x16 accP = epnn_splat16(0.f), accR = epnn_splat16(0.f);
 #pragma unroll
     for (int s = 0; s < EPNN_KA; ++s) {
-        accP = epnn_mfma(wp[M.wiF + s * 64 + lane], bv[s], accP);
-        accR = epnn_mfma(wp[M.wjF + s * 64 + lane], bv[s], accR);
+        if (WHAT & 1) accP = epnn_mfma(PRE ? wA[s] : wp[M.wiF + s * 64 + lane], bv[s], accP);
+        if (WHAT & 2) accR = epnn_mfma(PRE && !(WHAT & 1) ? wA[s] : wp[M.wjF + s * 64 + lane], bv[s], accR);
     }
     if (c < tl.y) {
-        epnn_st16(L.P + (size_t)at * 32 + hh * 16, accP);
-        epnn_st16(L.R + (size_t)at * 32 + hh * 16, accR);
+        if (WHAT & 1) epnn_st16(L.P + (size_t)at * 32 + hh * 16, accP);
+        if (WHAT & 2) epnn_st16(L.R + (size_t)at * 32 + hh * 16, accR);
     }
-    if (with_zp) {
+    if ((WHAT & 1) && with_zp) {
         // padded partner: R = 0, G = 0  ->  zp_i = relu(W2^T relu(P_i) + b2); rows = atoms, cols = out
         f32x16 acc = epnn_splat16(wp[M.b2 + c]);
 #pragma unroll
@@ -184,6 +188,15 @@ __global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int
         }
     }
 }
+__global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int with_zp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
+    const int it = blockIdx.x * 4 + wave;
+    if (it >= L.natiles) return;
+    const int4 tl = L.atiles[it];
+    const int at = tl.x + (c < tl.y ? c : 0);
+    const float none[EPNN_KA] = {};
+    lg_proj_wave<3, false>(L, M, with_zp, tl, L.a_eo + (size_t)at * EPNN_AST + hh * 32, lane, none);
+}
 
 // ------------------------------------------------------------------------------------------------ all-pairs sweep
 // workgroup = up to 4 atom tiles (one per wave) x one j-chunk of the same molecule; R_j staged in LDS.
@@ -192,8 +205,16 @@ __global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int
 // co-resident wavefronts' VALU work (two adds and two max per feature and pair) overlaps this MFMA shape better than
 // 32x32x2 (tools/micro/mfma_covalu.hip), which is what bounds the sweep.  W2 / b2 come from the fused kernel's pack.
 #define EPNN_LG_JC 64
-__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2off) {
+template <int MODE>
+__device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk);
+// Workgroups [0, nstasks) sweep; workgroups beyond them are the near-pair correction tiles of the same step (k_lg_pairs<0>'s
+// body): both need only this step's P and R, so they share a launch instead of waiting for each other.
+__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2off, PairMlpPack Mpair, int with_pairs) {
     __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
+    if (with_pairs && (int)blockIdx.x >= L.nstasks) {
+        lg_pairs_body<0>(L, Mpair, (int)blockIdx.x - L.nstasks);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
     const int4 tk = L.stasks[blockIdx.x];            // first atile, #atiles, j_lo, j_hi (global atom indices)
     const int chunk = L.stask_chunk[blockIdx.x];
@@ -253,11 +274,11 @@ __global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2
 // ------------------------------------------------------------------------------------------------ pair tiles
 // one wave per 32 listed pairs.  mode 0: GNN correction -> corr[p][side][32]; mode 1: EPN -> dl[p]
 template <int MODE>
-__global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
+__device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
     const int np = L.row_off[L.A];
     if (np > L.pcap) return;
-    const int slot = (blockIdx.x * 4 + wave) * 32 + c;
+    const int slot = (blk * 4 + wave) * 32 + c;
     bool valid = slot < np;
     int gi = 0, gj = 0, sym = 0;
     if (valid) {
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
             b0 = epnn_mfma(fmaxf(v0, 0.f), w2[s], b0);
             bG = epnn_mfma(fmaxf(v0 + g[s], 0.f), w2[s], bG);
         }
-        const int base = (blockIdx.x * 4 + wave) * 32;
+        const int base = (blk * 4 + wave) * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = base + epnn_kappa(hh, r);
@@ -321,21 +342,17 @@ __global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
     }
     (void)sym;
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
+    lg_pairs_body<MODE>(L, M, (int)blockIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------------ update
 // S_i = sum_chunk S0 + sum of the atom's corrections + (N-n) zp_i, one thread per (atom, out), fixed order.
 // Written as its own wide launch: the update kernel has only natiles/4 workgroups, far too few to hide ~50
 // dependent global loads per element.
-__global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin) {
-    if (L.row_off[L.A] > L.pcap) return;
-    const int it = blockIdx.x;                 // one workgroup per 8 atoms of a tile list entry
-    const int o = threadIdx.x & 31, a8 = threadIdx.x >> 5;
-    const int4 tl = L.atiles[it >> 2];
-    const int a = (it & 3) * 8 + a8;
-    if (a >= tl.y) return;
-    const int at = tl.x + a;
-    const int n = L.moff[tl.z + 1] - L.moff[tl.z];
-    const int nchunk = tl.w;
+// S of one (atom, output): chunk partials in chunk order, the atom's corrections as first index, as second index, padding
+__device__ __forceinline__ float lg_reduce_elem(const LargeArgs &L, int at, int o, int n, int nchunk) {
     float s = 0.f;
     {   // eight loads in flight, added in chunk order (the order of the sum is part of the result)
         const float *src = L.S0 + (size_t)at * 32 + o;
@@ -366,72 +383,134 @@ __global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin) {
         const int e0 = L.dn_off[at], e1 = L.dn_off[at + 1];
         int e = e0;
         for (; e + 4 <= e1; e += 4) {
-            int pp[4], sy[4];
+            int pp[4];
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) pp[u] = L.dn_ent[e + u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sy[u] = L.psym[pp[u]];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = L.corr[((size_t)pp[u] * 2 + 1) * 32 + o];
+            for (int u = 0; u < 4; ++u) v[u] = L.corr[((size_t)(pp[u] & EPNN_DN_SLOT) * 2 + 1) * 32 + o];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (sy[u]) s += v[u];
+                if (pp[u] >= 0) s += v[u];
         }
         for (; e < e1; ++e) {
             const int p = L.dn_ent[e];
-            if (L.psym[p]) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
+            if (p >= 0) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
         }
     }
     s += (float)(L.N - n) * L.zp[(size_t)at * 32 + o];
-    Sfin[(size_t)at * 32 + o] = s;
+    return s;
+}
+// The same sums for four atoms of a tile at once (atoms a8, a8+8, a8+16, a8+24 of the tile, one output o): every stage keeps
+// the loads of all four in flight together, each element still adds its own terms in the same order as lg_reduce_elem.
+__device__ __forceinline__ void lg_reduce4(const LargeArgs &L, const int4 tl, int a8, int o, int n, float (&out)[4]) {
+    const int nchunk = tl.w;
+    int at[4];
+    bool ok[4];
+    float s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ok[k] = a8 + 8 * k < tl.y;
+        at[k] = tl.x + (ok[k] ? a8 + 8 * k : 0);
+        s[k] = 0.f;
+    }
+    // the list bounds of the later stages are requested now, they arrive under the chunk loads
+    int p[4], p1[4], e[4], e1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        p[k] = L.row_off[at[k]];
+        p1[k] = L.row_off[at[k] + 1];
+        e[k] = L.dn_off[at[k]];
+        e1[k] = L.dn_off[at[k] + 1];
+    }
+    {
+        const size_t step = (size_t)L.A * 32;
+        for (int ch = 0; ch < nchunk; ch += 16) {             // 64 loads of a thread in flight: a round trip per 16 chunks
+            float v[4][16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[k][u] = ch + u < nchunk ? L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (ch + u < nchunk) s[k] += v[k][u];
+        }
+    }
+    {   // corrections of the pairs in which the atom is the first index
+        int left = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) left = max(left, p1[k] - p[k]);
+        for (; left > 0; left -= 8) {
+            float v[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[k][u] = p[k] + u < p1[k] ? L.corr[((size_t)(p[k] + u) * 2 + 0) * 32 + o] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (p[k] + u < p1[k]) s[k] += v[k][u];
+                p[k] += 8;
+            }
+        }
+    }
+    {   // ... and the second index: entry -> correction (one-sided entries carry none)
+        int left = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) left = max(left, e1[k] - e[k]);
+        for (; left > 0; left -= 8) {
+            int pp[4][8];
+            float v[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pp[k][u] = e[k] + u < e1[k] ? L.dn_ent[e[k] + u] : EPNN_DN_ONESIDED;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[k][u] = L.corr[((size_t)(pp[k][u] & EPNN_DN_SLOT) * 2 + 1) * 32 + o];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (pp[k][u] >= 0) s[k] += v[k][u];
+                e[k] += 8;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = ok[k] ? s[k] + (float)(L.N - n) * L.zp[(size_t)at[k] * 32 + o] : 0.f;
+}
+__global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin) {
+    if (L.row_off[L.A] > L.pcap) return;
+    const int it = blockIdx.x;                 // one workgroup per 8 atoms of a tile list entry
+    const int o = threadIdx.x & 31, a8 = threadIdx.x >> 5;
+    const int4 tl = L.atiles[it >> 2];
+    const int a = (it & 3) * 8 + a8;
+    if (a >= tl.y) return;
+    const int at = tl.x + a;
+    Sfin[(size_t)at * 32 + o] = lg_reduce_elem(L, at, o, L.moff[tl.z + 1] - L.moff[tl.z], tl.w);
 }
 
-// workgroup = up to 4 atom tiles, one wave per tile runs the update MLP on the reduced S
-__global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int maxchunk, const float *Sfin) {
-    __shared__ float Ss[4 * 32 * EPNN_SST];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
-    const int t0 = blockIdx.x * 4;
-    const int np = L.row_off[L.A];
-    if (np > L.pcap) return;
-    // every weight fragment of the three layers is requested before anything else: the kernel has natiles/4 workgroups and
-    // is pure latency, so the 88 loads travel while S is staged instead of one by one in front of their MFMAs
-    const float *wp = L.wpack;
-    float w1[40], w2[16], w3[32];
-#pragma unroll
-    for (int s = 0; s < 40; ++s) w1[s] = wp[U.u1F + s * 64 + lane];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) w2[s] = wp[U.u2F + s * 64 + lane];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) w3[s] = wp[U.u3F + s * 64 + lane];
-    {   // stage S of the workgroup's four tiles: the tile descriptors first, then all sixteen loads of a thread in flight
-        int4 tls[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) tls[w] = t0 + w < L.natiles ? L.atiles[t0 + w] : make_int4(0, 0, 0, 0);
-        const int o = tid & 31, a8 = tid >> 5;
-        float v[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int w = it >> 2, a = a8 + 8 * (it & 3);
-            v[it] = a < tls[w].y ? Sfin[(size_t)(tls[w].x + a) * 32 + o] : 0.f;
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) Ss[((it >> 2) * 32 + a8 + 8 * (it & 3)) * EPNN_SST + o] = v[it];
-    }
-    (void)maxchunk;
-    __syncthreads();
-    if (t0 + wave >= L.natiles) return;
-    const int4 tl = L.atiles[t0 + wave];
+// The update MLP (charge_gn.py:71-74) of one 32-atom tile by one wave: weights w1 / w2 / w3 already in registers, the
+// atom's h features from `arow` (its half hh of the even/odd feature row, offset to the first h slot), its reduced message
+// sum from `srow` ([32] out-major).  New h goes to `dst` (a full even/odd row; global a_eo, and `dst2` when not null).
+__device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack &U, const float (&w1)[40], const float (&w2)[16],
+                                               const float (&w3)[32], const int4 tl, const float *arow, const float *srow,
+                                               float *dst, float *dst2, int lane) {
+    const int c = lane & 31, hh = lane >> 5;
     const bool live = c < tl.y;
     const int at = tl.x + (live ? c : 0);
     const int nx = L.nx;
-    const int u0 = (nx - hh + 1) >> 1;
-    const float *arow = L.a_eo + (size_t)at * EPNN_AST + hh * 32 + u0;
+    const float *wp = L.wpack;
     float hv[24], sv[16];
 #pragma unroll
     for (int s = 0; s < 24; ++s) hv[s] = arow[s];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) sv[s] = Ss[(wave * 32 + c) * EPNN_SST + 2 * s + hh];
+    for (int s = 0; s < 16; ++s) sv[s] = srow[2 * s + hh];
     float cb[16], b1[16];
     epnn_ld16(wp + U.cb3p + hh * 16, cb);
     epnn_ld16(wp + U.bu1p + hh * 16, b1);
@@ -467,33 +546,152 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
         o1 = epnn_mfma(w3[16 + s], u2[s], o1);
     }
     if (live) {
-        float *dst = L.a_eo + (size_t)at * EPNN_AST;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = epnn_kappa(hh, r);
             dst[epnn_aeo(nx + f)] = nmc * o0[r];
             if (r < 8) dst[epnn_aeo(nx + 32 + f)] = nmc * o1[r];
+            if (dst2) {
+                dst2[epnn_aeo(nx + f)] = nmc * o0[r];
+                if (r < 8) dst2[epnn_aeo(nx + 32 + f)] = nmc * o1[r];
+            }
         }
     }
 }
+#define LG_LOAD_UPD_WEIGHTS(w1, w2, w3, U)                                            \
+    _Pragma("unroll") for (int s = 0; s < 40; ++s) w1[s] = wp[U.u1F + s * 64 + lane]; \
+    _Pragma("unroll") for (int s = 0; s < 16; ++s) w2[s] = wp[U.u2F + s * 64 + lane]; \
+    _Pragma("unroll") for (int s = 0; s < 32; ++s) w3[s] = wp[U.u3F + s * 64 + lane];
+
+// workgroup = up to 4 atom tiles, one wave per tile runs the update MLP on the reduced S (used when a partition's exchange
+// sits between the reduction and the update)
+__global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int maxchunk, const float *Sfin) {
+    __shared__ float Ss[4 * 32 * EPNN_SST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    const int t0 = blockIdx.x * 4;
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    // every weight fragment of the three layers is requested before anything else: the kernel has natiles/4 workgroups and
+    // is pure latency, so the 88 loads travel while S is staged instead of one by one in front of their MFMAs
+    const float *wp = L.wpack;
+    float w1[40], w2[16], w3[32];
+    LG_LOAD_UPD_WEIGHTS(w1, w2, w3, U)
+    {   // stage S of the workgroup's four tiles: the tile descriptors first, then all sixteen loads of a thread in flight
+        int4 tls[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tls[w] = t0 + w < L.natiles ? L.atiles[t0 + w] : make_int4(0, 0, 0, 0);
+        const int o = tid & 31, a8 = tid >> 5;
+        float v[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int w = it >> 2, a = a8 + 8 * (it & 3);
+            v[it] = a < tls[w].y ? Sfin[(size_t)(tls[w].x + a) * 32 + o] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) Ss[((it >> 2) * 32 + a8 + 8 * (it & 3)) * EPNN_SST + o] = v[it];
+    }
+    (void)maxchunk;
+    __syncthreads();
+    if (t0 + wave >= L.natiles) return;
+    const int4 tl = L.atiles[t0 + wave];
+    const int at = tl.x + (c < tl.y ? c : 0);
+    const int u0 = (L.nx - hh + 1) >> 1;
+    lg_update_wave(L, U, w1, w2, w3, tl, L.a_eo + (size_t)at * EPNN_AST + hh * 32 + u0, Ss + (wave * 32 + c) * EPNN_SST,
+                   L.a_eo + (size_t)at * EPNN_AST, nullptr, lane);
+}
+
+// ---- one launch for everything between two sweeps (GNN) / two pair passes (EPN): workgroup = one 32-atom tile.
+// GNN: all 256 threads reduce the tile's S (chunk partials, corrections, padding) into LDS, wave 0 runs the update MLP and
+// then the NEXT step's projections from an LDS image of the tile's feature rows.  The three kernels this replaces
+// (k_lg_reduce, k_lg_update, k_lg_proj) are 6-9 us of latency each on a 2220-atom system.  Same device functions, same
+// operand values, same order: bit-identical to the separate launches (tests: partition == whole).
+struct LgNext {
+    PairMlpPack M;       // projections of the next sweep / pair pass
+    int run;             // 0: nothing follows
+    int with_zp;
+};
+__global__ __launch_bounds__(256) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgNext X) {
+    __shared__ __attribute__((aligned(16))) float Ss[32 * EPNN_SST];
+    __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    if (L.row_off[L.A] > L.pcap) return;
+    const int4 tl = L.atiles[blockIdx.x];
+    const float *wp = L.wpack;
+    // every weight fragment is requested before the reduction: wave 0 the update MLP's, waves 1 / 2 the next projections'
+    // Wi / Wj -- they travel while the partial sums are collected
+    float w1[40], w2[16], w3[32], wA[EPNN_KA];
+    if (wave == 0) { LG_LOAD_UPD_WEIGHTS(w1, w2, w3, U) }
+    if (X.run && (wave == 1 || wave == 2)) {
+        const int off = wave == 1 ? X.M.wiF : X.M.wjF;
+#pragma unroll
+        for (int s = 0; s < EPNN_KA; ++s) wA[s] = wp[off + s * 64 + lane];
+    }
+    for (int i = tid; i < tl.y * EPNN_AST; i += 256) Ai[i] = L.a_eo[(size_t)tl.x * EPNN_AST + i];
+    {
+        const int o = tid & 31, a8 = tid >> 5, n = L.moff[tl.z + 1] - L.moff[tl.z];
+        float sv[4];
+        lg_reduce4(L, tl, a8, o, n, sv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Ss[(a8 + 8 * k) * EPNN_SST + o] = sv[k];
+    }
+    __syncthreads();
+    const int row = c < tl.y ? c : 0;
+    if (wave == 0) {
+        const int u0 = (L.nx - hh + 1) >> 1;
+        lg_update_wave(L, U, w1, w2, w3, tl, Ai + row * EPNN_AST + hh * 32 + u0, Ss + c * EPNN_SST,
+                       L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane);
+    }
+    if (!X.run) return;
+    __syncthreads();                                            // the image now holds the new h
+    if (wave == 1) lg_proj_wave<1, true>(L, X.M, X.with_zp, tl, Ai + row * EPNN_AST + hh * 32, lane, wA);
+    if (wave == 2) lg_proj_wave<2, true>(L, X.M, X.with_zp, tl, Ai + row * EPNN_AST + hh * 32, lane, wA);
+}
 
 // q_i += sum_j antisym_ij (charge_gn.py:118); thread per atom, fixed order (own row first, then the down list)
+__device__ __forceinline__ float lg_apply_atom(const LargeArgs &L, int at) {
+    float acc = 0.f;
+    for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
+        const int p = L.dn_ent[e] & EPNN_DN_SLOT;
+        acc -= L.pwj[p] * L.dl[p];
+    }
+    for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) acc += L.pwi[p] * L.dl[p];
+    return acc;
+}
 __global__ __launch_bounds__(256) void k_lg_apply(LargeArgs L, int last) {
     if (L.row_off[L.A] > L.pcap) return;
     const int fq = L.nx + EPNN_EDIM;
     for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
         if (!L.mflag[L.mol_of[at]]) continue;
-        float acc = 0.f;
-        for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
-            const int p = L.dn_ent[e];
-            acc -= L.pwj[p] * L.dl[p];
-        }
-        for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) acc += L.pwi[p] * L.dl[p];
         float *qp = L.a_eo + (size_t)at * EPNN_AST + epnn_aeo(fq);
-        const float q = *qp + acc;
+        const float q = *qp + lg_apply_atom(L, at);
         *qp = q;
         if (last && L.q_out) L.q_out[at] = q;
     }
+}
+// EPN counterpart of k_lg_gnn_tail: workgroup (one wave) = one 32-atom tile: charge update of its atoms, then the next
+// step's projections from the LDS image (k_lg_apply + k_lg_proj in one launch).
+__global__ __launch_bounds__(64) void k_lg_epn_tail(LargeArgs L, LgNext X, int last) {
+    __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
+    const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
+    if (L.row_off[L.A] > L.pcap) return;
+    const int4 tl = L.atiles[blockIdx.x];
+    const int fq = L.nx + EPNN_EDIM;
+    for (int i = lane; i < tl.y * EPNN_AST; i += 64) Ai[i] = L.a_eo[(size_t)tl.x * EPNN_AST + i];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane < tl.y) {
+        const int at = tl.x + lane;
+        const float q = Ai[lane * EPNN_AST + epnn_aeo(fq)] + lg_apply_atom(L, at);
+        Ai[lane * EPNN_AST + epnn_aeo(fq)] = q;
+        L.a_eo[(size_t)at * EPNN_AST + epnn_aeo(fq)] = q;
+        if (last && L.q_out) L.q_out[at] = q;
+    }
+    if (!X.run) return;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int row = c < tl.y ? c : 0;
+    const float none[EPNN_KA] = {};
+    lg_proj_wave<3, false>(L, X.M, X.with_zp, tl, Ai + row * EPNN_AST + hh * 32, lane, none);
 }
 
 __global__ __launch_bounds__(256) void k_lg_export_h(LargeArgs L) {
@@ -640,30 +838,56 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     hipLaunchKernelGGL(k_lg_dn_scan, dim3(1), dim3(1024), 0, st, L, h->l_csr_off.as<int>());
     hipLaunchKernelGGL(k_lg_dn_fill, dim3(gP), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
     hipLaunchKernelGGL(k_lg_dn_sort, dim3(gAt), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
-    for (int t = 0; t < (run_gnn ? L.T : 0); ++t) {
-        hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[t], 1);
-        if (L.nstasks > 0)
-            hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
-        hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
-        hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
-        if (h->part_world > 1) {
-            // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms): the caller's
-            // exchange fills them in; everything after this point is computed by every process for every atom
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));
-            if (!h->part_exchange) EPNN_FAIL("forward: a partition is set but no exchange function");
-            if (h->part_exchange(h->part_ctx, h->l_sfin.as<float>(), 32, P.A, h->part_row_lo, h->part_row_hi))
-                EPNN_FAIL("forward: the partition's exchange function reported an error");
+    // Launch sequence (the single-process case): proj(0) | per GNN step: sweep + correction tiles, tail (reduce, update,
+    // next projections) | per EPN step: pair tiles, tail (charge update, next projections).  With a partition the other
+    // processes' rows of S arrive between the reduction and the update, so those stay separate launches.
+    const bool split = h->part_world > 1 || !h->opt_large_fused;
+    const int Tg = run_gnn ? L.T : 0, Te = run_epn ? L.T : 0;
+    const unsigned gTile = (unsigned)L.natiles;
+    auto next_after_gnn = [&](int t) {
+        LgNext X{};
+        if (t + 1 < Tg) { X.M = h->widx.msg[t + 1]; X.run = 1; X.with_zp = 1; }
+        else if (Te > 0) { X.M = h->widx.pas[0]; X.run = 1; X.with_zp = 0; }
+        return X;
+    };
+    if (Tg > 0) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[0], 1);
+    else if (Te > 0) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.pas[0], 0);
+    for (int t = 0; t < Tg; ++t) {
+        if (split) {
+            if (L.nstasks > 0)
+                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2, h->widx.msg[t], 0);
+            hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
+            hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
+            if (h->part_world > 1) {
+                // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms): the caller's
+                // exchange fills them in; everything after this point is computed by every process for every atom
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(st));
+                if (!h->part_exchange) EPNN_FAIL("forward: a partition is set but no exchange function");
+                if (h->part_exchange(h->part_ctx, h->l_sfin.as<float>(), 32, P.A, h->part_row_lo, h->part_row_hi))
+                    EPNN_FAIL("forward: the partition's exchange function reported an error");
+            }
+            hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk, h->l_sfin.as<float>());
+            const LgNext X = next_after_gnn(t);
+            if (X.run) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, X.with_zp);
+        } else {
+            hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks + gPT), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2, h->widx.msg[t], 1);
+            hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(256), 0, st, L, h->widx.upd[t], next_after_gnn(t));
         }
-        hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk, h->l_sfin.as<float>());
     }
     if (d_hout) hipLaunchKernelGGL(k_lg_export_h, dim3(gA), dim3(256), 0, st, L);
-    for (int t = 0; t < (run_epn ? L.T : 0); ++t) {
-        hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.pas[t], 0);
+    for (int t = 0; t < Te; ++t) {
         hipLaunchKernelGGL(k_lg_pairs<1>, dim3(gPT), dim3(256), 0, st, L, h->widx.pas[t]);
-        hipLaunchKernelGGL(k_lg_apply, dim3(gAt), dim3(256), 0, st, L, 0);
+        LgNext X{};
+        if (t + 1 < Te) { X.M = h->widx.pas[t + 1]; X.run = 1; X.with_zp = 0; }
+        if (split) {
+            hipLaunchKernelGGL(k_lg_apply, dim3(gAt), dim3(256), 0, st, L, t + 1 == Te);
+            if (X.run) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, 0);
+        } else {
+            hipLaunchKernelGGL(k_lg_epn_tail, dim3(gTile), dim3(64), 0, st, L, X, t + 1 == Te);
+        }
     }
-    if (d_q) hipLaunchKernelGGL(k_lg_export_q, dim3(gAt), dim3(256), 0, st, L);
+    if (d_q && Te == 0) hipLaunchKernelGGL(k_lg_export_q, dim3(gAt), dim3(256), 0, st, L);
     HIPCHK(hipGetLastError());
     return 0;
 }
