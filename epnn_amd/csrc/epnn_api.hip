@@ -120,13 +120,13 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     for (DevBuf *b : bufs) b->release();
     if (h->train) {
         TrainState *ts = train_state(h);
-        if (ts->comm) (void)ncclCommDestroy(ts->comm);
         if (ts->gexec) (void)hipGraphExecDestroy(ts->gexec);
         if (ts->graph) (void)hipGraphDestroy(ts->graph);
         for (DevBuf *b : {&ts->theta, &ts->grad, &ts->m, &ts->v, &ts->part, &ts->arena, &ts->loss}) b->release();
         delete ts;
         h->train = nullptr;
     }
+    if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->h_status) (void)hipHostFree(h->h_status);
     (void)hipEventDestroy(h->ev_t0);
     if (h->ev_ctl) (void)hipEventDestroy(h->ev_ctl);
@@ -835,7 +835,9 @@ extern "C" int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t 
 // own row range, on a synchronised stream; epnn_memcpy_d2h / _h2d move rows).  Everything else is computed by every
 // process, so all of them end with all the charges.  world = 1 switches the partition off.
 extern "C" int epnn_set_partition(epnn_handle *h, int rank, int world, epnn_exchange_fn exchange, void *ctx) {
-    if (!h || world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) EPNN_FAIL("epnn_set_partition: bad argument");
+    if (!h || world < 1 || rank < 0 || rank >= world) EPNN_FAIL("epnn_set_partition: bad argument");
+    if (world > 1 && !exchange && !(h->comm && h->comm_world == world && h->comm_rank == rank))
+        EPNN_FAIL("epnn_set_partition: world %d needs an exchange function or a communicator of that size (epnn_comm_init) with this rank", world);
     if (h->pending.active && finish_forward(h)) return 1;
     h->part_rank = rank;
     h->part_world = world;
@@ -1031,6 +1033,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
+    else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
@@ -1485,13 +1488,13 @@ extern "C" int epnn_comm_unique_id(char *out128) {
 extern "C" int epnn_comm_init(epnn_handle *h, const char *id128, int rank, int world) {
     if (!h || !id128 || world < 1 || rank < 0 || rank >= world) EPNN_FAIL("epnn_comm_init: bad argument");
     HIPCHK(hipSetDevice(h->device));
-    TrainState *ts = train_state(h);
-    if (ts->comm) { (void)ncclCommDestroy(ts->comm); ts->comm = nullptr; }
+    if (h->pending.active && finish_forward(h)) return 1;
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
     ncclUniqueId id;
     memcpy(&id, id128, 128);
-    ncclResult_t rc = ncclCommInitRank(&ts->comm, world, id, rank);
+    ncclResult_t rc = ncclCommInitRank(&h->comm, world, id, rank);
     if (rc != ncclSuccess) EPNN_FAIL("ncclCommInitRank failed: %s", ncclGetErrorString(rc));
-    ts->world = world;
-    ts->rank = rank;
+    h->comm_world = world;
+    h->comm_rank = rank;
     return 0;
 }

@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "../../include/epnn.h"
 #include "epnn_common.h"
 
@@ -135,6 +137,11 @@ struct epnn_handle {
     int part_row_lo = 0, part_row_hi = 0;
     epnn_exchange_fn part_exchange = nullptr;
     void *part_ctx = nullptr;
+    std::vector<int> part_lo, part_hi;       // every process's row range (the plan is the same everywhere)
+    int opt_part_collective = 0;             // developer switch: run the partition's RCCL exchange even at world size 1
+    // RCCL communicator (epnn_comm_init): gradient all-reduce of the train step, row exchange of a partitioned system
+    ncclComm_t comm = nullptr;
+    int comm_world = 1, comm_rank = 0;
     int l_natiles = 0, l_nstasks = 0, l_maxchunk = 0;
     // options / stats
     int opt_profile = 0, opt_force_path = 0;

@@ -729,6 +729,8 @@ static int large_plan(epnn_handle *h) {
     int gidx = 0;
     h->part_row_lo = P.A;
     h->part_row_hi = 0;
+    h->part_lo.assign(h->part_world, P.A);
+    h->part_hi.assign(h->part_world, 0);
     for (int b : P.large_list) {
         const int a0 = P.offsets[b], n = P.offsets[b + 1] - a0;
         const int first_tile = (int)lp.atiles.size();
@@ -746,6 +748,12 @@ static int large_plan(epnn_handle *h) {
         for (int i0 = 0; i0 < n; i0 += 32) lp.atiles.push_back(make_int4(a0 + i0, std::min(32, n - i0), b, nchunk));
         lp.maxchunk = std::max(lp.maxchunk, nchunk);
         for (int tg = 0; tg < ntile; tg += 4, ++gidx) {
+            {   // owner of this tile group (same formula on every process)
+                int r = 0;
+                while (r + 1 < h->part_world && gidx >= (int)((long long)total_groups * (r + 1) / h->part_world)) ++r;
+                h->part_lo[r] = std::min(h->part_lo[r], a0 + tg * 32);
+                h->part_hi[r] = std::max(h->part_hi[r], a0 + std::min(n, (tg + 4) * 32));
+            }
             if (gidx < g_own0 || gidx >= g_own1) continue;
             h->part_row_lo = std::min(h->part_row_lo, a0 + tg * 32);
             h->part_row_hi = std::max(h->part_row_hi, a0 + std::min(n, (tg + 4) * 32));
@@ -757,6 +765,8 @@ static int large_plan(epnn_handle *h) {
         }
     }
     if (h->part_row_hi < h->part_row_lo) h->part_row_lo = h->part_row_hi = 0;        // no group of its own
+    for (int r = 0; r < h->part_world; ++r)
+        if (h->part_hi[r] < h->part_lo[r]) h->part_lo[r] = h->part_hi[r] = 0;
     h->l_natiles = (int)lp.atiles.size();
     h->l_nstasks = (int)lp.stasks.size();
     h->l_maxchunk = lp.maxchunk;
@@ -841,7 +851,8 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     // Launch sequence (the single-process case): proj(0) | per GNN step: sweep + correction tiles, tail (reduce, update,
     // next projections) | per EPN step: pair tiles, tail (charge update, next projections).  With a partition the other
     // processes' rows of S arrive between the reduction and the update, so those stay separate launches.
-    const bool split = h->part_world > 1 || !h->opt_large_fused;
+    const bool collective = h->part_world > 1 || h->opt_part_collective;
+    const bool split = collective || !h->opt_large_fused;
     const int Tg = run_gnn ? L.T : 0, Te = run_epn ? L.T : 0;
     const unsigned gTile = (unsigned)L.natiles;
     auto next_after_gnn = [&](int t) {
@@ -858,14 +869,30 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
                 hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2, h->widx.msg[t], 0);
             hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
             hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
-            if (h->part_world > 1) {
-                // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms): the caller's
-                // exchange fills them in; everything after this point is computed by every process for every atom
+            if (collective) {
+                // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms); everything
+                // after this point is computed by every process for every atom
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(st));
-                if (!h->part_exchange) EPNN_FAIL("forward: a partition is set but no exchange function");
-                if (h->part_exchange(h->part_ctx, h->l_sfin.as<float>(), 32, P.A, h->part_row_lo, h->part_row_hi))
-                    EPNN_FAIL("forward: the partition's exchange function reported an error");
+                if (h->part_exchange) {                       // the caller's exchange (host-staged: gloo tests, no communicator)
+                    HIPCHK(hipStreamSynchronize(st));
+                    if (h->part_exchange(h->part_ctx, h->l_sfin.as<float>(), 32, P.A, h->part_row_lo, h->part_row_hi))
+                        EPNN_FAIL("forward: the partition's exchange function reported an error");
+                } else {
+                    // all-gather of unequal row ranges on the handle's stream: every process broadcasts its own rows in
+                    // place, grouped into one RCCL operation (xGMI is point to point: `world` concurrent broadcasts use every
+                    // link at once); no host synchronisation, the update kernel simply follows on the stream
+                    if (!h->comm || h->comm_world != h->part_world) EPNN_FAIL("forward: a partition is set but neither an exchange function nor a communicator");
+                    ncclResult_t rc = ncclGroupStart();
+                    for (int r = 0; r < h->part_world && rc == ncclSuccess; ++r) {
+                        const size_t cnt = (size_t)(h->part_hi[r] - h->part_lo[r]) * 32;
+                        if (cnt == 0) continue;
+                        float *rows = h->l_sfin.as<float>() + (size_t)h->part_lo[r] * 32;
+                        rc = ncclBroadcast(rows, rows, cnt, ncclFloat, r, h->comm, st);
+                    }
+                    const ncclResult_t rc2 = ncclGroupEnd();
+                    if (rc != ncclSuccess || rc2 != ncclSuccess)
+                        EPNN_FAIL("forward: RCCL row exchange failed: %s", ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
+                }
             }
             hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk, h->l_sfin.as<float>());
             const LgNext X = next_after_gnn(t);

@@ -317,7 +317,6 @@ __global__ __launch_bounds__(256) void k_t_adam(float *theta, const float *grad,
 }
 
 // ================================================================================================ host side
-#include <rccl/rccl.h>
 
 struct TrainState {
     bool ready = false;
@@ -327,8 +326,6 @@ struct TrainState {
     long step = 0;
     float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     bool dev_newer = false;                      // device masters are ahead of the host copies
-    ncclComm_t comm = nullptr;
-    int world = 1, rank = 0;
     // the ~340 launches of one forward + backward, captured once per (B, N, buffer set) and replayed as one hipGraph
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -683,8 +680,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
 
 static int train_apply(epnn_handle *h) {
     TrainState *ts = train_state(h);
-    if (ts->comm && ts->world > 1) {
-        ncclResult_t rc = ncclAllReduce(ts->grad.p, ts->grad.p, (size_t)ts->P, ncclFloat, ncclSum, ts->comm, h->stream);
+    if (h->comm && h->comm_world > 1) {
+        ncclResult_t rc = ncclAllReduce(ts->grad.p, ts->grad.p, (size_t)ts->P, ncclFloat, ncclSum, h->comm, h->stream);
         if (rc != ncclSuccess) EPNN_FAIL("ncclAllReduce failed: %s", ncclGetErrorString(rc));
     }
     ts->step += 1;

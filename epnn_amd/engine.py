@@ -270,10 +270,10 @@ class Engine:
     def set_partition(self, rank, world, exchange=None):
         """One large system on `world` processes: this engine computes the all-pairs sums of its own
         rows of atoms and `exchange(d_rows_ptr, row_len, n_rows, row_lo, row_hi) -> None` completes the others' after
-        every GNN step (shard.make_row_exchange builds one on torch.distributed).  world = 1 switches it off."""
-        if world > 1:
-            if exchange is None:
-                raise EpnnError("set_partition: an exchange function is needed for world > 1")
+        every GNN step (shard.make_row_exchange builds one on torch.distributed).  With exchange=None and world > 1 the
+        engine's RCCL communicator (comm_init with the same rank / world) exchanges the rows on the engine's stream -- the
+        multi-GPU form, no host synchronisation inside the forward.  world = 1 switches the partition off."""
+        if world > 1 and exchange is not None:
 
             def _cb(ctx, d_rows, row_len, n_rows, row_lo, row_hi):
                 try:

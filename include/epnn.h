@@ -87,7 +87,10 @@ int epnn_forward_xyz_end(epnn_handle *h, float *q_out);
  * GNN step the library calls `exchange(ctx, d_rows, row_len, n_rows, row_lo, row_hi)`: d_rows is a device array
  * [n_rows][row_len] float of which this process has filled rows row_lo..row_hi-1; the function must fill in the rows the
  * other processes own (an all-gather; epnn_memcpy_d2h / epnn_memcpy_h2d move rows) and return 0.  Molecules of at most 32
- * atoms are not partitioned.  Results are bit-identical to the unpartitioned run. */
+ * atoms are not partitioned.  Results are bit-identical to the unpartitioned run.
+ * With exchange == NULL the handle's RCCL communicator (epnn_comm_init, same world size and rank) does it: every process
+ * broadcasts its own rows in place, all of them grouped into one RCCL operation on the handle's stream -- no host
+ * synchronisation inside the forward (one GPU per process; this is the multi-GPU form, the callback is the portable one). */
 typedef int (*epnn_exchange_fn)(void *ctx, float *d_rows, int row_len, int n_rows, int row_lo, int row_hi);
 int epnn_set_partition(epnn_handle *h, int rank, int world, epnn_exchange_fn exchange, void *ctx);
 /* Same with device-resident xyz/x/Q/q_out (offsets stay on the host); asynchronous. */
@@ -131,7 +134,8 @@ int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, co
 int epnn_get_gradients(epnn_handle *h, float *out, int64_t count);
 int epnn_set_gradients(epnn_handle *h, const float *in, int64_t count);
 int epnn_train_apply(epnn_handle *h);
-/* RCCL communicator (one rank per GPU): the gradient is summed with ONE ncclAllReduce of the flat vector. */
+/* RCCL communicator (one rank per GPU): the gradient is summed with ONE ncclAllReduce of the flat vector; the same
+ * communicator carries the row exchange of a partitioned large system (epnn_set_partition with exchange == NULL). */
 int epnn_comm_unique_id(char *out128);
 int epnn_comm_init(epnn_handle *h, const char *id128, int rank, int world);
 

@@ -579,3 +579,73 @@ def test_box_subbox_4096_vs_oracle(gpu_engine_factory, box100k):
     print(f"sub-box 4096 atoms: |dq| {err:.3e}; |q| up to {np.abs(ref).max():.3f}; sum q {q.sum(dtype=np.float64):.6f}")
     assert err <= TOL
     assert abs(float(q.sum(dtype=np.float64)) - 1.0) < 1e-4
+
+
+def test_partition_rccl_exchange_in_stream_world1(gpu_engine_factory):
+    """The row exchange of a partitioned system through the handle's RCCL communicator (epnn_set_partition with no
+    callback): grouped in-place broadcasts on the handle's stream, no host synchronisation.  One GPU here, so a
+    world-size-1 communicator with the developer switch that runs the collective anyway: charges bit-identical to the
+    unpartitioned forward (separate launches and fused tail are the same arithmetic), also for a batch that mixes tiled
+    systems with small molecules."""
+    from epnn_amd import synth
+    from epnn_amd.engine import Engine
+    w = random_weights(9, 3, seed=5, scale=0.35)
+    offs, bxyz, bx, bQ, bN = synth.box_system(n_atoms=700, seed=3)
+    so, sxyz, sx, sQ, sN = synth.qm9_like_batch(B=5, seed=1)
+    off = np.concatenate([[0, 700], 700 + so[1:]]).astype(np.int32)
+    xyz, x, Q = np.concatenate([bxyz, sxyz]), np.concatenate([bx, sx]), np.concatenate([bQ, sQ]).astype(np.float32)
+    eng = gpu_engine_factory(nx=9, T=3)
+    eng.set_weights(w)
+    whole = eng.forward_xyz(off, xyz, x, Q, 700)
+    eng.comm_init(Engine.comm_unique_id(), 0, 1)
+    eng.set_option("part_collective", 1)
+    coll = eng.forward_xyz(off, xyz, x, Q, 700)
+    assert np.array_equal(coll, whole)
+    eng.set_option("part_collective", 0)
+    eng.set_option("large_fused", 0)                      # one kernel per stage, no collective
+    assert np.array_equal(eng.forward_xyz(off, xyz, x, Q, 700), whole)
+    with pytest.raises(Exception, match="exchange function or a communicator"):
+        eng.set_partition(0, 2)                           # world 2 with a world-1 communicator and no callback
+
+
+_RCCL_PART_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+from epnn_amd import synth
+from epnn_amd.engine import Engine
+from epnn_amd.rendezvous import Rendezvous
+from conftest import random_weights
+r = Rendezvous()
+eng = Engine(nx=9, T=3, device=r.rank)
+eng.set_weights(random_weights(9, 3, seed=5, scale=0.35))
+off, xyz, x, Q, N = synth.box_system(n_atoms=3000, seed=3)
+whole = eng.forward_xyz(off, xyz, x, Q, N)
+eng.comm_init(r.broadcast(Engine.comm_unique_id() if r.rank == 0 else None, name="id"), r.rank, r.world)
+eng.set_partition(r.rank, r.world)                        # no callback: RCCL on the engine's stream
+part = eng.forward_xyz(off, xyz, x, Q, N)
+assert np.array_equal(part, whole), float(np.abs(part - whole).max())
+same = r.all_gather(part.tobytes(), name="q")
+assert all(s == same[0] for s in same)
+r.barrier(); r.close(); eng.close()
+if r.rank == 0:
+    print("RCCL_PARTITION_OK", r.world)
+'''
+
+
+def test_partition_rccl_two_gpus(tmp_path):
+    """Two processes, one GPU each, the row exchange over RCCL (xGMI) inside the forward: bit-identical to the whole-system
+    run on every rank.  Needs two devices (the driver's multi-GPU node); skipped on a one-GPU box, where RCCL cannot join
+    two ranks of one device."""
+    import subprocess, sys
+    from conftest import ROOT
+    from epnn_amd import _lib
+    if _lib.load().epnn_device_count() < 2:
+        pytest.skip("one GPU visible: a multi-rank RCCL communicator needs one device per rank")
+    script = tmp_path / "w.py"
+    script.write_text(_RCCL_PART_WORKER)
+    drv = ("import sys; sys.path.insert(0, sys.argv[1]); from epnn_amd.rendezvous import launch_ranks; "
+           "sys.exit(launch_ranks(sys.argv[2], sys.argv[1:2], 2))")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", drv, ROOT, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_PARTITION_OK 2" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

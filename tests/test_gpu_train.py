@@ -428,3 +428,51 @@ def test_loss_curve_on_the_recorded_split_matches_oracle(gpu_engine_factory, tra
           f"(step {int(rel.argmax())}); sum of losses {losses.sum():.5f} vs {ref.sum():.5f}")
     assert rel[0] < 1e-4                                             # step 0: same weights, forward parity
     assert rel.max() < 2e-2 and abs(losses.sum() - ref.sum()) < 2e-3 * ref.sum()
+
+
+_RCCL_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+from epnn_amd.engine import Engine
+from epnn_amd.rendezvous import Rendezvous
+from conftest import random_weights
+from test_train_oracle import _tiny_batch
+from oracle import epnn_oracle_train as ot
+r = Rendezvous()
+nx, T, N = 9, 2, 10
+w = random_weights(nx, T, seed=4, scale=0.5)
+h, e, x, q, mask, y = _tiny_batch(nx, N, [9, 7], seed=3)          # molecule `rank` is this rank's share of the step
+eng = Engine(nx=nx, T=T, device=r.rank)
+eng.set_weights(w); eng.train_init()
+eng.comm_init(r.broadcast(Engine.comm_unique_id() if r.rank == 0 else None, name="id"), r.rank, r.world)
+k = r.rank
+eng.train_step_dense(h[k:k+1], e[k:k+1], x[k:k+1], q[k:k+1], mask[k:k+1], y[k:k+1], apply=True)   # all-reduce + Adam on the device
+g = eng.get_gradients().astype(np.float64)                        # the summed gradient (the all-reduce is in place)
+ref = ot.flatten(ot.loss_and_grads(h, e, x, q, mask, y, w)[2])    # oracle gradient of BOTH molecules = sum of the ranks' gradients
+assert np.abs(g - ref).max() <= 2e-4 * np.abs(ref).max(), float(np.abs(g - ref).max() / np.abs(ref).max())
+wts = r.all_gather(ot.flatten(eng.get_weights()).tobytes(), name="w")
+assert all(b == wts[0] for b in wts)                              # every rank took the same Adam step
+r.barrier(); r.close(); eng.close()
+if r.rank == 0:
+    print("RCCL_DP_OK", r.world)
+'''
+
+
+def test_rccl_gradient_allreduce_two_gpus(tmp_path):
+    """Data-parallel train step on two GPUs (BASELINE.json configs[2] at world size 2): every rank runs forward + backward
+    of its own molecule, ONE ncclAllReduce of the flat gradient on the device, the same Adam step everywhere.  The
+    all-reduced gradient equals the float64 oracle's gradient of the two-molecule batch.  Needs two devices; skipped on a
+    one-GPU box (RCCL cannot join two ranks of one device; train.py's host-staged sum covers the rest of the path there)."""
+    import subprocess, sys
+    from conftest import ROOT
+    from epnn_amd import _lib
+    if _lib.load().epnn_device_count() < 2:
+        pytest.skip("one GPU visible: a multi-rank RCCL communicator needs one device per rank")
+    script = tmp_path / "w.py"
+    script.write_text(_RCCL_DP_WORKER)
+    drv = ("import sys; sys.path.insert(0, sys.argv[1]); from epnn_amd.rendezvous import launch_ranks; "
+           "sys.exit(launch_ranks(sys.argv[2], sys.argv[1:2], 2))")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", drv, ROOT, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_DP_OK 2" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

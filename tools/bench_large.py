@@ -2,7 +2,9 @@
 """Large-system timings (BASELINE.json configs[3] and [4]): the 2220-atom protein and a synthetic box.
     python tools/bench_large.py protein | box100k | box<N>k [steps]
 One system on several GPUs (row-block partition of the all-pairs sweep):
+    python tools/bench_large.py box100k 5 --gpus N       one process per GPU, row exchange over RCCL on the engines' streams
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_large.py box100k
+                                                          (ranks sharing a GPU: the exchange is host-staged over gloo)
 """
 import os, sys, time
 import numpy as np
@@ -12,23 +14,38 @@ from epnn_amd import checkpoint, synth, charge_gn
 from epnn_amd.engine import Engine
 
 def main():
-    what = sys.argv[1] if len(sys.argv) > 1 else "protein"
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    argv = [a for a in sys.argv[1:] if not a.startswith("--gpus")]
+    gpus = next((int(a.split("=")[1]) if "=" in a else int(sys.argv[sys.argv.index(a) + 1]) for a in sys.argv[1:] if a.startswith("--gpus")), 0)
+    if gpus:
+        argv = [a for a in argv if a != str(gpus)] if "--gpus" in sys.argv[1:] else argv
+    if gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from epnn_amd.rendezvous import launch_ranks
+        sys.exit(launch_ranks(__file__, sys.argv[1:], gpus))
+    what = argv[0] if len(argv) > 0 else "protein"
+    steps = int(argv[1]) if len(argv) > 1 else 5
     w = checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights"))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    device = 0
+    device, how = 0, ""
+    from epnn_amd import _lib
+    ndev = _lib.load().epnn_device_count()
+    rccl = world > 1 and ndev >= world
     if world > 1:
-        import torch
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
+    eng = Engine(nx=9, T=5, device=device)
+    eng.set_weights(w)
+    if rccl:
+        from epnn_amd.rendezvous import Rendezvous
+        rdzv = Rendezvous(rank, world)
+        eng.comm_init(rdzv.broadcast(Engine.comm_unique_id() if rank == 0 else None, name="id"), rank, world)
+        eng.set_partition(rank, world)                                    # rows exchanged over RCCL, in stream
+        how = "RCCL in stream"
+    elif world > 1:
         import torch.distributed as dist
         from epnn_amd import shard
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ndev = torch.cuda.device_count()
-        device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
-        dist.init_process_group("gloo", rank=rank, world_size=world)      # the exchange is host-staged
-    eng = Engine(nx=9, T=5, device=device)
-    eng.set_weights(w)
-    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # ranks share a device: host-staged exchange
         eng.set_partition(rank, world, shard.make_row_exchange(eng, dist, rank, world))
+        how = "host-staged over gloo"
     if what == "protein":
         xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(ROOT, "tests/golden/protein/6qlp_capped.xyz"), 9)
         offsets = np.array([0, len(x)], dtype=np.int32)
@@ -55,7 +72,7 @@ def main():
     q = dq.download((A,))
     flops = synth.algorithmic_flops([A], int(stats[0]))
     if rank == 0:
-      print((f"[{world} processes, rows of atoms partitioned] " if world > 1 else "") + f"{what}: {A} atoms, {stats[0]} near pairs; {dt*1e3:.3f} ms/forward wall, device stages front/fused/tiled/total ms = {np.round(st,3)}; "
+      print((f"[{world} processes, rows of atoms partitioned, exchange {how}] " if world > 1 else "") + f"{what}: {A} atoms, {stats[0]} near pairs; {dt*1e3:.3f} ms/forward wall, device stages front/fused/tiled/total ms = {np.round(st,3)}; "
           f"{A/dt:.3e} atoms/s; algorithmic {flops/1e9:.1f} Gflop -> {flops/(st[3]*1e-3)/1e12:.1f} TFLOP/s; sum q = {q.sum(dtype=np.float64):.6f}", flush=True)
     eng.close()
 
