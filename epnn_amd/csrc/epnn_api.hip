@@ -65,6 +65,9 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     h->cfg = *cfg;
     h->device = device;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t0));
     HIPCHK(hipEventCreateWithFlags(&h->ev_ctl, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t1));
@@ -135,6 +138,9 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     h->pin_out.release();
     (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->stream2);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;

@@ -91,6 +91,8 @@ struct epnn_handle {
     epnn_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;    // side stream of the tiled path (correction tiles beside the sweep), forked / joined by events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)
     int ev_next = 0;                  // forwards recorded since the option was set

@@ -205,16 +205,7 @@ __global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int
 // co-resident wavefronts' VALU work (two adds and two max per feature and pair) overlaps this MFMA shape better than
 // 32x32x2 (tools/micro/mfma_covalu.hip), which is what bounds the sweep.  W2 / b2 come from the fused kernel's pack.
 #define EPNN_LG_JC 64
-template <int MODE>
-__device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk);
-// Workgroups [0, nstasks) sweep; workgroups beyond them are the near-pair correction tiles of the same step (k_lg_pairs<0>'s
-// body): both need only this step's P and R, so they share a launch instead of waiting for each other.
-__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2off, PairMlpPack Mpair, int with_pairs) {
-    __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
-    if (with_pairs && (int)blockIdx.x >= L.nstasks) {
-        lg_pairs_body<0>(L, Mpair, (int)blockIdx.x - L.nstasks);
-        return;
-    }
+__device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, int b2off, float *Rs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
     const int4 tk = L.stasks[blockIdx.x];            // first atile, #atiles, j_lo, j_hi (global atom indices)
     const int chunk = L.stask_chunk[blockIdx.x];
@@ -269,6 +260,25 @@ __global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2
         if (n16 < tl.y) w16_st(dst + (size_t)(tl.x + n16) * 32 + 16 * rb + fo, S0[rb]);
         if (16 + n16 < tl.y) w16_st(dst + (size_t)(tl.x + 16 + n16) * 32 + 16 * rb + fo, S1[rb]);
     }
+}
+template <int MODE>
+__device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk);
+// The sweep alone: ~110 registers, four wavefronts per SIMD -- what a large system's thousands of workgroups need.
+__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2off) {
+    __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
+    lg_sweep_body(L, w2off, b2off, Rs);
+}
+// The sweep plus, as extra workgroups, the near-pair correction tiles of the same step (both need only this step's P and
+// R).  The pair tiles' registers halve the kernel's occupancy (179 registers: two wavefronts per SIMD), so this form is for
+// systems whose sweep has at most two workgroups per CU anyway (the 2220-atom protein: 504), where it saves a launch per
+// step; larger systems run the two kernels side by side on two streams.
+__global__ __launch_bounds__(256) void k_lg_sweep_pairs(LargeArgs L, int w2off, int b2off, PairMlpPack Mpair) {
+    __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
+    if ((int)blockIdx.x >= L.nstasks) {
+        lg_pairs_body<0>(L, Mpair, (int)blockIdx.x - L.nstasks);
+        return;
+    }
+    lg_sweep_body(L, w2off, b2off, Rs);
 }
 
 // ------------------------------------------------------------------------------------------------ pair tiles
@@ -866,7 +876,7 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     for (int t = 0; t < Tg; ++t) {
         if (split) {
             if (L.nstasks > 0)
-                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2, h->widx.msg[t], 0);
+                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
             hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
             hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
             if (collective) {
@@ -898,7 +908,19 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
             const LgNext X = next_after_gnn(t);
             if (X.run) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, X.with_zp);
         } else {
-            hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks + gPT), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2, h->widx.msg[t], 1);
+            if (L.nstasks > 0 && L.nstasks <= 512) {
+                hipLaunchKernelGGL(k_lg_sweep_pairs, dim3((unsigned)L.nstasks + gPT), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2, h->widx.msg[t]);
+                hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(256), 0, st, L, h->widx.upd[t], next_after_gnn(t));
+                continue;
+            }
+            // correction tiles beside the sweep (both need only this step's P and R): fork to the second stream, join before the tail
+            HIPCHK(hipEventRecord(h->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+            hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, h->stream2, L, h->widx.msg[t]);
+            HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+            if (L.nstasks > 0)
+                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
+            HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
             hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(256), 0, st, L, h->widx.upd[t], next_after_gnn(t));
         }
     }

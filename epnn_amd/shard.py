@@ -70,13 +70,29 @@ def forward_sharded(compute, offsets, xyz, x, Q, N, rank=0, world=1, dist=None):
 # --------------------------------------------------------------------------------------------- one large system
 def make_row_exchange(engine, dist, rank, world):
     """Exchange function for Engine.set_partition: all-gather of the rows of S every process owns, through
-    torch.distributed (host-staged, so it runs on gloo and on nccl alike; the rows of one GNN step of a 100 000-atom
-    system are 12.8 MB).  Every process calls it at the same points of the forward (after each GNN step)."""
+    torch.distributed on the host (gloo; the rows of one GNN step of a 100 000-atom system are 12.8 MB).  This is the
+    portable form (ranks sharing a GPU, CPU-side tests); with one GPU per process leave the callback out and give the
+    engine a communicator (Engine.comm_init): the rows then travel over RCCL on the engine's stream.  Every process calls it
+    at the same points of the forward (after each GNN step).
+
+    A failure on one rank must not leave the others waiting in the collective: every call first all-gathers a status word
+    (local preparation done / failed); if any rank failed, ALL ranks raise, so the partitioned forward aborts on every
+    process together (each then exits non-zero) instead of hanging."""
     import torch
     known = {}                                   # (n_rows, row_lo, row_hi) -> every process's row range (fixed per plan)
 
     def exchange(d_rows, row_len, n_rows, row_lo, row_hi):
-        mine = engine.copy_rows_to_host(d_rows, row_len, row_lo, row_hi)
+        mine, err = None, None
+        try:
+            mine = engine.copy_rows_to_host(d_rows, row_len, row_lo, row_hi)
+        except Exception as exc:                 # noqa: BLE001 -- reported to every rank below
+            err = exc
+        status = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+        every = [torch.zeros_like(status) for _ in range(world)]
+        dist.all_gather(every, status)
+        bad = [r for r, t in enumerate(every) if int(t.item()) != 0]
+        if bad:
+            raise RuntimeError(f"row exchange aborted on every rank: rank(s) {bad} failed" + (f" ({err})" if err else ""))
         key = (int(n_rows), int(row_lo), int(row_hi))
         if key not in known:
             ranges = [None] * world
@@ -87,14 +103,11 @@ def make_row_exchange(engine, dist, rank, world):
         width = max(hi - lo for lo, hi in ranges)
         send = torch.zeros((max(width, 1), row_len), dtype=torch.float32)
         send[:mine.shape[0]] = torch.from_numpy(mine)
-        on_gpu = dist.get_backend() == "nccl"
-        if on_gpu:
-            send = send.cuda()
         recv = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(recv, send)
         for r, (lo, hi) in enumerate(ranges):
             if r != rank and hi > lo:
-                engine.copy_rows_to_device(d_rows, row_len, lo, recv[r][:hi - lo].cpu().numpy())
+                engine.copy_rows_to_device(d_rows, row_len, lo, recv[r][:hi - lo].numpy())
 
     return exchange
 

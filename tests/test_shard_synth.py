@@ -136,3 +136,59 @@ def test_data_parallel_gradient_sum_world2_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "DP_OK" in out.stdout
+
+
+_EXCH_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch.distributed as dist
+from epnn_amd import shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+class FakeEngine:                                  # host arrays stand in for the device rows
+    def __init__(self, rows, fail=False):
+        self.rows, self.fail = rows, fail
+    def copy_rows_to_host(self, d_ptr, row_len, lo, hi):
+        if self.fail:
+            raise OSError("device copy failed")
+        return self.rows[lo:hi].copy()
+    def copy_rows_to_device(self, d_ptr, row_len, lo, rows):
+        self.rows[lo:lo + len(rows)] = rows
+
+n, L = 10, 4
+full = np.arange(n * L, dtype=np.float32).reshape(n, L)
+lo, hi = (0, 6) if rank == 0 else (6, 10)          # unequal ranges, like tile groups
+rows = np.zeros_like(full); rows[lo:hi] = full[lo:hi]
+ex = shard.make_row_exchange(FakeEngine(rows), dist, rank, world)
+ex(0, L, n, lo, hi)
+assert np.array_equal(rows, full)
+ex(0, L, n, lo, hi)                                # second call: cached ranges
+# a failure on ONE rank aborts the exchange on EVERY rank (nobody is left waiting in the collective)
+bad = shard.make_row_exchange(FakeEngine(rows, fail=(rank == 1)), dist, rank, world)
+t0 = time.time()
+try:
+    bad(0, L, n, lo, hi)
+    raise SystemExit("exchange did not fail")
+except RuntimeError as exc:
+    assert "rank(s) [1] failed" in str(exc), str(exc)
+assert time.time() - t0 < 30
+dist.barrier()
+if rank == 0:
+    print("EXCHANGE_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_row_exchange_all_gathers_and_fails_together_world2_gloo(tmp_path):
+    """shard.make_row_exchange (the host-staged exchange of a partitioned large system): unequal row ranges are gathered
+    on every rank; a failure on one rank raises on all of them instead of leaving the others in the collective."""
+    script = tmp_path / "ex_worker.py"
+    script.write_text(_EXCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29521", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29521", str(script), ROOT],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "EXCHANGE_OK" in out.stdout
