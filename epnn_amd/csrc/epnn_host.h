@@ -83,6 +83,7 @@ struct Plan {                 // what the host derives from `offsets`
     std::vector<int> small_order;   // molecules on the fused path, largest first
     std::vector<int> large_list;    // molecules on the tiled path
     int small_nmax = 0;
+    int small_nbig = 0;             // how many of small_order (sorted largest first) have more than 16 atoms
     int pair_slots = 0;             // sum of n(n-1)/2 over the small molecules (capacity of the in-kernel front-end)
     bool valid = false;
 };
@@ -126,6 +127,8 @@ struct epnn_handle {
     int opt_train_fused = 1;          // training: row-fused pair-MLP kernels (0: the layer-by-layer kernels)
     int opt_train_graph = 1;          // training: replay the step's launch sequence as a hipGraph (0: launch kernel by kernel)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
+    int opt_wave_split = 1;           // fused kernel with its own front-end: molecules of <= 16 atoms run as a one-column-block variant at
+                                      // three wavefronts per SIMD, beside the others, on the second stream
     int opt_large_fused = 1;          // tiled path: one launch between two sweeps / pair passes (0: one kernel per stage)
     int opt_wave_prio = 18;           // fused kernel: molecules with >= this many atoms run at raised wave priority (0: off);
                                       // measured on the QM9-sized batch: 211 M atoms/s with 18 or 20, 206-208 M with 0 / 25 / 28

@@ -62,6 +62,7 @@ struct WaveArgs {
     const float *etab;     // [tab_n][16] B^T e(D) on the grid D = i / tab_inv_h, i = 0 .. tab_n - 1 (last point = cutoff)
     double tab_inv_h, dsafe;
     int tab_n;
+    int total_waves;       // wavefronts of this forward over all its launches of this kernel (the last one to finish hands off)
     int prio_n;            // molecules with at least this many atoms run at raised wave priority (0: off), see k_wave_forward
     int handoff;           // in-kernel front-end and nothing else runs: the last wave reports to host_status and re-zeroes `status`
     int *host_status;      // pinned host ints [0] status bits [1] near pairs of the batch: written by the last wave to finish
@@ -166,8 +167,10 @@ __device__ __forceinline__ void w16_feed(const f32x4 (&a)[2], float (&in)[8]) {
     for (int s = 0; s < 8; ++s) in[s] = a[s >> 2][s & 3];
 }
 
-template <bool GNN, bool EPN, bool FRONT>
-__global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveArgs A, WaveIndex X) {
+// TWOB = false: the variant for molecules of at most 16 atoms -- one column block, so every register of the second block is
+// gone (~150 instead of 233) and three wavefronts fit a SIMD.  The same code: `two` is then false at compile time.
+template <bool GNN, bool EPN, bool FRONT, bool TWOB = true>
+__global__ __launch_bounds__(64, TWOB ? EPNN_WAVES_PER_SIMD : 3) void k_wave_forward(WaveArgs A, WaveIndex X) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, q = lane >> 4, n16 = lane & 15;
     const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     // Column block 0 holds atoms 0..15.  Block 1 holds the m = n - 16 atoms beyond them, C = 16 / m COPIES of each (column
     // n16 = atom 16 + n16 % m, copy n16 / m): every per-atom chain computes all 16 columns anyway, so the copies come for
     // free, and the pair sweep gives each copy a different partner -- block 1 is done after (n + 1) / C tiles instead of n + 1.
-    const bool two = n > 16;
+    const bool two = TWOB && n > 16;
     const int m1 = two ? n - 16 : 16, C1 = 16 / m1;
     const int copy1 = n16 / m1;
     const int col1 = 16 + n16 % m1;
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         // the last wave to finish hands status + pair count to the host and re-zeroes the control words
         atomicAdd(A.status + 1, np);
         __threadfence();
-        if (atomicAdd(A.status + 2, 1) == (int)gridDim.x - 1) {
+        if (atomicAdd(A.status + 2, 1) == A.total_waves - 1) {
             __threadfence();
             const int st = atomicExch(A.status + 0, 0), cnt = atomicExch(A.status + 1, 0);
             atomicExch(A.status + 2, 0);
