@@ -127,8 +127,9 @@ struct epnn_handle {
     int opt_train_fused = 1;          // training: row-fused pair-MLP kernels (0: the layer-by-layer kernels)
     int opt_train_graph = 1;          // training: replay the step's launch sequence as a hipGraph (0: launch kernel by kernel)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
-    int opt_wave_split = 1;           // fused kernel with its own front-end: molecules of <= 16 atoms run as a one-column-block variant at
-                                      // three wavefronts per SIMD, beside the others, on the second stream
+    int opt_wave_split = 0;           // fused kernel with its own front-end: molecules of <= 16 atoms run as a one-column-block variant at
+                                      // three wavefronts per SIMD (168 registers, 13 KB LDS), beside the others, on the second stream.
+                                      // Measured SLOWER (196.6 vs 206.5 M atoms/s: 12 spilled registers, more G rows in HBM): off
     int opt_large_fused = 1;          // tiled path: one launch between two sweeps / pair passes (0: one kernel per stage)
     int opt_wave_prio = 18;           // fused kernel: molecules with >= this many atoms run at raised wave priority (0: off);
                                       // measured on the QM9-sized batch: 211 M atoms/s with 18 or 20, 206-208 M with 0 / 25 / 28
