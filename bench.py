@@ -215,7 +215,14 @@ def main():
                 dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                         device_id=torch.device("cuda", local_rank))       # RCCL on ROCm
                 sync_dev = torch.device("cuda", local_rank)
-            except Exception:
+                probe = torch.ones(1, device=sync_dev)
+                dist.all_reduce(probe)                                                    # the communicator really works (all
+                torch.cuda.synchronize()                                                  # ranks fail or succeed together)
+                assert int(probe.item()) == world
+            except Exception as exc:                                                      # noqa: BLE001
+                print(f"[bench rank {rank}] RCCL process group unavailable ({exc}); timing exchange over gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
                 sync_dev = torch.device("cpu")
         else:

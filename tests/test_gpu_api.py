@@ -178,6 +178,32 @@ def test_infer_entry_point(tmp_path):
     assert float(line.rsplit(" ", 1)[1]) <= 2e-6
 
 
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_on_this_box(tmp_path, launcher):
+    """`python bench.py --gpus 2` WITHOUT a launcher starts its two rank processes itself (fresh children; on a one-GPU box
+    they share the device and the timing exchange runs over gloo) and prints ONE valid JSON line with n_gpus = 2, the
+    per-rank rates and their sum; the torch.distributed.run form gives the same kind of line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "6", "--no-cpu-baseline", "--no-extras"]
+    if launcher == "self":
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29541"] + args
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["steps"] == 40 and o["unit"] == "atoms/s" and o["scaling"] == "weak" and o["dtype"] == "f32"
+    assert o["config"]["workload"] == "qm9_like_b1024_N29" and o["vs_baseline"] is None
+    per = o["ranks"]["atoms_per_s_per_rank"]
+    assert o["ranks"]["world_size"] == 2 and len(per) == 2 and o["ranks"]["timing_backend"] in ("gloo", "nccl")
+    assert 0.5 * sum(per) < o["value"] <= 1.001 * sum(per) and o["value"] > 2e7          # max-over-ranks time: value <= sum of the rates
+    assert 0 < o["roofline"]["frac"] < 1.3 and o["roofline"]["bound"] == "mfma"
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
