@@ -591,7 +591,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     const size_t o_pu = sz((size_t)T * BN * EPNN_TF_PU);
     if (ts->arena.ensure(need * 4)) return 1;
     const size_t lds_fwd = ((size_t)N * FS + (size_t)N * 49 + (size_t)D * 32 + 4 * (size_t)N * 33 + EPNN_TF_NG * 32 + 32 + 2 * (size_t)N) * 4;
-    const size_t lds_bwd = ((size_t)N * FS + (size_t)N * 49 + 8 * (size_t)N * 33 + 32 * 33 + 192 + N) * 4;
+    const size_t lds_bwd = ((size_t)N * FS + (size_t)N * 49 + 8 * (size_t)N * 33 + 32 * 33 + 192 + N + 336) * 4;
     if (!ts->fused_attr) {
         const int cap = 160 * 1024;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -627,8 +627,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->msg[t], hcur, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
-        hipLaunchKernelGGL(k_tf_pair_fwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A);
-        hipLaunchKernelGGL(k_tf_update_fwd, dim3(BN), dim3(64), 0, st, upd_args(t, hcur));
+        hipLaunchKernelGGL(k_tf_pair_fwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
         hcur = P(gs[t].hn);
     }
     const float *feats = hcur;
@@ -637,7 +636,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->pas[t], feats, qcur);
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.qn = P(es[t].qn);
-        hipLaunchKernelGGL(k_tf_pair_fwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A);
+        hipLaunchKernelGGL(k_tf_pair_fwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         qcur = P(es[t].qn);
     }
     HIPCHK(hipMemcpyAsync(d_pred, qcur, (size_t)BN * 4, hipMemcpyDeviceToDevice, st));
@@ -649,17 +648,16 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = T - 1; t >= 0; --t) {
         TfPair A = pair_args(ts->pas[t], feats, t ? P(es[t - 1].qn) : d_q0);
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.gq = gq; A.part = P(o_pp[t]); A.gacc = gfeat;
-        hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A);
+        hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, TfUpd{});
         hipLaunchKernelGGL(k_tb_atoms<1>, dim3(BN), dim3(128), 0, st, A);
     }
     // ================================================================ backward: GNN
     HIPCHK(hipMemcpyAsync(gh, gfeat, (size_t)BN * H * 4, hipMemcpyDeviceToDevice, st));
     for (int t = T - 1; t >= 0; --t) {
         const float *hin = t ? P(gs[t - 1].hn) : d_h0;
-        hipLaunchKernelGGL(k_tb_update_bwd, dim3(BN), dim3(64), 0, st, upd_args(t, hin));
         TfPair A = pair_args(ts->msg[t], hin, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.dU0 = P(o_dU0); A.part = P(o_pm[t]); A.gacc = gh;
-        hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A);
+        hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, upd_args(t, hin));     // update backward first
         hipLaunchKernelGGL(k_tb_atoms<0>, dim3(BN), dim3(128), 0, st, A);
     }
     // ================================================================ gradient = sum of the workgroups' partials

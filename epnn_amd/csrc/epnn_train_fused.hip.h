@@ -35,6 +35,18 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     float *gacc;                 // atoms kernel: pass network gfeat [BN][48] (+=), message network gh [BN][48] (=)
 };
 
+// ---------------------------------------------------------------------------------------------- update MLP arguments
+struct TfUpd {
+    const float *h, *M, *nm, *theta;          // h [BN][48] (input of the step), M [BN][32]
+    int oW0, ob0, oW1, ob1, oW2, ob2;
+    float *U0, *U1, *U2, *hn;                 // [BN][80], [BN][32], [BN][32], [BN][48] = update(...) * nm   (charge_gn.py:71-74)
+    const float *gh;                          // backward: gradient w.r.t. hn [BN][48]
+    float *dU0;                               // [BN][80]
+    float *part;                              // [BN][Pu], Pu = 80*32 + 32 + 32*32 + 32 + 32*48 + 48
+};
+#define EPNN_TF_PU (80 * 32 + 32 + 32 * 32 + 32 + 32 * 48 + 48)
+
+
 // Staging loops: `total` elements, element idx loaded by ld(idx) and placed by st(idx, value).  Four loads of a thread are
 // in flight before the first store (a plain loop would wait for every load in front of its LDS write: the loop trip
 // counts are run-time values, the compiler does not overlap the iterations).
@@ -57,8 +69,10 @@ __device__ __forceinline__ void tf_stage(int total, int tid, LD &&ld, ST &&st) {
 
 // ---------------------------------------------------------------------------------------------- forward, pair MLP
 // MODE 0: message network (out_dim 32, summed over ALL N partners); MODE 1: pass network (out_dim 1, both orders).
+// MODE 0 with U.theta set also runs the update MLP of its atom (charge_gn.py:71-74: it needs only the atom's own h and
+// summed message), which used to be a launch of its own per step.
 template <int MODE>
-__global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A) {
+__global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
     const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
     const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
@@ -160,10 +174,46 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A) {
             red[EPNN_TF_NG * 32 + tid] = s;
         }
         __syncthreads();
+        float *u0 = red, *u1 = red + 80, *u2 = red + 112;       // the group sums red[0 .. NG*32) are dead by now
+        const bool upd = U.theta != nullptr;
+        const float nm = upd ? U.nm[bi] : 0.f;
         if (tid < 32) {
             float mo = (float)N * A.theta[A.ob3 + tid];
             for (int k = 0; k < 32; ++k) mo = fmaf(red[EPNN_TF_NG * 32 + k], A.theta[A.oW3 + k * 32 + tid], mo);
             A.M[(size_t)bi * 32 + tid] = mo;
+            if (upd) {
+                const float v = mo * nm;
+                u0[48 + tid] = v;
+                U.U0[(size_t)bi * 80 + 48 + tid] = v;
+            }
+        } else if (upd && tid >= 64 && tid < 112) {
+            const int k = tid - 64;
+            const float v = U.h[(size_t)bi * 48 + k] * nm;
+            u0[k] = v;
+            U.U0[(size_t)bi * 80 + k] = v;
+        }
+        if (!upd) return;
+        __syncthreads();
+        if (tid < 32) {
+            float z = U.theta[U.ob0 + tid];
+            for (int k = 0; k < 80; ++k) z = fmaf(u0[k], U.theta[U.oW0 + k * 32 + tid], z);
+            z = fmaxf(z, 0.f);
+            u1[tid] = z;
+            U.U1[(size_t)bi * 32 + tid] = z;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float z = U.theta[U.ob1 + tid];
+            for (int k = 0; k < 32; ++k) z = fmaf(u1[k], U.theta[U.oW1 + k * 32 + tid], z);
+            z = fmaxf(z, 0.f);
+            u2[tid] = z;
+            U.U2[(size_t)bi * 32 + tid] = z;
+        }
+        __syncthreads();
+        if (tid < 48) {
+            float z = U.theta[U.ob2 + tid];
+            for (int k = 0; k < 32; ++k) z = fmaf(u2[k], U.theta[U.oW2 + k * 48 + tid], z);
+            U.hn[(size_t)bi * 48 + tid] = z * nm;
         }
     } else {
         float *fs = red;                      // [2][N]
@@ -183,8 +233,10 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A) {
 }
 
 // ---------------------------------------------------------------------------------------------- backward, pair MLP
+// MODE 0 with U.theta set first runs the update MLP's backward for its atom (it needs only the atom's own rows: gh, U0..U2)
+// and takes dM_i straight from LDS; the stand-alone k_tb_update_bwd is the same arithmetic.
 template <int MODE>
-__global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A) {
+__global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
     const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
     const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
@@ -200,6 +252,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A) {
     float *W2s = D2s + ND * N * 33;           // [32][33]
     float *vec = W2s + 32 * 33;               // dms [32] | vs [32] | s1 [2][32] | sb2 [32] | c2 / dw3 [32] | df [N]
     float *dms = vec, *vs = vec + 32, *s1 = vec + 64, *sb2 = vec + 128, *c2 = vec + 160, *dfs = vec + 192;
+    float *ub = dfs + N;                      // MODE 0, fused update backward: u0 [80] | u1 [32] | u2 [32] | dh [48] | du2 [32] | du1 [32] | dU0 [80]
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
     tf_stage(N * F, tid,
@@ -219,7 +272,50 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A) {
     }
     tf_stage(1024, tid, [&](int idx) { return A.theta[A.oW2 + idx]; }, [&](int idx, float v) { W2s[(idx >> 5) * 33 + (idx & 31)] = v; });
     if (MODE == 0) {
-        if (tid < 32) dms[tid] = A.dU0[(size_t)bi * 80 + 48 + tid] * A.nm[bi];     // dM_i: the same for every partner row
+        if (U.theta != nullptr) {
+            float *u0 = ub, *u1 = ub + 80, *u2 = ub + 112, *dh = ub + 144, *du2 = ub + 192, *du1 = ub + 224, *dU = ub + 256;
+            const float nm = U.nm[bi];
+            if (tid < 80) u0[tid] = U.U0[(size_t)bi * 80 + tid];
+            else if (tid < 112) u1[tid - 80] = U.U1[(size_t)bi * 32 + tid - 80];
+            else if (tid < 144) u2[tid - 112] = U.U2[(size_t)bi * 32 + tid - 112];
+            else if (tid < 192) dh[tid - 144] = U.gh[(size_t)bi * 48 + tid - 144] * nm;
+            __syncthreads();
+            if (tid < 32) {
+                float sacc = 0.f;
+                for (int oo = 0; oo < 48; ++oo) sacc = fmaf(dh[oo], U.theta[U.oW2 + tid * 48 + oo], sacc);
+                du2[tid] = u2[tid] > 0.f ? sacc : 0.f;
+            }
+            __syncthreads();
+            if (tid < 32) {
+                float sacc = 0.f;
+                for (int oo = 0; oo < 32; ++oo) sacc = fmaf(du2[oo], U.theta[U.oW1 + tid * 32 + oo], sacc);
+                du1[tid] = u1[tid] > 0.f ? sacc : 0.f;
+            }
+            __syncthreads();
+            if (tid < 80) {
+                float sacc = 0.f;
+                for (int oo = 0; oo < 32; ++oo) sacc = fmaf(du1[oo], U.theta[U.oW0 + tid * 32 + oo], sacc);
+                dU[tid] = sacc;
+                U.dU0[(size_t)bi * 80 + tid] = sacc;
+            }
+            // weight-gradient partials of this atom (rank one per layer), parameter order
+            float *Pu = U.part + (size_t)bi * EPNN_TF_PU;
+            for (int idx = tid; idx < 80 * 32; idx += EPNN_TF_NT) Pu[idx] = u0[idx >> 5] * du1[idx & 31];
+            Pu += 80 * 32;
+            if (tid < 32) Pu[tid] = du1[tid];
+            Pu += 32;
+            for (int idx = tid; idx < 32 * 32; idx += EPNN_TF_NT) Pu[idx] = u1[idx >> 5] * du2[idx & 31];
+            Pu += 32 * 32;
+            if (tid < 32) Pu[tid] = du2[tid];
+            Pu += 32;
+            for (int idx = tid; idx < 32 * 48; idx += EPNN_TF_NT) Pu[idx] = u2[idx / 48] * dh[idx % 48];
+            Pu += 32 * 48;
+            if (tid < 48) Pu[tid] = dh[tid];
+            __syncthreads();
+            if (tid < 32) dms[tid] = dU[48 + tid] * nm;                            // dM_i: the same for every partner row
+        } else if (tid < 32) {
+            dms[tid] = A.dU0[(size_t)bi * 80 + 48 + tid] * A.nm[bi];
+        }
     } else {
         const float gqi = 0.5f * A.gq[bi];
         for (int j = tid; j < N; j += EPNN_TF_NT) dfs[j] = gqi * A.wgt[rowbase + j];      // df_ij; the swapped row gets -df_ij
@@ -396,17 +492,7 @@ __global__ __launch_bounds__(128) void k_tb_atoms(TfPair A) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- update MLP
-struct TfUpd {
-    const float *h, *M, *nm, *theta;          // h [BN][48] (input of the step), M [BN][32]
-    int oW0, ob0, oW1, ob1, oW2, ob2;
-    float *U0, *U1, *U2, *hn;                 // [BN][80], [BN][32], [BN][32], [BN][48] = update(...) * nm   (charge_gn.py:71-74)
-    const float *gh;                          // backward: gradient w.r.t. hn [BN][48]
-    float *dU0;                               // [BN][80]
-    float *part;                              // [BN][Pu], Pu = 80*32 + 32 + 32*32 + 32 + 32*48 + 48
-};
-#define EPNN_TF_PU (80 * 32 + 32 + 32 * 32 + 32 + 32 * 48 + 48)
-
+// ---------------------------------------------------------------------------------------------- update MLP (stand-alone launches)
 __global__ __launch_bounds__(64) void k_tf_update_fwd(TfUpd U) {
     __shared__ float u0[80], u1[32], u2[32];
     const int a = blockIdx.x, tid = threadIdx.x;
