@@ -135,7 +135,7 @@ struct epnn_handle {
                                       // measured on the QM9-sized batch: 211 M atoms/s with 18 or 20, 206-208 M with 0 / 25 / 28
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     // large path workspace (epnn_large.hip.h)
-    DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
+    DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_csr_ent2, l_cnt, l_nm;
     DevBuf l_stasks, l_schunk, l_sfin;
     // row-block partition of the all-pairs sweep over `part_world` processes (epnn_set_partition): this one runs the tile
     // groups [part_g0, part_g1) = atoms [part_row_lo, part_row_hi) and the callback completes S after every GNN step

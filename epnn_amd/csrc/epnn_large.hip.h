@@ -133,20 +133,19 @@ __global__ __launch_bounds__(256) void k_lg_dn_fill(LargeArgs L, int *dn_ent_w) 
             dn_ent_w[L.dn_off[j] + pos] = p | (L.psym[p] ? 0 : EPNN_DN_ONESIDED);     // flag: no GNN correction through this entry
         }
 }
-// order every atom's list by pair slot so that sums over it have a fixed order
-__global__ __launch_bounds__(256) void k_lg_dn_sort(LargeArgs L, int *dn_ent_w) {
+// order every atom's list by pair slot so that sums over it have a fixed order: one thread per entry counts the entries
+// of its list with a smaller slot and writes itself to that position of the second buffer (lists have ~12 entries; the
+// insertion sort per atom this replaces was 17 us of dependent loads on the 2220-atom protein)
+__global__ __launch_bounds__(256) void k_lg_dn_rank(LargeArgs L, const int *dn_in, int *dn_out) {
     if (L.row_off[L.A] > L.pcap) return;
-    for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
-        const int lo = L.dn_off[at], hi = L.dn_off[at + 1];
-        for (int a = lo + 1; a < hi; ++a) {
-            const int v = dn_ent_w[a];
-            int b = a - 1;
-            while (b >= lo && (dn_ent_w[b] & EPNN_DN_SLOT) > (v & EPNN_DN_SLOT)) {
-                dn_ent_w[b + 1] = dn_ent_w[b];
-                --b;
-            }
-            dn_ent_w[b + 1] = v;
-        }
+    const int total = L.dn_off[L.A];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int v = dn_in[e], slot = v & EPNN_DN_SLOT;
+        const int j = L.pj[slot];
+        const int lo = L.dn_off[j], hi = L.dn_off[j + 1];
+        int rank = 0;
+        for (int k = lo; k < hi; ++k) rank += (dn_in[k] & EPNN_DN_SLOT) < slot ? 1 : 0;
+        dn_out[lo + rank] = v;
     }
 }
 
@@ -803,7 +802,9 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     const Plan &P = h->plan;
     if (P.large_list.empty()) return 0;
     const size_t pc = (size_t)h->pcap;
-    if (h->l_corr.ensure(pc * 2 * 32 * 4) || h->l_dl.ensure(pc * 4) || h->l_csr_ent.ensure(pc * sizeof(int))) return 1;
+    if (h->l_corr.ensure(pc * 2 * 32 * 4) || h->l_dl.ensure(pc * 4) || h->l_csr_ent.ensure(pc * sizeof(int)) ||
+        h->l_csr_ent2.ensure(pc * sizeof(int)))
+        return 1;
     LargeArgs L{};
     L.wpack = h->d_wpack.as<float>();
     L.wi = h->widx;
@@ -856,8 +857,8 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     HIPCHK(hipMemsetAsync(L.dn_cnt, 0, ((size_t)P.A + 1) * sizeof(int), st));
     hipLaunchKernelGGL(k_lg_dn_count, dim3(gP), dim3(256), 0, st, L);
     hipLaunchKernelGGL(k_lg_dn_scan, dim3(1), dim3(1024), 0, st, L, h->l_csr_off.as<int>());
-    hipLaunchKernelGGL(k_lg_dn_fill, dim3(gP), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
-    hipLaunchKernelGGL(k_lg_dn_sort, dim3(gAt), dim3(256), 0, st, L, h->l_csr_ent.as<int>());
+    hipLaunchKernelGGL(k_lg_dn_fill, dim3(gP), dim3(256), 0, st, L, h->l_csr_ent2.as<int>());
+    hipLaunchKernelGGL(k_lg_dn_rank, dim3(gP), dim3(256), 0, st, L, h->l_csr_ent2.as<int>(), h->l_csr_ent.as<int>());
     // Launch sequence (the single-process case): proj(0) | per GNN step: sweep + correction tiles, tail (reduce, update,
     // next projections) | per EPN step: pair tiles, tail (charge update, next projections).  With a partition the other
     // processes' rows of S arrive between the reduction and the update, so those stay separate launches.
