@@ -2,7 +2,8 @@
 non-zero diagonal, fractional and asymmetric masks, padded atoms, systems of 1..47 atoms -- against the float64 oracle
 (not collected by pytest; run by hand on a GPU box):   python tests/fuzz_dense.py [seed] [seconds]
 Round 1 found with it: a fractional node mask (only possible when an atom's mask column sums to less than 1, i.e. in
-tiny systems with fractional masks) was applied twice to the h block of the first update step."""
+tiny systems with fractional masks) was applied twice to the h block of the first update step.
+Round 2 (seed 22, 90 s): 551 cases, worst error 4.0 % of the tolerance."""
 import os
 import sys
 import time

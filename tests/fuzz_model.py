@@ -1,6 +1,7 @@
 """Randomised check of the literal make_model call (epnn_model_forward_dense: the (B,N,N,.) tensors and their reductions,
 charge_gn.py:382-384) on arbitrary inputs -- tiled like the featuriser's or not, rank-3 or rank-4 mask -- against the float64
-oracle (not collected by pytest; run by hand on a GPU box).  Round 1: 1867 cases, worst error 6 % of the tolerance."""
+oracle (not collected by pytest; run by hand on a GPU box).  Round 1: 1867 cases, worst error 6 % of the tolerance.
+Round 2 (seed 23, 60 s): 1673 cases, worst error 5.5 % of the tolerance."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

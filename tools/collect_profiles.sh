@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/big -- python3 $R/b
 stats $OUT/big $OUT/r02_big_launch_kernel_stats.csv
 echo "big launch done"
 # 2. the default bench command (six batches in flight)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --no-cpu-baseline > $OUT/r02_bench_line_under_rocprof.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --no-cpu-baseline --no-extras > $OUT/r02_bench_line_under_rocprof.json 2> $OUT/bench.err
 stats $OUT/bench $OUT/r02_bench_kernel_stats.csv
 echo "bench done"
 # 3. the driver's command
