@@ -180,14 +180,14 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-launch and host-to-host measurements")
     ap.add_argument("--pmc", action="store_true", help="first run the rocprofv3 counter passes of this workload (writes profiles/r02_pmc_bench.json)")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight per GPU (handles/streams used round robin); 0 = by run "
-                    "length: 6 for long runs (best steady state), for short ones the divisor of --steps among 5, 4, 6 -- the last "
+                    "length: 8 for long runs (steady state: 7-10 deep measured 213-215 M atoms/s, 6 deep 207 M on the same box), for short ones the divisor of --steps among 5, 4, 6 -- the last "
                     "round of launches then fills every lane (a launch takes ~0.3 ms whatever shares the GPU with it, so a short run "
                     "that ends with two of six lanes busy pays for it: K = 20 runs at 184 M atoms/s five deep, 175 M six deep)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
     args = ap.parse_args()
 
     if args.depth <= 0:
-        args.depth = 6 if args.steps >= 200 else next((d for d in (5, 4, 6) if args.steps % d == 0), 6)
+        args.depth = 8 if args.steps >= 200 else next((d for d in (5, 4, 6) if args.steps % d == 0), 6)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the rank processes from here, before this process makes any GPU call (it never makes one)
         from epnn_amd.rendezvous import launch_ranks

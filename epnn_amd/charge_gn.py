@@ -348,7 +348,7 @@ class EPNNModel(_Stack):
         """Compact entry: flat atom arrays instead of dense tensors; N defaults to the model's natom."""
         return self._eng().forward_xyz(offsets, xyz, x, Q, self.natom if N is None else N)
 
-    def predict_xyz_stream(self, batches, N=None, depth=6):
+    def predict_xyz_stream(self, batches, N=None, depth=8):
         """Charges of every (offsets, xyz, x, Q) batch of `batches`, in order, with `depth` batches in flight on the GPU
         (engine.Pipeline.map: the loop of infer.py:62-76 at the throughput of the compact entry)."""
         from .engine import Pipeline

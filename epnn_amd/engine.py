@@ -345,11 +345,11 @@ class Pipeline:
     the calls round robin.  The fused kernel runs one wavefront per molecule and an MI355X holds 2048 of them
     (8 per CU), so one batch of 1024 molecules fills half the machine and its largest molecules finish long after
     the smallest: the wavefronts of the next batches fill those slots.  A launch lasts as long as its largest molecule
-    (~3x the mean under load), so about six batches in flight keep every slot busy; each needs its own hardware queue
+    (~3x the mean under load), so six to ten batches in flight keep every slot busy (default 8); each needs its own hardware queue
     (GPU_MAX_HW_QUEUES, raised to 16 in _lib.load(); with the runtime's default of 4 use depth 3).
     All handles carry the same weights.  Results of call k are complete after `sync()`."""
 
-    def __init__(self, depth=6, **engine_kwargs):
+    def __init__(self, depth=8, **engine_kwargs):
         self.engines = [Engine(**engine_kwargs) for _ in range(max(1, int(depth)))]
         self._next = 0
 
