@@ -41,7 +41,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
-KNAME = "k_wave_forward<true,true,true>"
+KNAME = "k_wave_forward<true,true,true,true>"
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
 
 
