@@ -195,6 +195,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: libraries that write to file descriptor 1 themselves (gloo announces its
+    # connections there) are sent to stderr for the whole run, the line goes to a saved copy of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if args.pmc and world == 1:
@@ -398,7 +403,8 @@ def main():
             out["host_to_host"] = extras["host_to_host"]
         if not args.no_cpu_baseline and world == 1:         # the reported CPU baseline belongs to the N=1 line only
             out["cpu_baseline"] = cpu_baseline(offsets, xyz, x, Q, N, weights)
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
 
     for lane in lanes:
         for d in lane[1:]:
