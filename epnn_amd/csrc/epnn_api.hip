@@ -593,6 +593,14 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
         for (int n = EPNN_SMALL_NMAX; n >= 0; --n) { start[n] = at; at += count[n]; }
         std::vector<int> sorted(P.small_order.size());
         for (int b : P.small_order) sorted[start[offsets[b + 1] - offsets[b]]++] = b;
+        if (h->opt_wave_order == 1) {            // developer switch: largest, smallest, second largest, second smallest, ...
+            std::vector<int> mix(sorted.size());
+            size_t lo = 0, hi = sorted.size();
+            for (size_t k = 0; k < sorted.size(); ++k) mix[k] = (k & 1) ? sorted[--hi] : sorted[lo++];
+            sorted.swap(mix);
+        } else if (h->opt_wave_order == 2) {     // smallest first
+            std::reverse(sorted.begin(), sorted.end());
+        }
         P.small_order.swap(sorted);
         P.small_nbig = 0;
         for (int n = EPNN_SMALL_NMAX; n > 16; --n) P.small_nbig += count[n];
@@ -1058,6 +1066,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "wave_split")) { h->opt_wave_split = value; }
+    else if (!strcmp(name, "wave_order")) { h->opt_wave_order = value; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }

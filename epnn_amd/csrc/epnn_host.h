@@ -127,6 +127,7 @@ struct epnn_handle {
     int opt_train_fused = 1;          // training: row-fused pair-MLP kernels (0: the layer-by-layer kernels)
     int opt_train_graph = 1;          // training: replay the step's launch sequence as a hipGraph (0: launch kernel by kernel)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
+    int opt_wave_order = 0;           // order of a launch's wavefronts: 0 largest molecule first, 1 ends interleaved, 2 smallest first
     int opt_wave_split = 0;           // fused kernel with its own front-end: molecules of <= 16 atoms run as a one-column-block variant at
                                       // three wavefronts per SIMD (168 registers, 13 KB LDS), beside the others, on the second stream.
                                       // Measured SLOWER (196.6 vs 206.5 M atoms/s: 12 spilled registers, more G rows in HBM): off
