@@ -74,6 +74,16 @@ def main():
     if rank == 0:
       print((f"[{world} processes, rows of atoms partitioned, exchange {how}] " if world > 1 else "") + f"{what}: {A} atoms, {stats[0]} near pairs; {dt*1e3:.3f} ms/forward wall, device stages front/fused/tiled/total ms = {np.round(st,3)}; "
           f"{A/dt:.3e} atoms/s; algorithmic {flops/1e9:.1f} Gflop -> {flops/(st[3]*1e-3)/1e12:.1f} TFLOP/s; sum q = {q.sum(dtype=np.float64):.6f}", flush=True)
+      import json
+      # the same facts as ONE JSON line in bench.py's vocabulary (last line of the output)
+      print(json.dumps({"metric": "atoms/sec (inference), one large system", "value": A / dt, "unit": "atoms/s", "n_gpus": world,
+                        "steps": steps, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic" if what != "protein" else "6qlp_capped.xyz",
+                        "config": {"workload": what, "atoms": A, "pairs_under_cutoff": int(stats[0]), "N": int(N), "weights": "decay_model_weights",
+                                   "parallelism": f"rows of atoms partitioned x{world} ({how})" if world > 1 else "one GPU"},
+                        "roofline": {"bound": "mfma", "kernel": "k_lg_sweep (all-pairs sum of charge_gn.py:70) + per-step tails", "achieved": flops / (st[3] * 1e-3) / 1e12,
+                                     "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (st[3] * 1e-3) / 1e12 / 157.3, "traffic": None,
+                                     "algorithmic_gflop_per_forward": flops / 1e9, "device_ms_per_forward": float(st[3]),
+                                     "note": "whole forward (hipEvents on the handle's stream), not the sweep kernel alone"}}), flush=True)
     eng.close()
 
 if __name__ == "__main__":
