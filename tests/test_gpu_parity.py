@@ -675,3 +675,43 @@ def test_all_real_qm9_molecules_vs_oracle(gpu_engine_factory, weights_decay, val
     print(f"{len(mols)} real QM9 molecules ({int(sizes.sum())} atoms, n = {sizes.min()}..{sizes.max()}): worst |dq| vs float64 oracle {worst:.2e}, "
           f"vs the stored TensorFlow output ({nval} systems) {gold_worst:.2e}; worst |sum q - Q| {drift:.1e}")
     assert worst <= TOL and gold_worst <= TOL and drift < 5e-6
+
+
+def test_limits_of_the_configuration_vs_oracle(gpu_engine_factory):
+    """The largest configuration the C ABI accepts: T = 8 steps (EPNN_MAXT) and nx = 10 atom-feature columns (the reference's
+    larger element table; the feature row of the kernels has 59 slots + the constant), random non-degenerate weights with
+    arbitrary (not one-hot) values in the feature columns, molecules on both paths (1..32 atoms fused, 40 and 70 atoms tiled),
+    N beyond the largest; float64 oracle.  One more column or step is refused at epnn_create."""
+    from epnn_amd import synth
+    from epnn_amd._lib import EpnnError
+    from epnn_amd.engine import Engine
+    nx, T, N = 10, 8, 75
+    w = random_weights(nx, T, seed=31, scale=0.3)
+    rng = np.random.default_rng(8)
+    mols = []
+    for n in (1, 5, 16, 17, 29, 32, 40, 70):
+        span = max(1.5, 1.8 * n ** (1.0 / 3.0))
+        while True:
+            pts = rng.uniform(0, span, size=(n, 3))
+            d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 10
+            if d.min() > 0.75:
+                break
+        x = np.concatenate([synth.features(rng.choice(["H", "C", "N", "O"], size=n)), rng.uniform(0, 1, size=(n, nx - 9)).astype(np.float32)], axis=1)
+        x[:, 1:5] += rng.uniform(0, 0.3, size=(n, 4)).astype(np.float32)
+        mols.append((pts.astype(np.float32), x, float(rng.integers(-1, 2))))
+    off, xyz, x, Q = _batch(mols)
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+    q = eng.forward_xyz(off, xyz, x, Q, N=N)
+    st = eng.last_stats()
+    assert st[1] == 6 and st[2] == 2
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    worst = max(np.abs(q[off[k]:off[k + 1]] - ref[k][:m[1].shape[0]]).max() for k, m in enumerate(mols))
+    print(f"nx = 10, T = 8: worst |dq| {worst:.2e}; float32 oracle noise {noise:.2e}")
+    assert worst <= max(TOL, 4 * noise)
+    with pytest.raises(EpnnError, match="nx must be"):
+        Engine(nx=11, T=8)
+    with pytest.raises(EpnnError, match="T must be"):
+        Engine(nx=9, T=9)
