@@ -6,6 +6,7 @@
 #include "epnn_host.h"
 #include "epnn_frontend.hip.h"
 #include "epnn_wave.hip.h"
+#include "epnn_wave3.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
 #include "epnn_mlp.hip.h"
@@ -537,9 +538,11 @@ static int pack_weights(epnn_handle *h) {
 }
 
 // ------------------------------------------------------------------------------------------------ plan
-static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
+// allow_mid: molecules of 33..48 atoms may take the three-block fused kernel (compact entry with its in-kernel front-end only)
+static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false) {
     Plan &P = h->plan;
-    if (P.valid && P.B == B && P.N == N && (int)P.offsets.size() == B + 1 &&
+    allow_mid = allow_mid && h->opt_wave3 && h->opt_force_path == 0;
+    if (P.valid && P.B == B && P.N == N && P.allow_mid == allow_mid && (int)P.offsets.size() == B + 1 &&
         memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0)
         return 0;
     if (B < 1) EPNN_FAIL("forward: batch must have at least one molecule");
@@ -549,7 +552,9 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
     P.N = N;
     P.A = offsets[B];
     P.offsets.assign(offsets, offsets + B + 1);
+    P.allow_mid = allow_mid;
     P.small_order.clear();
+    P.mid_order.clear();
     P.large_list.clear();
     P.small_nmax = 0;
     // index arrays of the plan, written straight into page-locked memory and uploaded without waiting:
@@ -573,17 +578,20 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
         const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
-        c_mflag[b] = small ? 0 : 1;
+        const bool mid = !small && allow_mid && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W3_NMAX;
+        c_mflag[b] = small || mid ? 0 : 1;
         if (small) {
             P.small_order.push_back(b);
             P.small_nmax = std::max(P.small_nmax, n);
             count[n] += 1;
+        } else if (mid) {
+            P.mid_order.push_back(b);
         } else {
             P.large_list.push_back(b);
         }
         // pair slots of the in-kernel front-end: every i<j pair of every molecule
         pbase[b] = (int)run;
-        run += n <= EPNN_SMALL_NMAX ? (long long)n * (n - 1) / 2 : 0;
+        run += small || mid ? (long long)n * (n - 1) / 2 : 0;
     }
     if (run > 0x7fffffffLL / 64) EPNN_FAIL("forward: batch too large (%lld pair slots)", run);
     P.pair_slots = (int)run;
@@ -607,6 +615,12 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets) {
         for (size_t k = 0; k < P.small_order.size(); ++k) {
             const int b = P.small_order[k];
             c_wblk[k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
+        }
+        // the three-block kernel's molecules behind them, largest first
+        std::stable_sort(P.mid_order.begin(), P.mid_order.end(), [&](int a, int c) { return offsets[a + 1] - offsets[a] > offsets[c + 1] - offsets[c]; });
+        for (size_t k = 0; k < P.mid_order.size(); ++k) {
+            const int b = P.mid_order[k];
+            c_wblk[P.small_order.size() + k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
         }
     }
     // the device copy has the same layout: ONE upload per plan
@@ -712,7 +726,23 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.dsafe = h->dsafe;
     const dim3 grid((unsigned)P.small_order.size());
     const WaveIndex &X = h->wvidx;
-    A.total_waves = (int)P.small_order.size();
+    A.total_waves = (int)(P.small_order.size() + P.mid_order.size());
+    if (!P.mid_order.empty()) {
+        // molecules of 33..48 atoms: the three-block variant (one wavefront per SIMD, 40 KB of LDS), queued FIRST so that its
+        // few long wavefronts run beside this forward's other launch... of the other streams (same stream: in order)
+        if (!S.d_xyz) EPNN_FAIL("forward: internal error (three-block kernel without the in-kernel front-end)");
+        WaveArgs A3 = A;
+        A3.wblk = A.wblk + P.small_order.size();
+        const int lds3 = 40960;
+        A3.lds_words = lds3 / 4;
+        if (!h->wave3_attr) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward3), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+            h->wave3_attr = true;
+        }
+        hipLaunchKernelGGL(k_wave_forward3, dim3((unsigned)P.mid_order.size()), dim3(64), (size_t)lds3, h->stream, A3, h->wvidx);
+        HIPCHK(hipGetLastError());
+        if (P.small_order.empty()) return 0;
+    }
     const int nbig = P.small_nbig, nsmall = (int)P.small_order.size() - nbig;
     if (S.d_xyz && h->opt_wave_split && nbig > 0 && nsmall > 0) {
         // two launches side by side: the one-column-block variant (n <= 16; 13 KB of LDS, three wavefronts per SIMD) on the
@@ -737,7 +767,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
 }
 
 static int launch_small(epnn_handle *h, const PairSource &S) {
-    if (h->plan.small_order.empty()) return 0;
+    if (h->plan.small_order.empty() && h->plan.mid_order.empty()) return 0;
     return launch_wave(h, S);
 }
 
@@ -780,13 +810,14 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
                                const float *d_x, const float *d_Q, float *d_q) {
     HIPCHK(hipSetDevice(h->device));
     if (pack_weights(h)) return 1;
-    if (build_plan(h, B, N, offsets)) return 1;
+    const bool front_ok = h->opt_wave_front && h->cfg.e_dim == EPNN_EDIM && h->edge_res < 1e-8;
+    if (build_plan(h, B, N, offsets, front_ok)) return 1;
     const Plan &P = h->plan;
     // Small molecules (fused kernel): the wavefront builds its molecule's pair list itself (slots for every i<j pair, so
     // nothing can overflow; G products in the 16-dimensional edge basis, used only when it represents the features to
     // 1e-8).  Which path a molecule takes does not depend on what else is in the batch.  With small molecules only no
     // other kernel runs and the kernel's last wave also hands status + pair count to the host.
-    const bool front_small = h->opt_wave_front && !P.small_order.empty() && h->cfg.e_dim == EPNN_EDIM && h->edge_res < 1e-8;
+    const bool front_small = front_ok && (!P.small_order.empty() || !P.mid_order.empty());
     const bool pure = front_small && P.large_list.empty();
     if (!pure && ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
     if (!pure || !h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
@@ -815,7 +846,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
         HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
-    h->stats[1] = (int64_t)P.small_order.size();
+    h->stats[1] = (int64_t)(P.small_order.size() + P.mid_order.size());
     h->stats[2] = (int64_t)P.large_list.size();
     return 0;
 }
@@ -1062,7 +1093,8 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "force_path")) { h->opt_force_path = value; h->plan.valid = false; }
     else if (!strcmp(name, "pair_cap_per_atom")) { h->pair_cap_per_atom = std::max(1, value); }
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
-    else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; }
+    else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; h->plan.valid = false; }
+    else if (!strcmp(name, "wave3")) { h->opt_wave3 = value; h->plan.valid = false; }
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "wave_split")) { h->opt_wave_split = value; }

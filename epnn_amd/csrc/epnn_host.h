@@ -81,6 +81,8 @@ struct Plan {                 // what the host derives from `offsets`
     int B = 0, A = 0, N = 0;
     std::vector<int> offsets;
     std::vector<int> small_order;   // molecules on the fused path, largest first
+    std::vector<int> mid_order;     // molecules of 33..48 atoms on the three-block fused kernel (compact entry only), largest first
+    bool allow_mid = false;
     std::vector<int> large_list;    // molecules on the tiled path
     int small_nmax = 0;
     int small_nbig = 0;             // how many of small_order (sorted largest first) have more than 16 atoms
@@ -127,6 +129,8 @@ struct epnn_handle {
     int opt_train_fused = 1;          // training: row-fused pair-MLP kernels (0: the layer-by-layer kernels)
     int opt_train_graph = 1;          // training: replay the step's launch sequence as a hipGraph (0: launch kernel by kernel)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
+    int opt_wave3 = 1;                // molecules of 33..48 atoms take the three-block fused kernel (0: the tiled kernels)
+    bool wave3_attr = false;
     int opt_wave_order = 0;           // order of a launch's wavefronts: 0 largest molecule first, 1 ends interleaved, 2 smallest first
     int opt_wave_split = 0;           // fused kernel with its own front-end: molecules of <= 16 atoms run as a one-column-block variant at
                                       // three wavefronts per SIMD (168 registers, 13 KB LDS), beside the others, on the second stream.

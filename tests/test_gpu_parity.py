@@ -71,23 +71,28 @@ def _batch(mols):
 
 
 def test_val_golden_all(gpu_engine_factory, weights_decay, val_dir, val_names, val_gold):
-    """All 871 validation systems in ONE mixed batch (n <= 32 on the fused kernel, larger ones on the tiled
-    kernels) vs the stored TensorFlow predictions."""
-    eng = gpu_engine_factory(nx=9, T=5)
-    eng.set_weights(weights_decay)
+    """All 871 validation systems in ONE mixed batch vs the stored TensorFlow predictions: n <= 32 on the two-block fused
+    kernel, the 22 systems of 33..38 atoms on its three-block variant; and once more with those 22 on the tiled kernels
+    ("wave3" = 0), which is where every system above 48 atoms goes."""
     mols, offsets, xyz, x, Q = load_molecules(val_dir, val_names)
-    q = eng.forward_xyz(offsets, xyz, x, Q, N=41)
-    st = eng.last_stats()
-    assert st[1] > 0 and st[2] > 0, st          # both paths were exercised
-    worst = 0.0
-    for i, m in enumerate(mols):
-        n = m[1].shape[0]
-        qi = q[offsets[i]:offsets[i + 1]]
-        worst = max(worst, np.abs(qi - val_gold[i, :n]).max())
-        assert abs(float(qi.sum(dtype=np.float64)) - float(m[2])) < 5e-6
-        assert np.all(val_gold[i, n:] == 0)      # the reference's padded atoms stay exactly 0
-    print(f"871 systems: worst |dq| vs TF golden {worst:.3e}; paths fused/tiled = {st[1]}/{st[2]}")
-    assert worst <= TOL, worst
+    nmid = sum(1 for m in mols if m[1].shape[0] > 32)
+    assert nmid == 22 and max(m[1].shape[0] for m in mols) == 38
+    for wave3 in (1, 0):
+        eng = gpu_engine_factory(nx=9, T=5)
+        eng.set_weights(weights_decay)
+        eng.set_option("wave3", wave3)
+        q = eng.forward_xyz(offsets, xyz, x, Q, N=41)
+        st = eng.last_stats()
+        assert (st[1], st[2]) == ((871, 0) if wave3 else (871 - nmid, nmid)), st
+        worst = 0.0
+        for i, m in enumerate(mols):
+            n = m[1].shape[0]
+            qi = q[offsets[i]:offsets[i + 1]]
+            worst = max(worst, np.abs(qi - val_gold[i, :n]).max())
+            assert abs(float(qi.sum(dtype=np.float64)) - float(m[2])) < 5e-6
+            assert np.all(val_gold[i, n:] == 0)      # the reference's padded atoms stay exactly 0
+        print(f"871 systems (wave3 = {wave3}): worst |dq| vs TF golden {worst:.3e}; fused / tiled = {st[1]} / {st[2]}")
+        assert worst <= TOL, worst
 
 
 def test_protein_golden(gpu_engine_factory, weights_decay, golden_dir):
@@ -680,7 +685,7 @@ def test_all_real_qm9_molecules_vs_oracle(gpu_engine_factory, weights_decay, val
 def test_limits_of_the_configuration_vs_oracle(gpu_engine_factory):
     """The largest configuration the C ABI accepts: T = 8 steps (EPNN_MAXT) and nx = 10 atom-feature columns (the reference's
     larger element table; the feature row of the kernels has 59 slots + the constant), random non-degenerate weights with
-    arbitrary (not one-hot) values in the feature columns, molecules on both paths (1..32 atoms fused, 40 and 70 atoms tiled),
+    arbitrary (not one-hot) values in the feature columns, molecules on all three kernels (1..32 atoms, 40 atoms, 70 atoms tiled),
     N beyond the largest; float64 oracle.  One more column or step is refused at epnn_create."""
     from epnn_amd import synth
     from epnn_amd._lib import EpnnError
@@ -704,7 +709,7 @@ def test_limits_of_the_configuration_vs_oracle(gpu_engine_factory):
     eng.set_weights(w)
     q = eng.forward_xyz(off, xyz, x, Q, N=N)
     st = eng.last_stats()
-    assert st[1] == 6 and st[2] == 2
+    assert st[1] == 7 and st[2] == 1                     # 1..32 two-block kernel, 40 three-block kernel, 70 tiled kernels
     ref = _oracle_batch(mols, w, N)
     ref32 = _oracle_batch(mols, w, N, np.float32)
     noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
@@ -715,3 +720,66 @@ def test_limits_of_the_configuration_vs_oracle(gpu_engine_factory):
         Engine(nx=11, T=8)
     with pytest.raises(EpnnError, match="T must be"):
         Engine(nx=9, T=9)
+
+
+def test_three_block_kernel_every_size_vs_oracle(gpu_engine_factory):
+    """Molecules of 33..48 atoms through the compact entry take the three-column-block variant of the fused kernel
+    (epnn_wave3.hip.h; the reference's `mixed` set goes up to 41 atoms).  Every size at two densities (the sparse ones keep
+    their G rows in LDS, the dense ones spill them to HBM), random non-degenerate weights, nx = 10, N beyond the largest,
+    non-zero total charges; float64 oracle.  The same molecules on the tiled kernels ("wave3" = 0) agree to float32
+    rounding, and a batch that mixes all three kernels gives every molecule the bits it gets alone."""
+    from epnn_amd import synth
+    nx, T, N = 10, 3, 50
+    w = random_weights(nx, T, seed=13, scale=0.35)
+    rng = np.random.default_rng(17)
+    mols = []
+    for n in range(33, 49):
+        for span_per_atom in (1.0, 2.2):
+            span = max(1.2, span_per_atom * n ** (1.0 / 3.0) * 1.6)
+            while True:
+                pts = rng.uniform(0, span, size=(n, 3))
+                d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 10
+                if d.min() > 0.7:
+                    break
+            x = np.concatenate([synth.features(rng.choice(["H", "C", "N", "O", "F"], size=n)), rng.uniform(0, 1, size=(n, 1)).astype(np.float32)], axis=1)
+            mols.append((pts.astype(np.float32), x, float(rng.integers(-1, 2))))
+    off, xyz, x, Q = _batch(mols)
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+    q = eng.forward_xyz(off, xyz, x, Q, N=N)
+    st = eng.last_stats()
+    assert st[1] == len(mols) and st[2] == 0, st                       # all on the fused kernels
+    worst, at = 0.0, -1
+    for k, m in enumerate(mols):
+        n = m[1].shape[0]
+        err = float(np.abs(q[off[k]:off[k + 1]] - ref[k][:n]).max())
+        assert abs(float(q[off[k]:off[k + 1]].sum(dtype=np.float64)) - m[2]) < 2e-5
+        if err > worst:
+            worst, at = err, n
+    npairs = sum(int(((np.linalg.norm(m[0][:, None].astype(np.float64) - m[0][None].astype(np.float64), axis=-1) < 3.0).sum() - m[0].shape[0]) // 2) for m in mols)
+    assert st[0] == npairs
+    print(f"sizes 33..48: worst |dq| {worst:.2e} (n = {at}); float32 oracle noise {noise:.2e}; {npairs} pairs")
+    assert worst <= max(TOL, 4 * noise), (worst, at)
+    tiled = gpu_engine_factory(nx=nx, T=T)
+    tiled.set_weights(w)
+    tiled.set_option("wave3", 0)
+    qt = tiled.forward_xyz(off, xyz, x, Q, N=N)
+    assert tiled.last_stats()[2] == len(mols)
+    assert np.abs(qt - q).max() <= max(3e-6, 4 * noise)
+    # mixed batch: small (two-block kernel), mid (three-block), large (tiled): each molecule's charges do not depend on the others
+    so, sxyz, sx9, sQ, _ = synth.qm9_like_batch(B=6, seed=2)
+    sx = np.concatenate([sx9, np.zeros((sx9.shape[0], 1), np.float32)], axis=1)
+    _, bxyz, bx9, bQ, bn = synth.box_system(n_atoms=90, seed=4)
+    bx = np.concatenate([bx9, np.zeros((90, 1), np.float32)], axis=1)
+    pick = [0, 7, 31]
+    parts = [(sxyz[so[b]:so[b + 1]], sx[so[b]:so[b + 1]], float(sQ[b])) for b in range(6)] + [mols[k] for k in pick] + [(bxyz, bx, 0.0)]
+    moff, mxyz, mx, mQ = _batch(parts)
+    qm = eng.forward_xyz(moff, mxyz, mx, mQ, N=90)
+    st = eng.last_stats()
+    assert st[1] == 9 and st[2] == 1, st
+    alone = eng.forward_xyz(*_batch([mols[k] for k in pick]), N=90)
+    got = np.concatenate([qm[moff[6 + j]:moff[7 + j]] for j in range(3)])
+    assert np.array_equal(got, alone)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Timing of the reference's 871-system validation batch (molecules of 3..41 atoms: those above 32 take the tiled path)."""
+"""Timing of REAL data: the reference's 871-system validation batch of its `mixed` set (molecules of 3..38 atoms, N = 41):
+molecules up to 32 atoms on the two-block fused kernel, 33..48 on the three-block variant (`--opt wave3=0`: on the tiled
+kernels, as before round 2).   python tools/bench_mixed.py [depth]"""
 import os, sys, tarfile, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
