@@ -21,6 +21,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
                       (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); `single_launch` = a launch with the GPU to itself
                       (65536 molecules, depth 1: flops / hipEvent duration IS its fraction, reproducible from
                       profiles/r02_big_launch_kernel_stats.csv)
+  parity              max |dq| of the reference's 871 validation systems against the TensorFlow predictions it stored for them
+  real_data           atoms/s on that batch (real molecules of 3..38 atoms, N = 41), device-resident, pipelined
   host_to_host        the same forward from host arrays to host arrays (Pipeline.map, a DIFFERENT batch every call)
   cpu_baseline        the oracle (CPU restatement of the reference's algorithm, not TensorFlow) on this host's cores
 """
@@ -349,6 +351,55 @@ def main():
                                   "what": "Pipeline.map (epnn_forward_xyz_begin/_end): host xyz/x/Q -> host q, a different "
                                           f"batch of {B} molecules every call, {len(lanes)} in flight; PCIe inclusive, not `value`"}
 
+    if rank == 0 and not args.no_extras:
+        # (3) the metric's second half, "max |dq| vs reference", and a REAL-data rate: the 871 systems of the reference's
+        #     recorded validation split (tests/golden/mixed_val.tar.gz, 3..38 atoms, N = 41) against the TensorFlow
+        #     predictions the reference stored for them (models/model_systems/test_pred_charges.npy), then the same batch
+        #     device-resident through every lane of the pipeline
+        try:
+            import tarfile
+            import tempfile
+            from epnn_amd import charge_gn
+            gdir = os.path.join(ROOT, "tests", "golden")
+            names = [str(nm) for nm in np.load(os.path.join(gdir, "val_names.npy"), allow_pickle=True)]
+            gold = np.load(os.path.join(gdir, "test_pred_charges.npy"))
+            with tempfile.TemporaryDirectory() as tmp:
+                with tarfile.open(os.path.join(gdir, "mixed_val.tar.gz")) as tf:
+                    tf.extractall(tmp)
+                mols = [charge_gn.read_xyz(os.path.join(tmp, "mixed_val", nm + ".xyz"), 9) for nm in names]
+            v_off = np.zeros(len(mols) + 1, np.int32)
+            v_off[1:] = np.cumsum([len(m[1]) for m in mols])
+            v_xyz, v_x = np.concatenate([m[0] for m in mols]), np.concatenate([m[1] for m in mols])
+            v_Q = np.array([m[2] for m in mols], np.float32)
+            vq = pipe.engines[0].forward_xyz(v_off, v_xyz, v_x, v_Q, 41)
+            dq = max(float(np.abs(vq[v_off[i]:v_off[i + 1]] - gold[i, :v_off[i + 1] - v_off[i]]).max()) for i in range(len(mols)))
+            drift = float(np.abs(np.add.reduceat(vq.astype(np.float64), v_off[:-1]) - v_Q).max())
+            vl = [(e, e.to_device(v_xyz), e.to_device(v_x), e.to_device(v_Q), e.alloc(int(v_off[-1]) * 4)) for e in pipe.engines]
+            for k in range(2 * len(vl)):
+                e, a_, b_, c_, d_ = vl[k % len(vl)]
+                e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
+            pipe.sync()
+            nrep = 25 * len(vl)
+            t1 = time.perf_counter()
+            for k in range(nrep):
+                e, a_, b_, c_, d_ = vl[k % len(vl)]
+                e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
+            pipe.sync()
+            v_dt = (time.perf_counter() - t1) / nrep
+            for lane in vl:
+                for d in lane[1:]:
+                    d.free()
+            extras["parity"] = {"max_abs_dq_vs_reference": dq, "tolerance": 1e-5, "max_abs_total_charge_error": drift,
+                                "systems": len(mols), "atoms": int(v_off[-1]),
+                                "reference": "TensorFlow predictions stored by the reference for its validation split "
+                                             "(models/model_systems/test_pred_charges.npy, decay_model_weights, N = 41)"}
+            extras["real_data"] = {"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
+                                   "workload": f"the reference's {len(mols)}-system validation split of `mixed` (3..38 atoms, "
+                                               f"{int(v_off[-1])} atoms), N = 41, device-resident, {len(vl)} batches in flight"}
+            assert dq <= 1e-5, dq
+        except (OSError, KeyError) as exc:                  # fixtures missing: the synthetic figures stand alone
+            print(f"[bench] real-data / parity extras skipped: {exc}", file=sys.stderr)
+
     if rank == 0:
         k_ms = float(stage[:, 1].mean())                   # duration of one launch (hipEvents on its stream)
         step_ms = dt_max / args.steps * 1e3
@@ -399,8 +450,9 @@ def main():
         if world > 1:
             out["ranks"] = {"world_size": world, "timing_backend": backend,
                             "atoms_per_s_per_rank": [a * args.steps / d for d, a in per_rank]}
-        if "host_to_host" in extras:
-            out["host_to_host"] = extras["host_to_host"]
+        for key in ("parity", "real_data", "host_to_host"):
+            if key in extras:
+                out[key] = extras[key]
         if not args.no_cpu_baseline and world == 1:         # the reported CPU baseline belongs to the N=1 line only
             out["cpu_baseline"] = cpu_baseline(offsets, xyz, x, Q, N, weights)
         real_stdout.write(json.dumps(out) + "\n")
