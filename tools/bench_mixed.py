@@ -29,7 +29,7 @@ def timeit(sel, label):
 only_pipe = len(sys.argv) > 1
 if not only_pipe: timeit(range(len(mols)), "all")
 if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] <= 32], "n <= 32 (fused kernel)")
-if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] > 32], "n > 32 (tiled kernels)")
+if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] > 32], "n > 32 (three-block fused kernel; tiled with wave3=0)")
 eng.close()
 from epnn_amd.engine import Pipeline
 for depth in ((int(sys.argv[1]),) if only_pipe else (1, 4, 8)):
