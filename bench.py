@@ -69,7 +69,20 @@ def _cpu_worker(args):
         orc.forward_xyz(xyz, x, Q, weights, N=N, dtype=np.float32)
         atoms += x.shape[0]
         calls += 1
-    return atoms, calls, time.perf_counter() - t0
+    per_call = (atoms, calls, time.perf_counter() - t0)
+    # the same algorithm with 16 molecules per call ("and also batched"): dense inputs built outside the clock
+    nb = min(16, len(mols))
+    dense = [orc.dense_inputs(xyz, x, Q, N) for xyz, x, Q in mols[:nb]]
+    h, e, xd, q, mask = (np.stack([d[k] for d in dense]).astype(np.float32) for k in range(5))
+    b_atoms = sum(m[1].shape[0] for m in mols[:nb])
+    orc.model_forward(h, e, xd, q, mask, weights, dtype=np.float32)
+    batoms = bcalls = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s / 3:
+        orc.model_forward(h, e, xd, q, mask, weights, dtype=np.float32)
+        batoms += b_atoms
+        bcalls += 1
+    return per_call + (batoms, bcalls, time.perf_counter() - t0, nb)
 
 
 def usable_cores():
@@ -109,7 +122,9 @@ def cpu_baseline(offsets, xyz, x, Q, N, weights, budget_s=12.0):
     atoms = sum(r[0] for r in res)
     calls = sum(r[1] for r in res)
     dt = max(r[2] for r in res)
-    return {"value": atoms / dt, "unit": "atoms/s", "cores": workers, "cores_total": os.cpu_count(), "kind": "port",
+    batched = {"value": sum(r[3] for r in res) / max(r[5] for r in res), "unit": "atoms/s", "molecules_per_call": res[0][6],
+               "calls": sum(r[4] for r in res), "what": "the same workers, one model call on the dense (B,N,N,.) inputs of `molecules_per_call` molecules at a time (inputs built outside the clock)"}
+    return {"value": atoms / dt, "unit": "atoms/s", "cores": workers, "cores_total": os.cpu_count(), "kind": "port", "batched": batched,
             "what": "CPU restatement of the reference algorithm (oracle/epnn_oracle.py, NumPy float32), not TensorFlow",
             "sample": f"{calls} molecule calls ({atoms} atoms) of the same batch, padded to N={N}, one molecule per call like "
                       f"infer.py, {workers} single-threaded worker processes (one per usable core of {os.cpu_count()}), {dt:.1f} s each"}
