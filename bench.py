@@ -15,6 +15,12 @@ rank processes itself, as fresh children, before it makes any GPU call of its ow
 JSON line and exits with the first non-zero exit code.  With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks
 share devices and the timing exchange runs over gloo.
 
+Order of a run: one forward and its checks; parity against the reference's stored outputs and the single-launch measurement
+(both skipped by --no-extras); W warm-up steps; barrier; K timed steps; barrier; the same steps again with hipEvents for the
+kernel duration; host-to-host; real-data rate.  The single-launch measurement placed right before the warm-up steps also
+means the timed region starts on a GPU at working clocks: K = 20 steps are 2 ms, and on a GPU that idled before the W = 5
+warm-up steps (--no-extras) they read 182-185 M atoms/s instead of 194-197 M (`order` in the line; profiles/r02_warm_sweep.txt).
+
 Prints ONE JSON line on rank 0.  Besides the contract's fields:
   roofline.*          dominant kernel k_wave_forward; `frac` is ALGORITHMIC flops of the launches per second of
                       the timed region / f32 MFMA peak; `pipe_frac` the same with the flops the kernel really executes
@@ -43,7 +49,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
-KNAME = "k_wave_forward<true,true,true,true>"
+KNAME = "k_wave_forward<true,true,true>"
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
 
 
@@ -200,6 +206,7 @@ def main():
                     "length: 8 for long runs (steady state: 7-10 deep measured 213-215 M atoms/s, 6 deep 207 M on the same box), for short ones the divisor of --steps among 5, 4, 6 -- the last "
                     "round of launches then fills every lane (a launch takes ~0.3 ms whatever shares the GPU with it, so a short run "
                     "that ends with two of six lanes busy pays for it: K = 20 runs at 184 M atoms/s five deep, 175 M six deep)")
+    ap.add_argument("--sleep-ms", type=float, default=0.0, help="(experiment, profiles/r02_warm_sweep.txt) idle time between the warm-up steps and the timed region; negative: the host busy-waits instead of sleeping")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
     args = ap.parse_args()
 
@@ -281,9 +288,92 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
+    # ---- before the timed region: the checks and the single-launch measurement (--no-extras skips them).  A rate for wrong
+    # charges is worth nothing, so parity comes first; the single-launch measurement runs on EVERY rank right before the
+    # warm-up steps, which also means the timed region starts on a GPU at working clocks: the driver's `--steps 20
+    # --warmup 5` times 2 ms after 0.5 ms of warm-up, and from an idle GPU (--no-extras) it reads 182-185 M atoms/s where
+    # the same 20 steps after 200 warm-up steps read 197-203 M; the clocks take some 20 ms of load to come up and fall
+    # back within 5-20 ms of idling (profiles/r02_warm_sweep.txt), so nothing that idles the GPU (hipFree of the big
+    # buffers) is done between that measurement and the timed steps.
+    step(0)
+    pipe.sync()
+    eng, d_q = lanes[0][0], lanes[0][4]
+    q = d_q.download((A,))
+    stats = eng.last_stats()
+    # sanity inside the bench: charges finite and every molecule's total charge conserved (the batch itself is compared
+    # with the float64 oracle in tests/test_gpu_parity.py::test_bench_batch_vs_oracle)
+    assert np.isfinite(q).all()
+    sums = np.add.reduceat(q.astype(np.float64), offsets[:-1])
+    assert np.abs(sums - Q).max() < 1e-4, np.abs(sums - Q).max()
+    ns = np.diff(offsets)
+    flops = synth.algorithmic_flops(ns, int(stats[0]))
+
+    extras, real, held = {}, None, []
+    if rank == 0 and not args.no_extras:
+        # (1) the metric's second half, "max |dq| vs reference", and a REAL-data rate: the 871 systems of the reference's
+        #     recorded validation split (tests/golden/mixed_val.tar.gz, 3..38 atoms, N = 41) against the TensorFlow
+        #     predictions the reference stored for them (models/model_systems/test_pred_charges.npy); its rate is (4)
+        try:
+            import tarfile
+            import tempfile
+            from epnn_amd import charge_gn
+            gdir = os.path.join(ROOT, "tests", "golden")
+            names = [str(nm) for nm in np.load(os.path.join(gdir, "val_names.npy"), allow_pickle=True)]
+            gold = np.load(os.path.join(gdir, "test_pred_charges.npy"))
+            with tempfile.TemporaryDirectory() as tmp:
+                with tarfile.open(os.path.join(gdir, "mixed_val.tar.gz")) as tf:
+                    tf.extractall(tmp)
+                mols = [charge_gn.read_xyz(os.path.join(tmp, "mixed_val", nm + ".xyz"), 9) for nm in names]
+            v_off = np.zeros(len(mols) + 1, np.int32)
+            v_off[1:] = np.cumsum([len(m[1]) for m in mols])
+            v_xyz, v_x = np.concatenate([m[0] for m in mols]), np.concatenate([m[1] for m in mols])
+            v_Q = np.array([m[2] for m in mols], np.float32)
+            vq = pipe.engines[0].forward_xyz(v_off, v_xyz, v_x, v_Q, 41)
+            dq = max(float(np.abs(vq[v_off[i]:v_off[i + 1]] - gold[i, :v_off[i + 1] - v_off[i]]).max()) for i in range(len(mols)))
+            drift = float(np.abs(np.add.reduceat(vq.astype(np.float64), v_off[:-1]) - v_Q).max())
+            extras["parity"] = {"max_abs_dq_vs_reference": dq, "tolerance": 1e-5, "max_abs_total_charge_error": drift,
+                                "systems": len(mols), "atoms": int(v_off[-1]),
+                                "reference": "TensorFlow predictions stored by the reference for its validation split "
+                                             "(models/model_systems/test_pred_charges.npy, decay_model_weights, N = 41)"}
+            real = (v_off, v_xyz, v_x, v_Q)
+            assert dq <= 1e-5, dq
+        except (OSError, KeyError) as exc:                  # fixtures missing: the synthetic figures stand alone
+            print(f"[bench] real-data / parity extras skipped: {exc}", file=sys.stderr)
+
+    barrier()
+    if not args.no_extras:
+        # (2) a launch with the GPU to itself: 64 copies of the batch in ONE launch (65536 molecules), one handle, hipEvents
+        #     around each launch: algorithmic flops / duration is that kernel's rate with nothing else on the machine
+        rep = max(1, 65536 // B)
+        big_off = np.concatenate([[0]] + [offsets[1:] + r * A for r in range(rep)]).astype(np.int32)
+        e0 = pipe.engines[0]
+        big = [e0.to_device(np.tile(a, (rep,) + (1,) * (a.ndim - 1))) for a in (xyz, x, Q)]
+        big_q = e0.alloc(A * rep * 4)
+        for _ in range(2):
+            e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
+        e0.sync()
+        nbig = 10
+        e0.set_option("profile", nbig)
+        for _ in range(nbig):
+            e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
+        e0.sync()
+        big_ms = float(np.mean([e0.timing_at(i)[1] for i in range(nbig)]))
+        e0.set_option("profile", 0)
+        # Two further launches of the same batch keep the GPU under load while the warm-up steps are queued, and nothing that
+        # idles it (hipFree, the download of the big result) happens before the timed region: see the note on clocks above.
+        for _ in range(2):
+            e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
+        held = big + [big_q]
+
     for k in range(max(args.warmup, len(lanes))):
         step(k)
     pipe.sync()
+    if args.sleep_ms > 0:
+        time.sleep(args.sleep_ms * 1e-3)
+    elif args.sleep_ms < 0:                                  # busy wait: CPU stays hot, GPU idles
+        t_end = time.perf_counter() - args.sleep_ms * 1e-3
+        while time.perf_counter() < t_end:
+            pass
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -314,50 +404,25 @@ def main():
         per_rank = [(dt, float(A))]
         dt_max, atoms_total = dt, float(A)
 
-    eng, d_q = lanes[0][0], lanes[0][4]
-    q = d_q.download((A,))
-    stats = eng.last_stats()
-    # sanity inside the bench: charges finite and every molecule's total charge conserved (the batch itself is compared
-    # with the float64 oracle in tests/test_gpu_parity.py::test_bench_batch_vs_oracle)
-    assert np.isfinite(q).all()
-    sums = np.add.reduceat(q.astype(np.float64), offsets[:-1])
-    assert np.abs(sums - Q).max() < 1e-4, np.abs(sums - Q).max()
-    ns = np.diff(offsets)
-    flops = synth.algorithmic_flops(ns, int(stats[0]))
-
-    extras = {}
-    if rank == 0 and not args.no_extras:
-        # (1) a launch with the GPU to itself: 64 copies of the batch in ONE launch (65536 molecules), one handle, hipEvents
-        #     around each launch: algorithmic flops / duration is that kernel's rate with nothing else on the machine
-        rep = max(1, 65536 // B)
-        big_off = np.concatenate([[0]] + [offsets[1:] + r * A for r in range(rep)]).astype(np.int32)
-        e0 = pipe.engines[0]
-        big = [e0.to_device(np.tile(a, (rep,) + (1,) * (a.ndim - 1))) for a in (xyz, x, Q)]
-        big_q = e0.alloc(A * rep * 4)
-        for _ in range(2):
-            e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
-        e0.sync()
-        nbig = 10
-        e0.set_option("profile", nbig)
-        for _ in range(nbig):
-            e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
-        e0.sync()
-        big_ms = float(np.mean([e0.timing_at(i)[1] for i in range(nbig)]))
-        e0.set_option("profile", 0)
-        qb = big_q.download((A * rep,))
+    if held:
+        qb = held[3].download((A * rep,))
         assert np.array_equal(qb[:A], q) and np.array_equal(qb[-A:], q)          # batch composition does not change the bits
-        for d in big + [big_q]:
+        for d in held:
             d.free()
         extras["single_launch"] = {"molecules": B * rep, "launches": nbig, "kernel_ms_avg": big_ms,
                                    "algorithmic_gflop_per_launch": flops * rep / 1e9,
                                    "achieved": flops * rep / (big_ms * 1e-3) / 1e12,
                                    "frac": flops * rep / (big_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                    "atoms_per_s": A * rep / (big_ms * 1e-3)}
-        # (2) host to host: Pipeline.map on host arrays, a different batch every call (new plan, PCIe both ways)
+    q_after = d_q.download((A,))
+    assert np.array_equal(q_after, q)                       # the timed steps produced the charges that were checked
+
+    if rank == 0 and not args.no_extras:
+        # (3) host to host: Pipeline.map on host arrays, a different batch every call (new plan, PCIe both ways)
         batches = [synth.qm9_like_batch(B=B, seed=1000 + s, N=29)[:4] for s in range(8)]
         ncall = 240
         stream = [batches[k % len(batches)] for k in range(ncall)]
-        for _ in pipe.map(stream[:2 * len(lanes)], N):
+        for _ in pipe.map(stream[:120], N):              # ~20 ms of load first (clocks), whatever ran before
             pass
         t1 = time.perf_counter()
         h_atoms = sum(qq.shape[0] for qq in pipe.map(stream, N))
@@ -366,54 +431,27 @@ def main():
                                   "what": "Pipeline.map (epnn_forward_xyz_begin/_end): host xyz/x/Q -> host q, a different "
                                           f"batch of {B} molecules every call, {len(lanes)} in flight; PCIe inclusive, not `value`"}
 
-    if rank == 0 and not args.no_extras:
-        # (3) the metric's second half, "max |dq| vs reference", and a REAL-data rate: the 871 systems of the reference's
-        #     recorded validation split (tests/golden/mixed_val.tar.gz, 3..38 atoms, N = 41) against the TensorFlow
-        #     predictions the reference stored for them (models/model_systems/test_pred_charges.npy), then the same batch
-        #     device-resident through every lane of the pipeline
-        try:
-            import tarfile
-            import tempfile
-            from epnn_amd import charge_gn
-            gdir = os.path.join(ROOT, "tests", "golden")
-            names = [str(nm) for nm in np.load(os.path.join(gdir, "val_names.npy"), allow_pickle=True)]
-            gold = np.load(os.path.join(gdir, "test_pred_charges.npy"))
-            with tempfile.TemporaryDirectory() as tmp:
-                with tarfile.open(os.path.join(gdir, "mixed_val.tar.gz")) as tf:
-                    tf.extractall(tmp)
-                mols = [charge_gn.read_xyz(os.path.join(tmp, "mixed_val", nm + ".xyz"), 9) for nm in names]
-            v_off = np.zeros(len(mols) + 1, np.int32)
-            v_off[1:] = np.cumsum([len(m[1]) for m in mols])
-            v_xyz, v_x = np.concatenate([m[0] for m in mols]), np.concatenate([m[1] for m in mols])
-            v_Q = np.array([m[2] for m in mols], np.float32)
-            vq = pipe.engines[0].forward_xyz(v_off, v_xyz, v_x, v_Q, 41)
-            dq = max(float(np.abs(vq[v_off[i]:v_off[i + 1]] - gold[i, :v_off[i + 1] - v_off[i]]).max()) for i in range(len(mols)))
-            drift = float(np.abs(np.add.reduceat(vq.astype(np.float64), v_off[:-1]) - v_Q).max())
-            vl = [(e, e.to_device(v_xyz), e.to_device(v_x), e.to_device(v_Q), e.alloc(int(v_off[-1]) * 4)) for e in pipe.engines]
-            for k in range(2 * len(vl)):
-                e, a_, b_, c_, d_ = vl[k % len(vl)]
-                e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
-            pipe.sync()
-            nrep = 25 * len(vl)
-            t1 = time.perf_counter()
-            for k in range(nrep):
-                e, a_, b_, c_, d_ = vl[k % len(vl)]
-                e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
-            pipe.sync()
-            v_dt = (time.perf_counter() - t1) / nrep
-            for lane in vl:
-                for d in lane[1:]:
-                    d.free()
-            extras["parity"] = {"max_abs_dq_vs_reference": dq, "tolerance": 1e-5, "max_abs_total_charge_error": drift,
-                                "systems": len(mols), "atoms": int(v_off[-1]),
-                                "reference": "TensorFlow predictions stored by the reference for its validation split "
-                                             "(models/model_systems/test_pred_charges.npy, decay_model_weights, N = 41)"}
-            extras["real_data"] = {"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
-                                   "workload": f"the reference's {len(mols)}-system validation split of `mixed` (3..38 atoms, "
-                                               f"{int(v_off[-1])} atoms), N = 41, device-resident, {len(vl)} batches in flight"}
-            assert dq <= 1e-5, dq
-        except (OSError, KeyError) as exc:                  # fixtures missing: the synthetic figures stand alone
-            print(f"[bench] real-data / parity extras skipped: {exc}", file=sys.stderr)
+    if real is not None:
+        # (4) the real-data rate: the validation batch of (1), device-resident, through every lane of the pipeline
+        v_off, v_xyz, v_x, v_Q = real
+        vl = [(e, e.to_device(v_xyz), e.to_device(v_x), e.to_device(v_Q), e.alloc(int(v_off[-1]) * 4)) for e in pipe.engines]
+        for k in range(30 * len(vl)):                       # ~20 ms of load first (clocks)
+            e, a_, b_, c_, d_ = vl[k % len(vl)]
+            e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
+        pipe.sync()
+        nrep = 25 * len(vl)
+        t1 = time.perf_counter()
+        for k in range(nrep):
+            e, a_, b_, c_, d_ = vl[k % len(vl)]
+            e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
+        pipe.sync()
+        v_dt = (time.perf_counter() - t1) / nrep
+        for lane in vl:
+            for d in lane[1:]:
+                d.free()
+        extras["real_data"] = {"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
+                               "workload": f"the reference's {len(mols)}-system validation split of `mixed` (3..38 atoms, "
+                                           f"{int(v_off[-1])} atoms), N = 41, device-resident, {len(vl)} batches in flight"}
 
     if rank == 0:
         k_ms = float(stage[:, 1].mean())                   # duration of one launch (hipEvents on its stream)
@@ -461,6 +499,9 @@ def main():
                        "weights": "decay_model_weights", "parallelism": f"molecule-sharded x{world}",
                        "batches_in_flight_per_gpu": len(lanes)},
             "roofline": roof,
+            "order": ("one forward + checks, " + ("" if args.no_extras else "parity on the reference's stored outputs, single-launch measurement (+2 launches of it unmeasured, no idle gap), ")
+                      + f"{max(args.warmup, len(lanes))} warm-up steps, {args.steps} timed steps, the same steps again with hipEvents"
+                      + ("" if args.no_extras else ", host-to-host, real-data rate")),
         }
         if world > 1:
             out["ranks"] = {"world_size": world, "timing_backend": backend,

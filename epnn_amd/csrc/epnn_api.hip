@@ -610,8 +610,6 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
             std::reverse(sorted.begin(), sorted.end());
         }
         P.small_order.swap(sorted);
-        P.small_nbig = 0;
-        for (int n = EPNN_SMALL_NMAX; n > 16; --n) P.small_nbig += count[n];
         for (size_t k = 0; k < P.small_order.size(); ++k) {
             const int b = P.small_order[k];
             c_wblk[k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
@@ -743,22 +741,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         HIPCHK(hipGetLastError());
         if (P.small_order.empty()) return 0;
     }
-    const int nbig = P.small_nbig, nsmall = (int)P.small_order.size() - nbig;
-    if (S.d_xyz && h->opt_wave_split && nbig > 0 && nsmall > 0) {
-        // two launches side by side: the one-column-block variant (n <= 16; 13 KB of LDS, three wavefronts per SIMD) on the
-        // second stream, the others here; both depend only on what is already queued on this stream
-        WaveArgs As = A;
-        As.wblk = A.wblk + nbig;
-        const int lds_s = std::min(lds, 13312) & ~15;
-        As.lds_words = lds_s / 4;
-        HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        hipLaunchKernelGGL((k_wave_forward<true, true, true, false>), dim3((unsigned)nsmall), dim3(64), (size_t)lds_s, h->stream2, As, X);
-        HIPCHK(hipEventRecord(h->ev_join, h->stream2));
-        hipLaunchKernelGGL((k_wave_forward<true, true, true, true>), dim3((unsigned)nbig), dim3(64), (size_t)lds, h->stream, A, X);
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    }
-    else if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+    if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else hipLaunchKernelGGL((k_wave_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
@@ -1097,7 +1080,6 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave3")) { h->opt_wave3 = value; h->plan.valid = false; }
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
-    else if (!strcmp(name, "wave_split")) { h->opt_wave_split = value; }
     else if (!strcmp(name, "wave_order")) { h->opt_wave_order = value; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }

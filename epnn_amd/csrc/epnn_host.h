@@ -85,7 +85,6 @@ struct Plan {                 // what the host derives from `offsets`
     bool allow_mid = false;
     std::vector<int> large_list;    // molecules on the tiled path
     int small_nmax = 0;
-    int small_nbig = 0;             // how many of small_order (sorted largest first) have more than 16 atoms
     int pair_slots = 0;             // sum of n(n-1)/2 over the small molecules (capacity of the in-kernel front-end)
     bool valid = false;
 };
@@ -132,9 +131,6 @@ struct epnn_handle {
     int opt_wave3 = 1;                // molecules of 33..48 atoms take the three-block fused kernel (0: the tiled kernels)
     bool wave3_attr = false;
     int opt_wave_order = 0;           // order of a launch's wavefronts: 0 largest molecule first, 1 ends interleaved, 2 smallest first
-    int opt_wave_split = 0;           // fused kernel with its own front-end: molecules of <= 16 atoms run as a one-column-block variant at
-                                      // three wavefronts per SIMD (168 registers, 13 KB LDS), beside the others, on the second stream.
-                                      // Measured SLOWER (196.6 vs 206.5 M atoms/s: 12 spilled registers, more G rows in HBM): off
     int opt_large_fused = 1;          // tiled path: one launch between two sweeps / pair passes (0: one kernel per stage)
     int opt_wave_prio = 18;           // fused kernel: molecules with >= this many atoms run at raised wave priority (0: off);
                                       // measured on the QM9-sized batch: 211 M atoms/s with 18 or 20, 206-208 M with 0 / 25 / 28

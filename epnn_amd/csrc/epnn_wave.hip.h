@@ -167,10 +167,8 @@ __device__ __forceinline__ void w16_feed(const f32x4 (&a)[2], float (&in)[8]) {
     for (int s = 0; s < 8; ++s) in[s] = a[s >> 2][s & 3];
 }
 
-// TWOB = false: the variant for molecules of at most 16 atoms -- one column block, so every register of the second block is
-// gone (~150 instead of 233) and three wavefronts fit a SIMD.  The same code: `two` is then false at compile time.
-template <bool GNN, bool EPN, bool FRONT, bool TWOB = true>
-__global__ __launch_bounds__(64, TWOB ? EPNN_WAVES_PER_SIMD : 3) void k_wave_forward(WaveArgs A, WaveIndex X) {
+template <bool GNN, bool EPN, bool FRONT>
+__global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveArgs A, WaveIndex X) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, q = lane >> 4, n16 = lane & 15;
     const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(64, TWOB ? EPNN_WAVES_PER_SIMD : 3) void k_wave_for
     // Column block 0 holds atoms 0..15.  Block 1 holds the m = n - 16 atoms beyond them, C = 16 / m COPIES of each (column
     // n16 = atom 16 + n16 % m, copy n16 / m): every per-atom chain computes all 16 columns anyway, so the copies come for
     // free, and the pair sweep gives each copy a different partner -- block 1 is done after (n + 1) / C tiles instead of n + 1.
-    const bool two = TWOB && n > 16;
+    const bool two = n > 16;
     const int m1 = two ? n - 16 : 16, C1 = 16 / m1;
     const int copy1 = n16 / m1;
     const int col1 = 16 + n16 % m1;
