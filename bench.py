@@ -446,10 +446,13 @@ def main():
             e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
         pipe.sync()
         v_dt = (time.perf_counter() - t1) / nrep
+        v_flops = synth.algorithmic_flops(np.diff(v_off), int(vl[0][0].last_stats()[0]))
         for lane in vl:
             for d in lane[1:]:
                 d.free()
         extras["real_data"] = {"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
+                               "algorithmic_gflop_per_batch": v_flops / 1e9,
+                               "frac": v_flops / v_dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                "workload": f"the reference's {len(mols)}-system validation split of `mixed` (3..38 atoms, "
                                            f"{int(v_off[-1])} atoms), N = 41, device-resident, {len(vl)} batches in flight"}
 
