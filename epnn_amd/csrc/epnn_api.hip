@@ -45,6 +45,8 @@ static void shape_layers(epnn_handle *h) {
 }
 
 static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, std::vector<double> &Bout, std::vector<float> &tab);
+static int create_resources(epnn_handle *h);
+extern "C" int epnn_destroy(epnn_handle *h);
 
 extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out) {
     if (!cfg || !out) EPNN_FAIL("epnn_create: null argument");
@@ -65,6 +67,17 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
     epnn_handle *h = new epnn_handle();
     h->cfg = *cfg;
     h->device = device;
+    if (create_resources(h)) {                   // the message is set; nothing of a half-built handle stays behind
+        const std::string why = g_epnn_err;
+        epnn_destroy(h);
+        g_epnn_err = why;
+        return 1;
+    }
+    *out = h;
+    return 0;
+}
+static int create_resources(epnn_handle *h) {
+    const epnn_config *cfg = &h->cfg;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -106,14 +119,13 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
         }
         h->dsafe = lo;
     }
-    *out = h;
     return 0;
 }
 
 extern "C" int epnn_destroy(epnn_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_mu_ex, &h->d_moff, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
@@ -132,17 +144,17 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     }
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->h_status) (void)hipHostFree(h->h_status);
-    (void)hipEventDestroy(h->ev_t0);
+    if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_ctl) (void)hipEventDestroy(h->ev_ctl);
     h->pin_ctl.release();
     h->pin_in.release();
     h->pin_out.release();
-    (void)hipEventDestroy(h->ev_t1);
+    if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(h->ev_fork);
-    (void)hipEventDestroy(h->ev_join);
-    (void)hipStreamDestroy(h->stream2);
-    (void)hipStreamDestroy(h->stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
@@ -547,6 +559,11 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         return 0;
     if (B < 1) EPNN_FAIL("forward: batch must have at least one molecule");
     if (offsets[0] != 0) EPNN_FAIL("forward: offsets[0] must be 0");
+    for (int b = 0; b < B; ++b) {                   // before anything is sized by offsets[B] or indexed by an offset
+        const long long n = (long long)offsets[b + 1] - (long long)offsets[b];
+        if (n < 1) EPNN_FAIL("forward: molecule %d has %lld atoms", b, n);
+        if (n > N) EPNN_FAIL("forward: molecule %d has %lld atoms but the padded size N is %d", b, n, N);
+    }
     P.valid = false;
     P.B = B;
     P.N = N;
@@ -572,8 +589,6 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     const bool wave_ok = h->cfg.nx + 3 <= 4 * EPNN_XS;       // the fused kernel's xq block holds nx + 3 inputs
     for (int b = 0; b < B; ++b) {
         const int n = offsets[b + 1] - offsets[b];
-        if (n < 1) EPNN_FAIL("forward: molecule %d has %d atoms", b, n);
-        if (n > N) EPNN_FAIL("forward: molecule %d has %d atoms but the padded size N is %d", b, n, N);
         for (int a = offsets[b]; a < offsets[b + 1]; ++a) c_molof[a] = b;
         const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))

@@ -229,6 +229,13 @@ def test_error_behaviour_at_the_boundary(weights_decay):
         eng.forward_xyz(bad, xyz, x, Q, N)                          # offsets must start at 0
     with pytest.raises(EpnnError, match="shapes"):
         eng.forward_xyz(offsets, xyz[:-1], x, Q, N)                 # arrays do not match the offsets
+    bad = offsets.copy()
+    bad[3], bad[4] = offsets[4], offsets[3]                         # not ascending: refused before any buffer is sized or
+    with pytest.raises(EpnnError, match="atoms"):                   # indexed by an offset
+        eng.forward_xyz(bad, xyz, x, Q, N)
+    d = [eng.to_device(a) for a in (xyz, x, Q)] + [eng.alloc(int(offsets[-1]) * 4)]
+    with pytest.raises(EpnnError, match="atoms"):
+        eng.forward_xyz_dev(bad, d[0], d[1], d[2], d[3], N)
     with pytest.raises(EpnnError, match="unknown option"):
         eng.set_option("no_such_option", 1)
     eng.forward_xyz_begin(offsets, xyz, x, Q, N)
