@@ -419,7 +419,11 @@ def main():
 
     if rank == 0 and not args.no_extras:
         # (3) host to host: Pipeline.map on host arrays, a different batch every call (new plan, PCIe both ways)
-        batches = [synth.qm9_like_batch(B=B, seed=1000 + s, N=29)[:4] for s in range(8)]
+        # the number of distinct batches shares no factor with the depth, so every lane really sees a different batch (and
+        # builds a new plan) on every call; with 8 batches on 8 lanes each lane would keep meeting the same one
+        import math
+        nb = next(n for n in range(7, 40) if math.gcd(n, len(lanes)) == 1)
+        batches = [synth.qm9_like_batch(B=B, seed=1000 + s, N=29)[:4] for s in range(nb)]
         ncall = 240
         stream = [batches[k % len(batches)] for k in range(ncall)]
         for _ in pipe.map(stream[:120], N):              # ~20 ms of load first (clocks), whatever ran before
@@ -429,7 +433,7 @@ def main():
         h_dt = time.perf_counter() - t1
         extras["host_to_host"] = {"value": h_atoms / h_dt, "unit": "atoms/s", "ms_per_batch": h_dt / ncall * 1e3, "calls": ncall,
                                   "what": "Pipeline.map (epnn_forward_xyz_begin/_end): host xyz/x/Q -> host q, a different "
-                                          f"batch of {B} molecules every call, {len(lanes)} in flight; PCIe inclusive, not `value`"}
+                                          f"batch of {B} molecules (a new plan) every call on every lane, {len(lanes)} in flight; PCIe inclusive, not `value`"}
 
     if real is not None:
         # (4) the real-data rate: the validation batch of (1), device-resident, through every lane of the pipeline

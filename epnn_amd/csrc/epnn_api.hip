@@ -147,7 +147,6 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_ctl) (void)hipEventDestroy(h->ev_ctl);
     h->pin_ctl.release();
-    h->pin_in.release();
     h->pin_out.release();
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
@@ -551,11 +550,18 @@ static int pack_weights(epnn_handle *h) {
 
 // ------------------------------------------------------------------------------------------------ plan
 // allow_mid: molecules of 33..48 atoms may take the three-block fused kernel (compact entry with its in-kernel front-end only)
-static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false) {
+// payload_bytes / ctl_fresh (host entry): room for the call's inputs behind the index arrays, in the page-locked staging and
+// in its device mirror alike, so that ONE host-to-device copy carries everything a forward needs (plan_payload_offset);
+// with ctl_fresh given, the upload of freshly built index arrays is left to the caller, who sends them with the payload.
+static size_t plan_payload_offset(int B, int A) { return (((size_t)6 * B + 1 + A) * sizeof(int) + 255) & ~size_t(255); }
+static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
+                      bool *ctl_fresh = nullptr) {
     Plan &P = h->plan;
     allow_mid = allow_mid && h->opt_wave3 && h->opt_force_path == 0;
+    if (ctl_fresh) *ctl_fresh = false;
     if (P.valid && P.B == B && P.N == N && P.allow_mid == allow_mid && (int)P.offsets.size() == B + 1 &&
-        memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0)
+        memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0 &&
+        (payload_bytes == 0 || plan_payload_offset(B, P.A) + payload_bytes <= std::min(h->d_ctl.cap, h->pin_ctl.cap)))
         return 0;
     if (B < 1) EPNN_FAIL("forward: batch must have at least one molecule");
     if (offsets[0] != 0) EPNN_FAIL("forward: offsets[0] must be 0");
@@ -580,7 +586,8 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         HIPCHK(hipEventSynchronize(h->ev_ctl));
         h->ctl_uploading = false;
     }
-    if (h->pin_ctl.ensure(((size_t)6 * B + 1 + P.A) * sizeof(int))) return 1;
+    const size_t ctl_total = plan_payload_offset(B, P.A) + payload_bytes;
+    if (h->pin_ctl.ensure(ctl_total)) return 1;
     int4 *c_wblk = h->pin_ctl.as<int4>();
     int *c_moff = h->pin_ctl.as<int>() + 4 * (size_t)B, *c_mflag = c_moff + B + 1, *c_molof = c_mflag + B;
     std::vector<int> pbase(B);
@@ -638,16 +645,20 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     }
     // the device copy has the same layout: ONE upload per plan
     const size_t ctl_ints = (size_t)6 * B + 1 + P.A;
-    if (h->d_ctl.ensure(ctl_ints * sizeof(int)) || h->d_rowcnt.ensure((P.A + 1) * sizeof(int)) ||
+    if (h->d_ctl.ensure(ctl_total) || h->d_rowcnt.ensure((P.A + 1) * sizeof(int)) ||
         h->d_rowoff.ensure((P.A + 1) * sizeof(int)))
         return 1;
     h->p_wblk = h->d_ctl.as<int4>();
     h->p_moff = h->d_ctl.as<int>() + 4 * (size_t)B;
     h->p_mflag = h->p_moff + B + 1;
     h->p_molof = h->p_mflag + B;
-    HIPCHK(hipMemcpyAsync(h->d_ctl.p, h->pin_ctl.p, ctl_ints * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->ev_ctl, h->stream));
-    h->ctl_uploading = true;
+    if (ctl_fresh) {
+        *ctl_fresh = true;                          // the caller uploads index arrays + payload in one copy
+    } else {
+        HIPCHK(hipMemcpyAsync(h->d_ctl.p, h->pin_ctl.p, ctl_ints * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipEventRecord(h->ev_ctl, h->stream));
+        h->ctl_uploading = true;
+    }
     if (large_plan(h)) return 1;
     P.valid = true;
     return 0;
@@ -804,11 +815,12 @@ static int run_frontend_xyz(epnn_handle *h, const float *d_xyz) {
     return 0;
 }
 
+static bool wave_front_ok(const epnn_handle *h) { return h->opt_wave_front && h->cfg.e_dim == EPNN_EDIM && h->edge_res < 1e-8; }
 static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offsets, const float *d_xyz,
                                const float *d_x, const float *d_Q, float *d_q) {
     HIPCHK(hipSetDevice(h->device));
     if (pack_weights(h)) return 1;
-    const bool front_ok = h->opt_wave_front && h->cfg.e_dim == EPNN_EDIM && h->edge_res < 1e-8;
+    const bool front_ok = wave_front_ok(h);
     if (build_plan(h, B, N, offsets, front_ok)) return 1;
     const Plan &P = h->plan;
     // Small molecules (fused kernel): the wavefront builds its molecule's pair list itself (slots for every i<j pair, so
@@ -928,24 +940,37 @@ extern "C" int epnn_forward_xyz_begin(epnn_handle *h, int B, int N, const int32_
     if (A < 1) EPNN_FAIL("epnn_forward_xyz: no atoms");
     const int nx = h->cfg.nx;
     if (h->pending.active && finish_forward(h)) return 1;
+    auto up256 = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
     const size_t n_xyz = (size_t)A * 3, n_x = (size_t)A * nx;
-    if (h->s_xyz.ensure(n_xyz * 4) || h->s_x.ensure(n_x * 4) || h->s_Q.ensure((size_t)B * 4) ||
-        h->pin_in.ensure((n_xyz + n_x + (size_t)B) * 4) || h->pin_out.ensure((size_t)A * 4))
-        return 1;
-    float *p_xyz = h->pin_in.as<float>(), *p_x = p_xyz + n_xyz, *p_Q = p_x + n_x;
-    memcpy(p_xyz, xyz, n_xyz * 4);
-    memcpy(p_x, x, n_x * 4);
-    memcpy(p_Q, Q, (size_t)B * 4);
-    HIPCHK(hipMemcpyAsync(h->s_xyz.p, p_xyz, n_xyz * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->s_x.p, p_x, n_x * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->s_Q.p, p_Q, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
+    const size_t o_x = up256(n_xyz * 4), o_Q = o_x + up256(n_x * 4), in_bytes = o_Q + (size_t)B * 4;
+    // ONE host-to-device copy per forward: the inputs are staged behind the plan's index arrays in the same page-locked
+    // buffer, whose device mirror has the same layout.  (Separate copies for xyz, x, Q and the index arrays kept the copy
+    // engine busy 73 us per batch of 1024 molecules -- of the 86 us the GPU needs for it -- and the kernels of different
+    // handles then started one after the other: 2.9 launches in flight instead of 8.)
+    bool fresh = false;
+    if (build_plan(h, B, N, offsets, wave_front_ok(h), in_bytes, &fresh)) return 1;
+    if (h->pin_out.ensure((size_t)A * 4)) return 1;
+    const size_t off = plan_payload_offset(B, A);
+    if (h->ctl_uploading) {                         // (a cached plan: build_plan did not wait for the staging's last upload)
+        HIPCHK(hipEventSynchronize(h->ev_ctl));
+        h->ctl_uploading = false;
+    }
+    char *stage = h->pin_ctl.as<char>() + off;
+    memcpy(stage, xyz, n_xyz * 4);
+    memcpy(stage + o_x, x, n_x * 4);
+    memcpy(stage + o_Q, Q, (size_t)B * 4);
+    const size_t from = fresh ? 0 : off;
+    HIPCHK(hipMemcpyAsync(h->d_ctl.as<char>() + from, h->pin_ctl.as<char>() + from, off + in_bytes - from, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_ctl, h->stream));
+    h->ctl_uploading = true;
+    const char *dev = h->d_ctl.as<char>() + off;
+    const float *d_xyz = reinterpret_cast<const float *>(dev), *d_x = reinterpret_cast<const float *>(dev + o_x),
+                *d_Q = reinterpret_cast<const float *>(dev + o_Q);
     // The charges are written by the kernels straight into the page-locked result buffer (device-visible host memory):
     // no device-to-host copy is queued.  With one, the copy engine's queue holds "results of batch k" (which waits for
     // kernel k) in front of "inputs of batch k+1", and the kernels of different handles run one after the other instead
     // of side by side (kernel trace: 0.75 instead of 4.2 kernels in flight).
-    if (epnn_forward_xyz_dev(h, B, N, offsets, h->s_xyz.as<float>(), h->s_x.as<float>(), h->s_Q.as<float>(),
-                             h->pin_out.as<float>()))
-        return 1;
+    if (epnn_forward_xyz_dev(h, B, N, offsets, d_xyz, d_x, d_Q, h->pin_out.as<float>())) return 1;
     h->hostcall.active = true;
     h->hostcall.A = A;
     return 0;
@@ -1239,11 +1264,9 @@ static int dense_dev(epnn_handle *h, int B, int N, int mode, const float *d_h, c
                      const float *d_q, const float *d_mask, float *d_out) {
     if (!h || !d_h || !d_e || !d_x || !d_q || !d_mask || !d_out) EPNN_FAIL("dense forward: null argument");
     if (h->pending.active && finish_forward(h)) return 1;
-    const int saved_force = h->opt_force_path;
     if (enqueue_dense(h, B, N, mode, d_h, d_e, d_x, d_q, d_mask, d_out)) return 1;
     h->pending.active = true;
     h->pending.redo = [=]() { return enqueue_dense(h, B, N, mode, d_h, d_e, d_x, d_q, d_mask, d_out); };
-    (void)saved_force;
     return 0;
 }
 
@@ -1476,6 +1499,7 @@ extern "C" int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *
                                      const float *q_inp, const float *mask_inp, const float *y, float *pred_out,
                                      float *loss_out, int apply) {
     if (!h || !h_inp || !e_inp || !x_inp || !q_inp || !mask_inp || !y) EPNN_FAIL("epnn_train_step_dense: null argument");
+    if (B < 1 || N < 1) EPNN_FAIL("epnn_train_step_dense: B and N must be positive");
     HIPCHK(hipSetDevice(h->device));
     if (h->pending.active && finish_forward(h)) return 1;
     const int nx = h->cfg.nx;
@@ -1507,6 +1531,7 @@ extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *
     if (!h || !offsets || !xyz || !x || !Q || !y_flat) EPNN_FAIL("epnn_train_step_xyz: null argument");
     HIPCHK(hipSetDevice(h->device));
     if (h->pending.active && finish_forward(h)) return 1;
+    if (B < 1 || N < 1 || offsets[0] != 0) EPNN_FAIL("epnn_train_step_xyz: B and N must be positive and offsets[0] must be 0");
     const int nx = h->cfg.nx, A = offsets[B];
     for (int b = 0; b < B; ++b)
         if (offsets[b + 1] - offsets[b] > N || offsets[b + 1] - offsets[b] < 1) EPNN_FAIL("epnn_train_step_xyz: molecule %d does not fit N=%d", b, N);

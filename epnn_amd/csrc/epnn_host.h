@@ -154,9 +154,9 @@ struct epnn_handle {
     int opt_profile = 0, opt_force_path = 0;
     float timing[4] = {0, 0, 0, 0};
     int64_t stats[4] = {0, 0, 0, 0};
-    // page-locked staging: the plan's index arrays (reused once ev_ctl says the previous upload has run), and the
-    // inputs / charges of the asynchronous host entry (epnn_forward_xyz_begin / _end)
-    PinBuf pin_ctl, pin_in, pin_out;
+    // page-locked staging: the plan's index arrays with, behind them, the inputs of the host entry (one upload per forward;
+    // reused once ev_ctl says the previous upload has run); the charges of the asynchronous host entry
+    PinBuf pin_ctl, pin_out;
     hipEvent_t ev_ctl = nullptr;
     bool ctl_uploading = false;
     struct HostCall {
