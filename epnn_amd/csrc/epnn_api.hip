@@ -126,9 +126,9 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_mu_ex, &h->d_moff, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
+    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_mu_ex, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
-                      &h->s_x, &h->s_Q, &h->s_q, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
+                      &h->s_train, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_csr_ent2, &h->l_cnt, &h->l_nm,
                       &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
@@ -147,6 +147,8 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_ctl) (void)hipEventDestroy(h->ev_ctl);
     h->pin_ctl.release();
+    h->pin_train.release();
+    h->pin_tout.release();
     h->pin_out.release();
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
@@ -1481,13 +1483,16 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
         if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss)) return 1;
     }
     if (apply && train_apply(h)) return 1;
-    if (pred_host) HIPCHK(hipMemcpyAsync(pred_host, d_pred, (size_t)B * N * 4, hipMemcpyDeviceToHost, h->stream));
-    std::vector<float> lb(B);
-    HIPCHK(hipMemcpyAsync(lb.data(), d_loss, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    // the step's loss terms and predictions are neighbours on the device: one download into page-locked memory
+    const size_t nback = (size_t)B + (pred_host ? (size_t)B * N : 0);
+    if (h->pin_tout.ensure(nback * 4)) return 1;
+    HIPCHK(hipMemcpyAsync(h->pin_tout.p, d_loss, nback * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    const float *back = h->pin_tout.as<float>();
+    if (pred_host) memcpy(pred_host, back + B, (size_t)B * N * 4);
     if (loss_host) {
         double s = 0;
-        for (float v : lb) s += v;
+        for (int b = 0; b < B; ++b) s += back[b];
         *loss_host = (float)s;
     }
     return 0;
@@ -1536,20 +1541,27 @@ extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *
     for (int b = 0; b < B; ++b)
         if (offsets[b + 1] - offsets[b] > N || offsets[b + 1] - offsets[b] < 1) EPNN_FAIL("epnn_train_step_xyz: molecule %d does not fit N=%d", b, N);
     const size_t pairs = (size_t)B * N * N, slots = (size_t)B * N;
-    if (h->s_xyz.ensure((size_t)A * 3 * 4) || h->s_x.ensure((size_t)A * nx * 4) || h->s_Q.ensure((size_t)B * 4) ||
-        h->s_q.ensure((size_t)A * 4) || h->d_moff.ensure((size_t)(B + 1) * 4) || h->sd_e.ensure(pairs * EPNN_EDIM * 4) ||
+    // ONE upload per step: offsets | xyz | x | Q | y staged in page-locked memory, same layout on the device (five separate
+    // copies from pageable memory were ~50 us of a 0.5 ms step before its first kernel could start)
+    auto up256 = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+    const size_t o_xyz = up256((size_t)(B + 1) * 4), o_x = o_xyz + up256((size_t)A * 3 * 4), o_Q = o_x + up256((size_t)A * nx * 4),
+                 o_y = o_Q + up256((size_t)B * 4), in_bytes = o_y + (size_t)A * 4;
+    if (h->pin_train.ensure(in_bytes) || h->s_train.ensure(in_bytes) || h->sd_e.ensure(pairs * EPNN_EDIM * 4) ||
         h->sd_mask.ensure(pairs * 4) || h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) ||
         h->dn_qs.ensure(slots * 4) || h->sd_out.ensure(slots * 4))
         return 1;
-    h->plan.valid = false;                       // d_moff is shared with the inference plan
-    HIPCHK(hipMemcpyAsync(h->s_xyz.p, xyz, (size_t)A * 3 * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->s_x.p, x, (size_t)A * nx * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->s_Q.p, Q, (size_t)B * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->s_q.p, y_flat, (size_t)A * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_moff.p, offsets, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_t_pad_inputs, dim3(t_grid(pairs)), dim3(256), 0, h->stream, h->s_xyz.as<float>(), h->s_x.as<float>(),
-                       h->s_Q.as<float>(), h->s_q.as<float>(), h->d_moff.as<int>(), B, N, nx, h->cfg.e_dim, (double)h->cfg.cutoff,
-                       (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),
+    char *stage = h->pin_train.as<char>();
+    const char *dev = h->s_train.as<char>();
+    memcpy(stage, offsets, (size_t)(B + 1) * 4);             // (the previous step ended with a stream synchronisation)
+    memcpy(stage + o_xyz, xyz, (size_t)A * 3 * 4);
+    memcpy(stage + o_x, x, (size_t)A * nx * 4);
+    memcpy(stage + o_Q, Q, (size_t)B * 4);
+    memcpy(stage + o_y, y_flat, (size_t)A * 4);
+    HIPCHK(hipMemcpyAsync(h->s_train.p, stage, in_bytes, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_t_pad_inputs, dim3(t_grid(pairs)), dim3(256), 0, h->stream, reinterpret_cast<const float *>(dev + o_xyz),
+                       reinterpret_cast<const float *>(dev + o_x), reinterpret_cast<const float *>(dev + o_Q),
+                       reinterpret_cast<const float *>(dev + o_y), reinterpret_cast<const int *>(dev), B, N, nx, h->cfg.e_dim,
+                       (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),
                        h->dn_xs.as<float>(), h->dn_hs.as<float>(), h->dn_qs.as<float>(), h->sd_out.as<float>());
     HIPCHK(hipGetLastError());
     std::vector<float> pred(q_out_flat ? slots : 0);

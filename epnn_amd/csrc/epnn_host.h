@@ -113,20 +113,20 @@ struct epnn_handle {
     DevBuf d_ctl;                     // the plan's index arrays, one upload: wblk [B] int4 | moff [B+1] | mflag [B] | molof [A]
     int4 *p_wblk = nullptr;
     int *p_moff = nullptr, *p_mflag = nullptr, *p_molof = nullptr;
-    DevBuf d_moff;                    // molecule offsets of a train step (epnn_train_step_xyz)
     DevBuf d_rowcnt, d_rowoff, d_status, d_bsum;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     int pcap = 0;
     int pair_cap_per_atom = 16;
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
     // staging for the host-pointer entry points
-    DevBuf s_xyz, s_x, s_Q, s_q, s_misc, s_gx, s_pt;
+    DevBuf s_xyz, s_misc, s_gx, s_pt;
     double dsafe = 0.0;               // distance up to which every pair is a near pair (epnn_create)
     DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
     int opt_train_fused = 1;          // training: row-fused pair-MLP kernels (0: the layer-by-layer kernels)
-    int opt_train_graph = 1;          // training: replay the step's launch sequence as a hipGraph (0: launch kernel by kernel)
+    int opt_train_graph = 0;          // training: 1 replays the step's launch sequence as a hipGraph (frees the host thread; not faster:
+                                      // 0.47 vs 0.45 ms per step, the kernels are latency-bound, and a new buffer set means a new capture)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int opt_wave3 = 1;                // molecules of 33..48 atoms take the three-block fused kernel (0: the tiled kernels)
     bool wave3_attr = false;
@@ -157,6 +157,8 @@ struct epnn_handle {
     // page-locked staging: the plan's index arrays with, behind them, the inputs of the host entry (one upload per forward;
     // reused once ev_ctl says the previous upload has run); the charges of the asynchronous host entry
     PinBuf pin_ctl, pin_out;
+    PinBuf pin_train, pin_tout;       // inputs of epnn_train_step_xyz (one upload per step); loss terms + predictions of a train step
+    DevBuf s_train;
     hipEvent_t ev_ctl = nullptr;
     bool ctl_uploading = false;
     struct HostCall {

@@ -175,7 +175,7 @@ def test_adam_trajectory_matches_oracle(gpu_engine_factory):
 
 
 def test_graph_replay_equals_kernel_by_kernel(gpu_engine_factory):
-    """The train step replays its launch sequence as a hipGraph ("train_graph", default on): losses, predictions and the
+    """The train step replays its launch sequence as a hipGraph ("train_graph", an option): losses, predictions and the
     weights after five Adam steps must be bit-identical to launching kernel by kernel."""
     nx, T, N = 9, 2, 8
     w = random_weights(nx, T, seed=3, scale=0.5)
