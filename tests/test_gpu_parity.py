@@ -388,6 +388,17 @@ def test_pipeline_map_equals_one_call_at_a_time(weights_decay):
     eng = Engine(nx=9, T=5)
     with pytest.raises(Exception):
         eng.forward_xyz_end()
+    # One upload per forward: the host entry stages its inputs behind the plan's index arrays.  Every way the staging can
+    # meet a plan: built by the device-resident entry (no room for inputs yet) and then reused by the host entry with the
+    # same offsets; reused as it is (same batch again); rebuilt for a smaller and for a larger batch.
+    eng.set_weights(weights_decay)
+    b0, b1, b2 = batches[2], batches[0], batches[6]
+    d = [eng.to_device(a) for a in b0[1:4]] + [eng.alloc(int(b0[0][-1]) * 4)]
+    eng.forward_xyz_dev(b0[0], d[0], d[1], d[2], d[3], Nall)
+    q_dev = d[3].download((int(b0[0][-1]),))
+    for b, want in ((b0, ref[2]), (b0, ref[2]), (b1, ref[0]), (b2, ref[7]), (b0, ref[2])):
+        assert np.array_equal(eng.forward_xyz(*b[:4], Nall), want)
+    assert np.array_equal(q_dev, ref[2])
     eng.close()
 
 
