@@ -30,6 +30,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
   parity              max |dq| of the reference's 871 validation systems against the TensorFlow predictions it stored for them
   real_data           atoms/s on that batch (real molecules of 3..38 atoms, N = 41), device-resident, pipelined
   host_to_host        the same forward from host arrays to host arrays (Pipeline.map, a DIFFERENT batch every call)
+  blocking_call       one forward at a time, waited for: latency of the batch on a lone handle
   cpu_baseline        the oracle (CPU restatement of the reference's algorithm, not TensorFlow) on this host's cores
 """
 import argparse
@@ -267,6 +268,7 @@ def main():
     weights = checkpoint.load_epnn_weights(os.path.join(ROOT, "models", "decay_model_weights"))
     pipe = Pipeline(depth=args.depth, nx=9, T=5, device=device)
     pipe.set_weights(weights)
+    pipe.set_option("wave2", 0)          # the throughput kernel at every depth (Pipeline does this itself above depth 1)
     for kv in args.opt:
         name, value = kv.split("=")
         pipe.set_option(name, int(value))
@@ -435,6 +437,33 @@ def main():
                                   "what": "Pipeline.map (epnn_forward_xyz_begin/_end): host xyz/x/Q -> host q, a different "
                                           f"batch of {B} molecules (a new plan) every call on every lane, {len(lanes)} in flight; PCIe inclusive, not `value`"}
 
+    if rank == 0 and not args.no_extras:
+        # (3b) ONE blocking call at a time (what a caller without a pipeline sees): device-resident, the default mode of a
+        #      lone handle (molecules of 17+ atoms split over two wavefronts) and one wavefront per molecule
+        from epnn_amd.engine import Engine
+        e1 = Engine(nx=9, T=5, device=device)
+        e1.set_weights(weights)
+        b_in = [e1.to_device(a) for a in (xyz, x, Q)]
+        b_q = e1.alloc(A * 4)
+        blocking = {}
+        for label, opt in (("ms", -1), ("ms_one_wavefront_per_molecule", 0)):
+            e1.set_option("wave2", opt)
+            for _ in range(10):
+                e1.forward_xyz_dev(offsets, b_in[0], b_in[1], b_in[2], b_q, N)
+                e1.sync()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                e1.forward_xyz_dev(offsets, b_in[0], b_in[1], b_in[2], b_q, N)
+                e1.sync()
+            blocking[label] = (time.perf_counter() - t1) / 100 * 1e3
+        assert np.abs(b_q.download((A,)) - q).max() <= 1e-6
+        for d in b_in + [b_q]:
+            d.free()
+        e1.close()
+        blocking["atoms_per_s"] = A / (blocking["ms"] * 1e-3)
+        blocking["what"] = f"one forward of the batch of {B} molecules at a time, waited for (no pipeline), inputs resident in HBM"
+        extras["blocking_call"] = blocking
+
     if real is not None:
         # (4) the real-data rate: the validation batch of (1), device-resident, through every lane of the pipeline
         v_off, v_xyz, v_x, v_Q = real
@@ -513,7 +542,7 @@ def main():
         if world > 1:
             out["ranks"] = {"world_size": world, "timing_backend": backend,
                             "atoms_per_s_per_rank": [a * args.steps / d for d, a in per_rank]}
-        for key in ("parity", "real_data", "host_to_host"):
+        for key in ("parity", "real_data", "host_to_host", "blocking_call"):
             if key in extras:
                 out[key] = extras[key]
         if not args.no_cpu_baseline and world == 1:         # the reported CPU baseline belongs to the N=1 line only

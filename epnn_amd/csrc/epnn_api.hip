@@ -6,6 +6,7 @@
 #include "epnn_host.h"
 #include "epnn_frontend.hip.h"
 #include "epnn_wave.hip.h"
+#include "epnn_wave2.hip.h"
 #include "epnn_wave3.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
@@ -555,7 +556,10 @@ static int pack_weights(epnn_handle *h) {
 // payload_bytes / ctl_fresh (host entry): room for the call's inputs behind the index arrays, in the page-locked staging and
 // in its device mirror alike, so that ONE host-to-device copy carries everything a forward needs (plan_payload_offset);
 // with ctl_fresh given, the upload of freshly built index arrays is left to the caller, who sends them with the payload.
-static size_t plan_payload_offset(int B, int A) { return (((size_t)6 * B + 1 + A) * sizeof(int) + 255) & ~size_t(255); }
+// index arrays of a plan: wblk [2B + 2] int4 | moff [B + 1] | mflag [B] | molof [A]   (wblk: one entry per wavefront of the fused
+// kernels; the block-per-wavefront kernel has two per workgroup, 2 ceil(B / 2) at most, plus an idle one)
+static size_t plan_ctl_ints(int B, int A) { return (size_t)4 * (2 * (size_t)B + 2) + 2 * (size_t)B + 1 + (size_t)A; }
+static size_t plan_payload_offset(int B, int A) { return (plan_ctl_ints(B, A) * sizeof(int) + 255) & ~size_t(255); }
 static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
                       bool *ctl_fresh = nullptr) {
     Plan &P = h->plan;
@@ -579,11 +583,13 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     P.offsets.assign(offsets, offsets + B + 1);
     P.allow_mid = allow_mid;
     P.small_order.clear();
+    P.split_order.clear();
+    P.single_order.clear();
+    P.pair_wgs = 0;
     P.mid_order.clear();
     P.large_list.clear();
     P.small_nmax = 0;
-    // index arrays of the plan, written straight into page-locked memory and uploaded without waiting:
-    //   wblk [B] int4 | moff [B+1] | mflag [B] | molof [A]
+    // index arrays of the plan (plan_ctl_ints), written straight into page-locked memory and uploaded without waiting
     if (h->ctl_uploading) {                         // the previous plan's upload must have run before its staging is reused
         HIPCHK(hipEventSynchronize(h->ev_ctl));
         h->ctl_uploading = false;
@@ -591,7 +597,10 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     const size_t ctl_total = plan_payload_offset(B, P.A) + payload_bytes;
     if (h->pin_ctl.ensure(ctl_total)) return 1;
     int4 *c_wblk = h->pin_ctl.as<int4>();
-    int *c_moff = h->pin_ctl.as<int>() + 4 * (size_t)B, *c_mflag = c_moff + B + 1, *c_molof = c_mflag + B;
+    int *c_moff = h->pin_ctl.as<int>() + 4 * (2 * (size_t)B + 2), *c_mflag = c_moff + B + 1, *c_molof = c_mflag + B;
+    // the block-per-wavefront kernel takes molecules of >= thr2 atoms (split) and of <= 16 atoms (in pairs); 0: not used
+    const int want2 = h->opt_wave2 >= 0 ? h->opt_wave2 : (B <= EPNN_W2_AUTO_MAX ? 17 : 0);
+    const int thr2 = (allow_mid && want2 > 0) ? std::max(17, want2) : 0;
     std::vector<int> pbase(B);
     int count[EPNN_SMALL_NMAX + 2] = {0};
     long long run = 0;
@@ -605,9 +614,13 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         const bool mid = !small && allow_mid && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W3_NMAX;
         c_mflag[b] = small || mid ? 0 : 1;
         if (small) {
-            P.small_order.push_back(b);
             P.small_nmax = std::max(P.small_nmax, n);
-            count[n] += 1;
+            if (thr2 && n >= thr2) P.split_order.push_back(b);
+            else if (thr2 && n <= 16) P.single_order.push_back(b);
+            else {
+                P.small_order.push_back(b);
+                count[n] += 1;
+            }
         } else if (mid) {
             P.mid_order.push_back(b);
         } else {
@@ -638,20 +651,34 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
             const int b = P.small_order[k];
             c_wblk[k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
         }
+        auto larger_first = [&](int a, int c) { return offsets[a + 1] - offsets[a] > offsets[c + 1] - offsets[c]; };
+        // the block-per-wavefront kernel's workgroups behind them: two entries each, split molecules first
+        std::stable_sort(P.split_order.begin(), P.split_order.end(), larger_first);
+        std::stable_sort(P.single_order.begin(), P.single_order.end(), larger_first);
+        int4 *c_pair = c_wblk + P.small_order.size();
+        size_t e = 0;
+        for (int b : P.split_order) {
+            const int4 ent = make_int4(b, offsets[b], (offsets[b + 1] - offsets[b]) | (EPNN_W2_SPLIT << 8), pbase[b]);
+            c_pair[e++] = ent;
+            c_pair[e++] = ent;
+        }
+        for (int b : P.single_order) c_pair[e++] = make_int4(b, offsets[b], (offsets[b + 1] - offsets[b]) | (EPNN_W2_SINGLE << 8), pbase[b]);
+        if (e & 1) c_pair[e++] = make_int4(0, 0, EPNN_W2_IDLE << 8, 0);
+        P.pair_wgs = (int)(e / 2);
         // the three-block kernel's molecules behind them, largest first
-        std::stable_sort(P.mid_order.begin(), P.mid_order.end(), [&](int a, int c) { return offsets[a + 1] - offsets[a] > offsets[c + 1] - offsets[c]; });
+        std::stable_sort(P.mid_order.begin(), P.mid_order.end(), larger_first);
         for (size_t k = 0; k < P.mid_order.size(); ++k) {
             const int b = P.mid_order[k];
-            c_wblk[P.small_order.size() + k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
+            c_pair[e + k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
         }
     }
     // the device copy has the same layout: ONE upload per plan
-    const size_t ctl_ints = (size_t)6 * B + 1 + P.A;
+    const size_t ctl_ints = plan_ctl_ints(B, P.A);
     if (h->d_ctl.ensure(ctl_total) || h->d_rowcnt.ensure((P.A + 1) * sizeof(int)) ||
         h->d_rowoff.ensure((P.A + 1) * sizeof(int)))
         return 1;
     h->p_wblk = h->d_ctl.as<int4>();
-    h->p_moff = h->d_ctl.as<int>() + 4 * (size_t)B;
+    h->p_moff = h->d_ctl.as<int>() + 4 * (2 * (size_t)B + 2);
     h->p_mflag = h->p_moff + B + 1;
     h->p_molof = h->p_mflag + B;
     if (ctl_fresh) {
@@ -752,13 +779,13 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.dsafe = h->dsafe;
     const dim3 grid((unsigned)P.small_order.size());
     const WaveIndex &X = h->wvidx;
-    A.total_waves = (int)(P.small_order.size() + P.mid_order.size());
+    A.total_waves = (int)P.fused_count();          // reports to the hand-off: one per molecule
     if (!P.mid_order.empty()) {
         // molecules of 33..48 atoms: the three-block variant (one wavefront per SIMD, 40 KB of LDS), queued FIRST so that its
         // few long wavefronts run beside this forward's other launch... of the other streams (same stream: in order)
         if (!S.d_xyz) EPNN_FAIL("forward: internal error (three-block kernel without the in-kernel front-end)");
         WaveArgs A3 = A;
-        A3.wblk = A.wblk + P.small_order.size();
+        A3.wblk = A.wblk + P.small_order.size() + 2 * (size_t)P.pair_wgs;
         const int lds3 = 40960;
         A3.lds_words = lds3 / 4;
         if (!h->wave3_attr) {
@@ -767,8 +794,22 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         }
         hipLaunchKernelGGL(k_wave_forward3, dim3((unsigned)P.mid_order.size()), dim3(64), (size_t)lds3, h->stream, A3, h->wvidx);
         HIPCHK(hipGetLastError());
-        if (P.small_order.empty()) return 0;
     }
+    if (P.pair_wgs > 0) {
+        // block-per-wavefront kernel: 128-thread workgroups, twice the LDS budget of a wavefront of k_wave_forward
+        if (!S.d_xyz) EPNN_FAIL("forward: internal error (block-per-wavefront kernel without the in-kernel front-end)");
+        WaveArgs A2 = A;
+        A2.wblk = A.wblk + P.small_order.size();
+        const int lds2 = 2 * lds;
+        A2.lds_words = lds2 / 4;
+        if (!h->wave2_attr) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            h->wave2_attr = true;
+        }
+        hipLaunchKernelGGL(k_wave_forward2, dim3((unsigned)P.pair_wgs), dim3(128), (size_t)lds2, h->stream, A2, h->wvidx);
+        HIPCHK(hipGetLastError());
+    }
+    if (P.small_order.empty()) return 0;
     if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
@@ -778,7 +819,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
 }
 
 static int launch_small(epnn_handle *h, const PairSource &S) {
-    if (h->plan.small_order.empty() && h->plan.mid_order.empty()) return 0;
+    if (h->plan.fused_count() == 0) return 0;
     return launch_wave(h, S);
 }
 
@@ -829,7 +870,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     // nothing can overflow; G products in the 16-dimensional edge basis, used only when it represents the features to
     // 1e-8).  Which path a molecule takes does not depend on what else is in the batch.  With small molecules only no
     // other kernel runs and the kernel's last wave also hands status + pair count to the host.
-    const bool front_small = front_ok && (!P.small_order.empty() || !P.mid_order.empty());
+    const bool front_small = front_ok && P.fused_count() > 0;
     const bool pure = front_small && P.large_list.empty();
     if (!pure && ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
     if (!pure || !h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
@@ -858,7 +899,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
         HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
-    h->stats[1] = (int64_t)(P.small_order.size() + P.mid_order.size());
+    h->stats[1] = (int64_t)P.fused_count();
     h->stats[2] = (int64_t)P.large_list.size();
     return 0;
 }
@@ -1120,6 +1161,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_lds")) { h->wave_lds = value; }
     else if (!strcmp(name, "wave_front")) { h->opt_wave_front = value; h->plan.valid = false; }
     else if (!strcmp(name, "wave3")) { h->opt_wave3 = value; h->plan.valid = false; }
+    else if (!strcmp(name, "wave2")) { h->opt_wave2 = value; h->plan.valid = false; }
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "wave_order")) { h->opt_wave_order = value; h->plan.valid = false; }

@@ -81,6 +81,12 @@ struct Plan {                 // what the host derives from `offsets`
     int B = 0, A = 0, N = 0;
     std::vector<int> offsets;
     std::vector<int> small_order;   // molecules on the fused path, largest first
+    // block-per-wavefront kernel (epnn_wave2.hip.h; compact entry, option "wave2"): molecules split over two wavefronts and
+    // molecules of at most 16 atoms that share a workgroup in pairs, both largest first
+    std::vector<int> split_order, single_order;
+    int pair_wgs = 0;               // that kernel's workgroups: split molecules + pairs of single ones (two wblk entries each,
+                                    // behind the small_order entries; the three-block kernel's entries follow)
+    size_t fused_count() const { return small_order.size() + split_order.size() + single_order.size() + mid_order.size(); }
     std::vector<int> mid_order;     // molecules of 33..48 atoms on the three-block fused kernel (compact entry only), largest first
     bool allow_mid = false;
     std::vector<int> large_list;    // molecules on the tiled path
@@ -128,8 +134,15 @@ struct epnn_handle {
     int opt_train_graph = 0;          // training: 1 replays the step's launch sequence as a hipGraph (frees the host thread; not faster:
                                       // 0.47 vs 0.45 ms per step, the kernels are latency-bound, and a new buffer set means a new capture)
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
+    int opt_wave2 = -1;               // compact entry, block-per-wavefront kernel (epnn_wave2.hip.h): molecules with at least this many
+                                      // atoms (17..32) are split over two wavefronts, those of at most 16 run in pairs, the rest on
+                                      // k_wave_forward; 0: k_wave_forward for all; -1 (default): 17 for a batch of at most
+                                      // EPNN_W2_AUTO_MAX molecules -- a lone small batch leaves the GPU half empty and lasts as
+                                      // long as its largest molecule, which the split halves (0.21 -> 0.12-0.18 ms) --, else 0.
+                                      // Batches in flight side by side fill the GPU: there the split costs throughput (wavefront 1 of
+                                      // a 17..20-atom molecule mostly waits: 175 instead of 214 M atoms/s), so engine.Pipeline sets 0.
     int opt_wave3 = 1;                // molecules of 33..48 atoms take the three-block fused kernel (0: the tiled kernels)
-    bool wave3_attr = false;
+    bool wave3_attr = false, wave2_attr = false;
     int opt_wave_order = 0;           // order of a launch's wavefronts: 0 largest molecule first, 1 ends interleaved, 2 smallest first
     int opt_large_fused = 1;          // tiled path: one launch between two sweeps / pair passes (0: one kernel per stage)
     int opt_wave_prio = 18;           // fused kernel: molecules with >= this many atoms run at raised wave priority (0: off);

@@ -352,6 +352,9 @@ class Pipeline:
     def __init__(self, depth=8, **engine_kwargs):
         self.engines = [Engine(**engine_kwargs) for _ in range(max(1, int(depth)))]
         self._next = 0
+        if len(self.engines) > 1:
+            # batches side by side fill the GPU: every molecule on one wavefront (the split over two is for a lone batch)
+            self.set_option("wave2", 0)
 
     def set_weights(self, weights):
         for e in self.engines:

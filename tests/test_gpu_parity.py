@@ -332,12 +332,14 @@ def test_fused_kernel_every_size_vs_oracle(gpu_engine_factory):
     ref = _oracle_batch(mols, w, N)
     ref32 = _oracle_batch(mols, w, N, np.float32)
     noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
-    for opts in ({}, {"wave_front": 0}):
+    got = {}
+    for opts in ({}, {"wave_front": 0}, {"wave2": 0}, {"wave2": 25}):
         eng = gpu_engine_factory(nx=nx, T=T)
         eng.set_weights(w)
         for k, v in opts.items():
             eng.set_option(k, v)
         q = eng.forward_xyz(off, xyz, x, Q, N=N)
+        got[tuple(opts.items())] = q
         worst, at = 0.0, -1
         for k, m in enumerate(mols):
             n = m[1].shape[0]
@@ -346,6 +348,19 @@ def test_fused_kernel_every_size_vs_oracle(gpu_engine_factory):
                 worst, at = err, n
         print(f"sizes 1..32 {opts}: worst |dq| {worst:.2e} (n = {at}); float32 oracle noise {noise:.2e}")
         assert worst <= max(TOL, 4 * noise), (opts, worst, at)
+    # The block-per-wavefront kernel (default: molecules of 17+ atoms split over two wavefronts, smaller ones in pairs) against
+    # the one-wavefront kernel ("wave2" = 0): an unsplit molecule runs the very same instruction sequence (bit-identical); a
+    # split one runs the one-block code for the atoms of its second block too, where k_wave_forward has separately compiled
+    # two-block code -- same operands, same order of every sum, results within float32 rounding of each other.
+    base = got[(("wave2", 0),)]
+    for key, thr in (((), 17), ((("wave2", 25),), 25)):
+        for k, m in enumerate(mols):
+            n = m[1].shape[0]
+            a, b = got[key][off[k]:off[k + 1]], base[off[k]:off[k + 1]]
+            if n < thr:
+                assert np.array_equal(a, b), (key, n)
+            else:
+                assert np.abs(a - b).max() <= 2e-7, (key, n, np.abs(a - b).max())
 
 
 def test_pipeline_map_equals_one_call_at_a_time(weights_decay):
@@ -794,3 +809,58 @@ def test_three_block_kernel_every_size_vs_oracle(gpu_engine_factory):
     alone = eng.forward_xyz(*_batch([mols[k] for k in pick]), N=90)
     got = np.concatenate([qm[moff[6 + j]:moff[7 + j]] for j in range(3)])
     assert np.array_equal(got, alone)
+
+
+@pytest.mark.gpu
+def test_block_per_wave_kernel_batch_shapes(gpu_engine_factory):
+    """The block-per-wavefront kernel (epnn_wave2.hip.h; the default of a lone handle for batches of at most 1024 molecules)
+    on every shape of batch its workgroup table can take: only molecules that are split over two wavefronts, only ones that
+    share a workgroup in pairs, an odd number of those (one idle wavefront), a single molecule of either kind, a mix with
+    three-block and tiled molecules - against the float64 oracle; and where the automatic choice stops."""
+    from epnn_amd import synth
+    nx, T, N = 9, 2, 60
+    w = random_weights(nx, T, seed=21, scale=0.35)
+    off, xyz, x, Q, _ = synth.qm9_like_batch(B=48, seed=11, N=29)
+    mols = [(xyz[off[k]:off[k + 1]], x[off[k]:off[k + 1]], float(Q[k])) for k in range(48)]
+    rng = np.random.default_rng(4)
+    for n in (36, 45, 60):                                   # three-block kernel (2) and tiled path (1)
+        pts = np.cumsum(rng.normal(size=(n, 3)) * 0.75, axis=0).astype(np.float32)
+        mols.append((pts, synth.features(rng.choice(["H", "C", "N", "O"], size=n)), 0.0))
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    tol = max(TOL, 4 * max(np.abs(a - b).max() for a, b in zip(ref, ref32)))
+    ns = [m[1].shape[0] for m in mols]
+    singles = [k for k in range(48) if ns[k] <= 16]
+    splits = [k for k in range(48) if ns[k] >= 17]
+    assert len(singles) >= 5 and len(splits) >= 5
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+
+    def run(sel):
+        o = np.zeros(len(sel) + 1, np.int32)
+        o[1:] = np.cumsum([ns[k] for k in sel])
+        q = eng.forward_xyz(o, np.concatenate([mols[k][0] for k in sel]), np.concatenate([mols[k][1] for k in sel]),
+                            np.array([mols[k][2] for k in sel], np.float32), N)
+        return [q[o[i]:o[i + 1]] for i in range(len(sel))]
+
+    cases = {"splits only": splits, "pairs only": singles[:4], "odd number of singles": singles[:5], "one single": singles[:1],
+             "one split": splits[:1], "everything": list(range(len(mols))), "reversed": list(range(len(mols)))[::-1]}
+    for name, sel in cases.items():
+        got = run(sel)
+        worst = max(np.abs(g - ref[k][:ns[k]]).max() for g, k in zip(got, sel))
+        assert worst <= tol, (name, worst)
+        assert int(eng.last_stats()[1]) == sum(1 for k in sel if ns[k] <= 48), name      # fused-path molecules
+    # a molecule's charges do not depend on what else is in the batch (same kernel, same wavefront roles)
+    whole = run(list(range(len(mols))))
+    alone = run(splits[:1]) + run(singles[:1])
+    assert np.array_equal(alone[0], whole[splits[0]]) and np.array_equal(alone[1], whole[singles[0]])
+    # automatic choice: 1024 molecules still take the kernel, 1025 run one wavefront per molecule ("wave2" = 0)
+    sel = [k % 48 for k in range(1025)]
+    auto_1025 = np.concatenate(run(sel))
+    auto_1024 = np.concatenate(run(sel[:1024]))
+    eng.set_option("wave2", 0)
+    off_1025 = np.concatenate(run(sel))
+    eng.set_option("wave2", 17)
+    on_1024 = np.concatenate(run(sel[:1024]))
+    assert np.array_equal(auto_1025, off_1025) and np.array_equal(auto_1024, on_1024)
+    assert np.abs(auto_1025[:auto_1024.size] - auto_1024).max() <= 2e-7

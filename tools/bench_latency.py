@@ -24,6 +24,9 @@ def main():
     w = checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights"))
     eng = Engine(nx=9, T=5, device=0)
     eng.set_weights(w)
+    for kv in sys.argv[1:]:
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
     offsets, xyz, x, Q, N = synth.qm9_like_batch(B=1024, seed=0, N=29)
     ns = np.diff(offsets)
     print("one molecule per call (N = 29):  n   host->host ms   device-resident ms   kernel ms")
