@@ -16,7 +16,8 @@
 #pragma once
 #include "epnn_wave.hip.h"
 
-#define EPNN_W2_SCR 512      // floats at the end of the workgroup's LDS: scratch of the block-1 copies' reduction
+#define EPNN_W2_SCR 1600     // floats at the end of the workgroup's LDS (a split's): scratch of the block-1 copies' reduction [512] |
+                             // wavefront 1's share of block 0's message sums [512] | P rows of block 0 [16][PST]
 #define EPNN_W2_SINGLE 0      // wblk mode: the wavefront has a molecule (n <= 16) to itself
 #define EPNN_W2_SPLIT 1       // the workgroup's two wavefronts share a molecule (17 <= n <= 32)
 #define EPNN_W2_IDLE 2
@@ -50,6 +51,12 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
     const int col = blk1 ? 16 + n16 % m1 : n16;            // the column's atom
     const bool cat = blk1 ? copy < Cw : n16 < n;
     const bool own = cat && copy == 0;                      // the copy that stores the atom's rows / results
+    // The sweep of a split is balanced: block 0 has n + 1 partner tiles, block 1 (n + C1) / C1 -- three for 18 atoms --, so
+    // wavefront 1 also takes the tiles J0 .. n of block 0 (it reads block 0's P rows from LDS and hands its share of the
+    // message sums back through LDS); both then run about half of all tiles.
+    const int ms = split ? n - 16 : 16, nt0 = n + 1, nt1s = (n + 16 / ms) / (16 / ms);
+    const int J0 = split ? min(nt0, (nt0 + nt1s + 1) / 2) : nt0;
+    const int nxt = nt0 - J0;                               // block-0 tiles done by wavefront 1
     // what the two wavefronts of a split deal out alternately, an unsplit wavefront does alone
     const int dstep = split ? 2 : 1, doff = split ? w : 0;
     const int tid = split ? (int)threadIdx.x : lane, nthr = split ? 128 : 64;
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
     // ---- LDS layout: the one of k_wave_forward inside the workgroup's budget, the copies' scratch behind it
     const int lds_all = A.lds_words - EPNN_W2_SCR;
     const int lds_words = split ? lds_all : (A.lds_words / 2) & ~3;     // (the scratch is a split's)
-    float *scr = sm + lds_all;
+    float *scr = sm + lds_all, *scrx = scr + 512, *P0t = scr + 1024;
     float *smw = split ? sm : sm + w * lds_words;           // an unsplit wavefront has its half of the workgroup's LDS
     unsigned short *eij = reinterpret_cast<unsigned short *>(smw);
     const int eij_n = n * (n - 1) / 2;
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq, P, xs3);
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq, r, xs3);
             if (own) { w16_st(Rl + col * EPNN_PST + fo, r[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, r[1]); }
+            if (nxt > 0 && w == 0) { w16_st(P0t + n16 * EPNN_PST + fo, P[0]); w16_st(P0t + n16 * EPNN_PST + 16 + fo, P[1]); }
         }
         sync();
 
@@ -258,9 +266,12 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
             f32x4 S[2] = {w16_splat(0.f), w16_splat(0.f)};
             float u1s[2][8];
             {
-                // partner tiles of this block: tile tt gives copy k of an atom partner tt * Cw + k (see k_wave_forward)
+                // partner tiles of this block: tile tt gives copy k of an atom partner tt * Cw + k (see k_wave_forward); wavefront 0
+                // of a split stops at tile J0 of its block, wavefront 1 runs the rest of them after its own
                 const float *zrow = Gl + glds * EPNN_PST;
-                const int nt = (n + Cw) / Cw;
+                const int nt = blk1 ? nt1s : J0;
+                f32x4 Sx[2] = {w16_splat(0.f), w16_splat(0.f)}, Px[2] = {w16_splat(0.f), w16_splat(0.f)};
+                if (blk1 && nxt > 0) { Px[0] = w16_ld(P0t + n16 * EPNN_PST + fo); Px[1] = w16_ld(P0t + n16 * EPNN_PST + 16 + fo); }
                 auto sweep = [&](auto over_tag) {
                     constexpr bool OVER = decltype(over_tag)::value;
                     struct Ops { f32x4 r[2], g[2]; float w; };
@@ -273,45 +284,51 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
                             g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo);
                         }
                     };
-                    auto load_ops = [&](int tt, Ops &o_) {
-                        const int jp = tt * Cw + copy;
-                        const bool real = jp < n && cat;
-                        const float *rrow = real ? Rl + jp * EPNN_PST : zrow;
-                        o_.r[0] = w16_ld(rrow + fo);
-                        o_.r[1] = w16_ld(rrow + 16 + fo);
-                        grow(real ? (int)pm[jp * 32 + col] : 0xFFFF, o_.g);
-                        o_.w = jp < n ? 1.f : (jp == n ? padw : 0.f);
-                    };
-                    auto tile = [&](const Ops &o_) {
-                        const f32x4 za = w16_relu((P[0] + o_.r[0]) + o_.g[0]), zb = w16_relu((P[1] + o_.r[1]) + o_.g[1]);
-                        const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
-                        f32x4 d[2] = {b2v[0], b2v[1]};
-                        w16_mm<2, 8>(pb, z, d);
+                    // tiles tt = 0 .. ntile-1 of the column block whose column is atom `catom` (real: `creal`): partner jb + tt * jm
+                    auto run = [&](int ntile, int jb, int jm, int catom, bool creal, const f32x4 (&Pc)[2], f32x4 (&Sc)[2], bool last_phase) {
+                        auto load_ops = [&](int tt, Ops &o_) {
+                            const int jp = jb + tt * jm;
+                            const bool real = jp < n && creal;
+                            const float *rrow = real ? Rl + jp * EPNN_PST : zrow;
+                            o_.r[0] = w16_ld(rrow + fo);
+                            o_.r[1] = w16_ld(rrow + 16 + fo);
+                            grow(real ? (int)pm[jp * 32 + catom] : 0xFFFF, o_.g);
+                            o_.w = jp < n ? 1.f : (jp == n ? padw : 0.f);
+                        };
+                        auto tile = [&](const Ops &o_) {
+                            const f32x4 za = w16_relu((Pc[0] + o_.r[0]) + o_.g[0]), zb = w16_relu((Pc[1] + o_.r[1]) + o_.g[1]);
+                            const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+                            f32x4 d[2] = {b2v[0], b2v[1]};
+                            w16_mm<2, 8>(pb, z, d);
 #pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) S[rb] += o_.w * w16_relu(d[rb]);
-                    };
-                    Ops oa, ob;
-                    load_ops(0, oa);
-                    int tt = 0;
+                            for (int rb = 0; rb < 2; ++rb) Sc[rb] += o_.w * w16_relu(d[rb]);
+                        };
+                        Ops oa, ob;
+                        load_ops(0, oa);
+                        int tt = 0;
 #pragma unroll 1
-                    for (; tt + 2 < nt; tt += 2) {
-                        load_ops(tt + 1, ob);
-                        WAVE_FENCE();
-                        tile(oa);
-                        load_ops(tt + 2, oa);
-                        WAVE_FENCE();
-                        tile(ob);
-                    }
-                    W16_LD(u1s, M.u1s, 2, 8);
-                    if (tt + 1 < nt) {
-                        load_ops(tt + 1, ob);
-                        WAVE_FENCE();
-                        tile(oa);
-                        tile(ob);
-                    } else {
-                        WAVE_FENCE();
-                        tile(oa);
-                    }
+                        for (; tt + 2 < ntile; tt += 2) {
+                            load_ops(tt + 1, ob);
+                            WAVE_FENCE();
+                            tile(oa);
+                            load_ops(tt + 2, oa);
+                            WAVE_FENCE();
+                            tile(ob);
+                        }
+                        if (last_phase) { W16_LD(u1s, M.u1s, 2, 8); }         // first operand of the update MLP
+                        if (tt + 1 < ntile) {
+                            load_ops(tt + 1, ob);
+                            WAVE_FENCE();
+                            tile(oa);
+                            tile(ob);
+                        } else {
+                            WAVE_FENCE();
+                            tile(oa);
+                        }
+                    };
+                    const bool extra = blk1 && nxt > 0;
+                    run(nt, copy, Cw, col, cat, P, S, !extra);
+                    if (extra) run(nxt, J0, 1, n16, true, Px, Sx, true);
                 };
                 if (gover) sweep(std::true_type{});
                 else sweep(std::false_type{});
@@ -331,6 +348,13 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
                     S[0] = t0_;
                     S[1] = t1_;
                     wave_sync_lds();
+                }
+                if (split) {
+                    // both sweeps are over: the G rows and the R rows may be replaced, and block 0 gets the sums over its
+                    // partners J0 .. n from wavefront 1 (added last: a fixed order)
+                    if (blk1 && nxt > 0) { w16_st(scrx + (n16 * 4 + q) * 8, Sx[0]); w16_st(scrx + (n16 * 4 + q) * 8 + 4, Sx[1]); }
+                    wg2_sync();
+                    if (w == 0 && nxt > 0) { S[0] += w16_ld(scrx + (n16 * 4 + q) * 8); S[1] += w16_ld(scrx + (n16 * 4 + q) * 8 + 4); }
                 }
             }
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
@@ -361,7 +385,6 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
                 float wa[2][8 + EPNN_XS], wbm[2][8 + EPNN_XS], in[8 + EPNN_XS];
                 W16_LD(wa, M.pwi, 2, 8 + EPNN_XS);
                 WAVE_FENCE();
-                sync();                                     // both sweeps are over: the G rows and the R rows may be replaced
                 gtiles();
 #pragma unroll
                 for (int s = 0; s < 8; ++s) in[s] = Bv[s >> 2][s & 3];
@@ -379,6 +402,7 @@ __global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(Wave
                 f32x4 r[2] = {w16_splat(0.f), w16_splat(0.f)};
                 w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wbm, in, r, xs3);
                 if (own) { w16_st(Rl + col * EPNN_PST + fo, r[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, r[1]); }
+                if (nxt > 0 && w == 0) { w16_st(P0t + n16 * EPNN_PST + fo, P[0]); w16_st(P0t + n16 * EPNN_PST + 16 + fo, P[1]); }
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
                 vec2(X.g[t + 1].b2, b2v);
                 WAVE_FENCE();
