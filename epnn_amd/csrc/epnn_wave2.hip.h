@@ -29,7 +29,10 @@ __device__ __forceinline__ void wg2_sync() {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(128, EPNN_WAVES_PER_SIMD) void k_wave_forward2(WaveArgs A, WaveIndex X) {
+#ifndef EPNN_W2_WAVES
+#define EPNN_W2_WAVES EPNN_WAVES_PER_SIMD
+#endif
+__global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A, WaveIndex X) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, n16 = lane & 15;
     const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
