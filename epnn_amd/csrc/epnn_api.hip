@@ -7,7 +7,6 @@
 #include "epnn_frontend.hip.h"
 #include "epnn_wave.hip.h"
 #include "epnn_wave2.hip.h"
-#include "epnn_wave3.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
 #include "epnn_mlp.hip.h"
@@ -556,9 +555,10 @@ static int pack_weights(epnn_handle *h) {
 // payload_bytes / ctl_fresh (host entry): room for the call's inputs behind the index arrays, in the page-locked staging and
 // in its device mirror alike, so that ONE host-to-device copy carries everything a forward needs (plan_payload_offset);
 // with ctl_fresh given, the upload of freshly built index arrays is left to the caller, who sends them with the payload.
-// index arrays of a plan: wblk [2B + 2] int4 | moff [B + 1] | mflag [B] | molof [A]   (wblk: one entry per wavefront of the fused
-// kernels; the block-per-wavefront kernel has two per workgroup, 2 ceil(B / 2) at most, plus an idle one)
-static size_t plan_ctl_ints(int B, int A) { return (size_t)4 * (2 * (size_t)B + 2) + 2 * (size_t)B + 1 + (size_t)A; }
+// index arrays of a plan: wblk [3B + 3] int4 | moff [B + 1] | mflag [B] | molof [A]   (wblk: one entry per wavefront of the fused
+// kernels; the block-per-wavefront kernel has two or three per workgroup)
+static size_t plan_wblk_cap(int B) { return 3 * (size_t)B + 3; }
+static size_t plan_ctl_ints(int B, int A) { return 4 * plan_wblk_cap(B) + 2 * (size_t)B + 1 + (size_t)A; }
 static size_t plan_payload_offset(int B, int A) { return (plan_ctl_ints(B, A) * sizeof(int) + 255) & ~size_t(255); }
 static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
                       bool *ctl_fresh = nullptr) {
@@ -585,8 +585,8 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     P.small_order.clear();
     P.split_order.clear();
     P.single_order.clear();
+    P.split3_order.clear();
     P.pair_wgs = 0;
-    P.mid_order.clear();
     P.large_list.clear();
     P.small_nmax = 0;
     // index arrays of the plan (plan_ctl_ints), written straight into page-locked memory and uploaded without waiting
@@ -597,7 +597,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     const size_t ctl_total = plan_payload_offset(B, P.A) + payload_bytes;
     if (h->pin_ctl.ensure(ctl_total)) return 1;
     int4 *c_wblk = h->pin_ctl.as<int4>();
-    int *c_moff = h->pin_ctl.as<int>() + 4 * (2 * (size_t)B + 2), *c_mflag = c_moff + B + 1, *c_molof = c_mflag + B;
+    int *c_moff = h->pin_ctl.as<int>() + 4 * plan_wblk_cap(B), *c_mflag = c_moff + B + 1, *c_molof = c_mflag + B;
     // the block-per-wavefront kernel takes molecules of >= thr2 atoms (split) and of <= 16 atoms (in pairs); 0: not used
     const int want2 = h->opt_wave2 >= 0 ? h->opt_wave2 : (B <= EPNN_W2_AUTO_MAX ? 17 : 0);
     const int thr2 = (allow_mid && want2 > 0) ? std::max(17, want2) : 0;
@@ -611,7 +611,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
-        const bool mid = !small && allow_mid && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W3_NMAX;
+        const bool mid = !small && allow_mid && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX3;
         c_mflag[b] = small || mid ? 0 : 1;
         if (small) {
             P.small_nmax = std::max(P.small_nmax, n);
@@ -622,7 +622,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
                 count[n] += 1;
             }
         } else if (mid) {
-            P.mid_order.push_back(b);
+            P.split3_order.push_back(b);                    // three wavefronts each
         } else {
             P.large_list.push_back(b);
         }
@@ -665,11 +665,11 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         for (int b : P.single_order) c_pair[e++] = make_int4(b, offsets[b], (offsets[b + 1] - offsets[b]) | (EPNN_W2_SINGLE << 8), pbase[b]);
         if (e & 1) c_pair[e++] = make_int4(0, 0, EPNN_W2_IDLE << 8, 0);
         P.pair_wgs = (int)(e / 2);
-        // the three-block kernel's molecules behind them, largest first
-        std::stable_sort(P.mid_order.begin(), P.mid_order.end(), larger_first);
-        for (size_t k = 0; k < P.mid_order.size(); ++k) {
-            const int b = P.mid_order[k];
-            c_pair[e + k] = make_int4(b, offsets[b], offsets[b + 1] - offsets[b], pbase[b]);
+        // the molecules of 33..48 atoms behind them: three entries each
+        std::stable_sort(P.split3_order.begin(), P.split3_order.end(), larger_first);
+        for (int b : P.split3_order) {
+            const int4 ent = make_int4(b, offsets[b], (offsets[b + 1] - offsets[b]) | (EPNN_W2_SPLIT << 8), pbase[b]);
+            for (int k = 0; k < 3; ++k) c_pair[e++] = ent;
         }
     }
     // the device copy has the same layout: ONE upload per plan
@@ -678,7 +678,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         h->d_rowoff.ensure((P.A + 1) * sizeof(int)))
         return 1;
     h->p_wblk = h->d_ctl.as<int4>();
-    h->p_moff = h->d_ctl.as<int>() + 4 * (2 * (size_t)B + 2);
+    h->p_moff = h->d_ctl.as<int>() + 4 * plan_wblk_cap(B);
     h->p_mflag = h->p_moff + B + 1;
     h->p_molof = h->p_mflag + B;
     if (ctl_fresh) {
@@ -780,20 +780,29 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     const dim3 grid((unsigned)P.small_order.size());
     const WaveIndex &X = h->wvidx;
     A.total_waves = (int)P.fused_count();          // reports to the hand-off: one per molecule
-    if (!P.mid_order.empty()) {
-        // molecules of 33..48 atoms: the three-block variant (one wavefront per SIMD, 40 KB of LDS), queued FIRST so that its
-        // few long wavefronts run beside this forward's other launch... of the other streams (same stream: in order)
-        if (!S.d_xyz) EPNN_FAIL("forward: internal error (three-block kernel without the in-kernel front-end)");
-        WaveArgs A3 = A;
-        A3.wblk = A.wblk + P.small_order.size() + 2 * (size_t)P.pair_wgs;
-        const int lds3 = 40960;
-        A3.lds_words = lds3 / 4;
-        if (!h->wave3_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward3), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-            h->wave3_attr = true;
+    bool side_mid = false;
+    if (!P.split3_order.empty()) {
+        // Molecules of 33..48 atoms (the reference's `mixed` set goes up to 41): three wavefronts each.  In a lone batch (the
+        // block-per-wavefront kernel takes the smaller molecules too) this launch runs BESIDE the other one, on the handle's
+        // second stream -- on one stream the two run one after the other (0.12 + 0.16 ms for the reference's validation
+        // batch).  Pipeline lanes keep everything on their one stream.
+        if (!S.d_xyz) EPNN_FAIL("forward: internal error (block-per-wavefront kernel without the in-kernel front-end)");
+        WaveArgs A2 = A;
+        A2.wblk = A.wblk + P.small_order.size() + 2 * (size_t)P.pair_wgs;
+        const int lds23 = 3 * lds;
+        A2.lds_words = lds23 / 4;
+        if (!h->wave23_attr) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            h->wave23_attr = true;
         }
-        hipLaunchKernelGGL(k_wave_forward3, dim3((unsigned)P.mid_order.size()), dim3(64), (size_t)lds3, h->stream, A3, h->wvidx);
+        side_mid = P.pair_wgs > 0;
+        if (side_mid) {
+            HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        }
+        hipLaunchKernelGGL(k_wave_forward2<3>, dim3((unsigned)P.split3_order.size()), dim3(192), (size_t)lds23, side_mid ? h->stream2 : h->stream, A2, h->wvidx);
         HIPCHK(hipGetLastError());
+        if (side_mid) HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     }
     if (P.pair_wgs > 0) {
         // block-per-wavefront kernel: 128-thread workgroups, twice the LDS budget of a wavefront of k_wave_forward
@@ -803,12 +812,13 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         const int lds2 = 2 * lds;
         A2.lds_words = lds2 / 4;
         if (!h->wave2_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             h->wave2_attr = true;
         }
-        hipLaunchKernelGGL(k_wave_forward2, dim3((unsigned)P.pair_wgs), dim3(128), (size_t)lds2, h->stream, A2, h->wvidx);
+        hipLaunchKernelGGL(k_wave_forward2<2>, dim3((unsigned)P.pair_wgs), dim3(128), (size_t)lds2, h->stream, A2, h->wvidx);
         HIPCHK(hipGetLastError());
     }
+    if (side_mid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     if (P.small_order.empty()) return 0;
     if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);

@@ -1,7 +1,7 @@
 // One column block per wavefront: the fused forward of epnn_wave.hip.h (compact entry, in-kernel front-end, both stacks)
-// as a 128-thread workgroup whose two wavefronts either
-//   * SPLIT a molecule of 17..32 atoms: column block 0 (atoms 0..15) on wavefront 0, column block 1 (the other atoms, in
-//     partner copies) on wavefront 1, or
+// as a workgroup of NW = 2 or 3 wavefronts which either
+//   * SPLIT a molecule of 16 (NW - 1) + 1 .. 16 NW atoms: column block b (atoms 16 b .. 16 b + 15) on wavefront b, the last
+//     block (the remaining atoms, in partner copies) on the last wavefront, or
 //   * run one molecule of at most 16 atoms each, side by side, without ever meeting.
 // Everything per atom is per column in k_wave_forward, so each wavefront simply runs the one-block code for its own atoms
 // (half the registers of the two-block code).  In a split what the columns of one block read from the other -- the R_j
@@ -16,11 +16,13 @@
 #pragma once
 #include "epnn_wave.hip.h"
 
-#define EPNN_W2_SCR 1600     // floats at the end of the workgroup's LDS (a split's): scratch of the block-1 copies' reduction [512] |
-                             // wavefront 1's share of block 0's message sums [512] | P rows of block 0 [16][PST]
+// floats at the end of the workgroup's LDS (a split's): scratch of the last block's copies' reduction [512] | the last
+// wavefront's share of the full blocks' message sums [NW - 1][512] | P rows of the full blocks [16 (NW - 1)][PST]
+#define EPNN_W2_SCR(NW) (512 + ((NW) - 1) * (512 + 16 * EPNN_PST))
 #define EPNN_W2_SINGLE 0      // wblk mode: the wavefront has a molecule (n <= 16) to itself
 #define EPNN_W2_SPLIT 1       // the workgroup's two wavefronts share a molecule (17 <= n <= 32)
 #define EPNN_W2_IDLE 2
+#define EPNN_W2_NMAX3 48       // largest molecule of the three-wavefront form
 #define EPNN_W2_AUTO_MAX 1024  // option "wave2" = -1: batches of at most this many molecules take this kernel
 
 // both wavefronts: what either wrote (LDS or global memory) before the barrier is read by the other after it
@@ -29,14 +31,14 @@ __device__ __forceinline__ void wg2_sync() {
     __syncthreads();
 }
 
-#ifndef EPNN_W2_WAVES
-#define EPNN_W2_WAVES EPNN_WAVES_PER_SIMD
-#endif
-__global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A, WaveIndex X) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(WaveArgs A, WaveIndex X) {
+    constexpr int PMS = NW == 2 ? 32 : 16 * NW;            // row stride of the pair map (u16 entries): one per atom of the molecule
+    constexpr int DSTW = NW == 2 ? EPNN_DST : 16 * NW + 1;  // row stride of the transfer matrix
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, n16 = lane & 15;
     const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
-    const int4 wb = A.wblk[2 * blockIdx.x + w];            // one entry per wavefront: molecule, first atom, atoms | mode << 8, first pair slot
+    const int4 wb = A.wblk[NW * blockIdx.x + w];            // one entry per wavefront: molecule, first atom, atoms | mode << 8, first pair slot
     const int b = wb.x, a0 = wb.y, n = wb.z & 0xFF, mode = wb.z >> 8;
     if (mode == EPNN_W2_IDLE) return;                       // odd number of unsplit molecules: the last workgroup's second wavefront
     const bool split = mode == EPNN_W2_SPLIT;               // the same for both wavefronts of a workgroup (host)
@@ -47,31 +49,31 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
     const bool xs3 = nx + 3 <= 4 * (EPNN_XS - 1);
     const float *wp = A.wpack;
     // this wavefront's column block: block 0 = atoms 0..15, block 1 = the m1 atoms beyond them in C1 copies each
-    const bool blk1 = split && w == 1;
-    const int m1 = blk1 ? n - 16 : 16, C1 = 16 / m1;
+    const bool blk1 = split && w == NW - 1;                 // the last block: the atoms beyond the full blocks, m1 of them, C1 copies each
+    const int m1 = blk1 ? n - 16 * (NW - 1) : 16, C1 = 16 / m1;
     const int Cw = blk1 ? C1 : 1;
     const int copy = blk1 ? n16 / m1 : 0;
-    const int col = blk1 ? 16 + n16 % m1 : n16;            // the column's atom
-    const bool cat = blk1 ? copy < Cw : n16 < n;
+    const int col = split ? 16 * w + (blk1 ? n16 % m1 : n16) : n16;     // the column's atom
+    const bool cat = split ? (blk1 ? copy < Cw : true) : n16 < n;
     const bool own = cat && copy == 0;                      // the copy that stores the atom's rows / results
     // The sweep of a split is balanced: block 0 has n + 1 partner tiles, block 1 (n + C1) / C1 -- three for 18 atoms --, so
     // wavefront 1 also takes the tiles J0 .. n of block 0 (it reads block 0's P rows from LDS and hands its share of the
     // message sums back through LDS); both then run about half of all tiles.
-    const int ms = split ? n - 16 : 16, nt0 = n + 1, nt1s = (n + 16 / ms) / (16 / ms);
-    const int J0 = split ? min(nt0, (nt0 + nt1s + 1) / 2) : nt0;
-    const int nxt = nt0 - J0;                               // block-0 tiles done by wavefront 1
+    const int ms = split ? n - 16 * (NW - 1) : 16, nt0 = n + 1, nt1s = (n + 16 / ms) / (16 / ms);
+    const int nxt = split ? max(0, ((NW - 1) * nt0 + nt1s) / NW - nt1s) / (NW - 1) : 0;    // tiles of every full block done by the last wavefront
+    const int J0 = nt0 - nxt;
     // what the two wavefronts of a split deal out alternately, an unsplit wavefront does alone
-    const int dstep = split ? 2 : 1, doff = split ? w : 0;
-    const int tid = split ? (int)threadIdx.x : lane, nthr = split ? 128 : 64;
+    const int dstep = split ? NW : 1, doff = split ? w : 0;
+    const int tid = split ? (int)threadIdx.x : lane, nthr = split ? 64 * NW : 64;
     auto sync = [&]() {                                     // order the molecule's LDS / global traffic among all its lanes
         if (split) wg2_sync();
         else wave_sync_all();
     };
 
     // ---- LDS layout: the one of k_wave_forward inside the workgroup's budget, the copies' scratch behind it
-    const int lds_all = A.lds_words - EPNN_W2_SCR;
-    const int lds_words = split ? lds_all : (A.lds_words / 2) & ~3;     // (the scratch is a split's)
-    float *scr = sm + lds_all, *scrx = scr + 512, *P0t = scr + 1024;
+    const int lds_all = A.lds_words - EPNN_W2_SCR(NW);
+    const int lds_words = split ? lds_all : (A.lds_words / NW) & ~3;    // (the scratch is a split's)
+    float *scr = sm + lds_all, *scrx = scr + 512, *P0t = scr + 512 + (NW - 1) * 512;
     float *smw = split ? sm : sm + w * lds_words;           // an unsplit wavefront has its half of the workgroup's LDS
     unsigned short *eij = reinterpret_cast<unsigned short *>(smw);
     const int eij_n = n * (n - 1) / 2;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
     unsigned short *pm = reinterpret_cast<unsigned short *>(smw + o_x);
     float *Pl = smw + o_x;
     float *Dm = smw + o_x + n * EPNN_PST;
-    const int o_gg = o_x + ((n * 16 + 3) & ~3);
+    const int o_gg = o_x + ((n * (PMS / 2) + 3) & ~3);
     const int grows_g = (lds_words - o_gg) / EPNN_PST - 1;
     float *Gl = smw + o_gg;
     int glds = 0;
@@ -90,10 +92,10 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
 
     // ---- front-end: coordinates -> LDS (both wavefronts, same values)
     double *xs = reinterpret_cast<double *>(Rl);
-    if (hh == 0 && c < n) {
-        xs[3 * c + 0] = (double)A.xyz[3 * (size_t)(a0 + c) + 0];
-        xs[3 * c + 1] = (double)A.xyz[3 * (size_t)(a0 + c) + 1];
-        xs[3 * c + 2] = (double)A.xyz[3 * (size_t)(a0 + c) + 2];
+    if (lane < n) {
+        xs[3 * lane + 0] = (double)A.xyz[3 * (size_t)(a0 + lane) + 0];
+        xs[3 * lane + 1] = (double)A.xyz[3 * (size_t)(a0 + lane) + 1];
+        xs[3 * lane + 2] = (double)A.xyz[3 * (size_t)(a0 + lane) + 2];
     }
     // ---- per-column registers
     const float nm = cat ? 1.f : 0.f;
@@ -125,23 +127,37 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
     W16_LD(gw, X.g[0].we16, 2, KE);
     WAVE_FENCE();
 
-    for (int i = tid; i < n * 16; i += nthr) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < n * (PMS / 2); i += nthr) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
     sync();
     {
-        // ---- slots in row-major order (rows i0, i0+1 per step; the lower row's pairs first): both wavefronts
+        // ---- slots in row-major order: every wavefront of the molecule (same values to the same words)
         int base = 0;
-        for (int i0 = 0; i0 + 1 < n; i0 += 2) {
-            const int i = i0 + hh;
-            const bool near = c > i && c < n && wave_dist2(xs, i, c) < A.cut2;
-            const unsigned long long bal = __ballot(near);
-            const unsigned lo = (unsigned)bal, hi = (unsigned)(bal >> 32);
-            if (near) {
-                const int slot = base + (hh ? __popc(lo) : 0) + __popc((hh ? hi : lo) & ((1u << c) - 1u));
-                eij[slot] = (unsigned short)(i | (c << 8));
-                pm[c * 32 + i] = (unsigned short)slot;
-                pm[i * 32 + c] = (unsigned short)slot;
+        if (NW == 2) {                                      // up to 32 atoms: rows i0, i0+1 per step, the lower row's pairs first
+            for (int i0 = 0; i0 + 1 < n; i0 += 2) {
+                const int i = i0 + hh;
+                const bool near = c > i && c < n && wave_dist2(xs, i, c) < A.cut2;
+                const unsigned long long bal = __ballot(near);
+                const unsigned lo = (unsigned)bal, hi = (unsigned)(bal >> 32);
+                if (near) {
+                    const int slot = base + (hh ? __popc(lo) : 0) + __popc((hh ? hi : lo) & ((1u << c) - 1u));
+                    eij[slot] = (unsigned short)(i | (c << 8));
+                    pm[c * PMS + i] = (unsigned short)slot;
+                    pm[i * PMS + c] = (unsigned short)slot;
+                }
+                base += __popc(lo) + __popc(hi);
             }
-            base += __popc(lo) + __popc(hi);
+        } else {                                            // up to 48: one row per step, lane = partner
+            for (int i = 0; i + 1 < n; ++i) {
+                const bool near = lane > i && lane < n && wave_dist2(xs, i, lane) < A.cut2;
+                const unsigned long long bal = __ballot(near);
+                if (near) {
+                    const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    eij[slot] = (unsigned short)(i | (lane << 8));
+                    pm[lane * PMS + i] = (unsigned short)slot;
+                    pm[i * PMS + lane] = (unsigned short)slot;
+                }
+                base += __popcll(bal);
+            }
         }
         np = base;
         glds = min(np, grows_g);
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq, P, xs3);
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq, r, xs3);
             if (own) { w16_st(Rl + col * EPNN_PST + fo, r[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, r[1]); }
-            if (nxt > 0 && w == 0) { w16_st(P0t + n16 * EPNN_PST + fo, P[0]); w16_st(P0t + n16 * EPNN_PST + 16 + fo, P[1]); }
+            if (nxt > 0 && !blk1) { w16_st(P0t + col * EPNN_PST + fo, P[0]); w16_st(P0t + col * EPNN_PST + 16 + fo, P[1]); }
         }
         sync();
 
@@ -273,8 +289,6 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
                 // of a split stops at tile J0 of its block, wavefront 1 runs the rest of them after its own
                 const float *zrow = Gl + glds * EPNN_PST;
                 const int nt = blk1 ? nt1s : J0;
-                f32x4 Sx[2] = {w16_splat(0.f), w16_splat(0.f)}, Px[2] = {w16_splat(0.f), w16_splat(0.f)};
-                if (blk1 && nxt > 0) { Px[0] = w16_ld(P0t + n16 * EPNN_PST + fo); Px[1] = w16_ld(P0t + n16 * EPNN_PST + 16 + fo); }
                 auto sweep = [&](auto over_tag) {
                     constexpr bool OVER = decltype(over_tag)::value;
                     struct Ops { f32x4 r[2], g[2]; float w; };
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
                             const float *rrow = real ? Rl + jp * EPNN_PST : zrow;
                             o_.r[0] = w16_ld(rrow + fo);
                             o_.r[1] = w16_ld(rrow + 16 + fo);
-                            grow(real ? (int)pm[jp * 32 + catom] : 0xFFFF, o_.g);
+                            grow(real ? (int)pm[jp * PMS + catom] : 0xFFFF, o_.g);
                             o_.w = jp < n ? 1.f : (jp == n ? padw : 0.f);
                         };
                         auto tile = [&](const Ops &o_) {
@@ -331,7 +345,17 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
                     };
                     const bool extra = blk1 && nxt > 0;
                     run(nt, copy, Cw, col, cat, P, S, !extra);
-                    if (extra) run(nxt, J0, 1, n16, true, Px, Sx, true);
+                    if (extra) {
+                        // the tiles J0 .. n of every full block: its P rows come from LDS, the sums go back through LDS
+#pragma unroll 1
+                        for (int k = 0; k < NW - 1; ++k) {
+                            const f32x4 Px[2] = {w16_ld(P0t + (16 * k + n16) * EPNN_PST + fo), w16_ld(P0t + (16 * k + n16) * EPNN_PST + 16 + fo)};
+                            f32x4 Sx[2] = {w16_splat(0.f), w16_splat(0.f)};
+                            run(nxt, J0, 1, 16 * k + n16, true, Px, Sx, k == NW - 2);
+                            w16_st(scrx + k * 512 + (n16 * 4 + q) * 8, Sx[0]);
+                            w16_st(scrx + k * 512 + (n16 * 4 + q) * 8 + 4, Sx[1]);
+                        }
+                    }
                 };
                 if (gover) sweep(std::true_type{});
                 else sweep(std::false_type{});
@@ -355,9 +379,8 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
                 if (split) {
                     // both sweeps are over: the G rows and the R rows may be replaced, and block 0 gets the sums over its
                     // partners J0 .. n from wavefront 1 (added last: a fixed order)
-                    if (blk1 && nxt > 0) { w16_st(scrx + (n16 * 4 + q) * 8, Sx[0]); w16_st(scrx + (n16 * 4 + q) * 8 + 4, Sx[1]); }
                     wg2_sync();
-                    if (w == 0 && nxt > 0) { S[0] += w16_ld(scrx + (n16 * 4 + q) * 8); S[1] += w16_ld(scrx + (n16 * 4 + q) * 8 + 4); }
+                    if (!blk1 && nxt > 0) { S[0] += w16_ld(scrx + w * 512 + (n16 * 4 + q) * 8); S[1] += w16_ld(scrx + w * 512 + (n16 * 4 + q) * 8 + 4); }
                 }
             }
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
                 f32x4 r[2] = {w16_splat(0.f), w16_splat(0.f)};
                 w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wbm, in, r, xs3);
                 if (own) { w16_st(Rl + col * EPNN_PST + fo, r[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, r[1]); }
-                if (nxt > 0 && w == 0) { w16_st(P0t + n16 * EPNN_PST + fo, P[0]); w16_st(P0t + n16 * EPNN_PST + 16 + fo, P[1]); }
+                if (nxt > 0 && !blk1) { w16_st(P0t + col * EPNN_PST + fo, P[0]); w16_st(P0t + col * EPNN_PST + 16 + fo, P[1]); }
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
                 vec2(X.g[t + 1].b2, b2v);
                 WAVE_FENCE();
@@ -422,7 +445,7 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
     // ================================================================== EPN steps (charge_gn.py:98-118)
     {
         sync();                                             // the GNN's tables are dead: switch to the EPN layout
-        for (int i = tid; i < n * EPNN_DST; i += nthr) Dm[i] = 0.f;
+        for (int i = tid; i < n * DSTW; i += nthr) Dm[i] = 0.f;
         const int qs = (nx + 1) >> 2, ql = (nx + 1) & 3;
 #pragma unroll 1
         for (int t = 0; t < Te; ++t) {
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
             {
                 // blocks of 16 unordered near pairs; in a split dealt out alternately: this wavefront's k-th block is 2k + w
                 const int nblk = (np + 15) >> 4;
-                const int nown = split ? (nblk + 1 - w) >> 1 : nblk;
+                const int nown = split ? (nblk - w + NW - 1) / NW : nblk;
                 auto bidx = [&](int k) { return dstep * min(k, nown - 1) + doff; };
                 struct Rec { int ij; float wi, wj; };
                 struct Rows { float e[KE]; f32x4 pi_[2], rj_[2], pj_[2], ri_[2]; };
@@ -495,8 +518,8 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
                         for (int r = 0; r < 4; ++r) fd = fmaf(w3[rb][r], tt[r], fd);
                     }
                     const float d = 0.5f * w16_sumq(fd);               // charge_gn.py:116
-                    if (q == 0 && valid && r_.wi != 0.f) Dm[li * EPNN_DST + lj] = r_.wi * d;
-                    if (q == 1 && valid && r_.wj != 0.f) Dm[lj * EPNN_DST + li] = -(r_.wj * d);
+                    if (q == 0 && valid && r_.wi != 0.f) Dm[li * DSTW + lj] = r_.wi * d;
+                    if (q == 1 && valid && r_.wj != 0.f) Dm[lj * DSTW + li] = -(r_.wj * d);
                 };
                 if (nown > 0) {
                     Rec r0, r1;
@@ -529,7 +552,7 @@ __global__ __launch_bounds__(128, EPNN_W2_WAVES) void k_wave_forward2(WaveArgs A
             // step writes the matrix only behind its own barrier, which this wavefront reaches after these reads.)
             {
                 float dq = 0.f;
-                const float *row = Dm + (cat ? col : 0) * EPNN_DST;
+                const float *row = Dm + (cat ? col : 0) * DSTW;
                 for (int j = q; j < n; j += 4) dq += row[j];
                 dq = w16_sumq(dq);
 #pragma unroll

@@ -72,7 +72,7 @@ def _batch(mols):
 
 def test_val_golden_all(gpu_engine_factory, weights_decay, val_dir, val_names, val_gold):
     """All 871 validation systems in ONE mixed batch vs the stored TensorFlow predictions: n <= 32 on the two-block fused
-    kernel, the 22 systems of 33..38 atoms on its three-block variant; and once more with those 22 on the tiled kernels
+    kernel, the 22 systems of 33..38 atoms on three wavefronts of the block-per-wavefront kernel; and once more with those 22 on the tiled kernels
     ("wave3" = 0), which is where every system above 48 atoms goes."""
     mols, offsets, xyz, x, Q = load_molecules(val_dir, val_names)
     nmid = sum(1 for m in mols if m[1].shape[0] > 32)
@@ -735,7 +735,7 @@ def test_limits_of_the_configuration_vs_oracle(gpu_engine_factory):
     eng.set_weights(w)
     q = eng.forward_xyz(off, xyz, x, Q, N=N)
     st = eng.last_stats()
-    assert st[1] == 7 and st[2] == 1                     # 1..32 two-block kernel, 40 three-block kernel, 70 tiled kernels
+    assert st[1] == 7 and st[2] == 1                     # 1..32 and 40 on the fused kernels (40: three wavefronts), 70 on the tiled kernels
     ref = _oracle_batch(mols, w, N)
     ref32 = _oracle_batch(mols, w, N, np.float32)
     noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
@@ -749,8 +749,8 @@ def test_limits_of_the_configuration_vs_oracle(gpu_engine_factory):
 
 
 def test_three_block_kernel_every_size_vs_oracle(gpu_engine_factory):
-    """Molecules of 33..48 atoms through the compact entry take the three-column-block variant of the fused kernel
-    (epnn_wave3.hip.h; the reference's `mixed` set goes up to 41 atoms).  Every size at two densities (the sparse ones keep
+    """Molecules of 33..48 atoms through the compact entry run on three wavefronts of the block-per-wavefront kernel
+    (epnn_wave2.hip.h, k_wave_forward2<3>; the reference's `mixed` set goes up to 41 atoms).  Every size at two densities (the sparse ones keep
     their G rows in LDS, the dense ones spill them to HBM), random non-degenerate weights, nx = 10, N beyond the largest,
     non-zero total charges; float64 oracle.  The same molecules on the tiled kernels ("wave3" = 0) agree to float32
     rounding, and a batch that mixes all three kernels gives every molecule the bits it gets alone."""
@@ -789,13 +789,22 @@ def test_three_block_kernel_every_size_vs_oracle(gpu_engine_factory):
     assert st[0] == npairs
     print(f"sizes 33..48: worst |dq| {worst:.2e} (n = {at}); float32 oracle noise {noise:.2e}; {npairs} pairs")
     assert worst <= max(TOL, 4 * noise), (worst, at)
+    # ("wave2" = 0, what a pipeline lane sets: the same kernel for these molecules, on the handle's one stream)
+    one = gpu_engine_factory(nx=nx, T=T)
+    one.set_weights(w)
+    one.set_option("wave2", 0)
+    q1 = one.forward_xyz(off, xyz, x, Q, N=N)
+    assert one.last_stats()[1] == len(mols)
+    worst1 = max(float(np.abs(q1[off[k]:off[k + 1]] - ref[k][:m[1].shape[0]]).max()) for k, m in enumerate(mols))
+    print(f"sizes 33..48, one wavefront per molecule: worst |dq| {worst1:.2e}; |split - one wavefront| {np.abs(q1 - q).max():.2e}")
+    assert worst1 <= max(TOL, 4 * noise) and np.abs(q1 - q).max() <= max(1e-6, 4 * noise)
     tiled = gpu_engine_factory(nx=nx, T=T)
     tiled.set_weights(w)
     tiled.set_option("wave3", 0)
     qt = tiled.forward_xyz(off, xyz, x, Q, N=N)
     assert tiled.last_stats()[2] == len(mols)
     assert np.abs(qt - q).max() <= max(3e-6, 4 * noise)
-    # mixed batch: small (two-block kernel), mid (three-block), large (tiled): each molecule's charges do not depend on the others
+    # mixed batch: small, mid (three wavefronts), large (tiled): each molecule's charges do not depend on the others
     so, sxyz, sx9, sQ, _ = synth.qm9_like_batch(B=6, seed=2)
     sx = np.concatenate([sx9, np.zeros((sx9.shape[0], 1), np.float32)], axis=1)
     _, bxyz, bx9, bQ, bn = synth.box_system(n_atoms=90, seed=4)
@@ -823,7 +832,7 @@ def test_block_per_wave_kernel_batch_shapes(gpu_engine_factory):
     off, xyz, x, Q, _ = synth.qm9_like_batch(B=48, seed=11, N=29)
     mols = [(xyz[off[k]:off[k + 1]], x[off[k]:off[k + 1]], float(Q[k])) for k in range(48)]
     rng = np.random.default_rng(4)
-    for n in (36, 45, 60):                                   # three-block kernel (2) and tiled path (1)
+    for n in (36, 45, 60):                                   # three wavefronts (2) and tiled path (1)
         pts = np.cumsum(rng.normal(size=(n, 3)) * 0.75, axis=0).astype(np.float32)
         mols.append((pts, synth.features(rng.choice(["H", "C", "N", "O"], size=n)), 0.0))
     ref = _oracle_batch(mols, w, N)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of REAL data: the reference's 871-system validation batch of its `mixed` set (molecules of 3..38 atoms, N = 41):
-molecules up to 32 atoms on the two-block fused kernel, 33..48 on the three-block variant (`--opt wave3=0`: on the tiled
+molecules up to 32 atoms on the two-block fused kernel, 33..48 on three wavefronts of the block-per-wavefront kernel (`--opt wave3=0`: on the tiled
 kernels, as before round 2).   python tools/bench_mixed.py [depth]"""
 import os, sys, tarfile, tempfile, time
 import numpy as np
@@ -29,7 +29,7 @@ def timeit(sel, label):
 only_pipe = len(sys.argv) > 1
 if not only_pipe: timeit(range(len(mols)), "all")
 if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] <= 32], "n <= 32 (fused kernel)")
-if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] > 32], "n > 32 (three-block fused kernel; tiled with wave3=0)")
+if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] > 32], "n > 32 (three wavefronts per molecule; tiled with wave3=0)")
 eng.close()
 from epnn_amd.engine import Pipeline
 for depth in ((int(sys.argv[1]),) if only_pipe else (1, 4, 8)):
