@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *par
     __shared__ float sh[4][64];
     const int en = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int len = T.len[en], idx = blockIdx.x * 64 + lane;
-    if (blockIdx.x * 64 >= len) return;
+    if ((int)blockIdx.x * 64 >= len) return;
     const int nblk = T.nblk[en];
     const int lo = (int)((long long)nblk * w / 4), hi = (int)((long long)nblk * (w + 1) / 4);
     float s = 0.f;
