@@ -1,6 +1,6 @@
 """Randomised check of the literal make_model call (epnn_model_forward_dense: the (B,N,N,.) tensors and their reductions,
 charge_gn.py:382-384) on arbitrary inputs -- tiled like the featuriser's or not, rank-3 or rank-4 mask -- against the float64
-oracle (not collected by pytest; run by hand on a GPU box).  Round 1: 1867 cases, worst error 6 % of the tolerance.
+oracle (not collected by pytest; run by hand on a GPU box: python tests/fuzz_model.py [seed] [seconds]).  Round 1: 1867 cases, worst error 6 % of the tolerance.
 Round 2 (seed 23, 60 s): 1673 cases, worst error 5.5 % of the tolerance."""
 import os, sys, time
 import numpy as np
@@ -10,9 +10,10 @@ from conftest import random_weights
 from epnn_amd import charge_gn
 from oracle import epnn_oracle as orc
 from fuzz_dense import random_case
-rng = np.random.default_rng(21)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 21)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 t0 = time.time(); n = 0; worst = 0
-while time.time() - t0 < 150:
+while time.time() - t0 < budget:
     T, h, e, x, q, mask = random_case(rng)
     B, N = e.shape[:2]
     w = random_weights(9, T, seed=int(rng.integers(1 << 30)), scale=0.35)
