@@ -551,7 +551,7 @@ static int pack_weights(epnn_handle *h) {
 }
 
 // ------------------------------------------------------------------------------------------------ plan
-// allow_mid: molecules of 33..48 atoms may take the three-block fused kernel (compact entry with its in-kernel front-end only)
+// allow_mid: the block-per-wavefront kernel may be used (compact entry and the literal make_model entry: both stacks in one launch)
 // payload_bytes / ctl_fresh (host entry): room for the call's inputs behind the index arrays, in the page-locked staging and
 // in its device mirror alike, so that ONE host-to-device copy carries everything a forward needs (plan_payload_offset);
 // with ctl_fresh given, the upload of freshly built index arrays is left to the caller, who sends them with the payload.
@@ -563,7 +563,7 @@ static size_t plan_payload_offset(int B, int A) { return (plan_ctl_ints(B, A) * 
 static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
                       bool *ctl_fresh = nullptr) {
     Plan &P = h->plan;
-    allow_mid = allow_mid && h->opt_wave3 && h->opt_force_path == 0;
+    allow_mid = allow_mid && h->opt_force_path == 0;
     if (ctl_fresh) *ctl_fresh = false;
     if (P.valid && P.B == B && P.N == N && P.allow_mid == allow_mid && (int)P.offsets.size() == B + 1 &&
         memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0 &&
@@ -611,7 +611,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
-        const bool mid = !small && allow_mid && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX3;
+        const bool mid = !small && allow_mid && h->opt_wave3 && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX3;
         c_mflag[b] = small || mid ? 0 : 1;
         if (small) {
             P.small_nmax = std::max(P.small_nmax, n);
@@ -786,13 +786,14 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         // block-per-wavefront kernel takes the smaller molecules too) this launch runs BESIDE the other one, on the handle's
         // second stream -- on one stream the two run one after the other (0.12 + 0.16 ms for the reference's validation
         // batch).  Pipeline lanes keep everything on their one stream.
-        if (!S.d_xyz) EPNN_FAIL("forward: internal error (block-per-wavefront kernel without the in-kernel front-end)");
+        if (!(S.run_gnn && S.run_epn)) EPNN_FAIL("forward: internal error (block-per-wavefront kernel for a single stack)");
         WaveArgs A2 = A;
         A2.wblk = A.wblk + P.small_order.size() + 2 * (size_t)P.pair_wgs;
         const int lds23 = 3 * lds;
         A2.lds_words = lds23 / 4;
         if (!h->wave23_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             h->wave23_attr = true;
         }
         side_mid = P.pair_wgs > 0;
@@ -800,22 +801,25 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
             HIPCHK(hipEventRecord(h->ev_fork, h->stream));
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         }
-        hipLaunchKernelGGL(k_wave_forward2<3>, dim3((unsigned)P.split3_order.size()), dim3(192), (size_t)lds23, side_mid ? h->stream2 : h->stream, A2, h->wvidx);
+        if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward2<3, true>), dim3((unsigned)P.split3_order.size()), dim3(192), (size_t)lds23, side_mid ? h->stream2 : h->stream, A2, h->wvidx);
+        else hipLaunchKernelGGL((k_wave_forward2<3, false>), dim3((unsigned)P.split3_order.size()), dim3(192), (size_t)lds23, side_mid ? h->stream2 : h->stream, A2, h->wvidx);
         HIPCHK(hipGetLastError());
         if (side_mid) HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     }
     if (P.pair_wgs > 0) {
         // block-per-wavefront kernel: 128-thread workgroups, twice the LDS budget of a wavefront of k_wave_forward
-        if (!S.d_xyz) EPNN_FAIL("forward: internal error (block-per-wavefront kernel without the in-kernel front-end)");
+        if (!(S.run_gnn && S.run_epn)) EPNN_FAIL("forward: internal error (block-per-wavefront kernel for a single stack)");
         WaveArgs A2 = A;
         A2.wblk = A.wblk + P.small_order.size();
         const int lds2 = 2 * lds;
         A2.lds_words = lds2 / 4;
         if (!h->wave2_attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             h->wave2_attr = true;
         }
-        hipLaunchKernelGGL(k_wave_forward2<2>, dim3((unsigned)P.pair_wgs), dim3(128), (size_t)lds2, h->stream, A2, h->wvidx);
+        if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward2<2, true>), dim3((unsigned)P.pair_wgs), dim3(128), (size_t)lds2, h->stream, A2, h->wvidx);
+        else hipLaunchKernelGGL((k_wave_forward2<2, false>), dim3((unsigned)P.pair_wgs), dim3(128), (size_t)lds2, h->stream, A2, h->wvidx);
         HIPCHK(hipGetLastError());
     }
     if (side_mid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -1242,7 +1246,7 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     HIPCHK(hipStreamSynchronize(h->stream));       // the host plans tiles from the effective atom counts
     std::vector<int> offsets(B + 1, 0);
     for (int b = 0; b < B; ++b) offsets[b + 1] = offsets[b] + h->dn_neff_host[b];
-    if (build_plan(h, B, N, offsets.data())) return 1;
+    if (build_plan(h, B, N, offsets.data(), mode == 0)) return 1;     // both stacks: the block-per-wavefront kernel may take part
     const Plan &P = h->plan;
     const size_t A = (size_t)P.A;
     const int C = mode == 1 ? EPNN_EDIM : 1;
@@ -1309,7 +1313,7 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    h->stats[1] = (int64_t)P.small_order.size();
+    h->stats[1] = (int64_t)P.fused_count();
     h->stats[2] = (int64_t)P.large_list.size();
     return 0;
 }

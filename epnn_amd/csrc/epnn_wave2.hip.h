@@ -31,20 +31,24 @@ __device__ __forceinline__ void wg2_sync() {
     __syncthreads();
 }
 
-template <int NW>
+// FRONT: compact entry, the pair lists are built here from coordinates (edge features in the 16-dimensional basis, K = 16);
+// !FRONT: the literal make_model entry, pair lists and 48-channel e rows from the dense front-end (epnn_dense.hip.h), h, q and
+// a possibly fractional node mask given per atom.  Both stacks in either case.
+template <int NW, bool FRONT>
 __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(WaveArgs A, WaveIndex X) {
     constexpr int PMS = NW == 2 ? 32 : 16 * NW;            // row stride of the pair map (u16 entries): one per atom of the molecule
     constexpr int DSTW = NW == 2 ? EPNN_DST : 16 * NW + 1;  // row stride of the transfer matrix
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, n16 = lane & 15;
     const int c = lane & 31, hh = lane >> 5;               // lane naming of the front-end (row pairs x 32 partners)
+    if (!FRONT && (*A.status & EPNN_ST_PAIR_OVERFLOW)) return;      // (every wavefront sees the same word)
     const int4 wb = A.wblk[NW * blockIdx.x + w];            // one entry per wavefront: molecule, first atom, atoms | mode << 8, first pair slot
     const int b = wb.x, a0 = wb.y, n = wb.z & 0xFF, mode = wb.z >> 8;
     if (mode == EPNN_W2_IDLE) return;                       // odd number of unsplit molecules: the last workgroup's second wavefront
     const bool split = mode == EPNN_W2_SPLIT;               // the same for both wavefronts of a workgroup (host)
     if (A.prio_n > 0 && n >= A.prio_n) __builtin_amdgcn_s_setprio(3);
-    const int p0 = wb.w;
-    int np = 0;
+    const int p0 = FRONT ? wb.w : A.row_off[a0];
+    int np = FRONT ? 0 : A.row_off[a0 + n] - p0;
     const int nx = A.nx;
     const bool xs3 = nx + 3 <= 4 * (EPNN_XS - 1);
     const float *wp = A.wpack;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     float *scr = sm + lds_all, *scrx = scr + 512, *P0t = scr + 512 + (NW - 1) * 512;
     float *smw = split ? sm : sm + w * lds_words;           // an unsplit wavefront has its half of the workgroup's LDS
     unsigned short *eij = reinterpret_cast<unsigned short *>(smw);
-    const int eij_n = n * (n - 1) / 2;
+    const int eij_n = FRONT ? n * (n - 1) / 2 : np;        // in-kernel front-end: np is not known yet, every i<j pair has a place
     const int o_r = (((eij_n + 1) >> 1) + 3) & ~3;
     float *Rl = smw + o_r;
     const int o_x = o_r + n * EPNN_PST;
@@ -86,22 +90,22 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     const int o_gg = o_x + ((n * (PMS / 2) + 3) & ~3);
     const int grows_g = (lds_words - o_gg) / EPNN_PST - 1;
     float *Gl = smw + o_gg;
-    int glds = 0;
-    bool gover = false;
-    int ngt = 0;
+    int glds = min(np, grows_g);
+    bool gover = np > glds;
+    int ngt = (np + 31) >> 5;
 
     // ---- front-end: coordinates -> LDS (both wavefronts, same values)
     double *xs = reinterpret_cast<double *>(Rl);
-    if (lane < n) {
+    if (FRONT && lane < n) {
         xs[3 * lane + 0] = (double)A.xyz[3 * (size_t)(a0 + lane) + 0];
         xs[3 * lane + 1] = (double)A.xyz[3 * (size_t)(a0 + lane) + 1];
         xs[3 * lane + 2] = (double)A.xyz[3 * (size_t)(a0 + lane) + 2];
     }
     // ---- per-column registers
-    const float nm = cat ? 1.f : 0.f;
+    const float nm = cat ? (A.nm_in ? A.nm_in[a0 + col] : 1.f) : 0.f;
     float xq[EPNN_XS];
     {
-        const float qv = cat ? A.Q[b] / (float)n : 0.f;                               // charge_gn.py:337-338
+        const float qv = cat ? (A.q_in ? A.q_in[a0 + col] : A.Q[b] / (float)n) : 0.f;     // charge_gn.py:337-338
 #pragma unroll
         for (int s = 0; s < EPNN_XS; ++s) {
             const int phi = 4 * s + q;
@@ -113,23 +117,49 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
             xq[s] = v;
         }
     }
-    constexpr int KE = EPNN_ER / 4;
+    const bool have_h = !FRONT && A.h_in != nullptr;        // h given by the caller (make_model's h_inp); zeros with the compact entry
+    f32x4 hk[3] = {w16_splat(0.f), w16_splat(0.f), w16_splat(0.f)};
+    if (have_h && cat) {
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) hk[rb] = w16_ld(A.h_in + (size_t)(a0 + col) * EPNN_EDIM + 16 * rb + 4 * q);
+    }
+    // edge operand of the G products: the 16 basis coordinates of the pair (FRONT, K = 16: lane (q, n16) takes 4q..4q+3) or
+    // its 48-channel e row (K = 48: channels 12q..12q+11), see k_wave_forward
+    constexpr int KE = FRONT ? EPNN_ER / 4 : 12;
     auto load_e1 = [&](int slot, float (&e)[KE]) {
         const int sl = slot < np ? slot : 0;
-        const f32x4 v = w16_ld(A.pt + (size_t)(p0 + sl) * EPNN_ER + 4 * q);
-        e[0] = v[0]; e[1] = v[1]; e[2] = v[2]; e[3] = v[3];
+        if (FRONT) {
+            const f32x4 v = w16_ld(A.pt + (size_t)(p0 + sl) * EPNN_ER + 4 * q);
+            e[0] = v[0]; e[1] = v[1]; e[2] = v[2]; e[3] = v[3];
+        } else {
+            const float *r = A.pe + (size_t)(p0 + sl) * EPNN_EDIM + 12 * q;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 v = w16_ld(r + 4 * k);
+                e[(4 * k) % KE] = v[0]; e[(4 * k + 1) % KE] = v[1]; e[(4 * k + 2) % KE] = v[2]; e[(4 * k + 3) % KE] = v[3];
+            }
+        }
     };
     auto load_e = [&](int gt, float (&e0)[KE], float (&e1)[KE]) {
         load_e1(gt * 32 + n16, e0);
         load_e1(gt * 32 + 16 + n16, e1);
     };
     float gw[2][KE], ge0[KE], ge1[KE];
-    W16_LD(gw, X.g[0].we16, 2, KE);
+    W16_LD(gw, FRONT ? X.g[0].we16 : X.g[0].we, 2, KE);
+    if (!FRONT && ngt > 0) load_e(doff, ge0, ge1);
     WAVE_FENCE();
 
     for (int i = tid; i < n * (PMS / 2); i += nthr) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
     sync();
-    {
+    if (!FRONT) {
+        // pair map and pair records from the lists of the dense front-end
+        for (int p = tid; p < np; p += nthr) {
+            const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
+            pm[lj * PMS + li] = (unsigned short)p;                      // message into i = li from j = lj
+            if (A.psym[p0 + p]) pm[li * PMS + lj] = (unsigned short)p;
+            eij[p] = (unsigned short)(li | (lj << 8));
+        }
+    } else {
         // ---- slots in row-major order: every wavefront of the molecule (same values to the same words)
         int base = 0;
         if (NW == 2) {                                      // up to 32 atoms: rows i0, i0+1 per step, the lower row's pairs first
@@ -273,6 +303,17 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
             for (int rb = 0; rb < 2; ++rb) { P[rb] = w16_splat(0.f); U[rb] = w16_splat(0.f); }
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq, P, xs3);
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq, r, xs3);
+            if (have_h) {                                   // the h steps of Wi / Wj and the h block of the update MLP's first layer
+                float wh[2][12], hin[12];
+#pragma unroll
+                for (int s = 0; s < 12; ++s) hin[s] = hk[s >> 2][s & 3];
+                W16_LDX(wh, X.wi0, 2, 12, EPNN_XS + 12, EPNN_XS);
+                w16_mm<2, 12>(wh, hin, P);
+                W16_LDX(wh, X.wj0, 2, 12, EPNN_XS + 12, EPNN_XS);
+                w16_mm<2, 12>(wh, hin, r);
+                W16_LD(wh, X.u1h0, 2, 12);
+                w16_mm<2, 12>(wh, hin, U);
+            }
             if (own) { w16_st(Rl + col * EPNN_PST + fo, r[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, r[1]); }
             if (nxt > 0 && !blk1) { w16_st(P0t + col * EPNN_PST + fo, P[0]); w16_st(P0t + col * EPNN_PST + 16 + fo, P[1]); }
         }
@@ -398,8 +439,8 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) a_[rb] = w16_relu(nm * (d[rb] + Nf * cv[rb]) + bv[rb]);
                 vec2(M.bu2, bv);
-                if (!lastg) gprefetch(X.g[t + 1].we16);
-                else { W16_LD(gw, X.e[0].we16, 2, KE); }
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
+                else { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
                 WAVE_FENCE();
                 d[0] = bv[0]; d[1] = bv[1];
                 w16_feed(a_, in);
@@ -546,7 +587,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                 }
             }
             sync();                                         // every transfer of this step is in the matrix
-            if (t + 1 < Te) { W16_LD(gw, X.e[t + 1].we16, 2, KE); }
+            if (t + 1 < Te) { W16_LD(gw, FRONT ? X.e[t + 1].we16 : X.e[t + 1].we, 2, KE); }
             WAVE_FENCE();
             // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of its atom's row.  (The next
             // step writes the matrix only behind its own barrier, which this wavefront reaches after these reads.)

@@ -323,3 +323,48 @@ def test_fractional_node_mask():
     h_gpu = gnn.call(h, e, x, q, mask)
     h_ref = orc.gnn_layer(h, e, x, q, mask, w["msg"], w["upd"], dtype=np.float64)
     assert np.abs(h_gpu - h_ref).max() < 2e-6, np.abs(h_gpu - h_ref).max()
+
+
+def test_make_model_every_size_class_on_the_block_per_wave_kernel():
+    """model([h,e,x,q,mask]) on molecules of every size class of the block-per-wavefront kernel's dense-input form
+    (epnn_wave2.hip.h, !FRONT: pair lists and 48-channel e rows from the dense front-end, h given): two to a workgroup
+    (<= 16 atoms), split over two (17..32) and three wavefronts (33..48) -- float64 oracle, non-zero h, and the same call
+    with the kernel switched off ("wave2" = 0, "wave3" = 0: k_wave_forward and the tiled kernels)."""
+    from epnn_amd import charge_gn, synth
+    from oracle import epnn_oracle as orc
+    nx, T, N = 9, 3, 48
+    sizes = [3, 11, 16, 17, 20, 25, 32, 33, 38, 41, 48]
+    rng = np.random.default_rng(31)
+    B = len(sizes)
+    h = np.zeros((B, N, N, 48), np.float32); e = np.zeros((B, N, N, 48), np.float32)
+    x = np.zeros((B, N, N, nx), np.float32); q = np.zeros((B, N, N, 1), np.float32); mask = np.zeros((B, N, N, 1), np.float32)
+    for b, n in enumerate(sizes):
+        span = 1.6 * n ** (1 / 3.0) * 1.3
+        while True:
+            pts = rng.uniform(0, span, size=(n, 3))
+            d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 10
+            if d.min() > 0.8:
+                break
+        eb, _ = charge_gn.get_init_edges(pts.astype(np.float32), np.array([]), num=48)
+        e[b, :n, :n] = eb
+        x[b, :n, :n] = synth.features(rng.choice(["H", "C", "N", "O"], size=n))[None]
+        h[b, :n, :n] = (rng.normal(size=(n, 48)) * 0.2).astype(np.float32)[None]
+        q[b, :n, :n, 0] = np.float32(rng.integers(-1, 2)) / np.float32(n)
+        mask[b, :n, :n, 0] = 1
+    w = random_weights(nx, T, seed=17, scale=0.35)
+    model = charge_gn.make_model([32, 32], 48, T, nx, N)
+    model.set_weights_dict(w)
+    pred = model([h, e, x, q, mask])
+    ref = orc.model_forward(h, e, x, q, mask, w, dtype=np.float64)
+    ref32 = orc.model_forward(h, e, x, q, mask, w, dtype=np.float32)
+    err, noise = np.abs(pred - ref).max(), np.abs(ref32 - ref).max()
+    st = model.engine().last_stats()
+    assert st[1] == B and st[2] == 0, st                         # every molecule on the fused kernels
+    model.engine().set_option("wave2", 0)
+    model.engine().set_option("wave3", 0)
+    other = model([h, e, x, q, mask])
+    st = model.engine().last_stats()
+    assert st[2] == sum(1 for n in sizes if n > 32), st           # 33..48 on the tiled kernels now
+    print(f"dense model, sizes {sizes}: |dq| {err:.3e} (float32 oracle noise {noise:.3e}); |block-per-wave - other kernels| {np.abs(pred - other).max():.2e}")
+    assert err <= max(TOL, 4 * noise)
+    assert np.abs(other - ref).max() <= max(TOL, 4 * noise) and np.abs(pred - other).max() <= max(2e-6, 4 * noise)
