@@ -1,18 +1,22 @@
-// One column block per wavefront: the fused forward of epnn_wave.hip.h (compact entry, in-kernel front-end, both stacks)
-// as a workgroup of NW = 2 or 3 wavefronts which either
+// One column block per wavefront: the fused forward of epnn_wave.hip.h (both stacks, with the in-kernel front-end of the
+// compact entry or the pair lists of the dense one) as a workgroup of NW = 2 or 3 wavefronts which either
 //   * SPLIT a molecule of 16 (NW - 1) + 1 .. 16 NW atoms: column block b (atoms 16 b .. 16 b + 15) on wavefront b, the last
 //     block (the remaining atoms, in partner copies) on the last wavefront, or
 //   * run one molecule of at most 16 atoms each, side by side, without ever meeting.
 // Everything per atom is per column in k_wave_forward, so each wavefront simply runs the one-block code for its own atoms
-// (half the registers of the two-block code).  In a split what the columns of one block read from the other -- the R_j
-// rows, the G rows, the pair map, the EPN's P rows and transfer matrix -- is in the workgroup's LDS, and a workgroup barrier
-// stands wherever the one-wavefront kernel relies on program order between a table's writers and readers (two per step);
-// the G tiles, the EPN's pair blocks and the per-pair part of the front-end are dealt out alternately, the slot assignment
-// of the front-end is done by both (same values to the same words).  Same operands and the same order of every sum as
-// k_wave_forward: the charges are bit-identical (tests/test_gpu_parity.py::test_block_per_wave_kernel_is_bit_identical).
+// (215 registers).  In a split what the columns of one block read from the others -- the R_j rows, the G rows, the pair
+// map, the EPN's P rows and transfer matrix -- is in the workgroup's LDS, and a workgroup barrier stands wherever the
+// one-wavefront kernel relies on program order between a table's writers and readers (two per step); the G tiles, the EPN's
+// pair blocks and the per-pair part of the front-end are dealt out in turn, the slot assignment of the front-end is done by
+// all (same values to the same words), and the last wavefront, whose block has few partner tiles, also runs the last tiles of
+// the full blocks.  Same operands as k_wave_forward: an unsplit molecule runs the very same instruction sequence
+// (bit-identical), a split one agrees to float32 rounding (tests/test_gpu_parity.py::test_fused_kernel_every_size_vs_oracle,
+// test_block_per_wave_kernel_batch_shapes, test_three_block_kernel_every_size_vs_oracle; tests/test_gpu_api.py::
+// test_make_model_every_size_class_on_the_block_per_wave_kernel).
 //
 // Why: a launch lasts as long as its largest molecule, and a 25..32-atom molecule spends half its time in each block
-// (186 us alone on a SIMD at 29 atoms): that is the latency of every blocking call and the tail of every pipelined run.
+// (186 us alone on a SIMD at 29 atoms): that is the latency of every blocking call and the tail of every pipelined run.  And
+// three blocks on one wavefront need ~280 registers (one wavefront per SIMD), on three wavefronts 215.
 #pragma once
 #include "epnn_wave.hip.h"
 
@@ -20,7 +24,7 @@
 // wavefront's share of the full blocks' message sums [NW - 1][512] | P rows of the full blocks [16 (NW - 1)][PST]
 #define EPNN_W2_SCR(NW) (512 + ((NW) - 1) * (512 + 16 * EPNN_PST))
 #define EPNN_W2_SINGLE 0      // wblk mode: the wavefront has a molecule (n <= 16) to itself
-#define EPNN_W2_SPLIT 1       // the workgroup's two wavefronts share a molecule (17 <= n <= 32)
+#define EPNN_W2_SPLIT 1       // the workgroup's wavefronts share a molecule (17 <= n <= 32 on two, 33 <= n <= 48 on three)
 #define EPNN_W2_IDLE 2
 #define EPNN_W2_NMAX3 48       // largest molecule of the three-wavefront form
 #define EPNN_W2_AUTO_MAX 1024  // option "wave2" = -1: batches of at most this many molecules take this kernel
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     const int nx = A.nx;
     const bool xs3 = nx + 3 <= 4 * (EPNN_XS - 1);
     const float *wp = A.wpack;
-    // this wavefront's column block: block 0 = atoms 0..15, block 1 = the m1 atoms beyond them in C1 copies each
+    // this wavefront's column block
     const bool blk1 = split && w == NW - 1;                 // the last block: the atoms beyond the full blocks, m1 of them, C1 copies each
     const int m1 = blk1 ? n - 16 * (NW - 1) : 16, C1 = 16 / m1;
     const int Cw = blk1 ? C1 : 1;
@@ -60,13 +64,13 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     const int col = split ? 16 * w + (blk1 ? n16 % m1 : n16) : n16;     // the column's atom
     const bool cat = split ? (blk1 ? copy < Cw : true) : n16 < n;
     const bool own = cat && copy == 0;                      // the copy that stores the atom's rows / results
-    // The sweep of a split is balanced: block 0 has n + 1 partner tiles, block 1 (n + C1) / C1 -- three for 18 atoms --, so
-    // wavefront 1 also takes the tiles J0 .. n of block 0 (it reads block 0's P rows from LDS and hands its share of the
-    // message sums back through LDS); both then run about half of all tiles.
+    // The sweep of a split is balanced: a full block has n + 1 partner tiles, the last block (n + C1) / C1 -- three for 18
+    // atoms --, so the last wavefront also takes the tiles J0 .. n of every full block (it reads their P rows from LDS and
+    // hands its share of the message sums back through LDS); all wavefronts then run about the same number of tiles.
     const int ms = split ? n - 16 * (NW - 1) : 16, nt0 = n + 1, nt1s = (n + 16 / ms) / (16 / ms);
     const int nxt = split ? max(0, ((NW - 1) * nt0 + nt1s) / NW - nt1s) / (NW - 1) : 0;    // tiles of every full block done by the last wavefront
     const int J0 = nt0 - nxt;
-    // what the two wavefronts of a split deal out alternately, an unsplit wavefront does alone
+    // what the wavefronts of a split deal out in turn, an unsplit wavefront does alone
     const int dstep = split ? NW : 1, doff = split ? w : 0;
     const int tid = split ? (int)threadIdx.x : lane, nthr = split ? 64 * NW : 64;
     auto sync = [&]() {                                     // order the molecule's LDS / global traffic among all its lanes
