@@ -1337,6 +1337,34 @@ static int dense_host(epnn_handle *h, int B, int N, int mode, const float *hh, c
     const size_t nh = (mode == 0 ? pairs : atoms) * EPNN_EDIM, nxx = (mode == 0 ? pairs : atoms) * nx,
                  nq = mode == 0 ? pairs : atoms, ne = pairs * EPNN_EDIM, nm = pairs;
     const size_t nout = atoms * (mode == 1 ? EPNN_EDIM : 1);
+    auto up256 = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+    const size_t o_e = up256(nh * 4), o_x = o_e + up256(ne * 4), o_q = o_x + up256(nxx * 4), o_m = o_q + up256(nq * 4),
+                 in_bytes = o_m + nm * 4;
+    if (in_bytes <= ((size_t)4 << 20)) {
+        // A call on one or a few molecules (the reference's loop, infer.py:62-76) is made of latencies: the five tensors go
+        // through ONE page-locked staging buffer and ONE upload, the result comes back through page-locked memory (five
+        // uploads from pageable memory and a pageable download were ~50 us of a 0.3 ms call).  Larger batches keep the
+        // direct copies (staging 369 MB by hand would cost more than it saves).
+        if (h->pin_train.ensure(in_bytes) || h->s_train.ensure(in_bytes) || h->sd_out.ensure(nout * 4) || h->pin_tout.ensure(nout * 4))
+            return 1;
+        char *stage = h->pin_train.as<char>();
+        memcpy(stage, hh, nh * 4);
+        memcpy(stage + o_e, e, ne * 4);
+        memcpy(stage + o_x, x, nxx * 4);
+        memcpy(stage + o_q, q, nq * 4);
+        memcpy(stage + o_m, mask, nm * 4);
+        HIPCHK(hipMemcpyAsync(h->s_train.p, stage, in_bytes, hipMemcpyHostToDevice, h->stream));
+        const char *dev = h->s_train.as<char>();
+        if (dense_dev(h, B, N, mode, reinterpret_cast<const float *>(dev), reinterpret_cast<const float *>(dev + o_e),
+                      reinterpret_cast<const float *>(dev + o_x), reinterpret_cast<const float *>(dev + o_q),
+                      reinterpret_cast<const float *>(dev + o_m), h->sd_out.as<float>()))
+            return 1;
+        if (finish_forward(h)) return 1;
+        HIPCHK(hipMemcpyAsync(h->pin_tout.p, h->sd_out.p, nout * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(out, h->pin_tout.p, nout * 4);
+        return 0;
+    }
     if (h->sd_h.ensure(nh * 4) || h->sd_e.ensure(ne * 4) || h->sd_x.ensure(nxx * 4) || h->sd_q.ensure(nq * 4) ||
         h->sd_mask.ensure(nm * 4) || h->sd_out.ensure(nout * 4))
         return 1;

@@ -169,7 +169,8 @@ struct epnn_handle {
     // page-locked staging: the plan's index arrays with, behind them, the inputs of the host entry (one upload per forward;
     // reused once ev_ctl says the previous upload has run); the charges of the asynchronous host entry
     PinBuf pin_ctl, pin_out;
-    PinBuf pin_train, pin_tout;       // inputs of epnn_train_step_xyz (one upload per step); loss terms + predictions of a train step
+    PinBuf pin_train, pin_tout;       // inputs of epnn_train_step_xyz / of a small dense call (one upload); loss terms + predictions of a
+                                      // train step / charges of a small dense call
     DevBuf s_train;
     hipEvent_t ev_ctl = nullptr;
     bool ctl_uploading = false;
