@@ -1593,25 +1593,49 @@ extern "C" int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *
     if (h->pending.active && finish_forward(h)) return 1;
     const int nx = h->cfg.nx;
     const size_t pairs = (size_t)B * N * N, slots = (size_t)B * N;
-    if (h->sd_h.ensure(pairs * EPNN_EDIM * 4) || h->sd_e.ensure(pairs * EPNN_EDIM * 4) || h->sd_x.ensure(pairs * nx * 4) ||
-        h->sd_q.ensure(pairs * 4) || h->sd_mask.ensure(pairs * 4) || h->sd_out.ensure(slots * 4) ||
-        h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) || h->dn_qs.ensure(slots * 4) ||
+    if (h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) || h->dn_qs.ensure(slots * 4) ||
         h->dn_nms.ensure(slots * 4) || h->dn_flag.ensure(slots * 4))
         return 1;
-    HIPCHK(hipMemcpyAsync(h->sd_h.p, h_inp, pairs * EPNN_EDIM * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->sd_e.p, e_inp, pairs * EPNN_EDIM * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->sd_x.p, x_inp, pairs * nx * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->sd_q.p, q_inp, pairs * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->sd_mask.p, mask_inp, pairs * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->sd_out.p, y, slots * 4, hipMemcpyHostToDevice, h->stream));
     DenseArgs D{};
     D.B = B; D.N = N; D.nx = nx; D.model_level = 1;
-    D.h_in = h->sd_h.as<float>(); D.e_in = h->sd_e.as<float>(); D.x_in = h->sd_x.as<float>();
-    D.q_in = h->sd_q.as<float>(); D.mask_in = h->sd_mask.as<float>();
+    const float *d_y;
+    auto up256 = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
+    const size_t b_he = pairs * EPNN_EDIM * 4, o_e = up256(b_he), o_x = o_e + up256(b_he), o_q = o_x + up256(pairs * nx * 4),
+                 o_m = o_q + up256(pairs * 4), o_y = o_m + up256(pairs * 4), in_bytes = o_y + slots * 4;
+    if (in_bytes <= ((size_t)4 << 20)) {
+        // one molecule per step (the reference's loop): one page-locked staging buffer, one upload (as in dense_host)
+        if (h->pin_train.ensure(in_bytes) || h->s_train.ensure(in_bytes)) return 1;
+        char *stage = h->pin_train.as<char>();
+        memcpy(stage, h_inp, b_he);
+        memcpy(stage + o_e, e_inp, b_he);
+        memcpy(stage + o_x, x_inp, pairs * nx * 4);
+        memcpy(stage + o_q, q_inp, pairs * 4);
+        memcpy(stage + o_m, mask_inp, pairs * 4);
+        memcpy(stage + o_y, y, slots * 4);
+        HIPCHK(hipMemcpyAsync(h->s_train.p, stage, in_bytes, hipMemcpyHostToDevice, h->stream));
+        const char *dev = h->s_train.as<char>();
+        D.h_in = reinterpret_cast<const float *>(dev); D.e_in = reinterpret_cast<const float *>(dev + o_e);
+        D.x_in = reinterpret_cast<const float *>(dev + o_x); D.q_in = reinterpret_cast<const float *>(dev + o_q);
+        D.mask_in = reinterpret_cast<const float *>(dev + o_m);
+        d_y = reinterpret_cast<const float *>(dev + o_y);
+    } else {
+        if (h->sd_h.ensure(b_he) || h->sd_e.ensure(b_he) || h->sd_x.ensure(pairs * nx * 4) || h->sd_q.ensure(pairs * 4) ||
+            h->sd_mask.ensure(pairs * 4) || h->sd_out.ensure(slots * 4))
+            return 1;
+        HIPCHK(hipMemcpyAsync(h->sd_h.p, h_inp, b_he, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->sd_e.p, e_inp, b_he, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->sd_x.p, x_inp, pairs * nx * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->sd_q.p, q_inp, pairs * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->sd_mask.p, mask_inp, pairs * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->sd_out.p, y, slots * 4, hipMemcpyHostToDevice, h->stream));
+        D.h_in = h->sd_h.as<float>(); D.e_in = h->sd_e.as<float>(); D.x_in = h->sd_x.as<float>();
+        D.q_in = h->sd_q.as<float>(); D.mask_in = h->sd_mask.as<float>();
+        d_y = h->sd_out.as<float>();
+    }
     D.xs = h->dn_xs.as<float>(); D.hs = h->dn_hs.as<float>(); D.qs = h->dn_qs.as<float>(); D.nms = h->dn_nms.as<float>();
     D.flag = h->dn_flag.as<int>(); D.tol = h->cfg.near_tol;
     if (launch_dense_atoms(h, D)) return 1;                                                         // charge_gn.py:382-384
-    return train_step_slots(h, B, N, D.e_in, D.mask_in, D.xs, D.hs, D.qs, h->sd_out.as<float>(), pred_out, loss_out, apply);
+    return train_step_slots(h, B, N, D.e_in, D.mask_in, D.xs, D.hs, D.qs, d_y, pred_out, loss_out, apply);
 }
 
 // train_step from a flat coordinate batch: y_flat / q_out_flat are per real atom [A]
