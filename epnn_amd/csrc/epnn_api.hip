@@ -789,7 +789,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         if (!(S.run_gnn && S.run_epn)) EPNN_FAIL("forward: internal error (block-per-wavefront kernel for a single stack)");
         WaveArgs A2 = A;
         A2.wblk = A.wblk + P.small_order.size() + 2 * (size_t)P.pair_wgs;
-        const int lds23 = 3 * lds;
+        const int lds23 = std::min(3 * lds, 131072);
         A2.lds_words = lds23 / 4;
         if (!h->wave23_attr) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -811,7 +811,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         if (!(S.run_gnn && S.run_epn)) EPNN_FAIL("forward: internal error (block-per-wavefront kernel for a single stack)");
         WaveArgs A2 = A;
         A2.wblk = A.wblk + P.small_order.size();
-        const int lds2 = 2 * lds;
+        const int lds2 = std::min(2 * lds, 131072);
         A2.lds_words = lds2 / 4;
         if (!h->wave2_attr) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
