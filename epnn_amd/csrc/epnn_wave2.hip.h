@@ -150,7 +150,6 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     };
     float gw[2][KE], ge0[KE], ge1[KE];
     W16_LD(gw, FRONT ? X.g[0].we16 : X.g[0].we, 2, KE);
-    if (!FRONT && ngt > 0) load_e(doff, ge0, ge1);
     WAVE_FENCE();
 
     for (int i = tid; i < n * (PMS / 2); i += nthr) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
@@ -267,6 +266,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     auto gtiles = [&]() {
         float en0[KE], en1[KE];
         int gt = doff;
+        if (!FRONT && gt < ngt) load_e(gt, ge0, ge1);       // (48-channel rows: 24 registers, not held across the other phases)
 #pragma unroll 1
         for (; gt + dstep < ngt; gt += 2 * dstep) {
             load_e(gt + dstep, en0, en1);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     };
     auto gprefetch = [&](int weoff) {
         W16_LD(gw, weoff, 2, KE);
-        if (ngt > 0) load_e(doff, ge0, ge1);
+        if (FRONT && ngt > 0) load_e(doff, ge0, ge1);
     };
     auto vec2 = [&](int off, f32x4 (&v)[2]) {
         v[0] = w16_ld(wp + off + fo);
