@@ -206,6 +206,38 @@ def test_bench_two_ranks_on_this_box(tmp_path, launcher):
     assert 0 < o["roofline"]["frac"] < 1.3 and o["roofline"]["bound"] == "mfma"
 
 
+def test_bench_line_of_the_drivers_command(tmp_path):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (what the driver runs): ONE JSON line on stdout with every field of
+    the contract, the roofline and CPU-baseline objects, and this project's extras."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
+    o = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in o, key
+    assert o["n_gpus"] == 1 and o["steps"] == 20 and o["warmup"] == 5 and o["higher_is_better"] is True
+    assert o["unit"] == "atoms/s" and o["dtype"] == "f32" and o["data"] == "synthetic" and o["vs_baseline"] is None
+    assert o["config"]["workload"] == "qm9_like_b1024_N29" and "model" not in o["config"]
+    assert abs(o["value"] - o["config"]["atoms_per_gpu"] / (o["ms_per_step"] * 1e-3)) <= 1e-6 * o["value"]
+    r = o["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
+    c = o["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert o["parity"]["max_abs_dq_vs_reference"] <= 1e-5 and o["parity"]["systems"] == 871
+    for key in ("real_data", "host_to_host", "blocking_call", "order"):
+        assert key in o, key
+    assert o["blocking_call"]["ms"] < o["blocking_call"]["ms_one_wavefront_per_molecule"]
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
