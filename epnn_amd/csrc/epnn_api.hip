@@ -1195,6 +1195,13 @@ static int launch_dense_atoms(epnn_handle *h, DenseArgs &D) {
     if (h->dn_den.ensure(slots * 4)) return 1;
     float *den = h->dn_den.as<float>();
     HIPCHK(hipMemsetAsync(D.flag, 0, slots * sizeof(int), h->stream));
+    if (D.model_level && slots * D.N <= 65536) {            // one or a few molecules: one launch instead of four
+        const int N = D.N, CT = EPNN_EDIM + D.nx + 1;
+        hipLaunchKernelGGL(k_dn_feat_all, dim3((unsigned)((N * CT + 255) / 256), (unsigned)D.B), dim3(256), 0, h->stream, D, den);
+        hipLaunchKernelGGL(k_dn_escan, dim3((unsigned)std::min<size_t>((slots * D.N + 255) / 256, 16384)), dim3(256), 0, h->stream, D);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_dn_den, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->stream, D, den);
     if (D.model_level) {
         const int N = D.N;

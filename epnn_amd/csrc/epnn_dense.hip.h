@@ -76,6 +76,38 @@ __global__ __launch_bounds__(256) void k_dn_feat(DenseArgs D, const float *den) 
     if (v != 0.f) atomicOr(&D.flag[slot], 1);
 }
 
+// The same four passes (k_dn_den, k_dn_feat<0..2>) in ONE launch for calls on one or a few molecules, where a launch costs more
+// than its work: thread = (atom k, channel c of [h | x | q]), every thread adds up the mask column of its atom itself (same
+// order over j as k_dn_den: the same bits).
+__global__ __launch_bounds__(256) void k_dn_feat_all(DenseArgs D, float *den) {
+    const int N = D.N, CT = EPNN_EDIM + D.nx + 1;
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * CT) return;
+    const int k = idx / CT, c = idx - k * CT;
+    const int which = c < EPNN_EDIM ? 0 : (c < EPNN_EDIM + D.nx ? 1 : 2);
+    const int C = which == 0 ? EPNN_EDIM : (which == 1 ? D.nx : 1), cc = which == 0 ? c : (which == 1 ? c - EPNN_EDIM : 0);
+    const float *src = (which == 0 ? D.h_in : (which == 1 ? D.x_in : D.q_in)) + (size_t)b * N * N * C + (size_t)k * C + cc;
+    const float *mk = D.mask_in + (size_t)b * N * N + k;
+    float s = 0.f, dn = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < N; ++j) {
+        s += src[(size_t)j * N * C];
+        dn += mk[(size_t)j * N];
+    }
+    const float v = dn != 0.f ? s / dn : 0.f;
+    const size_t slot = (size_t)b * N + k;
+    if (which == 0) D.hs[slot * EPNN_EDIM + cc] = v;
+    else if (which == 1) D.xs[slot * D.nx + cc] = v;
+    else D.qs[slot] = v;
+    if (c == 0) {
+        den[slot] = dn;
+        D.nms[slot] = fminf(fmaxf(dn, 0.f), 1.f);
+        if (dn != 0.f) atomicOr(&D.flag[slot], 1);
+    }
+    if (v != 0.f) atomicOr(&D.flag[slot], 1);
+}
+
 // layer-level entry: per-atom tensors are given; copy and flag
 __global__ __launch_bounds__(256) void k_dn_copy_atoms(DenseArgs D) {
     const int F = D.nx + EPNN_EDIM + 1;
