@@ -865,7 +865,7 @@ static int run_frontend_xyz(epnn_handle *h, const float *d_xyz) {
         const unsigned nsb = (unsigned)((F.A + EPNN_SCAN_ELEMS - 1) / EPNN_SCAN_ELEMS);
         if (h->d_bsum.ensure((size_t)nsb * sizeof(int))) return 1;
         hipLaunchKernelGGL(k_front_scan1, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
-        hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+        if (nsb > 1) hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
     }
     hipLaunchKernelGGL(k_front_fill, dim3(rows), dim3(256), 0, h->stream, F);
     HIPCHK(hipGetLastError());
@@ -1295,7 +1295,7 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
         const unsigned nsb = (unsigned)((F.A + EPNN_SCAN_ELEMS - 1) / EPNN_SCAN_ELEMS);
         if (h->d_bsum.ensure((size_t)nsb * sizeof(int))) return 1;
         hipLaunchKernelGGL(k_front_scan1, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
-        hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+        if (nsb > 1) hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
     }
     hipLaunchKernelGGL(k_dn_pairs<1>, dim3(rows), dim3(256), 0, h->stream, D);
     HIPCHK(hipGetLastError());

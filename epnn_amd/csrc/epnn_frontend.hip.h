@@ -79,7 +79,13 @@ __global__ __launch_bounds__(256) void k_front_scan1(FrontArgs F, int *bsum) {
         if (base + k < F.A) F.row_off[base + k] = run;
         run += v[k];
     }
-    if (tid == 255) bsum[blockIdx.x] = run;
+    if (tid == 255) {
+        bsum[blockIdx.x] = run;
+        if (gridDim.x == 1) {                      // a single block: the total is known here, k_front_scan2 is not launched
+            F.row_off[F.A] = run;
+            if (run > F.pcap) atomicOr(F.status, EPNN_ST_PAIR_OVERFLOW);
+        }
+    }
 }
 __global__ __launch_bounds__(256) void k_front_scan2(FrontArgs F, const int *bsum) {
     __shared__ int wsum[4];
