@@ -1316,10 +1316,9 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     D.src = flat;
     D.C = C;
     const unsigned gO = (unsigned)std::min<size_t>((slots * C + 255) / 256, 8192);
+    D.host_status = h->h_status;                  // pinned, device-visible: written by the scatter kernel
     hipLaunchKernelGGL(k_dn_scatter, dim3(gO), dim3(256), 0, h->stream, D);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     h->stats[1] = (int64_t)P.fused_count();
     h->stats[2] = (int64_t)P.large_list.size();
     return 0;

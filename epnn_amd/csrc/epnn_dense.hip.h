@@ -33,6 +33,7 @@ struct DenseArgs {
     int *pi, *pj, *psym;
     float *pe, *pwi, *pwj;
     int *status;
+    int *host_status;               // pinned host ints: [0] status bits, [1] number of listed pairs (written by the last kernel of the call)
     float *out;                     // (B,N,C)
     const float *src;               // flat [A][C]
     int C;
@@ -224,5 +225,13 @@ __global__ __launch_bounds__(256) void k_dn_scatter(DenseArgs D) {
         const int b = (int)(slot / D.N), k = (int)(slot - (size_t)b * D.N);
         const int n = D.moff[b + 1] - D.moff[b];
         D.out[idx] = k < n ? D.src[(size_t)(D.moff[b] + k) * D.C + cidx] : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && D.host_status) {
+        // every kernel of the call ran before this one on the stream: hand status + pair count to the host from here (two
+        // device-to-host copies less at the end of a call that is made of latencies)
+        volatile int *hs = D.host_status;
+        hs[0] = *D.status;
+        hs[1] = D.row_off[D.A];
+        __threadfence_system();
     }
 }
