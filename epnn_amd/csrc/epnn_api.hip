@@ -555,9 +555,9 @@ static int pack_weights(epnn_handle *h) {
 // payload_bytes / ctl_fresh (host entry): room for the call's inputs behind the index arrays, in the page-locked staging and
 // in its device mirror alike, so that ONE host-to-device copy carries everything a forward needs (plan_payload_offset);
 // with ctl_fresh given, the upload of freshly built index arrays is left to the caller, who sends them with the payload.
-// index arrays of a plan: wblk [3B + 3] int4 | moff [B + 1] | mflag [B] | molof [A]   (wblk: one entry per wavefront of the fused
-// kernels; the block-per-wavefront kernel has two or three per workgroup)
-static size_t plan_wblk_cap(int B) { return 3 * (size_t)B + 3; }
+// index arrays of a plan: wblk [4B + 4] int4 | moff [B + 1] | mflag [B] | molof [A]   (wblk: one entry per wavefront of the fused
+// kernels; the block-per-wavefront kernel has two to four per workgroup)
+static size_t plan_wblk_cap(int B) { return 4 * (size_t)B + 4; }
 static size_t plan_ctl_ints(int B, int A) { return 4 * plan_wblk_cap(B) + 2 * (size_t)B + 1 + (size_t)A; }
 static size_t plan_payload_offset(int B, int A) { return (plan_ctl_ints(B, A) * sizeof(int) + 255) & ~size_t(255); }
 static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
@@ -586,6 +586,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     P.split_order.clear();
     P.single_order.clear();
     P.split3_order.clear();
+    P.split4_order.clear();
     P.pair_wgs = 0;
     P.large_list.clear();
     P.small_nmax = 0;
@@ -611,7 +612,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
-        const bool mid = !small && allow_mid && h->opt_wave3 && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX3;
+        const bool mid = !small && allow_mid && h->opt_wave3 && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX4;
         c_mflag[b] = small || mid ? 0 : 1;
         if (small) {
             P.small_nmax = std::max(P.small_nmax, n);
@@ -622,7 +623,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
                 count[n] += 1;
             }
         } else if (mid) {
-            P.split3_order.push_back(b);                    // three wavefronts each
+            (n <= EPNN_W2_NMAX3 ? P.split3_order : P.split4_order).push_back(b);     // three / four wavefronts each
         } else {
             P.large_list.push_back(b);
         }
@@ -670,6 +671,11 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         for (int b : P.split3_order) {
             const int4 ent = make_int4(b, offsets[b], (offsets[b + 1] - offsets[b]) | (EPNN_W2_SPLIT << 8), pbase[b]);
             for (int k = 0; k < 3; ++k) c_pair[e++] = ent;
+        }
+        std::stable_sort(P.split4_order.begin(), P.split4_order.end(), larger_first);
+        for (int b : P.split4_order) {
+            const int4 ent = make_int4(b, offsets[b], (offsets[b + 1] - offsets[b]) | (EPNN_W2_SPLIT << 8), pbase[b]);
+            for (int k = 0; k < 4; ++k) c_pair[e++] = ent;
         }
     }
     // the device copy has the same layout: ONE upload per plan
@@ -781,29 +787,44 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     const WaveIndex &X = h->wvidx;
     A.total_waves = (int)P.fused_count();          // reports to the hand-off: one per molecule
     bool side_mid = false;
-    if (!P.split3_order.empty()) {
-        // Molecules of 33..48 atoms (the reference's `mixed` set goes up to 41): three wavefronts each.  In a lone batch (the
-        // block-per-wavefront kernel takes the smaller molecules too) this launch runs BESIDE the other one, on the handle's
-        // second stream -- on one stream the two run one after the other (0.12 + 0.16 ms for the reference's validation
-        // batch).  Pipeline lanes keep everything on their one stream.
+    if (!P.split3_order.empty() || !P.split4_order.empty()) {
+        // Molecules of 33..48 atoms (the reference's `mixed` set goes up to 41) and 49..64: three / four wavefronts each.  In a
+        // lone batch (the block-per-wavefront kernel takes the smaller molecules too) these launches run BESIDE the other one,
+        // on the handle's second stream -- on one stream they run one after the other (0.12 + 0.16 ms for the reference's
+        // validation batch).  Pipeline lanes keep everything on their one stream.
         if (!(S.run_gnn && S.run_epn)) EPNN_FAIL("forward: internal error (block-per-wavefront kernel for a single stack)");
-        WaveArgs A2 = A;
-        A2.wblk = A.wblk + P.small_order.size() + 2 * (size_t)P.pair_wgs;
-        const int lds23 = std::min(3 * lds, 131072);
-        A2.lds_words = lds23 / 4;
         if (!h->wave23_attr) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             h->wave23_attr = true;
         }
         side_mid = P.pair_wgs > 0;
+        hipStream_t st = side_mid ? h->stream2 : h->stream;
         if (side_mid) {
             HIPCHK(hipEventRecord(h->ev_fork, h->stream));
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         }
-        if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward2<3, true>), dim3((unsigned)P.split3_order.size()), dim3(192), (size_t)lds23, side_mid ? h->stream2 : h->stream, A2, h->wvidx);
-        else hipLaunchKernelGGL((k_wave_forward2<3, false>), dim3((unsigned)P.split3_order.size()), dim3(192), (size_t)lds23, side_mid ? h->stream2 : h->stream, A2, h->wvidx);
-        HIPCHK(hipGetLastError());
+        WaveArgs A2 = A;
+        A2.wblk = A.wblk + P.small_order.size() + 2 * (size_t)P.pair_wgs;
+        if (!P.split3_order.empty()) {
+            const int lds23 = std::min(3 * lds, 131072);
+            A2.lds_words = lds23 / 4;
+            const dim3 g3((unsigned)P.split3_order.size());
+            if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward2<3, true>), g3, dim3(192), (size_t)lds23, st, A2, h->wvidx);
+            else hipLaunchKernelGGL((k_wave_forward2<3, false>), g3, dim3(192), (size_t)lds23, st, A2, h->wvidx);
+            HIPCHK(hipGetLastError());
+        }
+        if (!P.split4_order.empty()) {
+            A2.wblk += 3 * P.split3_order.size();
+            const int lds24 = std::min(4 * lds, 131072);
+            A2.lds_words = lds24 / 4;
+            const dim3 g4((unsigned)P.split4_order.size());
+            if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward2<4, true>), g4, dim3(256), (size_t)lds24, st, A2, h->wvidx);
+            else hipLaunchKernelGGL((k_wave_forward2<4, false>), g4, dim3(256), (size_t)lds24, st, A2, h->wvidx);
+            HIPCHK(hipGetLastError());
+        }
         if (side_mid) HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     }
     if (P.pair_wgs > 0) {

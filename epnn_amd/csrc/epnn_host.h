@@ -83,10 +83,11 @@ struct Plan {                 // what the host derives from `offsets`
     std::vector<int> small_order;   // molecules on the fused path, largest first
     // block-per-wavefront kernel (epnn_wave2.hip.h; compact entry, option "wave2"): molecules split over two wavefronts and
     // molecules of at most 16 atoms that share a workgroup in pairs, both largest first
-    std::vector<int> split_order, single_order, split3_order;    // (split3: 33..48 atoms over three wavefronts, behind the pair entries)
+    std::vector<int> split_order, single_order, split3_order, split4_order;    // (split3 / split4: 33..48 / 49..64 atoms over three / four
+                                                                                // wavefronts, behind the pair entries)
     int pair_wgs = 0;               // that kernel's workgroups: split molecules + pairs of single ones (two wblk entries each,
                                     // behind the small_order entries; the three-block kernel's entries follow)
-    size_t fused_count() const { return small_order.size() + split_order.size() + single_order.size() + split3_order.size(); }
+    size_t fused_count() const { return small_order.size() + split_order.size() + single_order.size() + split3_order.size() + split4_order.size(); }
     bool allow_mid = false;
     std::vector<int> large_list;    // molecules on the tiled path
     int small_nmax = 0;
@@ -140,7 +141,8 @@ struct epnn_handle {
                                       // long as its largest molecule, which the split halves (0.21 -> 0.12-0.18 ms) --, else 0.
                                       // Batches in flight side by side fill the GPU: there the split costs throughput (wavefront 1 of
                                       // a 17..20-atom molecule mostly waits: 175 instead of 214 M atoms/s), so engine.Pipeline sets 0.
-    int opt_wave3 = 1;                // compact entry: molecules of 33..48 atoms run on three wavefronts of the block-per-wavefront kernel (0: the tiled kernels)
+    int opt_wave3 = 1;                // molecules of 33..48 / 49..64 atoms run on three / four wavefronts of the block-per-wavefront kernel
+                                      // (0: the tiled kernels)
     bool wave2_attr = false, wave23_attr = false;
     int opt_wave_order = 0;           // order of a launch's wavefronts: 0 largest molecule first, 1 ends interleaved, 2 smallest first
     int opt_large_fused = 1;          // tiled path: one launch between two sweeps / pair passes (0: one kernel per stage)

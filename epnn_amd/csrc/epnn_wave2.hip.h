@@ -24,9 +24,10 @@
 // wavefront's share of the full blocks' message sums [NW - 1][512] | P rows of the full blocks [16 (NW - 1)][PST]
 #define EPNN_W2_SCR(NW) (512 + ((NW) - 1) * (512 + 16 * EPNN_PST))
 #define EPNN_W2_SINGLE 0      // wblk mode: the wavefront has a molecule (n <= 16) to itself
-#define EPNN_W2_SPLIT 1       // the workgroup's wavefronts share a molecule (17 <= n <= 32 on two, 33 <= n <= 48 on three)
+#define EPNN_W2_SPLIT 1       // the workgroup's wavefronts share a molecule (17 <= n <= 32 on two, 33 <= n <= 48 on three, 49 <= n <= 64 on four)
 #define EPNN_W2_IDLE 2
 #define EPNN_W2_NMAX3 48       // largest molecule of the three-wavefront form
+#define EPNN_W2_NMAX4 64       // ... of the four-wavefront form (one lane per partner in the front-end: 64 is the end of this design)
 #define EPNN_W2_AUTO_MAX 1024  // option "wave2" = -1: batches of at most this many molecules take this kernel
 
 // both wavefronts: what either wrote (LDS or global memory) before the barrier is read by the other after it
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                 }
                 base += __popc(lo) + __popc(hi);
             }
-        } else {                                            // up to 48: one row per step, lane = partner
+        } else {                                            // up to 64: one row per step, lane = partner
             for (int i = 0; i + 1 < n; ++i) {
                 const bool near = lane > i && lane < n && wave_dist2(xs, i, lane) < A.cut2;
                 const unsigned long long bal = __ballot(near);

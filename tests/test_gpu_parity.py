@@ -839,12 +839,12 @@ def test_block_per_wave_kernel_batch_shapes(gpu_engine_factory):
     share a workgroup in pairs, an odd number of those (one idle wavefront), a single molecule of either kind, a mix with
     three-block and tiled molecules - against the float64 oracle; and where the automatic choice stops."""
     from epnn_amd import synth
-    nx, T, N = 9, 2, 60
+    nx, T, N = 9, 2, 70
     w = random_weights(nx, T, seed=21, scale=0.35)
     off, xyz, x, Q, _ = synth.qm9_like_batch(B=48, seed=11, N=29)
     mols = [(xyz[off[k]:off[k + 1]], x[off[k]:off[k + 1]], float(Q[k])) for k in range(48)]
     rng = np.random.default_rng(4)
-    for n in (36, 45, 60):                                   # three wavefronts (2) and tiled path (1)
+    for n in (36, 45, 60, 70):                               # three wavefronts (2), four (1) and the tiled path (1)
         pts = np.cumsum(rng.normal(size=(n, 3)) * 0.75, axis=0).astype(np.float32)
         mols.append((pts, synth.features(rng.choice(["H", "C", "N", "O"], size=n)), 0.0))
     ref = _oracle_batch(mols, w, N)
@@ -870,7 +870,7 @@ def test_block_per_wave_kernel_batch_shapes(gpu_engine_factory):
         got = run(sel)
         worst = max(np.abs(g - ref[k][:ns[k]]).max() for g, k in zip(got, sel))
         assert worst <= tol, (name, worst)
-        assert int(eng.last_stats()[1]) == sum(1 for k in sel if ns[k] <= 48), name      # fused-path molecules
+        assert int(eng.last_stats()[1]) == sum(1 for k in sel if ns[k] <= 64), name      # fused-path molecules
     # a molecule's charges do not depend on what else is in the batch (same kernel, same wavefront roles)
     whole = run(list(range(len(mols))))
     alone = run(splits[:1]) + run(singles[:1])
@@ -885,3 +885,49 @@ def test_block_per_wave_kernel_batch_shapes(gpu_engine_factory):
     on_1024 = np.concatenate(run(sel[:1024]))
     assert np.array_equal(auto_1025, off_1025) and np.array_equal(auto_1024, on_1024)
     assert np.abs(auto_1025[:auto_1024.size] - auto_1024).max() <= 2e-7
+
+
+@pytest.mark.gpu
+def test_four_wavefront_sizes_vs_oracle(gpu_engine_factory):
+    """Molecules of 49..64 atoms through the compact entry run on FOUR wavefronts of the block-per-wavefront kernel
+    (k_wave_forward2<4>; 64 is where its one-lane-per-partner front-end ends, 65 atoms take the tiled kernels).  Sizes at
+    both ends and in between, sparse and dense, random non-degenerate weights, float64 oracle; the same molecules on the tiled
+    kernels ("wave3" = 0) agree to float32 rounding."""
+    from epnn_amd import synth
+    nx, T, N = 9, 2, 66
+    w = random_weights(nx, T, seed=23, scale=0.35)
+    rng = np.random.default_rng(29)
+    mols = []
+    for n in (49, 50, 53, 56, 60, 63, 64, 65):
+        for span_per_atom in (1.0, 2.2):
+            span = max(1.2, span_per_atom * n ** (1.0 / 3.0) * 1.6)
+            while True:
+                pts = rng.uniform(0, span, size=(n, 3))
+                d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 10
+                if d.min() > 0.7:
+                    break
+            mols.append((pts.astype(np.float32), synth.features(rng.choice(["H", "C", "N", "O", "F"], size=n)), float(rng.integers(-1, 2))))
+    off, xyz, x, Q = _batch(mols)
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+    q = eng.forward_xyz(off, xyz, x, Q, N=N)
+    st = eng.last_stats()
+    assert st[1] == len(mols) - 2 and st[2] == 2, st                # the two 65-atom systems on the tiled kernels
+    worst = max(float(np.abs(q[off[k]:off[k + 1]] - ref[k][:m[1].shape[0]]).max()) for k, m in enumerate(mols))
+    for k, m in enumerate(mols):
+        assert abs(float(q[off[k]:off[k + 1]].sum(dtype=np.float64)) - m[2]) < 2e-5
+    tiled = gpu_engine_factory(nx=nx, T=T)
+    tiled.set_weights(w)
+    tiled.set_option("wave3", 0)
+    qt = tiled.forward_xyz(off, xyz, x, Q, N=N)
+    assert tiled.last_stats()[2] == len(mols)
+    print(f"sizes 49..64: worst |dq| {worst:.2e}; float32 oracle noise {noise:.2e}; |four wavefronts - tiled| {np.abs(qt - q).max():.2e}")
+    assert worst <= max(TOL, 4 * noise) and np.abs(qt - q).max() <= max(3e-6, 4 * noise)
+    # on pipeline lanes ("wave2" = 0) the same kernel, on the lane's one stream
+    lane = gpu_engine_factory(nx=nx, T=T)
+    lane.set_weights(w)
+    lane.set_option("wave2", 0)
+    assert np.array_equal(lane.forward_xyz(off, xyz, x, Q, N=N), q)
