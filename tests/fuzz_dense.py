@@ -19,7 +19,7 @@ from oracle import epnn_oracle as orc        # noqa: E402
 
 
 def random_case(rng, nx=9):
-    T, B, N = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(2, 48))
+    T, B, N = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(2, 68))
     e = np.zeros((B, N, N, 48), np.float32)
     mask = np.zeros((B, N, N, 1), np.float32)
     x = np.zeros((B, N, nx), np.float32)
