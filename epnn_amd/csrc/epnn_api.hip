@@ -788,8 +788,8 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.total_waves = (int)P.fused_count();          // reports to the hand-off: one per molecule
     bool side_mid = false;
     if (!P.split3_order.empty() || !P.split4_order.empty()) {
-        // Molecules of 33..48 atoms (the reference's `mixed` set goes up to 41) and 49..64: three / four wavefronts each.  In a
-        // lone batch (the block-per-wavefront kernel takes the smaller molecules too) these launches run BESIDE the other one,
+        // Molecules of 33..48 atoms (the reference's `mixed` set goes up to 41) and 49..64: three / four wavefronts each.  On a
+        // lone handle ("wave2" != 0) these launches run BESIDE the launch of the smaller molecules,
         // on the handle's second stream -- on one stream they run one after the other (0.12 + 0.16 ms for the reference's
         // validation batch).  Pipeline lanes keep everything on their one stream.
         if (!(S.run_gnn && S.run_epn)) EPNN_FAIL("forward: internal error (block-per-wavefront kernel for a single stack)");
@@ -800,7 +800,8 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             h->wave23_attr = true;
         }
-        side_mid = P.pair_wgs > 0;
+        side_mid = h->opt_wave2 != 0 && (P.pair_wgs > 0 || !P.small_order.empty());     // a lone handle (engine.Pipeline sets 0 on its
+                                                                                        // lanes) with a launch to run beside
         hipStream_t st = side_mid ? h->stream2 : h->stream;
         if (side_mid) {
             HIPCHK(hipEventRecord(h->ev_fork, h->stream));
