@@ -25,7 +25,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench20 -- python3 
 stats $OUT/bench20 $OUT/r02_bench20_kernel_stats.csv
 # 4. PMC passes (bench.py --pmc runs them as children before touching the GPU) + the un-profiled lines
 cd $R
-# (the 20-step line first: right after counter passes its 2 ms timed region once read 111 instead of 194 M atoms/s)
+# (the 20-step line first: right after counter passes its 2 ms timed region once read 111 instead of 194 M atoms/s, and
+#  right after the traced runs above 186 M; four runs in fresh processes on an otherwise idle box: 191-196 M)
 python3 bench.py --steps 20 --warmup 5 > $OUT/r02_bench20_line.json 2> $OUT/pmc.err
 python3 bench.py --pmc > $OUT/r02_bench_line.json 2>> $OUT/pmc.err
 cp profiles/r02_pmc_bench.json $OUT/ 2>/dev/null
