@@ -42,3 +42,14 @@ def test_no_silent_cpu_fallback():
         Engine()
     src = open(os.path.join(ROOT, "epnn_amd", "charge_gn.py")).read() + open(os.path.join(ROOT, "epnn_amd", "engine.py")).read()
     assert "oracle" not in src
+
+
+def test_every_option_is_documented_in_the_header():
+    """epnn_set_option's names (epnn_api.hip) all appear in include/epnn.h."""
+    import re
+    src = open(os.path.join(ROOT, "epnn_amd", "csrc", "epnn_api.hip")).read()
+    hdr = open(os.path.join(ROOT, "include", "epnn.h")).read()
+    names = re.findall(r'!strcmp\(name, "([a-z0-9_]+)"\)', src)
+    assert len(names) >= 10
+    missing = [n for n in names if f'"{n}"' not in hdr]
+    assert not missing, missing
