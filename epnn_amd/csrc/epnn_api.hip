@@ -1303,9 +1303,7 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     h->ctl_clean = false;
     h->last_front = false;
-    const unsigned gA = (unsigned)std::min<size_t>((A * (nx + EPNN_EDIM + 2) + 255) / 256, 4096);
     const unsigned rows = (unsigned)((P.A + 3) / 4);
-    hipLaunchKernelGGL(k_dn_compact, dim3(gA), dim3(256), 0, h->stream, D);
     hipLaunchKernelGGL(k_dn_pairs<0>, dim3(rows), dim3(256), 0, h->stream, D);
     FrontArgs F{};
     F.A = P.A;

@@ -151,19 +151,6 @@ __global__ __launch_bounds__(64) void k_dn_neff(DenseArgs D) {
     if (lane == 0) D.neff[b] = last + 1;
 }
 
-__global__ __launch_bounds__(256) void k_dn_compact(DenseArgs D) {
-    const int F = D.nx + EPNN_EDIM + 2;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < D.A * F; idx += gridDim.x * 256) {
-        const int at = idx / F, f = idx - at * F;
-        const int b = D.mol_of[at];
-        const int slot = b * D.N + (at - D.moff[b]);
-        if (f < D.nx) D.xf[(size_t)at * D.nx + f] = D.xs[(size_t)slot * D.nx + f];
-        else if (f < D.nx + EPNN_EDIM) D.hf[(size_t)at * EPNN_EDIM + (f - D.nx)] = D.hs[(size_t)slot * EPNN_EDIM + (f - D.nx)];
-        else if (f == D.nx + EPNN_EDIM) D.qf[at] = D.qs[slot];
-        else D.nmf[at] = D.nms[slot];
-    }
-}
-
 // classification of the ordered pair (i,j) seen from row i: 0 none, 1 symmetric entry (only for j > i), 2 one-sided
 __device__ __forceinline__ int dn_classify(const DenseArgs &D, int b, int i, int j, float *wout) {
     const int N = D.N;
@@ -194,6 +181,15 @@ __global__ __launch_bounds__(256) void k_dn_pairs(DenseArgs D) {
     if (row >= D.A) return;
     if (FILL && D.row_off[D.A] > D.pcap) return;
     const int b = D.mol_of[row], a0 = D.moff[b], n = D.moff[b + 1] - a0, i = row - a0;
+    if (!FILL) {
+        // the atom's own features, slot (b, i) -> flat row (what used to be a launch of its own): one lane per feature
+        const int F = D.nx + EPNN_EDIM + 2, f = lane;
+        const int slot = b * D.N + i;
+        if (f < D.nx) D.xf[(size_t)row * D.nx + f] = D.xs[(size_t)slot * D.nx + f];
+        else if (f < D.nx + EPNN_EDIM) D.hf[(size_t)row * EPNN_EDIM + (f - D.nx)] = D.hs[(size_t)slot * EPNN_EDIM + (f - D.nx)];
+        else if (f == D.nx + EPNN_EDIM) D.qf[row] = D.qs[slot];
+        else if (f < F) D.nmf[row] = D.nms[slot];
+    }
     int base = FILL ? D.row_off[row] : 0;
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
