@@ -928,10 +928,14 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     S.handoff = pure;
     if (launch_small(h, S)) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
-    if (launch_large(h, S)) return 1;
+    h->want_large_handoff = !pure;
+    h->did_large_handoff = false;
+    const int rc_large = launch_large(h, S);
+    h->want_large_handoff = false;
+    if (rc_large) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
-    // status + pair count come back with the results
-    if (!pure) {
+    // status + pair count come back with the results (from the tiled path's last kernel when it ran)
+    if (!pure && !h->did_large_handoff) {
         HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }

@@ -124,6 +124,7 @@ struct epnn_handle {
     int pcap = 0;
     int pair_cap_per_atom = 16;
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
+    bool want_large_handoff = false, did_large_handoff = false;    // the tiled path's last kernel writes h_status itself
     // staging for the host-pointer entry points
     DevBuf s_xyz, s_misc, s_gx, s_pt;
     double dsafe = 0.0;               // distance up to which every pair is a near pair (epnn_create)

@@ -59,6 +59,7 @@ struct LargeArgs {
     int pcap;
     float *q_out, *h_out;
     int *status;
+    int *host_status;                       // pinned host ints, or null: the last kernel of the EPN stack hands status + pair count over
     int *dn_cnt;
 };
 
@@ -666,7 +667,15 @@ __device__ __forceinline__ float lg_apply_atom(const LargeArgs &L, int at) {
     for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) acc += L.pwi[p] * L.dl[p];
     return acc;
 }
+// status bits + number of listed pairs to the host (every other kernel of the forward ran before this one on the stream)
+__device__ __forceinline__ void lg_handoff(const LargeArgs &L) {
+    volatile int *hs = L.host_status;
+    hs[0] = *L.status;
+    hs[1] = L.row_off[L.A];
+    __threadfence_system();
+}
 __global__ __launch_bounds__(256) void k_lg_apply(LargeArgs L, int last) {
+    if (last && L.host_status && blockIdx.x == 0 && threadIdx.x == 0) lg_handoff(L);
     if (L.row_off[L.A] > L.pcap) return;
     const int fq = L.nx + EPNN_EDIM;
     for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
@@ -682,6 +691,7 @@ __global__ __launch_bounds__(256) void k_lg_apply(LargeArgs L, int last) {
 __global__ __launch_bounds__(64) void k_lg_epn_tail(LargeArgs L, LgNext X, int last) {
     __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
     const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
+    if (last && L.host_status && blockIdx.x == 0 && lane == 0) lg_handoff(L);
     if (L.row_off[L.A] > L.pcap) return;
     const int4 tl = L.atiles[blockIdx.x];
     const int fq = L.nx + EPNN_EDIM;
@@ -844,6 +854,9 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.stask_chunk = h->l_schunk.as<int>();
     L.nstasks = h->l_nstasks;
     L.pcap = h->pcap;
+    // compact entry: the forward's last kernel hands status + pair count to the host (two device-to-host copies less)
+    L.host_status = (h->want_large_handoff && run_epn && h->cfg.T > 0 && h->part_world == 1) ? h->h_status : nullptr;
+    h->did_large_handoff = L.host_status != nullptr;
     L.q_out = d_q;
     L.h_out = d_hout;
     L.status = h->d_status.as<int>();
