@@ -82,6 +82,7 @@ static int create_resources(epnn_handle *h) {
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t0));
     HIPCHK(hipEventCreateWithFlags(&h->ev_ctl, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t1));
@@ -129,7 +130,9 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_mu_ex, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_train, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
-                      &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_csr_ent2, &h->l_cnt, &h->l_nm,
+                      &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
+                      &h->d_deg, &h->d_incoff, &h->d_nbr, &h->d_desti, &h->d_destj, &h->d_prec, &h->l_Nn, &h->l_Yb, &h->l_qbuf,
+                      &h->l_Pst, &h->l_Rst, &h->l_lmol, &h->l_typrow, &h->l_typtab, &h->l_stype,
                       &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
                       &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
@@ -154,6 +157,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_lists) (void)hipEventDestroy(h->ev_lists);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -338,8 +342,12 @@ static int pack_weights(epnn_handle *h) {
         pk.b2p = alloc(32);
         pk.b2 = alloc(32);
         pk.w3p = alloc(32);
+        pk.wqi = alloc(32);
+        pk.wqj = alloc(32);
         for (int hh = 0; hh < 2; ++hh)
             for (int r = 0; r < 16; ++r) {
+                buf[pk.wqi + hh * 16 + r] = W1[(size_t)(F - 1) * 32 + epnn_kappa(hh, r)];          // q is the last atom feature
+                buf[pk.wqj + hh * 16 + r] = W1[(size_t)(2 * F - 1) * 32 + epnn_kappa(hh, r)];
                 buf[pk.b1p + hh * 16 + r] = b1[epnn_kappa(hh, r)];
                 buf[pk.b2p + hh * 16 + r] = b2[epnn_kappa(hh, r)];
                 buf[pk.w3p + hh * 16 + r] = is_pass ? m[2].W[epnn_kappa(hh, r)] : 0.f;
@@ -703,10 +711,20 @@ static int ensure_pairs(epnn_handle *h, int pcap) {
     if (pcap <= h->pcap) return 0;
     if (h->d_pi.ensure((size_t)pcap * sizeof(int)) || h->d_pj.ensure((size_t)pcap * sizeof(int)) ||
         h->d_psym.ensure((size_t)pcap * sizeof(int)) || h->d_pwi.ensure((size_t)pcap * sizeof(float)) ||
-        h->d_pwj.ensure((size_t)pcap * sizeof(float)) || h->d_pe.ensure((size_t)pcap * EPNN_EDIM * sizeof(float)))
+        h->d_pwj.ensure((size_t)pcap * sizeof(float)) || h->d_pe.ensure((size_t)pcap * EPNN_EDIM * sizeof(float)) ||
+        h->d_nbr.ensure(2 * (size_t)pcap * sizeof(int)) || h->d_desti.ensure((size_t)pcap * sizeof(int)) ||
+        h->d_destj.ensure((size_t)pcap * sizeof(int)) || h->d_prec.ensure(2 * (size_t)pcap * sizeof(int4)))
         return 1;
     h->pcap = pcap;
     return 0;
+}
+
+// cut2 = smallest double whose (correctly rounded, monotone) sqrt is >= cutoff: D < cutoff <=> D^2 < cut2, no sqrt per candidate
+static double cutoff_squared(double cutoff) {
+    double t = cutoff * cutoff;
+    while (sqrt(t) >= cutoff) t = nextafter(t, 0.0);
+    while (sqrt(t) < cutoff) t = nextafter(t, 1e300);
+    return t;
 }
 
 struct PairSource {     // where the fused / tiled kernels read atoms and pairs from
@@ -717,8 +735,8 @@ struct PairSource {     // where the fused / tiled kernels read atoms and pairs 
     int handoff = 0;                 // ... and its last wave hands status + pair count to the host (no other kernel ran)
 };
 
-static int launch_large(epnn_handle *h, const PairSource &S) {
-    return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_nm, S.d_q, S.d_hout, S.run_gnn, S.run_epn);
+static int launch_large(epnn_handle *h, const PairSource &S, bool have_inc = false, hipEvent_t lists_ev = nullptr) {
+    return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_nm, S.d_q, S.d_hout, S.run_gnn, S.run_epn, have_inc, lists_ev);
 }
 
 
@@ -771,12 +789,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.mu = h->d_mu.as<double>();
     A.cutoff = (double)h->cfg.cutoff;
     A.eta = (double)h->cfg.eta;
-    {   // D < cutoff decided without the sqrt: cut2 = smallest double whose (correctly rounded, monotone) sqrt is >= cutoff
-        double t = A.cutoff * A.cutoff;
-        while (sqrt(t) >= A.cutoff) t = nextafter(t, 0.0);
-        while (sqrt(t) < A.cutoff) t = nextafter(t, 1e300);
-        A.cut2 = t;
-    }
+    A.cut2 = cutoff_squared(A.cutoff);       // D < cutoff decided without the sqrt
     A.tol = h->cfg.near_tol;
     A.host_status = h->h_status;          // pinned, device-visible
     A.etab = h->d_etab.as<float>();
@@ -859,20 +872,29 @@ static int launch_small(epnn_handle *h, const PairSource &S) {
     return launch_wave(h, S);
 }
 
-static int run_frontend_xyz(epnn_handle *h, const float *d_xyz) {
+// pair list + incidence rows from coordinates, four launches on `st` (epnn_frontend.hip.h)
+static int run_frontend_xyz(epnn_handle *h, const float *d_xyz, hipStream_t st) {
     const Plan &P = h->plan;
+    if (h->d_deg.ensure(((size_t)P.A + 1) * sizeof(int)) || h->d_incoff.ensure(((size_t)P.A + 1) * sizeof(int))) return 1;
     FrontArgs F{};
     F.xyz = d_xyz;
     F.mol_of = h->p_molof;
     F.moff = h->p_moff;
     F.A = P.A;
     F.cutoff = (double)h->cfg.cutoff;
+    F.cut2 = cutoff_squared(F.cutoff);
     F.eta = (double)h->cfg.eta;
     F.tol = h->cfg.near_tol;
     F.e_dim = h->cfg.e_dim;
     F.mu = h->d_mu.as<double>();
     F.row_cnt = h->d_rowcnt.as<int>();
     F.row_off = h->d_rowoff.as<int>();
+    F.deg = h->d_deg.as<int>();
+    F.inc_off = h->d_incoff.as<int>();
+    F.nbr = h->d_nbr.as<int>();
+    F.dest_i = h->d_desti.as<int>();
+    F.dest_j = h->d_destj.as<int>();
+    F.prec = h->d_prec.as<int4>();
     F.pcap = h->pcap;
     F.pi = h->d_pi.as<int>();
     F.pj = h->d_pj.as<int>();
@@ -882,14 +904,10 @@ static int run_frontend_xyz(epnn_handle *h, const float *d_xyz) {
     F.pwj = h->d_pwj.as<float>();
     F.status = h->d_status.as<int>();
     const unsigned rows = (unsigned)((P.A + 3) / 4);
-    hipLaunchKernelGGL(k_front_count, dim3(rows), dim3(256), 0, h->stream, F);
-    {
-        const unsigned nsb = (unsigned)((F.A + EPNN_SCAN_ELEMS - 1) / EPNN_SCAN_ELEMS);
-        if (h->d_bsum.ensure((size_t)nsb * sizeof(int))) return 1;
-        hipLaunchKernelGGL(k_front_scan1, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
-        if (nsb > 1) hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
-    }
-    hipLaunchKernelGGL(k_front_fill, dim3(rows), dim3(256), 0, h->stream, F);
+    hipLaunchKernelGGL(k_front_count, dim3(rows), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(k_front_scan_both, dim3(1), dim3(1024), 0, st, F);
+    hipLaunchKernelGGL(k_front_fill, dim3(rows), dim3(256), 0, st, F);
+    hipLaunchKernelGGL(k_front_link, dim3((unsigned)std::min<size_t>(((size_t)h->pcap + 255) / 256, 4096)), dim3(256), 0, st, F);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -918,7 +936,20 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
         h->ev_next += 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
-    if (!pure && run_frontend_xyz(h, d_xyz)) return 1;
+    // The separate front-end (pair list + incidence rows, four launches) serves the tiled kernels and, when the in-kernel
+    // front-end is off, the fused ones.  With tiled molecules only waiting for it, it runs on the handle's second stream
+    // beside everything that needs just the atoms (feature rows, atom types, the first projections and type sums).
+    hipEvent_t lists_ev = nullptr;
+    if (!pure) {
+        const bool beside = h->opt_large_overlap && !P.large_list.empty() && (front_small || P.fused_count() == 0);
+        if (beside) {
+            HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+            if (run_frontend_xyz(h, d_xyz, h->stream2)) return 1;
+            HIPCHK(hipEventRecord(h->ev_lists, h->stream2));
+            lists_ev = h->ev_lists;
+        } else if (run_frontend_xyz(h, d_xyz, h->stream)) return 1;
+    }
     if (ev) HIPCHK(hipEventRecord(ev[1], h->stream));
     PairSource S;
     S.d_x = d_x;
@@ -930,7 +961,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
     h->want_large_handoff = !pure;
     h->did_large_handoff = false;
-    const int rc_large = launch_large(h, S);
+    const int rc_large = launch_large(h, S, true, lists_ev);
     h->want_large_handoff = false;
     if (rc_large) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
@@ -962,6 +993,7 @@ static int finish_forward(epnn_handle *h) {
         if (st & EPNN_ST_PAIR_OVERFLOW) {
             if (ensure_pairs(h, h->h_status[1] + h->h_status[1] / 8 + 1024)) return 1;
         }
+        if (st & EPNN_ST_TYPE_OVERFLOW) h->types_overflowed = true;     // this handle sweeps all pairs in the first step from now on
         if (h->pending.redo()) return 1;
     }
     EPNN_FAIL("forward: capacity regrow did not converge");
@@ -1204,6 +1236,9 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave2")) { h->opt_wave2 = value; h->plan.valid = false; }
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
+    else if (!strcmp(name, "large_dedupe")) { h->opt_large_dedupe = value; h->types_overflowed = false; }
+    else if (!strcmp(name, "large_pairs_beside")) { h->opt_large_pairs_beside = value; }
+    else if (!strcmp(name, "large_overlap")) { h->opt_large_overlap = value; }
     else if (!strcmp(name, "wave_order")) { h->opt_wave_order = value; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }

@@ -38,6 +38,7 @@ struct PairMlpPack {      // one message_fns[t] / pass_fns[t]
     int b2;               // [32]      b2[c]
     int b2p;              // [2][16]   b2[kappa(hh,r)]
     int w3p;              // [2][16]   w3[kappa(hh,r)]   (pass MLP only)
+    int wqi, wqj;         // [2][16]   the q rows of Wi / Wj, kappa-permuted: P(q) = P(q = 0) + q wqi (tiled EPN stack: only q changes between steps)
 };
 struct UpdPack {          // update_fn with message_fns[t]'s last Dense folded in
     int u1F;              // [40][64]  s<24: Wu1[h feature][c]; s>=24: (W3_t Wu1_M)[2(s-24)+hh][c]
@@ -100,6 +101,8 @@ __host__ __device__ static inline int epnn_aeo(int f) { return (f & 1) * 32 + (f
 
 // status bits written by kernels
 #define EPNN_ST_PAIR_OVERFLOW 1   // near-pair list capacity exceeded
+#define EPNN_ST_TYPE_OVERFLOW 2   // tiled path, first GNN step by atom types: a molecule has more distinct feature rows than the table holds
+#define EPNN_TYPE_MAX 64          // distinct atom-feature rows per molecule the first GNN step groups by (more: the all-pairs sweep runs)
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ f32x16 epnn_mfma(float a, float b, f32x16 c) {

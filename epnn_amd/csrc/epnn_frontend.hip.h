@@ -5,6 +5,12 @@
 // device keeps one entry per UNORDERED pair {i<j} with D_ij < cutoff (the only pairs whose e is non-zero), in
 // row-major (i, then j) order:  pi, pj (flat atom index), pe[48] (float32, computed in float64 like NumPy does),
 // wi = wj = near flag (max_k e_k > tol as float32, charge_gn.py:90-94) and sym = 1 (e_ij == e_ji).
+//
+// Beside the pair list every atom gets its INCIDENCE ROW: one slot per pair it takes part in (as either index), rows in
+// ascending partner order, inc_off[A+1] the row starts.  A pair's two slots (dest_i, dest_j) are where the tiled kernels
+// deposit what the pair contributes to its two atoms (GNN correction rows, EPN charge transfers); an atom then sums its
+// own contiguous row in slot order -- no second index list, no indirection, a fixed order.  Four launches: count (both
+// directions in one pass over the partners), scan (both prefix sums), fill, link (position of i in row j).
 #pragma once
 #include "epnn_common.h"
 
@@ -17,8 +23,14 @@ struct FrontArgs {
     float tol;
     int e_dim;
     const double *mu;      // [e_dim] linspace(0.1, cutoff, e_dim) evaluated like NumPy
-    int *row_cnt;          // [A]
+    int *row_cnt;          // [A]     pairs with this atom as FIRST index (partner j > i)
     int *row_off;          // [A+1]
+    int *deg;              // [A]     all partners under the cutoff, either side
+    int *inc_off;          // [A+1]   incidence rows (prefix sum of deg)
+    int *nbr;              // [2 pcap] partners of every atom, ascending
+    int *dest_i, *dest_j;  // [pcap]  incidence slots of a pair's first / second atom
+    int4 *prec;            // [2 pcap] per pair: (i, j, inc_lo_i, inc_hi_i), (inc_lo_j, inc_hi_j, dest_i, dest_j)
+    double cut2;           // smallest double whose correctly rounded sqrt reaches the cutoff: D < cutoff <=> D^2 < cut2
     int pcap;
     int *pi, *pj, *psym;
     float *pe, *pwi, *pwj;
@@ -34,20 +46,81 @@ __device__ __forceinline__ double epnn_dist(const float *xyz, int i, int j) {
     return sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
 }
 
-// one wave per row i: number of j > i (same molecule) with D < cutoff
+// squared distance in the same float64 arithmetic (no sqrt: the compare against the cutoff is made on cut2)
+__device__ __forceinline__ double epnn_dist2(const float *xyz, int i, int j) {
+    double dx = (double)xyz[3 * j + 0] - (double)xyz[3 * i + 0];
+    double dy = (double)xyz[3 * j + 1] - (double)xyz[3 * i + 1];
+    double dz = (double)xyz[3 * j + 2] - (double)xyz[3 * i + 2];
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// one wave per row i: partners j != i of the same molecule with D < cutoff -- how many in all, how many with j > i
 __global__ __launch_bounds__(256) void k_front_count(FrontArgs F) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= F.A) return;
-    const int end = F.moff[F.mol_of[row] + 1];
-    int cnt = 0;
-    for (int j0 = row + 1; j0 < end; j0 += 64) {
+    const int b = F.mol_of[row];
+    const int beg = F.moff[b], end = F.moff[b + 1];
+    int up = 0, all = 0;
+    for (int j0 = beg; j0 < end; j0 += 64) {
         const int j = j0 + lane;
         bool near = false;
-        if (j < end) near = epnn_dist(F.xyz, row, j) < F.cutoff;
-        cnt += __popcll(__ballot(near));
+        if (j < end && j != row) near = epnn_dist2(F.xyz, row, j) < F.cut2;
+        const unsigned long long bal = __ballot(near);
+        all += __popcll(bal);
+        up += __popcll(__ballot(near && j > row));
     }
-    if (lane == 0) F.row_cnt[row] = cnt;
+    if (lane == 0) {
+        F.row_cnt[row] = up;
+        F.deg[row] = all;
+    }
+}
+
+// both prefix sums in ONE single-workgroup launch (1024 threads x 8 elements per round, a carry between rounds): a
+// 2220-atom system is one round, 100 k atoms thirteen
+__global__ __launch_bounds__(1024) void k_front_scan_both(FrontArgs F) {
+    __shared__ int wsA[16], wsB[16];
+    __shared__ int carryA, carryB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carryA = 0; carryB = 0; }
+    __syncthreads();
+    for (int base = 0; base < F.A; base += 8192) {
+        const int i0 = base + tid * 8;
+        int va[8], vb[8], ta = 0, tb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            va[k] = i0 + k < F.A ? F.row_cnt[i0 + k] : 0;
+            vb[k] = i0 + k < F.A ? F.deg[i0 + k] : 0;
+            ta += va[k];
+            tb += vb[k];
+        }
+        int ia = ta, ib = tb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+            if (lane >= d) { ia += oa; ib += ob; }
+        }
+        if (lane == 63) { wsA[wave] = ia; wsB[wave] = ib; }
+        __syncthreads();
+        int wa = 0, wb = 0;
+        for (int w = 0; w < wave; ++w) { wa += wsA[w]; wb += wsB[w]; }
+        const int ca = carryA, cb = carryB;
+        int ra = ca + wa + ia - ta, rb = cb + wb + ib - tb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < F.A) { F.row_off[i0 + k] = ra; F.inc_off[i0 + k] = rb; }
+            ra += va[k];
+            rb += vb[k];
+        }
+        __syncthreads();
+        if (tid == 1023) { carryA = ra; carryB = rb; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        F.row_off[F.A] = carryA;
+        F.inc_off[F.A] = carryB;
+        if (carryA > F.pcap) atomicOr(F.status, EPNN_ST_PAIR_OVERFLOW);
+    }
 }
 
 // exclusive scan of row_cnt[0..A) -> row_off[0..A] in two passes: (1) every block of 256 threads scans 2048
@@ -107,7 +180,7 @@ __global__ __launch_bounds__(256) void k_front_scan2(FrontArgs F, const int *bsu
     }
 }
 
-// one wave per row: write the row's pairs
+// one wave per row: the atom's incidence row (partners, ascending) and the pairs in which it is the first index
 __global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
     __shared__ int s_j[4][64];
     __shared__ double s_D[4][64];
@@ -117,22 +190,31 @@ __global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
     const int row = blockIdx.x * 4 + wave;
     if (row >= F.A) return;
     if (F.row_off[F.A] > F.pcap) return;   // overflow: host regrows and reruns
-    const int end = F.moff[F.mol_of[row] + 1];
+    const int b = F.mol_of[row];
+    const int beg = F.moff[b], end = F.moff[b + 1];
     int slot0 = F.row_off[row];
+    int inc0 = F.inc_off[row];
     const double pi_d = 3.141592653589793;
-    for (int j0 = row + 1; j0 < end; j0 += 64) {
+    for (int j0 = beg; j0 < end; j0 += 64) {
         const int j = j0 + lane;
         bool near = false;
         double D = 0.0;
-        if (j < end) {
-            D = epnn_dist(F.xyz, row, j);
-            near = D < F.cutoff;
+        if (j < end && j != row) {
+            const double d2 = epnn_dist2(F.xyz, row, j);
+            near = d2 < F.cut2;
+            D = sqrt(d2);                                  // charge_gn.py:124 (scipy distance_matrix)
         }
         const unsigned long long bal = __ballot(near);
-        const int m = __popcll(bal);
+        if (bal == 0ull) continue;
+        const int pos = inc0 + __popcll(bal & ((1ull << lane) - 1ull));      // this partner's slot in the atom's incidence row
+        if (near) F.nbr[pos] = j;
+        inc0 += __popcll(bal);
+        const bool upn = near && j > row;
+        const unsigned long long bup = __ballot(upn);
+        const int m = __popcll(bup);
         if (m == 0) continue;
-        if (near) {
-            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (upn) {
+            const int rank = __popcll(bup & ((1ull << lane) - 1ull));
             s_j[wave][rank] = j;
             s_D[wave][rank] = D;
             // charge_gn.py:148-152: C = (cos(pi*D/cutoff)+1)/2 ; C[D<=0] = 1 (D>=cutoff excluded, diagonal not listed)
@@ -140,6 +222,7 @@ __global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
             if (D <= 0.0) C = 1.0;
             s_C[wave][rank] = C;
             s_max[wave][rank] = 0;
+            F.dest_i[slot0 + rank] = pos;
         }
         __builtin_amdgcn_wave_barrier();
         const int total = m * F.e_dim;
@@ -163,6 +246,29 @@ __global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
         }
         __builtin_amdgcn_wave_barrier();
         slot0 += m;
+    }
+}
+
+// one thread per pair (i, j): where does i sit in j's incidence row?  (rows are ascending and short: a few loads in flight)
+__global__ __launch_bounds__(256) void k_front_link(FrontArgs F) {
+    const int np = F.row_off[F.A];
+    if (np > F.pcap) return;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256) {
+        const int i = F.pi[p], j = F.pj[p];
+        const int lo = F.inc_off[j], hi = F.inc_off[j + 1];
+        int found = -1;
+        for (int k0 = lo; k0 < hi && found < 0; k0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + u < hi ? F.nbr[k0 + u] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] == i) found = k0 + u;
+        }
+        const int di = F.dest_i[p];
+        F.dest_j[p] = found;
+        F.prec[2 * p] = make_int4(i, j, F.inc_off[i], F.inc_off[i + 1]);
+        F.prec[2 * p + 1] = make_int4(lo, hi, di, found);
     }
 }
 

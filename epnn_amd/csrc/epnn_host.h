@@ -121,6 +121,7 @@ struct epnn_handle {
     int *p_moff = nullptr, *p_mflag = nullptr, *p_molof = nullptr;
     DevBuf d_rowcnt, d_rowoff, d_status, d_bsum;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
+    DevBuf d_deg, d_incoff, d_nbr, d_desti, d_destj, d_prec;   // incidence rows of the pair list (epnn_frontend.hip.h)
     int pcap = 0;
     int pair_cap_per_atom = 16;
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
@@ -151,8 +152,15 @@ struct epnn_handle {
                                       // measured on the QM9-sized batch: 211 M atoms/s with 18 or 20, 206-208 M with 0 / 25 / 28
     int wave_lds = 20480;             // LDS bytes per wavefront of the wave-autonomous kernel (8 per CU)
     // large path workspace (epnn_large.hip.h)
-    DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_csr_ent2, l_cnt, l_nm;
+    DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
     DevBuf l_stasks, l_schunk, l_sfin;
+    DevBuf l_Nn, l_Yb, l_qbuf, l_Pst, l_Rst;        // sweep operands (-R, b2 + W2^T R); EPN stack: charges, projections with q = 0
+    DevBuf l_lmol, l_typrow, l_typtab, l_stype;     // first GNN step by atom types
+    bool types_overflowed = false;                  // a molecule had more distinct feature rows than EPNN_TYPE_MAX: all-pairs sweep from now on
+    hipEvent_t ev_lists = nullptr;                  // compact entry: pair list + incidence rows are built on stream2
+    int opt_large_dedupe = 1;         // tiled path, compact entry: first GNN step by atom types instead of the all-pairs sweep
+    int opt_large_pairs_beside = 0;   // tiled path: 1 = correction tiles always as their own launch on the second stream
+    int opt_large_overlap = 1;        // compact entry: pair list construction on the second stream beside the first projections
     // row-block partition of the all-pairs sweep over `part_world` processes (epnn_set_partition): this one runs the tile
     // groups [part_g0, part_g1) = atoms [part_row_lo, part_row_hi) and the callback completes S after every GNN step
     int part_rank = 0, part_world = 1;

@@ -1,18 +1,30 @@
-// Tiled path for molecules the fused kernel cannot hold (n > 32: the 2220-atom protein, the 100k-atom box).
-// Same arithmetic as the fused kernel (epnn_wave.hip.h), split into per-step kernels with the per-atom state in HBM:
+// Tiled path for molecules the fused kernels cannot hold (the 2220-atom protein, the 100k-atom box; any size through the
+// dense / layer-level entries beyond 32 atoms).  Same arithmetic as the fused kernel (epnn_wave.hip.h), split into per-step
+// kernels with the per-atom state in HBM:
 //
 //   GNN step (charge_gn.py:60-74)
-//     k_lg_proj   P_i = Wi^T a_i + b1, R_j = Wj^T a_j, zp_i = relu(W2^T relu(P_i) + b2)       per 32-atom tile
-//     k_lg_sweep  S0[chunk][i] = sum_{j in chunk} relu(W2^T relu(P_i + R_j) + b2)              ALL pairs, G ignored
-//     k_lg_corr   for every listed pair: relu(W2^T relu(P_i+R_j+G)+b2) - relu(W2^T relu(P_i+R_j)+b2)   (both sides)
-//     k_lg_update S_i = sum_chunk S0 + sum corr + (N-n) zp_i ; h_i = node_mask * update MLP([h_i | M_i])
-//   EPN step (charge_gn.py:98-118)
-//     k_lg_proj, k_lg_epn (pair tiles: 0.5*(f_ij - f_ji)), k_lg_apply (q_i += sum over the atom's pairs)
+//     projections   P_i = Wi^T a_i + b1, R_j = Wj^T a_j, zp_i = relu(W2^T relu(P_i) + b2); for the sweep also
+//                   Nn_j = -R_j and Yb_j = b2 + W2^T R_j                                                per 32-atom tile
+//     k_lg_sweep    S0[chunk][i] = sum_{j in chunk} relu(W2^T relu(P_i + R_j) + b2)                     ALL pairs, G ignored
+//                   evaluated as relu(W2^T max(P_i, Nn_j) + Yb_j): relu(P + R) = max(P, -R) + R, and the R part of the
+//                   product is the same for every i -- one VALU instruction per element where add + max were two (f32 MFMA
+//                   and VALU share the SIMD's issue cycles: tools/micro/sweep_mix.hip)
+//     k_lg_tsweep   FIRST step of the compact entry (h = 0, q = Q/n): a_i depends on the atom's feature row x_i alone, so
+//                   P_i + R_j takes only (distinct rows)^2 values: S_i = sum over TYPES tau of count(tau) z2(P_i + R_tau),
+//                   a few hundred pair evaluations instead of n^2 (k_lg_types groups the atoms; exact algebra)
+//     k_lg_pairs<0> for every listed pair: relu(W2^T relu(P_i+R_j+G)+b2) - relu(W2^T relu(P_i+R_j)+b2)   (both sides),
+//                   deposited in the two atoms' incidence slots (epnn_frontend.hip.h)
+//     tail          S_i = sum_chunk S0 + the atom's slot row + (N-n) zp_i ; h_i = node_mask * update MLP([h_i | M_i]);
+//                   next projections
+//   EPN stack (charge_gn.py:98-118): h is fixed, only q changes between steps, so the projections of all T steps are
+//   taken ONCE with q = 0 (Pst_t, Rst_t) and a pair tile adds q_i w_q itself.  One launch per step: a pair's two lanes
+//   rebuild q_i, q_j of this step from the previous step's transfers in the atoms' slot rows (the first slot's pair
+//   stores the new q), evaluate 0.5 (f_ij - f_ji) and deposit +-w delta; a last launch adds the final transfers.
 //
 // The all-pairs sweep is the reference's semantics (charge_gn.py:70 sums over every j, near or not); the near
 // pairs are <1% of the pairs of a large system, so adding their G-term as a correction costs ~1%.
-// Both z2 evaluations of a correction use bit-identical inputs to the sweep's, so "without G" cancels exactly
-// against the sweep's term up to the summation order.  All sums are order-fixed (no float atomics).
+// All sums are order-fixed (no float atomics): results are bit-reproducible, and a row-block partition of the sweep over
+// several processes reproduces the single-process bits.
 #pragma once
 #include "epnn_host.h"
 #include "epnn_common.h"
@@ -44,23 +56,38 @@ struct LargeArgs {
     const float *xin, *Q, *h_in, *q_in, *nm_in;
     float *a_eo;                            // [A][AST]
     float *P, *R;                           // [A][32] kappa-permuted
+    float *Nn;                              // [A][32] -R, kappa-permuted            (GNN projections)
+    float *Yb;                              // [A][32] b2 + W2^T R, natural order     (GNN projections)
     float *zp;                              // [A][32]
     float *S0;                              // [maxchunk][A][32]
-    float *corr;                            // [pcap][2][32]
-    float *dl;                              // [pcap]
+    float *corrA;                           // [2 pcap][32] GNN corrections by incidence slot
+    float *dlA;                             // [2][2 pcap] EPN transfers by incidence slot (two steps alive)
+    float *qbuf;                            // [2][A]      charges of the EPN steps (two steps alive)
+    float *Pst, *Rst;                       // [T][A][32]  EPN projections with q = 0, kappa-permuted
     const int *row_off, *pi, *pj, *psym;
     const float *pe, *pwi, *pwj;
-    const int *dn_off, *dn_ent;             // per atom: pairs in which it is the second index
-    const int4 *atiles;                     // (first atom, count, molecule, first chunk-independent S0 row) per 32-atom tile
+    const int *inc_off, *dest_i, *dest_j;   // incidence rows and a pair's two slots (dest_j < 0: one-sided entry)
+    const int4 *prec;                       // [2 pcap] (i, j, lo_i, hi_i), (lo_j, hi_j, dest_i, dest_j)
+    const int4 *atiles;                     // (first atom, count, molecule, chunks of its molecule's sweep) per 32-atom tile
     int natiles;
-    const int4 *stasks;                     // sweep tasks: (first atile, natiles<=4, j_lo, j_hi | chunk<<... ) see host
+    const int4 *stasks;                     // sweep tasks: (first atile, natiles<=4, j_lo, j_hi)
     const int *stask_chunk;                 // chunk index of each sweep task
     int nstasks;
     int pcap;
+    // first GNN step by atom types (k_lg_types)
+    const int *lmol;                        // [nlarge] molecules on this path
+    int nlarge;
+    int *typ_row;                           // [A]  row of S_type the atom reads: EPNN_TYPE_MAX * (molecule's place in lmol) + its type
+    int *typ_rep, *typ_cnt;                 // [nlarge * EPNN_TYPE_MAX] first atom of a type, atoms of it
+    int *typ_n;                             // [nlarge] types of the molecule
+    float *S_type;                          // [nlarge * EPNN_TYPE_MAX][32]
     float *q_out, *h_out;
     int *status;
     int *host_status;                       // pinned host ints, or null: the last kernel of the EPN stack hands status + pair count over
-    int *dn_cnt;
+    // builders of the incidence rows for pair lists that come from the dense front-end
+    int *dn_cnt, *dn_cur, *dn_off, *dn_ent;
+    int *w_inc_off, *w_dest_i, *w_dest_j;
+    int4 *w_prec;
 };
 
 // ------------------------------------------------------------------------------------------------ init
@@ -75,26 +102,30 @@ __global__ __launch_bounds__(256) void k_lg_init(LargeArgs L) {
             const int f = (slot & 31) * 2 + (slot >> 5);
             if (f < L.nx) v = L.xin[(size_t)at * L.nx + f];
             else if (f < fq) v = L.h_in ? L.h_in[(size_t)at * EPNN_EDIM + (f - L.nx)] : 0.f;
-            else if (f == fq) v = L.q_in ? L.q_in[at] : L.Q[b] / (float)(L.moff[b + 1] - L.moff[b]);
+            else if (f == fq) {
+                v = L.q_in ? L.q_in[at] : L.Q[b] / (float)(L.moff[b + 1] - L.moff[b]);
+                L.qbuf[at] = v;                                  // the EPN stack's charges, both generations
+                L.qbuf[(size_t)L.A + at] = v;
+            }
             else if (f == EPNN_F1) v = 1.f;                      // carries the first Dense's bias (Wi row 59 = b1)
         }
         L.a_eo[idx] = v;
     }
 }
 
-// ------------------------------------------------------------------------------------------------ "down" lists
-// entry = pair slot; the top bit marks a one-sided entry (an arbitrary dense e / mask may list (i,j) without (j,i)): such an
-// entry carries the EPN weight pwj but no GNN correction for its second atom
-#define EPNN_DN_ONESIDED ((int)0x80000000)
-#define EPNN_DN_SLOT 0x7fffffff
+// ------------------------------------------------------------------------------------------------ incidence rows of a dense list
+// Pair lists that come from the dense front-end (arbitrary e / mask; an entry may be one-sided: (i,j) listed without a
+// matching (j,i)) have no incidence rows yet.  An atom's row = its pairs as first index, in list order, then the symmetric
+// pairs in which it is the second index, ordered by pair slot:
+//   inc_off[a] = row_off[a] + dn_off[a],  dest_i(p) = dn_off[i] + p,  dest_j(p) = row_off[j+1] + dn_off[j] + rank of p
 __global__ __launch_bounds__(256) void k_lg_dn_count(LargeArgs L) {
     const int np = L.row_off[L.A];
     if (np > L.pcap) return;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256)
-        if (L.psym[p] || L.pwj[p] != 0.f) atomicAdd(&L.dn_cnt[L.pj[p]], 1);
+        if (L.psym[p]) atomicAdd(&L.dn_cnt[L.pj[p]], 1);
 }
-// exclusive scan dn_cnt[0..A) -> dn_off[0..A]; dn_cnt is reused as the fill cursor (reset to 0)
-__global__ __launch_bounds__(1024) void k_lg_dn_scan(LargeArgs L, int *dn_off_w) {
+// exclusive scan dn_cnt[0..A) -> dn_off[0..A]
+__global__ __launch_bounds__(1024) void k_lg_dn_scan(LargeArgs L) {
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,48 +146,177 @@ __global__ __launch_bounds__(1024) void k_lg_dn_scan(LargeArgs L, int *dn_off_w)
         for (int w = 0; w < wave; ++w) woff += wsum[w];
         const int c0 = carry;
         if (idx < L.A) {
-            dn_off_w[idx] = c0 + woff + incl - v;
-            L.dn_cnt[idx] = 0;
+            const int d = c0 + woff + incl - v;
+            L.dn_off[idx] = d;
+            L.w_inc_off[idx] = L.row_off[idx] + d;
         }
         __syncthreads();
         if (tid == 1023) carry = c0 + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) dn_off_w[L.A] = carry;
+    if (tid == 0) {
+        L.dn_off[L.A] = carry;
+        L.w_inc_off[L.A] = L.row_off[L.A] + carry;
+    }
 }
-__global__ __launch_bounds__(256) void k_lg_dn_fill(LargeArgs L, int *dn_ent_w) {
+// the symmetric pairs of every second atom, in arrival order (dn_cnt, zeroed again by nobody: the scan read it, this pass
+// counts up from dn_cur = a second zeroed array)
+__global__ __launch_bounds__(256) void k_lg_dn_fill(LargeArgs L) {
     const int np = L.row_off[L.A];
     if (np > L.pcap) return;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256)
-        if (L.psym[p] || L.pwj[p] != 0.f) {
+        if (L.psym[p]) {
             const int j = L.pj[p];
-            const int pos = atomicAdd(&L.dn_cnt[j], 1);
-            dn_ent_w[L.dn_off[j] + pos] = p | (L.psym[p] ? 0 : EPNN_DN_ONESIDED);     // flag: no GNN correction through this entry
+            L.dn_ent[L.dn_off[j] + atomicAdd(&L.dn_cur[j], 1)] = p;
         }
 }
-// order every atom's list by pair slot so that sums over it have a fixed order: one thread per entry counts the entries
-// of its list with a smaller slot and writes itself to that position of the second buffer (lists have ~12 entries; the
-// insertion sort per atom this replaces was 17 us of dependent loads on the 2220-atom protein)
-__global__ __launch_bounds__(256) void k_lg_dn_rank(LargeArgs L, const int *dn_in, int *dn_out) {
-    if (L.row_off[L.A] > L.pcap) return;
-    const int total = L.dn_off[L.A];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int v = dn_in[e], slot = v & EPNN_DN_SLOT;
-        const int j = L.pj[slot];
-        const int lo = L.dn_off[j], hi = L.dn_off[j + 1];
-        int rank = 0;
-        for (int k = lo; k < hi; ++k) rank += (dn_in[k] & EPNN_DN_SLOT) < slot ? 1 : 0;
-        dn_out[lo + rank] = v;
+// one thread per pair: its two slots and its record.  A symmetric pair's place in its second atom's row = how many of that
+// atom's symmetric pairs have a smaller pair slot (its list is short: the arrival order above is made a fixed one here)
+__global__ __launch_bounds__(256) void k_lg_dn_link(LargeArgs L) {
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256) {
+        const int i = L.pi[p], j = L.pj[p];
+        const int di = L.dn_off[i] + p;
+        int dj = -1;
+        if (L.psym[p]) {
+            int rank = 0;
+            for (int k = L.dn_off[j]; k < L.dn_off[j + 1]; ++k) rank += L.dn_ent[k] < p ? 1 : 0;
+            dj = L.row_off[j + 1] + L.dn_off[j] + rank;
+        }
+        L.w_dest_i[p] = di;
+        L.w_dest_j[p] = dj;
+        L.w_prec[2 * p] = make_int4(i, j, L.row_off[i] + L.dn_off[i], L.row_off[i + 1] + L.dn_off[i + 1]);
+        L.w_prec[2 * p + 1] = make_int4(L.row_off[j] + L.dn_off[j], L.row_off[j + 1] + L.dn_off[j + 1], di, dj);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ atom types of the first step
+// One workgroup per molecule: atoms with bit-identical feature rows x share a type.  An open-addressed table in LDS keyed by
+// a hash of the row; the row of a slot's first atom is compared bit for bit afterwards, so a hash collision cannot merge two
+// types (it raises EPNN_ST_TYPE_OVERFLOW like a full table does: the host repeats the forward with the all-pairs sweep).
+// Types are numbered by their first atom, so the order of every sum over types is fixed.
+#define EPNN_TYPE_SLOTS 256
+__global__ __launch_bounds__(1024) void k_lg_types(LargeArgs L) {
+    __shared__ unsigned long long key[EPNN_TYPE_SLOTS];
+    __shared__ int first[EPNN_TYPE_SLOTS], cnt[EPNN_TYPE_SLOTS], num[EPNN_TYPE_SLOTS];
+    __shared__ int bad, used;
+    const int tid = threadIdx.x;
+    const int lm = blockIdx.x, b = L.lmol[lm];
+    const int a0 = L.moff[b], n = L.moff[b + 1] - a0;
+    for (int s = tid; s < EPNN_TYPE_SLOTS; s += 1024) { key[s] = 0ull; first[s] = 0x7fffffff; cnt[s] = 0; }
+    if (tid == 0) { bad = 0; used = 0; }
+    __syncthreads();
+    auto hash_row = [&](int at) {
+        unsigned long long hsh = 1469598103934665603ull;
+        for (int f = 0; f < L.nx; ++f) {
+            hsh ^= (unsigned long long)__float_as_uint(L.xin[(size_t)at * L.nx + f]);
+            hsh *= 1099511628211ull;
+        }
+        return hsh | 1ull;                                    // 0 marks an empty slot
+    };
+    auto find = [&](unsigned long long hsh, bool insert) {
+        int s = (int)((hsh >> 17) & (EPNN_TYPE_SLOTS - 1));
+        for (int probe = 0; probe < EPNN_TYPE_SLOTS; ++probe) {
+            unsigned long long cur = key[s];
+            if (cur == 0ull && insert) cur = atomicCAS(&key[s], 0ull, hsh);
+            if (cur == 0ull && insert) cur = hsh;             // this thread claimed the slot
+            if (cur == hsh) return s;
+            if (cur == 0ull) return -1;
+            s = (s + 1) & (EPNN_TYPE_SLOTS - 1);
+        }
+        return -1;
+    };
+    for (int k = tid; k < n; k += 1024) {
+        const int s = find(hash_row(a0 + k), true);
+        if (s < 0) atomicOr(&bad, 1);
+        else {
+            atomicMin(&first[s], a0 + k);
+            atomicAdd(&cnt[s], 1);
+        }
+    }
+    __syncthreads();
+    // number the slots in use by their first atom
+    if (tid < EPNN_TYPE_SLOTS) {
+        int rank = -1;
+        if (key[tid] != 0ull) {
+            rank = 0;
+            for (int s = 0; s < EPNN_TYPE_SLOTS; ++s) rank += (key[s] != 0ull && first[s] < first[tid]) ? 1 : 0;
+            atomicAdd(&used, 1);
+        }
+        num[tid] = rank;
+    }
+    __syncthreads();
+    if (used > EPNN_TYPE_MAX) { if (tid == 0) atomicOr(&bad, 1); }
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) {
+        const int at = a0 + k;
+        const int s = find(hash_row(at), false);
+        int row = 0;
+        if (s >= 0 && !bad) {
+            const int rep = first[s];
+            bool same = true;
+            for (int f = 0; f < L.nx; ++f)
+                same &= __float_as_uint(L.xin[(size_t)at * L.nx + f]) == __float_as_uint(L.xin[(size_t)rep * L.nx + f]);
+            if (!same) atomicOr(&bad, 1);
+            row = lm * EPNN_TYPE_MAX + num[s];
+        }
+        L.typ_row[at] = row;
+    }
+    __syncthreads();
+    if (tid < EPNN_TYPE_SLOTS && key[tid] != 0ull && !bad) {
+        L.typ_rep[lm * EPNN_TYPE_MAX + num[tid]] = first[tid];
+        L.typ_cnt[lm * EPNN_TYPE_MAX + num[tid]] = cnt[tid];
+    }
+    if (tid == 0) {
+        L.typ_n[lm] = bad ? 0 : used;
+        if (bad) atomicOr(L.status, EPNN_ST_TYPE_OVERFLOW);
+    }
+}
+
+// S_type[sigma][o] = sum_tau count(tau) relu(W2^T relu(P_sigma + R_tau) + b2)[o]: one wave per 32 types sigma of a molecule.
+// rows = types kappa(hh,r), cols = out c (the layout of the correction tiles below)
+__global__ __launch_bounds__(64) void k_lg_tsweep(LargeArgs L, PairMlpPack M) {
+    const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
+    const int lm = blockIdx.x >> 1, blk = blockIdx.x & 1;
+    const int U = L.typ_n[lm];
+    if (32 * blk >= U) return;
+    const float *wp = L.wpack;
+    const int sig = 32 * blk + c;
+    const int rep = L.typ_rep[lm * EPNN_TYPE_MAX + (sig < U ? sig : 0)];
+    float pr[16], w2[16];
+    epnn_ld16(L.P + (size_t)rep * 32 + hh * 16, pr);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
+    const f32x16 cb2 = epnn_splat16(wp[M.b2 + c]);
+    f32x16 S = epnn_splat16(0.f);
+    for (int tau = 0; tau < U; ++tau) {
+        const int rt = L.typ_rep[lm * EPNN_TYPE_MAX + tau];
+        const float cnt = (float)L.typ_cnt[lm * EPNN_TYPE_MAX + tau];
+        float rr[16];
+        epnn_ld16(L.R + (size_t)rt * 32 + hh * 16, rr);
+        f32x16 a = cb2;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a = epnn_mfma(fmaxf(pr[s] + rr[s], 0.f), w2[s], a);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = fmaf(cnt, fmaxf(a[r], 0.f), S[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * blk + epnn_kappa(hh, r);
+        if (row < U) L.S_type[((size_t)lm * EPNN_TYPE_MAX + row) * 32 + c] = S[r];
     }
 }
 
 // ------------------------------------------------------------------------------------------------ projection
 // one wave per 32-atom tile; `arow` = this lane's half (hh) of its atom's even/odd feature row (global a_eo or an LDS image).
-// WHAT: 3 = P, R (and zp) by this wave; 1 = P (and zp) only; 2 = R only (the tail kernel gives the halves to two waves).
-// `wA` = the wave's weight fragments (Wi for WHAT & 1, else Wj), already in registers when PRE.
-template <int WHAT, bool PRE>
-__device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPack &M, int with_zp, const int4 tl, const float *arow, int lane,
-                                             const float (&wA)[EPNN_KA]) {
+// WHAT: 3 = P, R (and zp, Nn, Yb) by this wave; 1 = P (and zp) only; 2 = R (and Nn, Yb) only (the tail kernel gives the halves
+// to two waves).  `wA` = the wave's weight fragments (Wi for WHAT & 1, else Wj), already in registers when PRE.
+// GNNP: projections of a GNN step (zp / Nn / Yb are wanted); ZQ: the charge feature reads as 0 and the results go to
+// `oP` / `oR` (the EPN stack's static projections).
+template <int WHAT, bool PRE, bool ZQ>
+__device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPack &M, int gnnp, const int4 tl, const float *arow, int lane,
+                                             const float (&wA)[EPNN_KA], float *oP, float *oR) {
     const int c = lane & 31, hh = lane >> 5;
     const int at = tl.x + (c < tl.y ? c : 0);
     const float *wp = L.wpack;
@@ -166,6 +326,12 @@ __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPa
         f32x4 v = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
         bv[4 * q] = v[0]; bv[4 * q + 1] = v[1]; bv[4 * q + 2] = v[2]; bv[4 * q + 3] = v[3];
     }
+    if (ZQ) {
+        const int fq = L.nx + EPNN_EDIM;                      // feature f sits in half f & 1 at position f >> 1
+#pragma unroll
+        for (int s = 0; s < EPNN_KA; ++s)
+            if (s == (fq >> 1) && hh == (fq & 1)) bv[s] = 0.f;
+    }
     f32x16 accP = epnn_splat16(0.f), accR = epnn_splat16(0.f);
 #pragma unroll
     for (int s = 0; s < EPNN_KA; ++s) {
@@ -173,10 +339,16 @@ __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPa
         if (WHAT & 2) accR = epnn_mfma(PRE && !(WHAT & 1) ? wA[s] : wp[M.wjF + s * 64 + lane], bv[s], accR);
     }
     if (c < tl.y) {
-        if (WHAT & 1) epnn_st16(L.P + (size_t)at * 32 + hh * 16, accP);
-        if (WHAT & 2) epnn_st16(L.R + (size_t)at * 32 + hh * 16, accR);
+        if (WHAT & 1) epnn_st16(oP + (size_t)at * 32 + hh * 16, accP);
+        if (WHAT & 2) epnn_st16(oR + (size_t)at * 32 + hh * 16, accR);
+        if ((WHAT & 2) && gnnp) {
+            f32x16 neg;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) neg[r] = -accR[r];
+            epnn_st16(L.Nn + (size_t)at * 32 + hh * 16, neg);
+        }
     }
-    if ((WHAT & 1) && with_zp) {
+    if ((WHAT & 1) && gnnp) {
         // padded partner: R = 0, G = 0  ->  zp_i = relu(W2^T relu(P_i) + b2); rows = atoms, cols = out
         f32x16 acc = epnn_splat16(wp[M.b2 + c]);
 #pragma unroll
@@ -187,25 +359,47 @@ __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPa
             if (row < tl.y) L.zp[(size_t)(tl.x + row) * 32 + c] = fmaxf(acc[r], 0.f);
         }
     }
+    if ((WHAT & 2) && gnnp) {
+        // the partner's share of the sweep's second Dense: Yb_j = b2 + W2^T R_j; rows = atoms, cols = out
+        f32x16 acc = epnn_splat16(wp[M.b2 + c]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = epnn_mfma(accR[s], wp[M.w2F + s * 64 + lane], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = epnn_kappa(hh, r);
+            if (row < tl.y) L.Yb[(size_t)(tl.x + row) * 32 + c] = acc[r];
+        }
+    }
 }
-__global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int with_zp) {
+__global__ __launch_bounds__(256) void k_lg_proj(LargeArgs L, PairMlpPack M, int gnnp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
     const int it = blockIdx.x * 4 + wave;
     if (it >= L.natiles) return;
     const int4 tl = L.atiles[it];
     const int at = tl.x + (c < tl.y ? c : 0);
     const float none[EPNN_KA] = {};
-    lg_proj_wave<3, false>(L, M, with_zp, tl, L.a_eo + (size_t)at * EPNN_AST + hh * 32, lane, none);
+    lg_proj_wave<3, false, false>(L, M, gnnp, tl, L.a_eo + (size_t)at * EPNN_AST + hh * 32, lane, none, L.P, L.R);
+}
+// the EPN stack's projections with q = 0, all T steps: one wave per (tile, step)
+__global__ __launch_bounds__(256) void k_lg_epn_static(LargeArgs L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
+    const int job = blockIdx.x * 4 + wave;
+    if (job >= L.natiles * L.T) return;
+    const int it = job / L.T, t = job - it * L.T;
+    const int4 tl = L.atiles[it];
+    const int at = tl.x + (c < tl.y ? c : 0);
+    const float none[EPNN_KA] = {};
+    lg_proj_wave<3, false, true>(L, L.wi.pas[t], 0, tl, L.a_eo + (size_t)at * EPNN_AST + hh * 32, lane, none,
+                                 L.Pst + (size_t)t * L.A * 32, L.Rst + (size_t)t * L.A * 32);
 }
 
 // ------------------------------------------------------------------------------------------------ all-pairs sweep
-// workgroup = up to 4 atom tiles (one per wave) x one j-chunk of the same molecule; R_j staged in LDS.
+// workgroup = up to 4 atom tiles (one per wave) x one j-chunk of the same molecule; Nn_j and Yb_j staged in LDS.
 // v_mfma_f32_16x16x4_f32 in the fused kernel's layout (epnn_wave.hip.h): lane (q, n16) owns atoms n16 and 16 + n16 of
-// the tile and features 16 rb + 4 q + r of each; tile j = "partner j of every atom", S accumulates in registers.  The
-// co-resident wavefronts' VALU work (two adds and two max per feature and pair) overlaps this MFMA shape better than
-// 32x32x2 (tools/micro/mfma_covalu.hip), which is what bounds the sweep.  W2 / b2 come from the fused kernel's pack.
+// the tile and features 16 rb + 4 q + r of each; tile j = "partner j of every atom", S accumulates in registers.  Per
+// partner and 32 atoms: 32 MFMAs, 16 max (first layer), 16 max + 16 add (second layer's relu and the sum).
 #define EPNN_LG_JC 64
-__device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, int b2off, float *Rs) {
+__device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, float *Ns, float *Ys) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
     const int4 tk = L.stasks[blockIdx.x];            // first atile, #atiles, j_lo, j_hi (global atom indices)
     const int chunk = L.stask_chunk[blockIdx.x];
@@ -213,25 +407,25 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, int
     const int4 tl = L.atiles[tk.x + (active ? wave : 0)];
     const float *wp = L.wpack;
     const bool two = tl.y > 16;                      // the tile's second column block holds atoms
-    // P and R rows are stored in the operand order of the 32x32x2 kernels (k_lg_proj): position 16 hh + r holds feature
+    // P and Nn rows are stored in the operand order of the 32x32x2 kernels (k_lg_proj): position 16 hh + r holds feature
     // kappa(hh, r) = 8 (r >> 2) + 4 hh + (r & 3), so this lane's features 16 rb + 4 q .. + 3 sit together at po + 8 rb
     const int po = 16 * (q & 1) + 4 * (q >> 1);
     const int c0 = n16 < tl.y ? n16 : 0, c1 = 16 + n16 < tl.y ? 16 + n16 : 0;
-    f32x4 P0[2], P1[2], S0[2], S1[2], b2v[2];
+    f32x4 P0[2], P1[2], S0[2], S1[2];
     float pb[2][8];
     W16_LD(pb, w2off, 2, 8);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         P0[rb] = w16_ld(L.P + (size_t)(tl.x + c0) * 32 + po + 8 * rb);
         P1[rb] = w16_ld(L.P + (size_t)(tl.x + c1) * 32 + po + 8 * rb);
-        b2v[rb] = w16_ld(wp + b2off + 16 * rb + fo);
         S0[rb] = w16_splat(0.f);
         S1[rb] = w16_splat(0.f);
     }
-    auto block = [&](const f32x4 (&Pc)[2], f32x4 (&Sc)[2], const f32x4 (&r)[2]) {
-        const f32x4 za = w16_relu(Pc[0] + r[0]), zb = w16_relu(Pc[1] + r[1]);
+    auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
+    auto block = [&](const f32x4 (&Pc)[2], f32x4 (&Sc)[2], const f32x4 (&nn)[2], const f32x4 (&yy)[2]) {
+        const f32x4 za = vmax(Pc[0], nn[0]), zb = vmax(Pc[1], nn[1]);
         const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
-        f32x4 d[2] = {b2v[0], b2v[1]};
+        f32x4 d[2] = {yy[0], yy[1]};
         w16_mm<2, 8>(pb, z, d);
         Sc[0] += w16_relu(d[0]);
         Sc[1] += w16_relu(d[1]);
@@ -239,17 +433,22 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, int
     for (int j0 = tk.z; j0 < tk.w; j0 += EPNN_LG_JC) {
         const int nj = min(EPNN_LG_JC, tk.w - j0);
         __syncthreads();
-        for (int i = tid; i < nj * 32; i += 256) Rs[i] = L.R[(size_t)j0 * 32 + i];
+        for (int i = tid; i < nj * 8; i += 256) {
+            reinterpret_cast<f32x4 *>(Ns)[i] = reinterpret_cast<const f32x4 *>(L.Nn + (size_t)j0 * 32)[i];
+            reinterpret_cast<f32x4 *>(Ys)[i] = reinterpret_cast<const f32x4 *>(L.Yb + (size_t)j0 * 32)[i];
+        }
         __syncthreads();
         if (active) {
-            f32x4 ra[2] = {w16_ld(Rs + po), w16_ld(Rs + po + 8)};
+            f32x4 na[2] = {w16_ld(Ns + po), w16_ld(Ns + po + 8)};
+            f32x4 ya[2] = {w16_ld(Ys + fo), w16_ld(Ys + 16 + fo)};
             for (int j = 0; j < nj; ++j) {
-                const float *nr = Rs + min(j + 1, nj - 1) * 32 + po;      // the next partner's row while this one is in the pipe
-                const f32x4 rn[2] = {w16_ld(nr), w16_ld(nr + 8)};
-                block(P0, S0, ra);
-                if (two) block(P1, S1, ra);
-                ra[0] = rn[0];
-                ra[1] = rn[1];
+                const int jn = min(j + 1, nj - 1);                         // the next partner's rows while this one is in the pipe
+                const f32x4 nn[2] = {w16_ld(Ns + jn * 32 + po), w16_ld(Ns + jn * 32 + po + 8)};
+                const f32x4 yn[2] = {w16_ld(Ys + jn * 32 + fo), w16_ld(Ys + jn * 32 + 16 + fo)};
+                block(P0, S0, na, ya);
+                if (two) block(P1, S1, na, ya);
+                na[0] = nn[0]; na[1] = nn[1];
+                ya[0] = yn[0]; ya[1] = yn[1];
             }
         }
     }
@@ -263,26 +462,28 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, int
 }
 template <int MODE>
 __device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk);
-// The sweep alone: ~110 registers, four wavefronts per SIMD -- what a large system's thousands of workgroups need.
-__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, int b2off) {
-    __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
-    lg_sweep_body(L, w2off, b2off, Rs);
+// The sweep alone: four wavefronts per SIMD -- what a large system's thousands of workgroups need.
+__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off) {
+    __shared__ __attribute__((aligned(16))) float Ns[EPNN_LG_JC * 32];
+    __shared__ __attribute__((aligned(16))) float Ys[EPNN_LG_JC * 32];
+    lg_sweep_body(L, w2off, Ns, Ys);
 }
 // The sweep plus, as extra workgroups, the near-pair correction tiles of the same step (both need only this step's P and
-// R).  The pair tiles' registers halve the kernel's occupancy (179 registers: two wavefronts per SIMD), so this form is for
+// R).  The pair tiles' registers halve the kernel's occupancy (two wavefronts per SIMD), so this form is for
 // systems whose sweep has at most two workgroups per CU anyway (the 2220-atom protein: 504), where it saves a launch per
 // step; larger systems run the two kernels side by side on two streams.
-__global__ __launch_bounds__(256) void k_lg_sweep_pairs(LargeArgs L, int w2off, int b2off, PairMlpPack Mpair) {
-    __shared__ __attribute__((aligned(16))) float Rs[EPNN_LG_JC * 32];
+__global__ __launch_bounds__(256) void k_lg_sweep_pairs(LargeArgs L, int w2off, PairMlpPack Mpair) {
+    __shared__ __attribute__((aligned(16))) float Ns[EPNN_LG_JC * 32];
+    __shared__ __attribute__((aligned(16))) float Ys[EPNN_LG_JC * 32];
     if ((int)blockIdx.x >= L.nstasks) {
         lg_pairs_body<0>(L, Mpair, (int)blockIdx.x - L.nstasks);
         return;
     }
-    lg_sweep_body(L, w2off, b2off, Rs);
+    lg_sweep_body(L, w2off, Ns, Ys);
 }
 
-// ------------------------------------------------------------------------------------------------ pair tiles
-// one wave per 32 listed pairs.  mode 0: GNN correction -> corr[p][side][32]; mode 1: EPN -> dl[p]
+// ------------------------------------------------------------------------------------------------ GNN correction tiles
+// one wave per 32 listed pairs: z2(P + R + G) - z2(P + R) for both directions -> the two atoms' incidence slots
 template <int MODE>
 __device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
@@ -290,14 +491,16 @@ __device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpP
     if (np > L.pcap) return;
     const int slot = (blk * 4 + wave) * 32 + c;
     bool valid = slot < np;
-    int gi = 0, gj = 0, sym = 0;
+    int gi = 0, gj = 0, di = -1, dj = -1;
     if (valid) {
         gi = L.pi[slot];
         gj = L.pj[slot];
-        sym = L.psym[slot];
+        di = L.dest_i[slot];
+        dj = L.dest_j[slot];
         valid = L.mflag[L.mol_of[gi]] != 0;
     }
     if (__ballot(valid) == 0ull) return;
+    if (!valid) { di = -1; dj = -1; }
     const float *wp = L.wpack;
     const f32x16 g = lg_gtile(wp + M.weF, L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24, valid, lane);
     float pi_[16], rj_[16], pj_[16], ri_[16], w2[16];
@@ -307,211 +510,117 @@ __device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpP
     epnn_ld16(L.R + (size_t)gi * 32 + hh * 16, ri_);
 #pragma unroll
     for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
-    if (MODE == 0) {
-        // rows = pairs kappa(hh,r), cols = out c
-        const f32x16 cb2 = epnn_splat16(wp[M.b2 + c]);
-        f32x16 aG = cb2, a0 = cb2, bG = cb2, b0 = cb2;
+    // rows = pairs kappa(hh,r), cols = out c
+    const f32x16 cb2 = epnn_splat16(wp[M.b2 + c]);
+    f32x16 aG = cb2, a0 = cb2, bG = cb2, b0 = cb2;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float u0 = pi_[s] + rj_[s], v0 = pj_[s] + ri_[s];
-            a0 = epnn_mfma(fmaxf(u0, 0.f), w2[s], a0);
-            aG = epnn_mfma(fmaxf(u0 + g[s], 0.f), w2[s], aG);
-            b0 = epnn_mfma(fmaxf(v0, 0.f), w2[s], b0);
-            bG = epnn_mfma(fmaxf(v0 + g[s], 0.f), w2[s], bG);
-        }
-        const int base = (blk * 4 + wave) * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = base + epnn_kappa(hh, r);
-            if (p < np) {
-                L.corr[((size_t)p * 2 + 0) * 32 + c] = fmaxf(aG[r], 0.f) - fmaxf(a0[r], 0.f);
-                L.corr[((size_t)p * 2 + 1) * 32 + c] = fmaxf(bG[r], 0.f) - fmaxf(b0[r], 0.f);
-            }
-        }
-    } else {
-        float b2v[16], w3[16];
-        epnn_ld16(wp + M.b2p + hh * 16, b2v);
-        epnn_ld16(wp + M.w3p + hh * 16, w3);
-        f32x16 au, av;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            au = epnn_mfma(w2[s], fmaxf((g[s] + pi_[s]) + rj_[s], 0.f), au);
-            av = epnn_mfma(w2[s], fmaxf((g[s] + pj_[s]) + ri_[s], 0.f), av);
-        }
-        float fu = 0.f, fv = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
-            fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
-        }
-        fu += epnn_swap32(fu);
-        fv += epnn_swap32(fv);
-        if (hh == 0 && valid) L.dl[slot] = 0.5f * (fu - fv);
+    for (int s = 0; s < 16; ++s) {
+        const float u0 = pi_[s] + rj_[s], v0 = pj_[s] + ri_[s];
+        a0 = epnn_mfma(fmaxf(u0, 0.f), w2[s], a0);
+        aG = epnn_mfma(fmaxf(u0 + g[s], 0.f), w2[s], aG);
+        b0 = epnn_mfma(fmaxf(v0, 0.f), w2[s], b0);
+        bG = epnn_mfma(fmaxf(v0 + g[s], 0.f), w2[s], bG);
     }
-    (void)sym;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = epnn_kappa(hh, r);                     // lane `row` (either half) holds that pair's slots
+        const int ti = __shfl(di, row, 64), tj = __shfl(dj, row, 64);
+        if (ti >= 0) L.corrA[(size_t)ti * 32 + c] = fmaxf(aG[r], 0.f) - fmaxf(a0[r], 0.f);
+        if (tj >= 0) L.corrA[(size_t)tj * 32 + c] = fmaxf(bG[r], 0.f) - fmaxf(b0[r], 0.f);
+    }
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
     lg_pairs_body<MODE>(L, M, (int)blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------ update
-// S_i = sum_chunk S0 + sum of the atom's corrections + (N-n) zp_i, one thread per (atom, out), fixed order.
-// Written as its own wide launch: the update kernel has only natiles/4 workgroups, far too few to hide ~50
-// dependent global loads per element.
-// S of one (atom, output): chunk partials in chunk order, the atom's corrections as first index, as second index, padding
-__device__ __forceinline__ float lg_reduce_elem(const LargeArgs &L, int at, int o, int n, int nchunk) {
-    float s = 0.f;
-    {   // eight loads in flight, added in chunk order (the order of the sum is part of the result)
-        const float *src = L.S0 + (size_t)at * 32 + o;
-        const size_t step = (size_t)L.A * 32;
-        int ch = 0;
-        for (; ch + 8 <= nchunk; ch += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(ch + u) * step];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; ch < nchunk; ++ch) s += src[(size_t)ch * step];
-    }
-    {
-        const int p0 = L.row_off[at], p1 = L.row_off[at + 1];
-        int p = p0;
-        for (; p + 4 <= p1; p += 4) {
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = L.corr[((size_t)(p + u) * 2 + 0) * 32 + o];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s += v[u];
-        }
-        for (; p < p1; ++p) s += L.corr[((size_t)p * 2 + 0) * 32 + o];
-    }
-    {   // the pairs in which this atom is the second one: entry -> pair -> correction, four chains in flight
-        const int e0 = L.dn_off[at], e1 = L.dn_off[at + 1];
-        int e = e0;
-        for (; e + 4 <= e1; e += 4) {
-            int pp[4];
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) pp[u] = L.dn_ent[e + u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = L.corr[((size_t)(pp[u] & EPNN_DN_SLOT) * 2 + 1) * 32 + o];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (pp[u] >= 0) s += v[u];
-        }
-        for (; e < e1; ++e) {
-            const int p = L.dn_ent[e];
-            if (p >= 0) s += L.corr[((size_t)p * 2 + 1) * 32 + o];
-        }
-    }
-    s += (float)(L.N - n) * L.zp[(size_t)at * 32 + o];
-    return s;
-}
-// The same sums for four atoms of a tile at once (atoms a8, a8+8, a8+16, a8+24 of the tile, one output o): every stage keeps
-// the loads of all four in flight together, each element still adds its own terms in the same order as lg_reduce_elem.
-__device__ __forceinline__ void lg_reduce4(const LargeArgs &L, const int4 tl, int a8, int o, int n, float (&out)[4]) {
+// ------------------------------------------------------------------------------------------------ reduction of S
+// S of (atom, output o): the sweep's chunk partials in chunk order (or the atom's type row in the first step), the atom's
+// incidence slots in slot order, the padded partners.  NA atoms per thread, the loads of all of them in flight together; every
+// element adds its own terms in the same order whatever NA is.
+template <int NA>
+__device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, const int (&a)[NA], int o, int n, int types, float (&out)[NA]) {
     const int nchunk = tl.w;
-    int at[4];
-    bool ok[4];
-    float s[4];
+    int at[NA], lo[NA], hi[NA];
+    bool ok[NA];
+    float s[NA];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ok[k] = a8 + 8 * k < tl.y;
-        at[k] = tl.x + (ok[k] ? a8 + 8 * k : 0);
+    for (int k = 0; k < NA; ++k) {
+        ok[k] = a[k] < tl.y;
+        at[k] = tl.x + (ok[k] ? a[k] : 0);
+        lo[k] = L.inc_off[at[k]];
+        hi[k] = L.inc_off[at[k] + 1];
         s[k] = 0.f;
     }
-    // the list bounds of the later stages are requested now, they arrive under the chunk loads
-    int p[4], p1[4], e[4], e1[4];
+    if (types) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        p[k] = L.row_off[at[k]];
-        p1[k] = L.row_off[at[k] + 1];
-        e[k] = L.dn_off[at[k]];
-        e1[k] = L.dn_off[at[k] + 1];
-    }
-    {
+        for (int k = 0; k < NA; ++k) s[k] = L.S_type[(size_t)L.typ_row[at[k]] * 32 + o];
+    } else {
         const size_t step = (size_t)L.A * 32;
-        for (int ch = 0; ch < nchunk; ch += 16) {             // 64 loads of a thread in flight: a round trip per 16 chunks
-            float v[4][16];
+        constexpr int CB = 32 / NA;                            // 32 partial sums of a thread in flight
+        for (int ch = 0; ch < nchunk; ch += CB) {
+            float v[NA][CB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < NA; ++k)
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[k][u] = ch + u < nchunk ? L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step] : 0.f;
+                for (int u = 0; u < CB; ++u) v[k][u] = ch + u < nchunk ? L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < NA; ++k)
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < CB; ++u)
                     if (ch + u < nchunk) s[k] += v[k][u];
         }
     }
-    {   // corrections of the pairs in which the atom is the first index
-        int left = 0;
+    int left = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) left = max(left, p1[k] - p[k]);
-        for (; left > 0; left -= 8) {
-            float v[4][8];
+    for (int k = 0; k < NA; ++k) left = max(left, hi[k] - lo[k]);
+    constexpr int SB = 32 / NA;
+    for (; left > 0; left -= SB) {
+        float v[NA][SB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NA; ++k)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[k][u] = p[k] + u < p1[k] ? L.corr[((size_t)(p[k] + u) * 2 + 0) * 32 + o] : 0.f;
+            for (int u = 0; u < SB; ++u) v[k][u] = lo[k] + u < hi[k] ? L.corrA[(size_t)(lo[k] + u) * 32 + o] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NA; ++k) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (p[k] + u < p1[k]) s[k] += v[k][u];
-                p[k] += 8;
-            }
-        }
-    }
-    {   // ... and the second index: entry -> correction (one-sided entries carry none)
-        int left = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) left = max(left, e1[k] - e[k]);
-        for (; left > 0; left -= 8) {
-            int pp[4][8];
-            float v[4][8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) pp[k][u] = e[k] + u < e1[k] ? L.dn_ent[e[k] + u] : EPNN_DN_ONESIDED;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[k][u] = L.corr[((size_t)(pp[k][u] & EPNN_DN_SLOT) * 2 + 1) * 32 + o];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (pp[k][u] >= 0) s[k] += v[k][u];
-                e[k] += 8;
-            }
+            for (int u = 0; u < SB; ++u)
+                if (lo[k] + u < hi[k]) s[k] += v[k][u];
+            lo[k] += SB;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = ok[k] ? s[k] + (float)(L.N - n) * L.zp[(size_t)at[k] * 32 + o] : 0.f;
+    for (int k = 0; k < NA; ++k) out[k] = ok[k] ? s[k] + (float)(L.N - n) * L.zp[(size_t)at[k] * 32 + o] : 0.f;
 }
-__global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin) {
+__global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin, int types) {
     if (L.row_off[L.A] > L.pcap) return;
     const int it = blockIdx.x;                 // one workgroup per 8 atoms of a tile list entry
     const int o = threadIdx.x & 31, a8 = threadIdx.x >> 5;
     const int4 tl = L.atiles[it >> 2];
-    const int a = (it & 3) * 8 + a8;
-    if (a >= tl.y) return;
-    const int at = tl.x + a;
-    Sfin[(size_t)at * 32 + o] = lg_reduce_elem(L, at, o, L.moff[tl.z + 1] - L.moff[tl.z], tl.w);
+    const int a[1] = {(it & 3) * 8 + a8};
+    if (a[0] >= tl.y) return;
+    float sv[1];
+    lg_reduce<1>(L, tl, a, o, L.moff[tl.z + 1] - L.moff[tl.z], types, sv);
+    Sfin[(size_t)(tl.x + a[0]) * 32 + o] = sv[0];
 }
 
 // The update MLP (charge_gn.py:71-74) of one 32-atom tile by one wave: weights w1 / w2 / w3 already in registers, the
 // atom's h features from `arow` (its half hh of the even/odd feature row, offset to the first h slot), its reduced message
 // sum from `srow` ([32] out-major).  New h goes to `dst` (a full even/odd row; global a_eo, and `dst2` when not null).
-__device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack &U, const float (&w1)[40], const float (&w2)[16],
-                                               const float (&w3)[32], const int4 tl, const float *arow, const float *srow,
+// LATE: only w1 is in registers at entry; the other two layers' fragments are requested here and travel under the first layer's
+// forty MFMAs (the fused tail keeps its registers for the reduction that runs before this).
+template <bool LATE>
+__device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack &U, const float (&w1)[40], float (&w2)[16],
+                                               float (&w3)[32], const int4 tl, const float *arow, const float *srow,
                                                float *dst, float *dst2, int lane) {
     const int c = lane & 31, hh = lane >> 5;
+    if (LATE) {
+        const float *wq = L.wpack;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) w2[s] = wq[U.u2F + s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) w3[s] = wq[U.u3F + s * 64 + lane];
+    }
     const bool live = c < tl.y;
     const int at = tl.x + (live ? c : 0);
     const int nx = L.nx;
@@ -575,7 +684,7 @@ __device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack
 
 // workgroup = up to 4 atom tiles, one wave per tile runs the update MLP on the reduced S (used when a partition's exchange
 // sits between the reduction and the update)
-__global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int maxchunk, const float *Sfin) {
+__global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, const float *Sfin) {
     __shared__ float Ss[4 * 32 * EPNN_SST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
     const int t0 = blockIdx.x * 4;
@@ -600,73 +709,88 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, int m
 #pragma unroll
         for (int it = 0; it < 16; ++it) Ss[((it >> 2) * 32 + a8 + 8 * (it & 3)) * EPNN_SST + o] = v[it];
     }
-    (void)maxchunk;
     __syncthreads();
     if (t0 + wave >= L.natiles) return;
     const int4 tl = L.atiles[t0 + wave];
     const int at = tl.x + (c < tl.y ? c : 0);
     const int u0 = (L.nx - hh + 1) >> 1;
-    lg_update_wave(L, U, w1, w2, w3, tl, L.a_eo + (size_t)at * EPNN_AST + hh * 32 + u0, Ss + (wave * 32 + c) * EPNN_SST,
-                   L.a_eo + (size_t)at * EPNN_AST, nullptr, lane);
+    lg_update_wave<false>(L, U, w1, w2, w3, tl, L.a_eo + (size_t)at * EPNN_AST + hh * 32 + u0, Ss + (wave * 32 + c) * EPNN_SST,
+                          L.a_eo + (size_t)at * EPNN_AST, nullptr, lane);
 }
 
-// ---- one launch for everything between two sweeps (GNN) / two pair passes (EPN): workgroup = one 32-atom tile.
-// GNN: all 256 threads reduce the tile's S (chunk partials, corrections, padding) into LDS, wave 0 runs the update MLP and
-// then the NEXT step's projections from an LDS image of the tile's feature rows.  The three kernels this replaces
-// (k_lg_reduce, k_lg_update, k_lg_proj) are 6-9 us of latency each on a 2220-atom system.  Same device functions, same
-// operand values, same order: bit-identical to the separate launches (tests: partition == whole).
+// ---- one launch for everything between two sweeps: workgroup (eight waves) = one 32-atom tile.  All 512 threads reduce the
+// tile's S -- one output of two atoms each, every partial sum of a thread in flight at once: three dependent round trips
+// (bounds, partials, slot rows) --, wave 0 runs the update MLP, then the NEXT thing's projections from an LDS image of the
+// tile's feature rows: waves 1 / 2 the next sweep's P (zp) and R (Nn, Yb), or after the last GNN step waves 1..7 the EPN
+// stack's 2T static projections.  Weight fragments are requested before the reduction so that they travel under it.
 struct LgNext {
-    PairMlpPack M;       // projections of the next sweep / pair pass
-    int run;             // 0: nothing follows
-    int with_zp;
+    PairMlpPack M;       // projections of the next sweep
+    int run;             // 0: nothing follows; 1: next GNN step; 2: the EPN stack's static projections
 };
-__global__ __launch_bounds__(256) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgNext X) {
+__global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgNext X, int types) {
     __shared__ __attribute__((aligned(16))) float Ss[32 * EPNN_SST];
     __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
     if (L.row_off[L.A] > L.pcap) return;
     const int4 tl = L.atiles[blockIdx.x];
     const float *wp = L.wpack;
-    // every weight fragment is requested before the reduction: wave 0 the update MLP's, waves 1 / 2 the next projections'
-    // Wi / Wj -- they travel while the partial sums are collected
     float w1[40], w2[16], w3[32], wA[EPNN_KA];
-    if (wave == 0) { LG_LOAD_UPD_WEIGHTS(w1, w2, w3, U) }
-    if (X.run && (wave == 1 || wave == 2)) {
+    if (wave == 0) {
+#pragma unroll
+        for (int s = 0; s < 40; ++s) w1[s] = wp[U.u1F + s * 64 + lane];
+    }
+    int job = -1;                                                // EPN static projections: job = 2 t + (0: P, 1: R)
+    if (X.run == 1 && (wave == 1 || wave == 2)) {
         const int off = wave == 1 ? X.M.wiF : X.M.wjF;
 #pragma unroll
         for (int s = 0; s < EPNN_KA; ++s) wA[s] = wp[off + s * 64 + lane];
-    }
-    for (int i = tid; i < tl.y * EPNN_AST; i += 256) Ai[i] = L.a_eo[(size_t)tl.x * EPNN_AST + i];
-    {
-        const int o = tid & 31, a8 = tid >> 5, n = L.moff[tl.z + 1] - L.moff[tl.z];
-        float sv[4];
-        lg_reduce4(L, tl, a8, o, n, sv);
+    } else if (X.run == 2 && wave >= 1 && wave - 1 < 2 * L.T) {
+        job = wave - 1;
+        const PairMlpPack &M = L.wi.pas[job >> 1];
+        const int off = (job & 1) ? M.wjF : M.wiF;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Ss[(a8 + 8 * k) * EPNN_SST + o] = sv[k];
+        for (int s = 0; s < EPNN_KA; ++s) wA[s] = wp[off + s * 64 + lane];
+    }
+    for (int i = tid; i < tl.y * (EPNN_AST / 4); i += 512)
+        reinterpret_cast<f32x4 *>(Ai)[i] = reinterpret_cast<const f32x4 *>(L.a_eo + (size_t)tl.x * EPNN_AST)[i];
+    {
+        const int o = tid & 31, a16 = tid >> 5, n = L.moff[tl.z + 1] - L.moff[tl.z];
+        const int a[2] = {a16, a16 + 16};
+        float sv[2];
+        lg_reduce<2>(L, tl, a, o, n, types, sv);
+        Ss[a16 * EPNN_SST + o] = sv[0];
+        Ss[(a16 + 16) * EPNN_SST + o] = sv[1];
     }
     __syncthreads();
     const int row = c < tl.y ? c : 0;
     if (wave == 0) {
         const int u0 = (L.nx - hh + 1) >> 1;
-        lg_update_wave(L, U, w1, w2, w3, tl, Ai + row * EPNN_AST + hh * 32 + u0, Ss + c * EPNN_SST,
-                       L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane);
+        lg_update_wave<true>(L, U, w1, w2, w3, tl, Ai + row * EPNN_AST + hh * 32 + u0, Ss + c * EPNN_SST,
+                             L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane);
     }
     if (!X.run) return;
     __syncthreads();                                            // the image now holds the new h
-    if (wave == 1) lg_proj_wave<1, true>(L, X.M, X.with_zp, tl, Ai + row * EPNN_AST + hh * 32, lane, wA);
-    if (wave == 2) lg_proj_wave<2, true>(L, X.M, X.with_zp, tl, Ai + row * EPNN_AST + hh * 32, lane, wA);
+    const float *arow = Ai + row * EPNN_AST + hh * 32;
+    if (X.run == 1) {
+        if (wave == 1) lg_proj_wave<1, true, false>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R);
+        if (wave == 2) lg_proj_wave<2, true, false>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R);
+        return;
+    }
+    for (; job >= 0 && job < 2 * L.T; job += 7) {
+        const int t = job >> 1;
+        float *oP = L.Pst + (size_t)t * L.A * 32, *oR = L.Rst + (size_t)t * L.A * 32;
+        if (job != wave - 1) {                                   // a second job of this wave: its fragments were not prefetched
+            const PairMlpPack &M = L.wi.pas[t];
+            const int off = (job & 1) ? M.wjF : M.wiF;
+#pragma unroll
+            for (int s = 0; s < EPNN_KA; ++s) wA[s] = wp[off + s * 64 + lane];
+        }
+        if (job & 1) lg_proj_wave<2, true, true>(L, L.wi.pas[t], 0, tl, arow, lane, wA, oP, oR);
+        else lg_proj_wave<1, true, true>(L, L.wi.pas[t], 0, tl, arow, lane, wA, oP, oR);
+    }
 }
 
-// q_i += sum_j antisym_ij (charge_gn.py:118); thread per atom, fixed order (own row first, then the down list)
-__device__ __forceinline__ float lg_apply_atom(const LargeArgs &L, int at) {
-    float acc = 0.f;
-    for (int e = L.dn_off[at]; e < L.dn_off[at + 1]; ++e) {
-        const int p = L.dn_ent[e] & EPNN_DN_SLOT;
-        acc -= L.pwj[p] * L.dl[p];
-    }
-    for (int p = L.row_off[at]; p < L.row_off[at + 1]; ++p) acc += L.pwi[p] * L.dl[p];
-    return acc;
-}
+// ------------------------------------------------------------------------------------------------ EPN stack
 // status bits + number of listed pairs to the host (every other kernel of the forward ran before this one on the stream)
 __device__ __forceinline__ void lg_handoff(const LargeArgs &L) {
     volatile int *hs = L.host_status;
@@ -674,43 +798,103 @@ __device__ __forceinline__ void lg_handoff(const LargeArgs &L) {
     hs[1] = L.row_off[L.A];
     __threadfence_system();
 }
-__global__ __launch_bounds__(256) void k_lg_apply(LargeArgs L, int last) {
-    if (last && L.host_status && blockIdx.x == 0 && threadIdx.x == 0) lg_handoff(L);
-    if (L.row_off[L.A] > L.pcap) return;
-    const int fq = L.nx + EPNN_EDIM;
-    for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
-        if (!L.mflag[L.mol_of[at]]) continue;
-        float *qp = L.a_eo + (size_t)at * EPNN_AST + epnn_aeo(fq);
-        const float q = *qp + lg_apply_atom(L, at);
-        *qp = q;
-        if (last && L.q_out) L.q_out[at] = q;
+// sum of an atom's incidence row of transfers, slot order
+__device__ __forceinline__ float lg_slot_sum(const float *dl, int lo, int hi) {
+    float acc = 0.f;
+    for (; lo < hi; lo += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = lo + u < hi ? dl[lo + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lo + u < hi) acc += v[u];
+    }
+    return acc;
+}
+// EPN step t (charge_gn.py:101-118): one wave per 32 listed pairs, one pair per column.  Lane (c, hh): half hh = 0 rebuilds
+// q of the pair's first atom, hh = 1 of its second (q_t = q_{t-1} + its slot row of step t-1), the halves swap them; the
+// pair whose slot opens an atom's row stores the atom's new q for step t+1's readers.  Then
+// z1 = relu(G + (Pst_i + q_i wqi) + (Rst_j + q_j wqj)) both ways, delta = 0.5 (f_ij - f_ji), deposits +w_i delta, -w_j delta.
+__global__ __launch_bounds__(256) void k_lg_epn_step(LargeArgs L, PairMlpPack M, int t) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    const int slot = (blockIdx.x * 4 + wave) * 32 + c;
+    bool valid = slot < np;
+    int4 ra = make_int4(0, 0, 0, 0), rb = make_int4(0, 0, 0, -1);
+    if (valid) {
+        ra = L.prec[2 * slot];
+        rb = L.prec[2 * slot + 1];
+        valid = L.mflag[L.mol_of[ra.x]] != 0;
+    }
+    if (__ballot(valid) == 0ull) return;
+    const int gi = ra.x, gj = ra.y;
+    const float *wp = L.wpack;
+    const float *Pst = L.Pst + (size_t)t * L.A * 32, *Rst = L.Rst + (size_t)t * L.A * 32;
+    // this half's atom: its charge of the previous step and the transfers it received there
+    const int mine = hh ? gj : gi, lo = hh ? rb.x : ra.z, hi = hh ? rb.y : ra.w;
+    const float *qprev = L.qbuf + (size_t)((t + 1) & 1) * L.A;          // q_{t-1} lives in generation (t-1) & 1
+    float *qnext = L.qbuf + (size_t)(t & 1) * L.A;
+    float qa = 0.f;
+    if (valid) {
+        qa = t == 0 ? L.qbuf[mine] : qprev[mine];
+        if (t > 0) {
+            qa += lg_slot_sum(L.dlA + (size_t)((t + 1) & 1) * 2 * L.pcap, lo, hi);
+            const int dest = hh ? rb.w : rb.z;
+            if (dest == lo) qnext[mine] = qa;                             // the pair that opens the atom's row keeps its charge
+        }
+    }
+    const float qo = epnn_swap32(qa);
+    const float qi = hh ? qo : qa, qj = hh ? qa : qo;
+    const f32x16 g = lg_gtile(wp + M.weF, L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24, valid, lane);
+    float pi_[16], rj_[16], pj_[16], ri_[16], w2[16], wqi[16], wqj[16];
+    epnn_ld16(Pst + (size_t)gi * 32 + hh * 16, pi_);
+    epnn_ld16(Rst + (size_t)gj * 32 + hh * 16, rj_);
+    epnn_ld16(Pst + (size_t)gj * 32 + hh * 16, pj_);
+    epnn_ld16(Rst + (size_t)gi * 32 + hh * 16, ri_);
+    epnn_ld16(wp + M.wqi + hh * 16, wqi);
+    epnn_ld16(wp + M.wqj + hh * 16, wqj);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
+    float b2v[16], w3[16];
+    epnn_ld16(wp + M.b2p + hh * 16, b2v);
+    epnn_ld16(wp + M.w3p + hh * 16, w3);
+    f32x16 au, av;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float pu = fmaf(qi, wqi[s], pi_[s]), ru = fmaf(qj, wqj[s], rj_[s]);
+        const float pv = fmaf(qj, wqi[s], pj_[s]), rv = fmaf(qi, wqj[s], ri_[s]);
+        au = epnn_mfma(w2[s], fmaxf((g[s] + pu) + ru, 0.f), au);
+        av = epnn_mfma(w2[s], fmaxf((g[s] + pv) + rv, 0.f), av);
+    }
+    float fu = 0.f, fv = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        fu = fmaf(w3[r], fmaxf(au[r], 0.f), fu);
+        fv = fmaf(w3[r], fmaxf(av[r], 0.f), fv);
+    }
+    fu += epnn_swap32(fu);
+    fv += epnn_swap32(fv);
+    if (valid) {
+        const float dl = 0.5f * (fu - fv);
+        float *out = L.dlA + (size_t)(t & 1) * 2 * L.pcap;
+        if (hh == 0) out[rb.z] = L.pwi[slot] * dl;
+        else if (rb.w >= 0) out[rb.w] = -(L.pwj[slot] * dl);
     }
 }
-// EPN counterpart of k_lg_gnn_tail: workgroup (one wave) = one 32-atom tile: charge update of its atoms, then the next
-// step's projections from the LDS image (k_lg_apply + k_lg_proj in one launch).
-__global__ __launch_bounds__(64) void k_lg_epn_tail(LargeArgs L, LgNext X, int last) {
-    __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
-    const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
-    if (last && L.host_status && blockIdx.x == 0 && lane == 0) lg_handoff(L);
+// after the last step: q_T = q_{T-1} + the atom's last slot row (thread per atom), and the hand-over to the host
+__global__ __launch_bounds__(256) void k_lg_epn_final(LargeArgs L) {
+    if (L.host_status && blockIdx.x == 0 && threadIdx.x == 0) lg_handoff(L);
     if (L.row_off[L.A] > L.pcap) return;
-    const int4 tl = L.atiles[blockIdx.x];
-    const int fq = L.nx + EPNN_EDIM;
-    for (int i = lane; i < tl.y * EPNN_AST; i += 64) Ai[i] = L.a_eo[(size_t)tl.x * EPNN_AST + i];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (lane < tl.y) {
-        const int at = tl.x + lane;
-        const float q = Ai[lane * EPNN_AST + epnn_aeo(fq)] + lg_apply_atom(L, at);
-        Ai[lane * EPNN_AST + epnn_aeo(fq)] = q;
-        L.a_eo[(size_t)at * EPNN_AST + epnn_aeo(fq)] = q;
-        if (last && L.q_out) L.q_out[at] = q;
+    const int gen = (L.T - 1) & 1;
+    for (int at = blockIdx.x * 256 + threadIdx.x; at < L.A; at += gridDim.x * 256) {
+        if (!L.mflag[L.mol_of[at]]) continue;
+        const float q = L.qbuf[(size_t)gen * L.A + at] +
+                        lg_slot_sum(L.dlA + (size_t)gen * 2 * L.pcap, L.inc_off[at], L.inc_off[at + 1]);
+        if (L.q_out) L.q_out[at] = q;
     }
-    if (!X.run) return;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int row = c < tl.y ? c : 0;
-    const float none[EPNN_KA] = {};
-    lg_proj_wave<3, false>(L, X.M, X.with_zp, tl, Ai + row * EPNN_AST + hh * 32, lane, none);
 }
 
 __global__ __launch_bounds__(256) void k_lg_export_h(LargeArgs L) {
@@ -790,14 +974,19 @@ static int large_plan(epnn_handle *h) {
     h->l_nstasks = (int)lp.stasks.size();
     h->l_maxchunk = lp.maxchunk;
     if (P.large_list.empty()) return 0;          // (the molecule flags travel with the plan's other index arrays)
-    const size_t A = (size_t)P.A;
+    const size_t A = (size_t)P.A, nl = P.large_list.size(), T = (size_t)std::max(1, h->cfg.T);
     if (h->l_tiles.ensure(lp.atiles.size() * sizeof(int4)) || h->l_stasks.ensure(lp.stasks.size() * sizeof(int4)) ||
         h->l_schunk.ensure(lp.stask_chunk.size() * sizeof(int)) || h->l_a.ensure(A * EPNN_AST * 4) ||
         h->l_P.ensure(A * 32 * 4) || h->l_R.ensure(A * 32 * 4) || h->l_zp.ensure(A * 32 * 4) ||
+        h->l_Nn.ensure(A * 32 * 4) || h->l_Yb.ensure(A * 32 * 4) || h->l_qbuf.ensure(2 * A * 4) ||
+        h->l_Pst.ensure(T * A * 32 * 4) || h->l_Rst.ensure(T * A * 32 * 4) ||
         h->l_S0.ensure((size_t)lp.maxchunk * A * 32 * 4) || h->l_csr_off.ensure((A + 1) * sizeof(int)) ||
-        h->l_cnt.ensure((A + 1) * sizeof(int)) || h->l_sfin.ensure(A * 32 * 4))
+        h->l_cnt.ensure(2 * (A + 1) * sizeof(int)) || h->l_sfin.ensure(A * 32 * 4) ||
+        h->l_lmol.ensure(nl * sizeof(int)) || h->l_typrow.ensure(A * sizeof(int)) ||
+        h->l_typtab.ensure(nl * (2 * EPNN_TYPE_MAX + 1) * sizeof(int)) || h->l_stype.ensure(nl * EPNN_TYPE_MAX * 32 * 4))
         return 1;
     HIPCHK(hipMemcpyAsync(h->l_tiles.p, lp.atiles.data(), lp.atiles.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->l_lmol.p, P.large_list.data(), nl * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (!lp.stasks.empty()) {
         HIPCHK(hipMemcpyAsync(h->l_stasks.p, lp.stasks.data(), lp.stasks.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->l_schunk.p, lp.stask_chunk.data(), lp.stask_chunk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -806,15 +995,26 @@ static int large_plan(epnn_handle *h) {
     return 0;
 }
 
-struct PairSource;
-static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
-                             const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn) {
-    const Plan &P = h->plan;
-    if (P.large_list.empty()) return 0;
+// capacity of everything that is sized by the pair list
+static int ensure_large_pairs(epnn_handle *h) {
     const size_t pc = (size_t)h->pcap;
-    if (h->l_corr.ensure(pc * 2 * 32 * 4) || h->l_dl.ensure(pc * 4) || h->l_csr_ent.ensure(pc * sizeof(int)) ||
-        h->l_csr_ent2.ensure(pc * sizeof(int)))
-        return 1;
+    return h->l_corr.ensure(pc * 2 * 32 * 4) || h->l_dl.ensure(2 * 2 * pc * 4) || h->l_csr_ent.ensure(pc * sizeof(int));
+}
+
+struct PairSource;
+// `have_inc`: the pair list came with its incidence rows (compact entry: epnn_frontend.hip.h); otherwise (dense front-end) they
+// are built here.  `lists_ev`: when not null the list is being built on the handle's second stream -- everything that needs
+// it waits for this event; what needs only the atoms (feature rows, atom types, first projections, the first step's type
+// sums) runs beside the list construction.
+static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
+                             const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn, bool have_inc, hipEvent_t lists_ev) {
+    const Plan &P = h->plan;
+    if (P.large_list.empty()) {
+        if (lists_ev) HIPCHK(hipStreamWaitEvent(h->stream, lists_ev, 0));
+        return 0;
+    }
+    if (ensure_large_pairs(h) || h->d_incoff.ensure(((size_t)P.A + 1) * sizeof(int))) return 1;
+    const size_t pc = (size_t)h->pcap;
     LargeArgs L{};
     L.wpack = h->d_wpack.as<float>();
     L.wi = h->widx;
@@ -834,10 +1034,15 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.a_eo = h->l_a.as<float>();
     L.P = h->l_P.as<float>();
     L.R = h->l_R.as<float>();
+    L.Nn = h->l_Nn.as<float>();
+    L.Yb = h->l_Yb.as<float>();
     L.zp = h->l_zp.as<float>();
     L.S0 = h->l_S0.as<float>();
-    L.corr = h->l_corr.as<float>();
-    L.dl = h->l_dl.as<float>();
+    L.corrA = h->l_corr.as<float>();
+    L.dlA = h->l_dl.as<float>();
+    L.qbuf = h->l_qbuf.as<float>();
+    L.Pst = h->l_Pst.as<float>();
+    L.Rst = h->l_Rst.as<float>();
     L.row_off = h->d_rowoff.as<int>();
     L.pi = h->d_pi.as<int>();
     L.pj = h->d_pj.as<int>();
@@ -845,15 +1050,31 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.pe = h->d_pe.as<float>();
     L.pwi = h->d_pwi.as<float>();
     L.pwj = h->d_pwj.as<float>();
+    L.inc_off = h->d_incoff.as<int>();
+    L.dest_i = h->d_desti.as<int>();
+    L.dest_j = h->d_destj.as<int>();
+    L.prec = h->d_prec.as<int4>();
+    L.dn_cnt = h->l_cnt.as<int>();
+    L.dn_cur = h->l_cnt.as<int>() + (size_t)P.A + 1;
     L.dn_off = h->l_csr_off.as<int>();
     L.dn_ent = h->l_csr_ent.as<int>();
-    L.dn_cnt = h->l_cnt.as<int>();
+    L.w_inc_off = h->d_incoff.as<int>();
+    L.w_dest_i = h->d_desti.as<int>();
+    L.w_dest_j = h->d_destj.as<int>();
+    L.w_prec = h->d_prec.as<int4>();
     L.atiles = h->l_tiles.as<int4>();
     L.natiles = h->l_natiles;
     L.stasks = h->l_stasks.as<int4>();
     L.stask_chunk = h->l_schunk.as<int>();
     L.nstasks = h->l_nstasks;
     L.pcap = h->pcap;
+    L.lmol = h->l_lmol.as<int>();
+    L.nlarge = (int)P.large_list.size();
+    L.typ_row = h->l_typrow.as<int>();
+    L.typ_rep = h->l_typtab.as<int>();
+    L.typ_cnt = L.typ_rep + (size_t)L.nlarge * EPNN_TYPE_MAX;
+    L.typ_n = L.typ_cnt + (size_t)L.nlarge * EPNN_TYPE_MAX;
+    L.S_type = h->l_stype.as<float>();
     // compact entry: the forward's last kernel hands status + pair count to the host (two device-to-host copies less)
     L.host_status = (h->want_large_handoff && run_epn && h->cfg.T > 0 && h->part_world == 1) ? h->h_status : nullptr;
     h->did_large_handoff = L.host_status != nullptr;
@@ -866,33 +1087,48 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     const unsigned gAt = (unsigned)std::min<size_t>(((size_t)P.A + 255) / 256, 4096);
     const unsigned gT = (unsigned)((L.natiles + 3) / 4);
     const unsigned gPT = (unsigned)((pc + 127) / 128);
+    const int Tg = run_gnn ? L.T : 0, Te = run_epn ? L.T : 0;
+    // the first GNN step by atom types: the compact entry only (h = 0 and one q per molecule: a feature row depends on x alone)
+    const bool types = Tg > 0 && h->opt_large_dedupe && !h->types_overflowed && !d_hin && !d_qin && !d_nm;
     hipLaunchKernelGGL(k_lg_init, dim3(gA), dim3(256), 0, st, L);
-    HIPCHK(hipMemsetAsync(L.dn_cnt, 0, ((size_t)P.A + 1) * sizeof(int), st));
-    hipLaunchKernelGGL(k_lg_dn_count, dim3(gP), dim3(256), 0, st, L);
-    hipLaunchKernelGGL(k_lg_dn_scan, dim3(1), dim3(1024), 0, st, L, h->l_csr_off.as<int>());
-    hipLaunchKernelGGL(k_lg_dn_fill, dim3(gP), dim3(256), 0, st, L, h->l_csr_ent2.as<int>());
-    hipLaunchKernelGGL(k_lg_dn_rank, dim3(gP), dim3(256), 0, st, L, h->l_csr_ent2.as<int>(), h->l_csr_ent.as<int>());
+    if (types) hipLaunchKernelGGL(k_lg_types, dim3((unsigned)L.nlarge), dim3(1024), 0, st, L);
     // Launch sequence (the single-process case): proj(0) | per GNN step: sweep + correction tiles, tail (reduce, update,
-    // next projections) | per EPN step: pair tiles, tail (charge update, next projections).  With a partition the other
+    // next projections) | per EPN step: pair tiles; a last launch adds the final transfers.  With a partition the other
     // processes' rows of S arrive between the reduction and the update, so those stay separate launches.
     const bool collective = h->part_world > 1 || h->opt_part_collective;
     const bool split = collective || !h->opt_large_fused;
-    const int Tg = run_gnn ? L.T : 0, Te = run_epn ? L.T : 0;
     const unsigned gTile = (unsigned)L.natiles;
     auto next_after_gnn = [&](int t) {
         LgNext X{};
-        if (t + 1 < Tg) { X.M = h->widx.msg[t + 1]; X.run = 1; X.with_zp = 1; }
-        else if (Te > 0) { X.M = h->widx.pas[0]; X.run = 1; X.with_zp = 0; }
+        if (t + 1 < Tg) { X.M = h->widx.msg[t + 1]; X.run = 1; }
+        else if (Te > 0) X.run = 2;
         return X;
     };
     if (Tg > 0) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[0], 1);
-    else if (Te > 0) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.pas[0], 0);
+    else if (Te > 0) hipLaunchKernelGGL(k_lg_epn_static, dim3((unsigned)((L.natiles * L.T + 3) / 4)), dim3(256), 0, st, L);
+    bool lists_ready = false;
+    auto need_lists = [&]() -> int {           // from here on the launches read the pair list / the incidence rows
+        if (lists_ready) return 0;
+        lists_ready = true;
+        if (lists_ev) HIPCHK(hipStreamWaitEvent(st, lists_ev, 0));
+        if (!have_inc) {
+            HIPCHK(hipMemsetAsync(L.dn_cnt, 0, 2 * ((size_t)P.A + 1) * sizeof(int), st));
+            hipLaunchKernelGGL(k_lg_dn_count, dim3(gP), dim3(256), 0, st, L);
+            hipLaunchKernelGGL(k_lg_dn_scan, dim3(1), dim3(1024), 0, st, L);
+            hipLaunchKernelGGL(k_lg_dn_fill, dim3(gP), dim3(256), 0, st, L);
+            hipLaunchKernelGGL(k_lg_dn_link, dim3(gP), dim3(256), 0, st, L);
+        }
+        return 0;
+    };
     for (int t = 0; t < Tg; ++t) {
+        const bool ty = types && t == 0;
+        if (ty) hipLaunchKernelGGL(k_lg_tsweep, dim3((unsigned)L.nlarge * 2), dim3(64), 0, st, L, h->widx.msg[0]);
         if (split) {
-            if (L.nstasks > 0)
-                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
+            if (!ty && L.nstasks > 0)
+                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2);
+            if (need_lists()) return 1;
             hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
-            hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>());
+            hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>(), ty ? 1 : 0);
             if (collective) {
                 // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms); everything
                 // after this point is computed by every process for every atom
@@ -918,38 +1154,35 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
                         EPNN_FAIL("forward: RCCL row exchange failed: %s", ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
                 }
             }
-            hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_maxchunk, h->l_sfin.as<float>());
+            hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_sfin.as<float>());
             const LgNext X = next_after_gnn(t);
-            if (X.run) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, X.with_zp);
+            if (X.run == 1) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, 1);
+            else if (X.run == 2) hipLaunchKernelGGL(k_lg_epn_static, dim3((unsigned)((L.natiles * L.T + 3) / 4)), dim3(256), 0, st, L);
+            continue;
+        }
+        if (ty) {
+            if (need_lists()) return 1;
+            hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
+        } else if (L.nstasks > 0 && L.nstasks <= 512 && h->opt_large_pairs_beside != 1) {
+            if (need_lists()) return 1;
+            hipLaunchKernelGGL(k_lg_sweep_pairs, dim3((unsigned)L.nstasks + gPT), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->widx.msg[t]);
         } else {
-            if (L.nstasks > 0 && L.nstasks <= 512) {
-                hipLaunchKernelGGL(k_lg_sweep_pairs, dim3((unsigned)L.nstasks + gPT), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2, h->widx.msg[t]);
-                hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(256), 0, st, L, h->widx.upd[t], next_after_gnn(t));
-                continue;
-            }
+            if (need_lists()) return 1;
             // correction tiles beside the sweep (both need only this step's P and R): fork to the second stream, join before the tail
             HIPCHK(hipEventRecord(h->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
             hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, h->stream2, L, h->widx.msg[t]);
             HIPCHK(hipEventRecord(h->ev_join, h->stream2));
             if (L.nstasks > 0)
-                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->wvidx.g[t].b2);
+                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2);
             HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
-            hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(256), 0, st, L, h->widx.upd[t], next_after_gnn(t));
         }
+        hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(512), 0, st, L, h->widx.upd[t], next_after_gnn(t), ty ? 1 : 0);
     }
+    if (need_lists()) return 1;
     if (d_hout) hipLaunchKernelGGL(k_lg_export_h, dim3(gA), dim3(256), 0, st, L);
-    for (int t = 0; t < Te; ++t) {
-        hipLaunchKernelGGL(k_lg_pairs<1>, dim3(gPT), dim3(256), 0, st, L, h->widx.pas[t]);
-        LgNext X{};
-        if (t + 1 < Te) { X.M = h->widx.pas[t + 1]; X.run = 1; X.with_zp = 0; }
-        if (split) {
-            hipLaunchKernelGGL(k_lg_apply, dim3(gAt), dim3(256), 0, st, L, t + 1 == Te);
-            if (X.run) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, 0);
-        } else {
-            hipLaunchKernelGGL(k_lg_epn_tail, dim3(gTile), dim3(64), 0, st, L, X, t + 1 == Te);
-        }
-    }
+    for (int t = 0; t < Te; ++t) hipLaunchKernelGGL(k_lg_epn_step, dim3(gPT), dim3(256), 0, st, L, h->widx.pas[t], t);
+    if (Te > 0) hipLaunchKernelGGL(k_lg_epn_final, dim3(gAt), dim3(256), 0, st, L);
     if (d_q && Te == 0) hipLaunchKernelGGL(k_lg_export_q, dim3(gAt), dim3(256), 0, st, L);
     HIPCHK(hipGetLastError());
     return 0;

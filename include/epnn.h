@@ -157,7 +157,13 @@ int epnn_last_timing(epnn_handle *h, float *out4);
 int epnn_timing_at(epnn_handle *h, int idx, float *out4);
 /* options: "profile" (0 = off, k > 0 = keep stage events of the last k forwards), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
  * "pair_cap_per_atom" (initial capacity of the near-pair list of the tiled / dense paths), "wave_front" (1: batches of small
- * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront), "wave3" (1, default: molecules of 33..48 / 49..64 atoms of the compact and the make_model entries run on three / four wavefronts of the block-per-wavefront fused kernel; 0: on the tiled kernels), "wave2" (block-per-wavefront kernel of the compact entry: molecules with at least this many atoms, 17..32, are split over two wavefronts and those of at most 16 run two to a workgroup; 0: one wavefront per molecule throughout; -1, default: 17 for batches of at most 1024 molecules, which halves the latency of a lone batch, else 0 -- set 0 on handles whose launches overlap), "large_fused" (0: the tiled path launches one kernel per stage), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
+ * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront), "wave3" (1, default: molecules of 33..48 / 49..64 atoms of the compact and the make_model entries run on three / four wavefronts of the block-per-wavefront fused kernel; 0: on the tiled kernels), "wave2" (block-per-wavefront kernel of the compact entry: molecules with at least this many atoms, 17..32, are split over two wavefronts and those of at most 16 run two to a workgroup; 0: one wavefront per molecule throughout; -1, default: 17 for batches of at most 1024 molecules, which halves the latency of a lone batch, else 0 -- set 0 on handles whose launches overlap), "large_fused" (0: the tiled path launches one kernel per stage),
+ * "large_dedupe" (1, default: the tiled path's first GNN step of the compact entry groups the atoms by feature row -- h = 0 and one
+ * q per molecule there, so the all-pairs sum of charge_gn.py:70 takes (distinct rows)^2 pair evaluations instead of n^2; 0: the
+ * all-pairs sweep; a molecule with more than 64 distinct rows switches the handle back to the sweep by itself),
+ * "large_overlap" (1, default: the compact entry builds the pair list of tiled molecules on the handle's second stream beside
+ * the first projections; 0: everything on one stream), "large_pairs_beside" (developer switch: 1 launches the tiled path's
+ * near-pair correction tiles on the second stream even where they would ride in the sweep's launch), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
  * "train_graph" (1: a train step's launch sequence is captured once and replayed as a hipGraph, 0, default: kernel by kernel),
  * "train_fused" (1: one workgroup per atom runs a whole pair MLP over its rows, forward and backward; 0: one launch per
  * Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS budget of 96 atoms). */
