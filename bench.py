@@ -12,12 +12,17 @@ and the MAX over ranks of the timed interval.
 Launch forms for N > 1: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* from the environment), or plain `python bench.py --gpus N ...`: this process then starts the N
 rank processes itself, as fresh children, before it makes any GPU call of its own (it never makes one), relays rank 0's
-JSON line and exits with the first non-zero exit code.  With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks
-share devices and the timing exchange runs over gloo.
+JSON line and exits with the first non-zero exit code (a rank that dies takes the others down: rendezvous.launch_ranks).  The
+barrier and the MAX over ranks of the timed interval go through the LIBRARY's own RCCL communicator (epnn_comm_init +
+epnn_comm_allreduce; the 128-byte id travels over epnn_amd/rendezvous.py): the scaling run exercises the product's RCCL path,
+and `ranks.rccl_ranks` (ncclCommCount) says how many ranks joined.  No torch anywhere.  With fewer GPUs than ranks (rehearsal
+on a one-GPU box: RCCL refuses two ranks on one device) the ranks share devices, take fewer hardware queues each, and the
+timing exchange runs over the rendezvous store.
 
-Order of a run: one forward and its checks; parity against the reference's stored outputs and the single-launch measurement
-(both skipped by --no-extras); W warm-up steps; barrier; K timed steps; barrier; the same steps again with hipEvents for the
-kernel duration; host-to-host; real-data rate.  The single-launch measurement placed right before the warm-up steps also
+Order of a run: one forward and its checks; the COLD measurement (`value_cold`: W warm-up + K timed steps started on a GPU that
+idled for 0.3 s, what a run without anything in front of its warm-up steps reads); parity against the reference's stored outputs
+and the single-launch measurement (all three skipped by --no-extras); W warm-up steps; barrier; K timed steps; barrier; the same
+steps again with hipEvents for the kernel duration; host-to-host; real-data rate.  The single-launch measurement placed right before the warm-up steps also
 means the timed region starts on a GPU at working clocks: K = 20 steps are 2 ms, and on a GPU that idled before the W = 5
 warm-up steps (--no-extras) they read 182-185 M atoms/s instead of 194-197 M (`order` in the line; profiles/r02_warm_sweep.txt).
 
@@ -46,8 +51,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# before anything (torch included) initialises HIP in this process: one hardware queue per batch in flight (epnn_amd/_lib.py)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (GPU_MAX_HW_QUEUES is decided in main(), before anything initialises HIP in this process: one hardware queue per batch in
+# flight, fewer when ranks share a device)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
 KNAME = "k_wave_forward<true,true,true>"
@@ -230,37 +235,30 @@ def main():
     if args.pmc and world == 1:
         collect_pmc(args)
 
-    dist = None
-    torch = None
+    from epnn_amd import _lib
     device = local_rank
+    rdzv = None
     backend = None
+    ranks_on_device = 1
     if world > 1:
-        import torch
-        import torch.distributed as dist
+        # devices are counted WITHOUT initialising HIP: the runtime reads GPU_MAX_HW_QUEUES when it starts
+        ndev = _lib.visible_gpu_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if ndev and ndev < local_world:
+            ranks_on_device = -(-local_world // ndev)
+    want_q = _lib.queues_for_shared_device(ranks_on_device)
+    if "GPU_MAX_HW_QUEUES" not in os.environ or (ranks_on_device > 1 and int(os.environ["GPU_MAX_HW_QUEUES"]) > want_q):
+        os.environ["GPU_MAX_HW_QUEUES"] = str(want_q)        # (a value inherited from a parent that sized it for one rank per device is cut)
+    if ranks_on_device > 1:                                 # fewer queues: fewer batches in flight
+        args.depth = max(1, min(args.depth, int(os.environ["GPU_MAX_HW_QUEUES"]) - 1))
+    if world > 1:
+        from epnn_amd.rendezvous import Rendezvous
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ndev = torch.cuda.device_count()
-        if ndev >= world:
-            torch.cuda.set_device(local_rank)
-            try:
-                dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank))       # RCCL on ROCm
-                sync_dev = torch.device("cuda", local_rank)
-                probe = torch.ones(1, device=sync_dev)
-                dist.all_reduce(probe)                                                    # the communicator really works (all
-                torch.cuda.synchronize()                                                  # ranks fail or succeed together)
-                assert int(probe.item()) == world
-            except Exception as exc:                                                      # noqa: BLE001
-                print(f"[bench rank {rank}] RCCL process group unavailable ({exc}); timing exchange over gloo", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-                sync_dev = torch.device("cpu")
-        else:
-            # fewer GPUs than ranks (rehearsal on a one-GPU box): ranks share devices, timing exchange over gloo
-            device = local_rank % max(1, ndev)
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            sync_dev = torch.device("cpu")
-        backend = dist.get_backend()
+        rdzv = Rendezvous(rank, world)
+        ndev = _lib.load().epnn_device_count()
+        if ndev < 1:
+            raise SystemExit("bench.py: no HIP device visible")
+        device = local_rank % ndev
 
     from epnn_amd import checkpoint, synth
     from epnn_amd.engine import Pipeline
@@ -269,6 +267,20 @@ def main():
     pipe = Pipeline(depth=args.depth, nx=9, T=5, device=device)
     pipe.set_weights(weights)
     pipe.set_option("wave2", 0)          # the throughput kernel at every depth (Pipeline does this itself above depth 1)
+    comm_eng = None
+    rccl_ranks = None
+    if world > 1:
+        from epnn_amd.engine import Engine
+        if ndev >= world:
+            # the library's own communicator on lane 0's handle: every rank joins or the run fails
+            comm_eng = pipe.engines[0]
+            comm_eng.comm_init(rdzv.broadcast(Engine.comm_unique_id() if rank == 0 else None, name="rccl_id"), rank, world)
+            rccl_ranks = comm_eng.comm_count()
+            assert rccl_ranks == world, (rccl_ranks, world)
+            assert comm_eng.comm_allreduce([1.0], "sum")[0] == float(world)
+            backend = "rccl (epnn_comm_allreduce on the library's communicator)"
+        else:
+            backend = "rendezvous store (ranks share a device: RCCL refuses two ranks on one GPU)"
     for kv in args.opt:
         name, value = kv.split("=")
         pipe.set_option(name, int(value))
@@ -285,10 +297,10 @@ def main():
 
     def barrier():
         pipe.sync()
-        if dist is not None:
-            if sync_dev.type == "cuda":
-                torch.cuda.synchronize()
-            dist.barrier()
+        if comm_eng is not None:
+            comm_eng.comm_allreduce([0.0], "sum")
+        elif rdzv is not None:
+            rdzv.barrier("b")
 
     # ---- before the timed region: the checks and the single-launch measurement (--no-extras skips them).  A rate for wrong
     # charges is worth nothing, so parity comes first; the single-launch measurement runs on EVERY rank right before the
@@ -309,6 +321,26 @@ def main():
     assert np.abs(sums - Q).max() < 1e-4, np.abs(sums - Q).max()
     ns = np.diff(offsets)
     flops = synth.algorithmic_flops(ns, int(stats[0]))
+
+    def timed_steps():
+        """W warm-up steps, barrier, K timed steps, barrier -> seconds of the timed region on this rank"""
+        for k in range(max(args.warmup, len(lanes))):
+            step(k)
+        pipe.sync()
+        barrier()
+        t_start = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        barrier()
+        return time.perf_counter() - t_start
+
+    cold_dt = None
+    if not args.no_extras:
+        # the same measurement from an IDLE GPU (nothing but a 0.3 s pause in front of the warm-up steps): the figure a run
+        # reads whose timed region is a few milliseconds long and has no load in front of it (clocks: DESIGN.md section 5)
+        pipe.sync()
+        time.sleep(0.3)
+        cold_dt = timed_steps()
 
     extras, real, held = {}, None, []
     if rank == 0 and not args.no_extras:
@@ -366,6 +398,7 @@ def main():
         for _ in range(2):
             e0.forward_xyz_dev(big_off, big[0], big[1], big[2], big_q, N)
         held = big + [big_q]
+        prewarm_ms = (nbig + 2) * big_ms                   # GPU time of the launches in front of the warm-up steps
 
     for k in range(max(args.warmup, len(lanes))):
         step(k)
@@ -395,16 +428,19 @@ def main():
     stage = np.array([lanes[l][0].timing_at(i) for l in range(len(lanes)) for i in range(per_lane[l])])
     pipe.set_option("profile", 0)
 
-    if dist is not None:
-        mine = torch.tensor([dt, float(A)], dtype=torch.float64, device=sync_dev)
-        every = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        per_rank = [(float(t[0]), float(t[1])) for t in every]
-        dt_max = max(d for d, _ in per_rank)
-        atoms_total = sum(a for _, a in per_rank)
+    if world > 1:
+        # MAX over ranks of the timed interval and the total of the atoms: over RCCL when every rank has its own device
+        if comm_eng is not None:
+            mx = comm_eng.comm_allreduce([dt, cold_dt or 0.0], "max")
+            atoms_total = comm_eng.comm_allreduce([float(A)], "sum")[0]
+        else:
+            mx = rdzv.all_reduce_max([dt, cold_dt or 0.0], name="dt")
+            atoms_total = sum(rdzv.all_gather(float(A), name="atoms"))
+        dt_max, cold_max = mx[0], mx[1]
+        per_rank = [(float(d), float(a)) for d, a in rdzv.all_gather((dt, float(A)), name="per_rank")]    # detail for the line
     else:
         per_rank = [(dt, float(A))]
-        dt_max, atoms_total = dt, float(A)
+        dt_max, atoms_total, cold_max = dt, float(A), (cold_dt or 0.0)
 
     if held:
         qb = held[3].download((A * rep,))
@@ -525,6 +561,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
+            "value_cold": (atoms_total * args.steps / cold_max) if cold_max else None,
+            "prewarm_ms": None if args.no_extras else prewarm_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -535,12 +573,13 @@ def main():
                        "weights": "decay_model_weights", "parallelism": f"molecule-sharded x{world}",
                        "batches_in_flight_per_gpu": len(lanes)},
             "roofline": roof,
-            "order": ("one forward + checks, " + ("" if args.no_extras else "parity on the reference's stored outputs, single-launch measurement (+2 launches of it unmeasured, no idle gap), ")
+            "order": ("one forward + checks, " + ("" if args.no_extras else "0.3 s idle + warm-up + timed steps (value_cold), parity on the reference's stored outputs, single-launch measurement (+2 launches of it unmeasured, no idle gap: prewarm_ms of GPU load), ")
                       + f"{max(args.warmup, len(lanes))} warm-up steps, {args.steps} timed steps, the same steps again with hipEvents"
                       + ("" if args.no_extras else ", host-to-host, real-data rate")),
         }
         if world > 1:
-            out["ranks"] = {"world_size": world, "timing_backend": backend,
+            out["ranks"] = {"world_size": world, "timing_backend": backend, "rccl_ranks": rccl_ranks,
+                            "ranks_per_device": ranks_on_device, "hw_queues_per_rank": int(os.environ["GPU_MAX_HW_QUEUES"]),
                             "atoms_per_s_per_rank": [a * args.steps / d for d, a in per_rank]}
         for key in ("parity", "real_data", "host_to_host", "blocking_call"):
             if key in extras:
@@ -553,10 +592,11 @@ def main():
     for lane in lanes:
         for d in lane[1:]:
             d.free()
+    if rdzv is not None:
+        rdzv.barrier("end")
     pipe.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.close()
 
 
 if __name__ == "__main__":

@@ -60,6 +60,9 @@ SIGNATURES = {
     "epnn_train_apply": (C.c_int, [_vp]),
     "epnn_comm_unique_id": (C.c_int, [C.c_char_p]),
     "epnn_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    "epnn_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "epnn_debug_pairs": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
+    "epnn_comm_allreduce": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int32, C.c_int32]),
     "epnn_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "epnn_dev_free": (C.c_int, [_vp, _vp]),
     "epnn_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -75,6 +78,39 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def visible_gpu_count():
+    """GPUs this process will see, WITHOUT initialising HIP (the runtime reads GPU_MAX_HW_QUEUES when it starts, so a driver
+    that wants to size its queues by ranks per device must count devices first): the *_VISIBLE_DEVICES lists if set, else
+    the KFD topology's nodes with SIMDs.  0 when neither says anything (the caller then asks the library)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        return 0
+    return n
+
+
+def queues_for_shared_device(ranks_on_device, default=16):
+    """Hardware queues a process should ask for when `ranks_on_device` processes share one GPU.  A device serves a limited
+    number of hardware queues at once; beyond it the firmware time-slices whole queues (milliseconds at a time): two bench
+    ranks with 16 queues each beside a third process fell from 200 M to 14 M atoms/s (gpurun_out/r2_fulltests2.log).  One
+    rank per device keeps the default."""
+    if ranks_on_device <= 1:
+        return default
+    return max(2, 8 // int(ranks_on_device))
 
 
 def load():

@@ -82,7 +82,6 @@ static int create_resources(epnn_handle *h) {
     HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t0));
     HIPCHK(hipEventCreateWithFlags(&h->ev_ctl, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t1));
@@ -132,7 +131,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
                       &h->s_train, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->d_deg, &h->d_incoff, &h->d_nbr, &h->d_desti, &h->d_destj, &h->d_prec, &h->l_Nn, &h->l_Yb, &h->l_qbuf,
-                      &h->l_Pst, &h->l_Rst, &h->l_lmol, &h->l_typrow, &h->l_typtab, &h->l_stype,
+                      &h->l_Pst, &h->l_Rst, &h->l_lmol, &h->l_typrow, &h->l_typtab, &h->l_stype, &h->l_typhash,
                       &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
                       &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
@@ -157,7 +156,6 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->ev_lists) (void)hipEventDestroy(h->ev_lists);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -621,7 +619,7 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
         const bool mid = !small && allow_mid && h->opt_wave3 && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX4;
-        c_mflag[b] = small || mid ? 0 : 1;
+        c_mflag[b] = small || mid ? 0 : 1 + (int)P.large_list.size();   // 1 + its place among the tiled molecules
         if (small) {
             P.small_nmax = std::max(P.small_nmax, n);
             if (thr2 && n >= thr2) P.split_order.push_back(b);
@@ -713,7 +711,7 @@ static int ensure_pairs(epnn_handle *h, int pcap) {
         h->d_psym.ensure((size_t)pcap * sizeof(int)) || h->d_pwi.ensure((size_t)pcap * sizeof(float)) ||
         h->d_pwj.ensure((size_t)pcap * sizeof(float)) || h->d_pe.ensure((size_t)pcap * EPNN_EDIM * sizeof(float)) ||
         h->d_nbr.ensure(2 * (size_t)pcap * sizeof(int)) || h->d_desti.ensure((size_t)pcap * sizeof(int)) ||
-        h->d_destj.ensure((size_t)pcap * sizeof(int)) || h->d_prec.ensure(2 * (size_t)pcap * sizeof(int4)))
+        h->d_destj.ensure((size_t)pcap * sizeof(int)) || h->d_prec.ensure(2 * ((size_t)pcap + 256) * sizeof(int4)))
         return 1;
     h->pcap = pcap;
     return 0;
@@ -735,8 +733,8 @@ struct PairSource {     // where the fused / tiled kernels read atoms and pairs 
     int handoff = 0;                 // ... and its last wave hands status + pair count to the host (no other kernel ran)
 };
 
-static int launch_large(epnn_handle *h, const PairSource &S, bool have_inc = false, hipEvent_t lists_ev = nullptr) {
-    return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_nm, S.d_q, S.d_hout, S.run_gnn, S.run_epn, have_inc, lists_ev);
+static int launch_large(epnn_handle *h, const PairSource &S, bool have_inc = false, const FrontArgs *front = nullptr) {
+    return launch_large_impl(h, S.d_x, S.d_Q, S.d_hin, S.d_qin, S.d_nm, S.d_q, S.d_hout, S.run_gnn, S.run_epn, have_inc, front);
 }
 
 
@@ -872,14 +870,15 @@ static int launch_small(epnn_handle *h, const PairSource &S) {
     return launch_wave(h, S);
 }
 
-// pair list + incidence rows from coordinates, four launches on `st` (epnn_frontend.hip.h)
-static int run_frontend_xyz(epnn_handle *h, const float *d_xyz, hipStream_t st) {
+// arguments of the front-end's launches: pair list + incidence rows from coordinates (epnn_frontend.hip.h)
+static int make_front_args(epnn_handle *h, const float *d_xyz, FrontArgs &F) {
     const Plan &P = h->plan;
     if (h->d_deg.ensure(((size_t)P.A + 1) * sizeof(int)) || h->d_incoff.ensure(((size_t)P.A + 1) * sizeof(int))) return 1;
-    FrontArgs F{};
+    F = FrontArgs{};
     F.xyz = d_xyz;
     F.mol_of = h->p_molof;
     F.moff = h->p_moff;
+    F.mflag = h->p_mflag;
     F.A = P.A;
     F.cutoff = (double)h->cfg.cutoff;
     F.cut2 = cutoff_squared(F.cutoff);
@@ -903,11 +902,14 @@ static int run_frontend_xyz(epnn_handle *h, const float *d_xyz, hipStream_t st) 
     F.pwi = h->d_pwi.as<float>();
     F.pwj = h->d_pwj.as<float>();
     F.status = h->d_status.as<int>();
-    const unsigned rows = (unsigned)((P.A + 3) / 4);
-    hipLaunchKernelGGL(k_front_count, dim3(rows), dim3(256), 0, st, F);
-    hipLaunchKernelGGL(k_front_scan_both, dim3(1), dim3(1024), 0, st, F);
-    hipLaunchKernelGGL(k_front_fill, dim3(rows), dim3(256), 0, st, F);
-    hipLaunchKernelGGL(k_front_link, dim3((unsigned)std::min<size_t>(((size_t)h->pcap + 255) / 256, 4096)), dim3(256), 0, st, F);
+    return 0;
+}
+static int run_frontend_xyz(epnn_handle *h, const FrontArgs &F) {
+    const unsigned rows = (unsigned)((F.A + 3) / 4);
+    hipLaunchKernelGGL(k_front_count, dim3(rows), dim3(256), 0, h->stream, F);
+    hipLaunchKernelGGL(k_front_scan_both, dim3(1), dim3(1024), 0, h->stream, F);
+    hipLaunchKernelGGL(k_front_fill, dim3(rows), dim3(256), 0, h->stream, F);
+    hipLaunchKernelGGL(k_front_link, dim3((unsigned)std::min<size_t>(((size_t)h->pcap + 255) / 256, 1024)), dim3(256), 0, h->stream, F);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -936,19 +938,16 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
         h->ev_next += 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
-    // The separate front-end (pair list + incidence rows, four launches) serves the tiled kernels and, when the in-kernel
-    // front-end is off, the fused ones.  With tiled molecules only waiting for it, it runs on the handle's second stream
-    // beside everything that needs just the atoms (feature rows, atom types, the first projections and type sums).
-    hipEvent_t lists_ev = nullptr;
+    // The separate front-end (pair list + incidence rows) serves the tiled kernels and, when the in-kernel front-end is off,
+    // the fused ones.  With only tiled molecules waiting for it, the tiled path drives its launches itself, merged with the work
+    // that needs just the atoms (feature rows, atom types, first projections: k_lg_first / k_lg_second); otherwise it runs
+    // here as four launches of its own.
+    FrontArgs F{};
+    const FrontArgs *front_later = nullptr;
     if (!pure) {
-        const bool beside = h->opt_large_overlap && !P.large_list.empty() && (front_small || P.fused_count() == 0);
-        if (beside) {
-            HIPCHK(hipEventRecord(h->ev_fork, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-            if (run_frontend_xyz(h, d_xyz, h->stream2)) return 1;
-            HIPCHK(hipEventRecord(h->ev_lists, h->stream2));
-            lists_ev = h->ev_lists;
-        } else if (run_frontend_xyz(h, d_xyz, h->stream)) return 1;
+        if (make_front_args(h, d_xyz, F)) return 1;
+        if (h->opt_large_merge && !P.large_list.empty() && (front_small || P.fused_count() == 0)) front_later = &F;
+        else if (run_frontend_xyz(h, F)) return 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], h->stream));
     PairSource S;
@@ -961,7 +960,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
     h->want_large_handoff = !pure;
     h->did_large_handoff = false;
-    const int rc_large = launch_large(h, S, true, lists_ev);
+    const int rc_large = launch_large(h, S, true, front_later);
     h->want_large_handoff = false;
     if (rc_large) return 1;
     if (ev) HIPCHK(hipEventRecord(ev[3], h->stream));
@@ -1237,8 +1236,8 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_prio")) { h->opt_wave_prio = value; }
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "large_dedupe")) { h->opt_large_dedupe = value; h->types_overflowed = false; }
-    else if (!strcmp(name, "large_pairs_beside")) { h->opt_large_pairs_beside = value; }
-    else if (!strcmp(name, "large_overlap")) { h->opt_large_overlap = value; }
+    else if (!strcmp(name, "large_merge")) { h->opt_large_merge = value; }
+    else if (!strcmp(name, "large_chunks")) { h->opt_large_chunks = value; h->plan.valid = false; }
     else if (!strcmp(name, "wave_order")) { h->opt_wave_order = value; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
@@ -1769,5 +1768,50 @@ extern "C" int epnn_comm_init(epnn_handle *h, const char *id128, int rank, int w
     if (rc != ncclSuccess) EPNN_FAIL("ncclCommInitRank failed: %s", ncclGetErrorString(rc));
     h->comm_world = world;
     h->comm_rank = rank;
+    return 0;
+}
+
+// Number of ranks that joined the handle's communicator (ncclCommCount): proof that N processes really met over RCCL.
+extern "C" int epnn_comm_count(epnn_handle *h, int32_t *ranks_out) {
+    if (!h || !ranks_out) EPNN_FAIL("epnn_comm_count: null argument");
+    if (!h->comm) EPNN_FAIL("epnn_comm_count: no communicator (epnn_comm_init)");
+    int n = 0;
+    ncclResult_t rc = ncclCommCount(h->comm, &n);
+    if (rc != ncclSuccess) EPNN_FAIL("ncclCommCount failed: %s", ncclGetErrorString(rc));
+    *ranks_out = n;
+    return 0;
+}
+// A small all-reduce of host doubles over the handle's communicator, on the handle's stream and waited for: the barrier
+// and the MAX / SUM over ranks a multi-process driver (bench.py --gpus N) needs, through the product's own RCCL path.
+// op: 0 sum, 1 max.
+extern "C" int epnn_comm_allreduce(epnn_handle *h, double *inout, int32_t n, int32_t op) {
+    if (!h || !inout || n < 1 || n > 1024 || (op != 0 && op != 1)) EPNN_FAIL("epnn_comm_allreduce: bad argument");
+    if (!h->comm) EPNN_FAIL("epnn_comm_allreduce: no communicator (epnn_comm_init)");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    if (h->s_misc.ensure(1024 * sizeof(double))) return 1;
+    HIPCHK(hipMemcpyAsync(h->s_misc.p, inout, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    ncclResult_t rc = ncclAllReduce(h->s_misc.p, h->s_misc.p, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, h->comm, h->stream);
+    if (rc != ncclSuccess) EPNN_FAIL("ncclAllReduce failed: %s", ncclGetErrorString(rc));
+    HIPCHK(hipMemcpyAsync(inout, h->s_misc.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// The pair list the separate front-end (or the dense front-end) built for the last forward: indices and near weights of up
+// to `cap` pairs (tests: the device's D < cutoff and is_near decisions against a host count).  Returns the number of pairs.
+extern "C" int epnn_debug_pairs(epnn_handle *h, int32_t *pi, int32_t *pj, float *pwi, int64_t cap, int64_t *count_out) {
+    if (!h || !pi || !pj || !pwi || !count_out || cap < 0) EPNN_FAIL("epnn_debug_pairs: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (finish_forward(h)) return 1;
+    if (!h->plan.valid || !h->d_rowoff.p || !h->d_pi.p) EPNN_FAIL("epnn_debug_pairs: no pair list (the last forward used the in-kernel front-end)");
+    int np = 0;
+    HIPCHK(hipMemcpy(&np, h->d_rowoff.as<int>() + h->plan.A, sizeof(int), hipMemcpyDeviceToHost));
+    if (np < 0 || np > h->pcap) EPNN_FAIL("epnn_debug_pairs: the list holds %d pairs, capacity %d", np, h->pcap);
+    const size_t n = (size_t)std::min<int64_t>(np, cap);
+    HIPCHK(hipMemcpy(pi, h->d_pi.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pj, h->d_pj.p, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pwi, h->d_pwi.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    *count_out = np;
     return 0;
 }

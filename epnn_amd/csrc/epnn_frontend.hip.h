@@ -18,6 +18,7 @@ struct FrontArgs {
     const float *xyz;      // [A][3]
     const int *mol_of;     // [A]
     const int *moff;       // [B+1]
+    const int *mflag;      // [B]  != 0: the molecule runs on the tiled path (its pairs' records are marked valid)
     int A;
     double cutoff, eta;
     float tol;
@@ -54,33 +55,91 @@ __device__ __forceinline__ double epnn_dist2(const float *xyz, int i, int j) {
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
 }
 
-// one wave per row i: partners j != i of the same molecule with D < cutoff -- how many in all, how many with j > i
-__global__ __launch_bounds__(256) void k_front_count(FrontArgs F) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= F.A) return;
-    const int b = F.mol_of[row];
-    const int beg = F.moff[b], end = F.moff[b + 1];
-    int up = 0, all = 0;
-    for (int j0 = beg; j0 < end; j0 += 64) {
-        const int j = j0 + lane;
-        bool near = false;
-        if (j < end && j != row) near = epnn_dist2(F.xyz, row, j) < F.cut2;
-        const unsigned long long bal = __ballot(near);
-        all += __popcll(bal);
-        up += __popcll(__ballot(near && j > row));
+// squared distance from the row atom (xi, yi, zi: its float32 coordinates as float64) to coordinates p[0..2]
+__device__ __forceinline__ double epnn_dist2p(double xi, double yi, double zi, const float *p) {
+    const double dx = (double)p[0] - xi, dy = (double)p[1] - yi, dz = (double)p[2] - zi;
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+// A workgroup = four consecutive rows, one wave each.  The candidates' coordinates go through LDS in blocks of
+// EPNN_FRONT_JB atoms, staged once for the four rows with every load of a thread in flight (a wave that fetched its 64
+// candidates per trip straight from memory paid one L2 round trip per trip: 35 of them for a 2220-atom system).  Rows of a
+// workgroup that belong to another molecule than its first row (molecule boundaries) read memory directly.
+#define EPNN_FRONT_JB 2048
+// calls body(j, near, d2) for every candidate j of the row's molecule, 64 per trip, lane = candidate; wave-uniform trips
+template <typename Body>
+__device__ __forceinline__ void front_scan_row(const FrontArgs &F, float *sx, int row, bool live, Body &&body) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int row0 = row - (tid >> 6);                        // the workgroup's first row
+    const int b0 = F.mol_of[row0], beg0 = F.moff[b0], end0 = F.moff[b0 + 1];
+    const int b = live ? F.mol_of[row] : b0;
+    const bool shared = live && b == b0;
+    double xi = 0.0, yi = 0.0, zi = 0.0;
+    float xf = 0.f, yf = 0.f, zf = 0.f;
+    if (live) {
+        xf = F.xyz[3 * row]; yf = F.xyz[3 * row + 1]; zf = F.xyz[3 * row + 2];
+        xi = (double)xf; yi = (double)yf; zi = (double)zf;
     }
-    if (lane == 0) {
+    // float32 first: only a candidate whose float32 squared distance comes within 1e-4 (relative) of the cutoff's gets the
+    // float64 evaluation that decides (float32 differences, squares and sums are good to a few 1e-7)
+    const float cut2f = (float)(F.cut2 * 1.0001);
+    for (int jb = beg0; jb < end0; jb += EPNN_FRONT_JB) {
+        const int nb = min(EPNN_FRONT_JB, end0 - jb);
+        __syncthreads();
+        for (int i = tid; i < nb * 3; i += 256) sx[i] = F.xyz[(size_t)jb * 3 + i];
+        __syncthreads();
+        if (shared)
+            for (int j0 = 0; j0 < nb; j0 += 64) {
+                const int j = j0 + lane;
+                double d2 = 0.0;
+                bool near = false;
+                if (j < nb && jb + j != row) {
+                    const float fx = sx[3 * j] - xf, fy = sx[3 * j + 1] - yf, fz = sx[3 * j + 2] - zf;
+                    if (fx * fx + fy * fy + fz * fz < cut2f) {
+                        d2 = epnn_dist2p(xi, yi, zi, sx + 3 * j);
+                        near = d2 < F.cut2;
+                    }
+                }
+                body(jb + j, near, d2);
+            }
+    }
+    if (live && !shared) {
+        const int beg = F.moff[b], end = F.moff[b + 1];
+        for (int j0 = beg; j0 < end; j0 += 64) {
+            const int j = j0 + lane;
+            double d2 = 0.0;
+            bool near = false;
+            if (j < end && j != row) {
+                d2 = epnn_dist2p(xi, yi, zi, F.xyz + 3 * j);
+                near = d2 < F.cut2;
+            }
+            body(j, near, d2);
+        }
+    }
+}
+
+// one wave per row i: partners j != i of the same molecule with D < cutoff -- how many in all, how many with j > i
+__device__ __forceinline__ void front_count_body(const FrontArgs &F, float *sx, int blk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blk * 4 + wave;
+    const bool live = row < F.A;
+    int up = 0, all = 0;
+    front_scan_row(F, sx, row, live, [&](int j, bool near, double) {
+        all += __popcll(__ballot(near));
+        up += __popcll(__ballot(near && j > row));
+    });
+    if (live && lane == 0) {
         F.row_cnt[row] = up;
         F.deg[row] = all;
     }
 }
+__global__ __launch_bounds__(256) void k_front_count(FrontArgs F) {
+    __shared__ float sx[EPNN_FRONT_JB * 3];
+    front_count_body(F, sx, (int)blockIdx.x);
+}
 
 // both prefix sums in ONE single-workgroup launch (1024 threads x 8 elements per round, a carry between rounds): a
 // 2220-atom system is one round, 100 k atoms thirteen
-__global__ __launch_bounds__(1024) void k_front_scan_both(FrontArgs F) {
-    __shared__ int wsA[16], wsB[16];
-    __shared__ int carryA, carryB;
+__device__ __forceinline__ void front_scan_both_body(const FrontArgs &F, int *wsA, int *wsB, int &carryA, int &carryB) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { carryA = 0; carryB = 0; }
     __syncthreads();
@@ -121,6 +180,11 @@ __global__ __launch_bounds__(1024) void k_front_scan_both(FrontArgs F) {
         F.inc_off[F.A] = carryB;
         if (carryA > F.pcap) atomicOr(F.status, EPNN_ST_PAIR_OVERFLOW);
     }
+}
+__global__ __launch_bounds__(1024) void k_front_scan_both(FrontArgs F) {
+    __shared__ int wsA[16], wsB[16];
+    __shared__ int carryA, carryB;
+    front_scan_both_body(F, wsA, wsB, carryA, carryB);
 }
 
 // exclusive scan of row_cnt[0..A) -> row_off[0..A] in two passes: (1) every block of 256 threads scans 2048
@@ -181,40 +245,38 @@ __global__ __launch_bounds__(256) void k_front_scan2(FrontArgs F, const int *bsu
 }
 
 // one wave per row: the atom's incidence row (partners, ascending) and the pairs in which it is the first index
-__global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
-    __shared__ int s_j[4][64];
-    __shared__ double s_D[4][64];
-    __shared__ double s_C[4][64];
-    __shared__ int s_max[4][64];
+struct FrontFillShared {
+    float sx[EPNN_FRONT_JB * 3];
+    int s_j[4][64];
+    double s_D[4][64];
+    double s_C[4][64];
+    int s_max[4][64];
+};
+__device__ __forceinline__ void front_fill_body(const FrontArgs &F, FrontFillShared &Sh, int blk) {
+    float *sx = Sh.sx;
+    auto &s_j = Sh.s_j;
+    auto &s_D = Sh.s_D;
+    auto &s_C = Sh.s_C;
+    auto &s_max = Sh.s_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= F.A) return;
-    if (F.row_off[F.A] > F.pcap) return;   // overflow: host regrows and reruns
-    const int b = F.mol_of[row];
-    const int beg = F.moff[b], end = F.moff[b + 1];
-    int slot0 = F.row_off[row];
-    int inc0 = F.inc_off[row];
+    const int row = blk * 4 + wave;
+    const bool live = row < F.A && F.row_off[F.A] <= F.pcap;   // overflow: host regrows and reruns
+    int slot0 = live ? F.row_off[row] : 0;
+    int inc0 = live ? F.inc_off[row] : 0;
     const double pi_d = 3.141592653589793;
-    for (int j0 = beg; j0 < end; j0 += 64) {
-        const int j = j0 + lane;
-        bool near = false;
-        double D = 0.0;
-        if (j < end && j != row) {
-            const double d2 = epnn_dist2(F.xyz, row, j);
-            near = d2 < F.cut2;
-            D = sqrt(d2);                                  // charge_gn.py:124 (scipy distance_matrix)
-        }
+    front_scan_row(F, sx, row, live, [&](int j, bool near, double d2) {
         const unsigned long long bal = __ballot(near);
-        if (bal == 0ull) continue;
+        if (bal == 0ull) return;
         const int pos = inc0 + __popcll(bal & ((1ull << lane) - 1ull));      // this partner's slot in the atom's incidence row
         if (near) F.nbr[pos] = j;
         inc0 += __popcll(bal);
         const bool upn = near && j > row;
         const unsigned long long bup = __ballot(upn);
         const int m = __popcll(bup);
-        if (m == 0) continue;
+        if (m == 0) return;
         if (upn) {
             const int rank = __popcll(bup & ((1ull << lane) - 1ull));
+            const double D = sqrt(d2);                         // charge_gn.py:124 (scipy distance_matrix)
             s_j[wave][rank] = j;
             s_D[wave][rank] = D;
             // charge_gn.py:148-152: C = (cos(pi*D/cutoff)+1)/2 ; C[D<=0] = 1 (D>=cutoff excluded, diagonal not listed)
@@ -246,14 +308,18 @@ __global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
         }
         __builtin_amdgcn_wave_barrier();
         slot0 += m;
-    }
+    });
+}
+__global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
+    __shared__ FrontFillShared Sh;
+    front_fill_body(F, Sh, (int)blockIdx.x);
 }
 
 // one thread per pair (i, j): where does i sit in j's incidence row?  (rows are ascending and short: a few loads in flight)
-__global__ __launch_bounds__(256) void k_front_link(FrontArgs F) {
+__device__ __forceinline__ void front_link_body(const FrontArgs &F, int blk, int nblk) {
     const int np = F.row_off[F.A];
     if (np > F.pcap) return;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256) {
+    for (int p = blk * 256 + threadIdx.x; p < np; p += nblk * 256) {
         const int i = F.pi[p], j = F.pj[p];
         const int lo = F.inc_off[j], hi = F.inc_off[j + 1];
         int found = -1;
@@ -267,10 +333,12 @@ __global__ __launch_bounds__(256) void k_front_link(FrontArgs F) {
         }
         const int di = F.dest_i[p];
         F.dest_j[p] = found;
-        F.prec[2 * p] = make_int4(i, j, F.inc_off[i], F.inc_off[i + 1]);
+        const int iv = F.mflag[F.mol_of[i]] ? i : -1 - i;
+        F.prec[2 * p] = make_int4(iv, j, F.inc_off[i], F.inc_off[i + 1]);
         F.prec[2 * p + 1] = make_int4(lo, hi, di, found);
     }
 }
+__global__ __launch_bounds__(256) void k_front_link(FrontArgs F) { front_link_body(F, (int)blockIdx.x, (int)gridDim.x); }
 
 // epnn_edges: dense (n,n,e_dim) tensor exactly like get_init_edges, one thread per (i,j,ch)
 __global__ __launch_bounds__(256) void k_edges_dense(const float *xyz, int n, int e_dim, double cutoff, double eta,

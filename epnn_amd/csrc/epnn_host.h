@@ -155,12 +155,12 @@ struct epnn_handle {
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
     DevBuf l_stasks, l_schunk, l_sfin;
     DevBuf l_Nn, l_Yb, l_qbuf, l_Pst, l_Rst;        // sweep operands (-R, b2 + W2^T R); EPN stack: charges, projections with q = 0
-    DevBuf l_lmol, l_typrow, l_typtab, l_stype;     // first GNN step by atom types
+    DevBuf l_lmol, l_typrow, l_typtab, l_stype, l_typhash;     // first GNN step by atom types
+    bool sweep_attr = false;                        // k_lg_sweep's dynamic LDS limit has been raised
     bool types_overflowed = false;                  // a molecule had more distinct feature rows than EPNN_TYPE_MAX: all-pairs sweep from now on
-    hipEvent_t ev_lists = nullptr;                  // compact entry: pair list + incidence rows are built on stream2
     int opt_large_dedupe = 1;         // tiled path, compact entry: first GNN step by atom types instead of the all-pairs sweep
-    int opt_large_pairs_beside = 0;   // tiled path: 1 = correction tiles always as their own launch on the second stream
-    int opt_large_overlap = 1;        // compact entry: pair list construction on the second stream beside the first projections
+    int opt_large_chunks = 0;         // developer switch: pieces the partner range of a tiled molecule's sweep is cut into (0: by size)
+    int opt_large_merge = 1;          // compact entry: the pair-list launches are merged with the first projections / type sums (0: separate launches)
     // row-block partition of the all-pairs sweep over `part_world` processes (epnn_set_partition): this one runs the tile
     // groups [part_g0, part_g1) = atoms [part_row_lo, part_row_hi) and the callback completes S after every GNN step
     int part_rank = 0, part_world = 1;

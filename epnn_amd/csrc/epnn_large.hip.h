@@ -80,6 +80,8 @@ struct LargeArgs {
     int *typ_row;                           // [A]  row of S_type the atom reads: EPNN_TYPE_MAX * (molecule's place in lmol) + its type
     int *typ_rep, *typ_cnt;                 // [nlarge * EPNN_TYPE_MAX] first atom of a type, atoms of it
     int *typ_n;                             // [nlarge] types of the molecule
+    unsigned long long *typ_hash;           // [A] hash of the atom's feature row (merged launches: hashed where the rows are built)
+    unsigned long long *typ_hsh;            // [nlarge * EPNN_TYPE_MAX] hash of a type's row
     float *S_type;                          // [nlarge * EPNN_TYPE_MAX][32]
     float *q_out, *h_out;
     int *status;
@@ -186,7 +188,8 @@ __global__ __launch_bounds__(256) void k_lg_dn_link(LargeArgs L) {
         }
         L.w_dest_i[p] = di;
         L.w_dest_j[p] = dj;
-        L.w_prec[2 * p] = make_int4(i, j, L.row_off[i] + L.dn_off[i], L.row_off[i + 1] + L.dn_off[i + 1]);
+        const int iv = L.mflag[L.mol_of[i]] ? i : -1 - i;         // pairs of molecules on the fused path are skipped by the tiles
+        L.w_prec[2 * p] = make_int4(iv, j, L.row_off[i] + L.dn_off[i], L.row_off[i + 1] + L.dn_off[i + 1]);
         L.w_prec[2 * p + 1] = make_int4(L.row_off[j] + L.dn_off[j], L.row_off[j + 1] + L.dn_off[j + 1], di, dj);
     }
 }
@@ -197,88 +200,124 @@ __global__ __launch_bounds__(256) void k_lg_dn_link(LargeArgs L) {
 // types (it raises EPNN_ST_TYPE_OVERFLOW like a full table does: the host repeats the forward with the all-pairs sweep).
 // Types are numbered by their first atom, so the order of every sum over types is fixed.
 #define EPNN_TYPE_SLOTS 256
-__global__ __launch_bounds__(1024) void k_lg_types(LargeArgs L) {
-    __shared__ unsigned long long key[EPNN_TYPE_SLOTS];
-    __shared__ int first[EPNN_TYPE_SLOTS], cnt[EPNN_TYPE_SLOTS], num[EPNN_TYPE_SLOTS];
-    __shared__ int bad, used;
-    const int tid = threadIdx.x;
-    const int lm = blockIdx.x, b = L.lmol[lm];
+struct LgTypeShared {
+    unsigned long long key[EPNN_TYPE_SLOTS];
+    int first[EPNN_TYPE_SLOTS], cnt[EPNN_TYPE_SLOTS], num[EPNN_TYPE_SLOTS], list[EPNN_TYPE_SLOTS];
+    int bad, used;
+};
+__device__ __forceinline__ unsigned long long lg_hash_step(unsigned long long hsh, float v) {
+    return (hsh ^ (unsigned long long)__float_as_uint(v)) * 1099511628211ull;
+}
+__device__ __forceinline__ unsigned long long lg_hash_row(const LargeArgs &L, int at) {
+    unsigned long long hsh = 1469598103934665603ull;
+    for (int f = 0; f < L.nx; ++f) hsh = lg_hash_step(hsh, L.xin[(size_t)at * L.nx + f]);
+    return hsh | 1ull;                                        // 0 marks an empty slot
+}
+__device__ __forceinline__ int lg_type_find(LgTypeShared &T, unsigned long long hsh, bool insert) {
+    int s = (int)((hsh >> 17) & (EPNN_TYPE_SLOTS - 1));
+    for (int probe = 0; probe < EPNN_TYPE_SLOTS; ++probe) {
+        unsigned long long cur = T.key[s];
+        if (cur == 0ull && insert) {
+            cur = atomicCAS(&T.key[s], 0ull, hsh);
+            if (cur == 0ull) {                                // this thread opened the slot
+                T.list[atomicAdd(&T.used, 1)] = s;
+                cur = hsh;
+            }
+        }
+        if (cur == hsh) return s;
+        if (cur == 0ull) return -1;
+        s = (s + 1) & (EPNN_TYPE_SLOTS - 1);
+    }
+    return -1;
+}
+// the table of molecule lm: its distinct row hashes, the first atom and the number of atoms of each, numbered by first atom.
+// HASHED: the atoms' hashes are in L.typ_hash already.
+template <int NT, bool HASHED>
+__device__ __forceinline__ void lg_types_table(const LargeArgs &L, LgTypeShared &T, int lm) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = L.lmol[lm];
     const int a0 = L.moff[b], n = L.moff[b + 1] - a0;
-    for (int s = tid; s < EPNN_TYPE_SLOTS; s += 1024) { key[s] = 0ull; first[s] = 0x7fffffff; cnt[s] = 0; }
-    if (tid == 0) { bad = 0; used = 0; }
+    for (int s = tid; s < EPNN_TYPE_SLOTS; s += NT) { T.key[s] = 0ull; T.first[s] = 0x7fffffff; T.cnt[s] = 0; }
+    if (tid == 0) { T.bad = 0; T.used = 0; }
     __syncthreads();
-    auto hash_row = [&](int at) {
-        unsigned long long hsh = 1469598103934665603ull;
-        for (int f = 0; f < L.nx; ++f) {
-            hsh ^= (unsigned long long)__float_as_uint(L.xin[(size_t)at * L.nx + f]);
-            hsh *= 1099511628211ull;
-        }
-        return hsh | 1ull;                                    // 0 marks an empty slot
-    };
-    auto find = [&](unsigned long long hsh, bool insert) {
-        int s = (int)((hsh >> 17) & (EPNN_TYPE_SLOTS - 1));
-        for (int probe = 0; probe < EPNN_TYPE_SLOTS; ++probe) {
-            unsigned long long cur = key[s];
-            if (cur == 0ull && insert) cur = atomicCAS(&key[s], 0ull, hsh);
-            if (cur == 0ull && insert) cur = hsh;             // this thread claimed the slot
-            if (cur == hsh) return s;
-            if (cur == 0ull) return -1;
-            s = (s + 1) & (EPNN_TYPE_SLOTS - 1);
-        }
-        return -1;
-    };
-    for (int k = tid; k < n; k += 1024) {
-        const int s = find(hash_row(a0 + k), true);
-        if (s < 0) atomicOr(&bad, 1);
-        else {
-            atomicMin(&first[s], a0 + k);
-            atomicAdd(&cnt[s], 1);
+    // a wavefront's atoms of equal hash are entered by ONE lane (a molecule has a handful of types: lane-by-lane atomics on
+    // five LDS words serialise the whole workgroup)
+    for (int k0 = 0; k0 < n; k0 += NT) {
+        const int k = k0 + tid;
+        const bool act = k < n;
+        const unsigned long long hsh = !act ? 0ull : HASHED ? L.typ_hash[a0 + k] : lg_hash_row(L, a0 + k);
+        unsigned long long todo = __ballot(act);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned long long lh = __shfl(hsh, leader, 64);
+            const unsigned long long same = __ballot(act && hsh == lh);
+            if (lane == leader) {                            // the lowest lane of its group: the group's first atom
+                const int s = lg_type_find(T, lh, true);
+                if (s < 0) atomicOr(&T.bad, 1);
+                else {
+                    atomicMin(&T.first[s], a0 + k);
+                    atomicAdd(&T.cnt[s], __popcll(same));
+                }
+            }
+            todo &= ~same;
         }
     }
     __syncthreads();
-    // number the slots in use by their first atom
-    if (tid < EPNN_TYPE_SLOTS) {
-        int rank = -1;
-        if (key[tid] != 0ull) {
-            rank = 0;
-            for (int s = 0; s < EPNN_TYPE_SLOTS; ++s) rank += (key[s] != 0ull && first[s] < first[tid]) ? 1 : 0;
-            atomicAdd(&used, 1);
-        }
-        num[tid] = rank;
+    const int nu = T.used;
+    // number the types by their first atom
+    for (int u0 = tid; u0 < nu; u0 += NT) {
+        const int s = T.list[u0];
+        int rank = 0;
+        for (int u = 0; u < nu; ++u) rank += T.first[T.list[u]] < T.first[s] ? 1 : 0;
+        T.num[s] = rank;
     }
+    if (tid == 0 && nu > EPNN_TYPE_MAX) T.bad = 1;
     __syncthreads();
-    if (used > EPNN_TYPE_MAX) { if (tid == 0) atomicOr(&bad, 1); }
-    __syncthreads();
-    for (int k = tid; k < n; k += 1024) {
-        const int at = a0 + k;
-        const int s = find(hash_row(at), false);
-        int row = 0;
-        if (s >= 0 && !bad) {
-            const int rep = first[s];
-            bool same = true;
-            for (int f = 0; f < L.nx; ++f)
-                same &= __float_as_uint(L.xin[(size_t)at * L.nx + f]) == __float_as_uint(L.xin[(size_t)rep * L.nx + f]);
-            if (!same) atomicOr(&bad, 1);
-            row = lm * EPNN_TYPE_MAX + num[s];
-        }
-        L.typ_row[at] = row;
-    }
-    __syncthreads();
-    if (tid < EPNN_TYPE_SLOTS && key[tid] != 0ull && !bad) {
-        L.typ_rep[lm * EPNN_TYPE_MAX + num[tid]] = first[tid];
-        L.typ_cnt[lm * EPNN_TYPE_MAX + num[tid]] = cnt[tid];
+    for (int u0 = tid; u0 < nu && !T.bad; u0 += NT) {
+        const int s = T.list[u0];
+        L.typ_rep[lm * EPNN_TYPE_MAX + T.num[s]] = T.first[s];
+        L.typ_cnt[lm * EPNN_TYPE_MAX + T.num[s]] = T.cnt[s];
+        L.typ_hsh[lm * EPNN_TYPE_MAX + T.num[s]] = T.key[s];
     }
     if (tid == 0) {
-        L.typ_n[lm] = bad ? 0 : used;
-        if (bad) atomicOr(L.status, EPNN_ST_TYPE_OVERFLOW);
+        L.typ_n[lm] = T.bad ? 0 : nu;
+        if (T.bad) atomicOr(L.status, EPNN_ST_TYPE_OVERFLOW);
     }
+}
+// an atom's type = the table entry with its hash; its row is compared bit for bit with the entry's first atom's
+__device__ __forceinline__ void lg_type_assign(const LargeArgs &L, int at, int lm, unsigned long long hsh) {
+    const int nu = L.typ_n[lm];
+    int tau = -1;
+    for (int u = 0; u < nu; ++u)
+        if (L.typ_hsh[lm * EPNN_TYPE_MAX + u] == hsh) tau = u;
+    bool ok = tau >= 0;
+    if (ok) {
+        const int rep = L.typ_rep[lm * EPNN_TYPE_MAX + tau];
+        for (int f = 0; f < L.nx; ++f)
+            ok &= __float_as_uint(L.xin[(size_t)at * L.nx + f]) == __float_as_uint(L.xin[(size_t)rep * L.nx + f]);
+    }
+    if (!ok && nu > 0) atomicOr(L.status, EPNN_ST_TYPE_OVERFLOW);
+    L.typ_row[at] = lm * EPNN_TYPE_MAX + (ok ? tau : 0);
+}
+template <int NT>
+__device__ __forceinline__ void lg_types_body(const LargeArgs &L, LgTypeShared &T, int lm) {
+    lg_types_table<NT, false>(L, T, lm);
+    __threadfence_block();
+    __syncthreads();                                         // the table is in global memory: this workgroup reads it back
+    const int b = L.lmol[lm];
+    const int a0 = L.moff[b], n = L.moff[b + 1] - a0;
+    for (int k = threadIdx.x; k < n; k += NT) lg_type_assign(L, a0 + k, lm, lg_hash_row(L, a0 + k));
+}
+__global__ __launch_bounds__(1024) void k_lg_types(LargeArgs L) {
+    __shared__ LgTypeShared T;
+    lg_types_body<1024>(L, T, (int)blockIdx.x);
 }
 
 // S_type[sigma][o] = sum_tau count(tau) relu(W2^T relu(P_sigma + R_tau) + b2)[o]: one wave per 32 types sigma of a molecule.
 // rows = types kappa(hh,r), cols = out c (the layout of the correction tiles below)
-__global__ __launch_bounds__(64) void k_lg_tsweep(LargeArgs L, PairMlpPack M) {
-    const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
-    const int lm = blockIdx.x >> 1, blk = blockIdx.x & 1;
+__device__ __forceinline__ void lg_tsweep_wave(const LargeArgs &L, const PairMlpPack &M, int job) {
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    const int lm = job >> 1, blk = job & 1;
     const int U = L.typ_n[lm];
     if (32 * blk >= U) return;
     const float *wp = L.wpack;
@@ -307,6 +346,7 @@ __global__ __launch_bounds__(64) void k_lg_tsweep(LargeArgs L, PairMlpPack M) {
         if (row < U) L.S_type[((size_t)lm * EPNN_TYPE_MAX + row) * 32 + c] = S[r];
     }
 }
+__global__ __launch_bounds__(64) void k_lg_tsweep(LargeArgs L, PairMlpPack M) { lg_tsweep_wave(L, M, (int)blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------ projection
 // one wave per 32-atom tile; `arow` = this lane's half (hh) of its atom's even/odd feature row (global a_eo or an LDS image).
@@ -399,6 +439,57 @@ __global__ __launch_bounds__(256) void k_lg_epn_static(LargeArgs L) {
 // the tile and features 16 rb + 4 q + r of each; tile j = "partner j of every atom", S accumulates in registers.  Per
 // partner and 32 atoms: 32 MFMAs, 16 max (first layer), 16 max + 16 add (second layer's relu and the sum).
 #define EPNN_LG_JC 64
+// the partners of one staged piece.  TWO: the tile's second column block holds atoms (wave-uniform: all but a molecule's last
+// tile).  Two partners per trip: the rows of partner j + 1 are fetched while partner j is in the matrix pipe, into the
+// other register set (no copies); the four accumulator chains of a partner (two column blocks x two row blocks) are issued
+// interleaved.
+template <bool TWO>
+__device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const float (&pb)[2][8],
+                                              const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
+    auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
+    auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
+        nn[0] = w16_ld(Ns + j * 32 + po);
+        nn[1] = w16_ld(Ns + j * 32 + po + 8);
+        yy[0] = w16_ld(Ys + j * 32 + fo);
+        yy[1] = w16_ld(Ys + j * 32 + 16 + fo);
+    };
+    auto partner = [&](const f32x4 (&nn)[2], const f32x4 (&yy)[2]) {
+        const f32x4 za = vmax(P0[0], nn[0]), zb = vmax(P0[1], nn[1]);
+        const float z0[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+        f32x4 d0[2] = {yy[0], yy[1]}, d1[2] = {yy[0], yy[1]};
+        if (TWO) {
+            const f32x4 zc = vmax(P1[0], nn[0]), zd = vmax(P1[1], nn[1]);
+            const float z1[8] = {zc[0], zc[1], zc[2], zc[3], zd[0], zd[1], zd[2], zd[3]};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                d0[0] = w16_mfma(pb[0][k], z0[k], d0[0]);
+                d0[1] = w16_mfma(pb[1][k], z0[k], d0[1]);
+                d1[0] = w16_mfma(pb[0][k], z1[k], d1[0]);
+                d1[1] = w16_mfma(pb[1][k], z1[k], d1[1]);
+            }
+            S1[0] += w16_relu(d1[0]);
+            S1[1] += w16_relu(d1[1]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                d0[0] = w16_mfma(pb[0][k], z0[k], d0[0]);
+                d0[1] = w16_mfma(pb[1][k], z0[k], d0[1]);
+            }
+        }
+        S0[0] += w16_relu(d0[0]);
+        S0[1] += w16_relu(d0[1]);
+    };
+    f32x4 na[2], ya[2], nb[2], yb[2];
+    fetch(0, na, ya);
+    int j = 0;
+    for (; j + 2 <= nj; j += 2) {
+        fetch(j + 1, nb, yb);
+        partner(na, ya);
+        fetch(min(j + 2, nj - 1), na, ya);
+        partner(nb, yb);
+    }
+    if (j < nj) partner(na, ya);
+}
 __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, float *Ns, float *Ys) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
     const int4 tk = L.stasks[blockIdx.x];            // first atile, #atiles, j_lo, j_hi (global atom indices)
@@ -406,7 +497,7 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
     const bool active = wave < tk.y;
     const int4 tl = L.atiles[tk.x + (active ? wave : 0)];
     const float *wp = L.wpack;
-    const bool two = tl.y > 16;                      // the tile's second column block holds atoms
+    const bool two = __builtin_amdgcn_readfirstlane(tl.y) > 16;      // the tile's second column block holds atoms
     // P and Nn rows are stored in the operand order of the 32x32x2 kernels (k_lg_proj): position 16 hh + r holds feature
     // kappa(hh, r) = 8 (r >> 2) + 4 hh + (r & 3), so this lane's features 16 rb + 4 q .. + 3 sit together at po + 8 rb
     const int po = 16 * (q & 1) + 4 * (q >> 1);
@@ -421,15 +512,6 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
         S0[rb] = w16_splat(0.f);
         S1[rb] = w16_splat(0.f);
     }
-    auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
-    auto block = [&](const f32x4 (&Pc)[2], f32x4 (&Sc)[2], const f32x4 (&nn)[2], const f32x4 (&yy)[2]) {
-        const f32x4 za = vmax(Pc[0], nn[0]), zb = vmax(Pc[1], nn[1]);
-        const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
-        f32x4 d[2] = {yy[0], yy[1]};
-        w16_mm<2, 8>(pb, z, d);
-        Sc[0] += w16_relu(d[0]);
-        Sc[1] += w16_relu(d[1]);
-    };
     for (int j0 = tk.z; j0 < tk.w; j0 += EPNN_LG_JC) {
         const int nj = min(EPNN_LG_JC, tk.w - j0);
         __syncthreads();
@@ -439,17 +521,8 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
         }
         __syncthreads();
         if (active) {
-            f32x4 na[2] = {w16_ld(Ns + po), w16_ld(Ns + po + 8)};
-            f32x4 ya[2] = {w16_ld(Ys + fo), w16_ld(Ys + 16 + fo)};
-            for (int j = 0; j < nj; ++j) {
-                const int jn = min(j + 1, nj - 1);                         // the next partner's rows while this one is in the pipe
-                const f32x4 nn[2] = {w16_ld(Ns + jn * 32 + po), w16_ld(Ns + jn * 32 + po + 8)};
-                const f32x4 yn[2] = {w16_ld(Ys + jn * 32 + fo), w16_ld(Ys + jn * 32 + 16 + fo)};
-                block(P0, S0, na, ya);
-                if (two) block(P1, S1, na, ya);
-                na[0] = nn[0]; na[1] = nn[1];
-                ya[0] = yn[0]; ya[1] = yn[1];
-            }
+            if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
+            else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
         }
     }
     if (!active) return;
@@ -460,47 +533,44 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
         if (16 + n16 < tl.y) w16_st(dst + (size_t)(tl.x + 16 + n16) * 32 + 16 * rb + fo, S1[rb]);
     }
 }
-template <int MODE>
-__device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk);
-// The sweep alone: four wavefronts per SIMD -- what a large system's thousands of workgroups need.
-__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off) {
-    __shared__ __attribute__((aligned(16))) float Ns[EPNN_LG_JC * 32];
-    __shared__ __attribute__((aligned(16))) float Ys[EPNN_LG_JC * 32];
-    lg_sweep_body(L, w2off, Ns, Ys);
-}
-// The sweep plus, as extra workgroups, the near-pair correction tiles of the same step (both need only this step's P and
-// R).  The pair tiles' registers halve the kernel's occupancy (two wavefronts per SIMD), so this form is for
-// systems whose sweep has at most two workgroups per CU anyway (the 2220-atom protein: 504), where it saves a launch per
-// step; larger systems run the two kernels side by side on two streams.
-__global__ __launch_bounds__(256) void k_lg_sweep_pairs(LargeArgs L, int w2off, PairMlpPack Mpair) {
-    __shared__ __attribute__((aligned(16))) float Ns[EPNN_LG_JC * 32];
-    __shared__ __attribute__((aligned(16))) float Ys[EPNN_LG_JC * 32];
-    if ((int)blockIdx.x >= L.nstasks) {
-        lg_pairs_body<0>(L, Mpair, (int)blockIdx.x - L.nstasks);
-        return;
-    }
-    lg_sweep_body(L, w2off, Ns, Ys);
-}
-
 // ------------------------------------------------------------------------------------------------ GNN correction tiles
-// one wave per 32 listed pairs: z2(P + R + G) - z2(P + R) for both directions -> the two atoms' incidence slots
-template <int MODE>
-__device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpPack &M, int blk) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
-    const int np = L.row_off[L.A];
-    if (np > L.pcap) return;
-    const int slot = (blk * 4 + wave) * 32 + c;
+// one wave per 32 listed pairs (tile `pt`): z2(P + R + G) - z2(P + R) for both directions -> the two atoms' incidence slots.
+// SEARCH: the pair records do not exist yet (the first step's tiles run in the launch that also links the list): the slot
+// of the pair in its second atom's row is looked up here.
+template <bool SEARCH>
+__device__ __forceinline__ void lg_pair_tile(const LargeArgs &L, const PairMlpPack &M, int pt, int np, const int *nbr) {
+    const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
+    const int slot = pt * 32 + c;
     bool valid = slot < np;
     int gi = 0, gj = 0, di = -1, dj = -1;
-    if (valid) {
-        gi = L.pi[slot];
-        gj = L.pj[slot];
-        di = L.dest_i[slot];
-        dj = L.dest_j[slot];
-        valid = L.mflag[L.mol_of[gi]] != 0;
+    if (SEARCH) {
+        if (valid) {
+            gi = L.pi[slot];
+            gj = L.pj[slot];
+            di = L.dest_i[slot];
+            valid = L.mflag[L.mol_of[gi]] != 0;
+        }
+        if (valid) {
+            const int lo = L.inc_off[gj], hi = L.inc_off[gj + 1];
+            for (int k0 = lo; k0 < hi && dj < 0; k0 += 8) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = k0 + u < hi ? nbr[k0 + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (v[u] == gi) dj = k0 + u;
+            }
+        }
+    } else if (valid) {
+        const int4 ra = L.prec[2 * slot], rb = L.prec[2 * slot + 1];
+        valid = ra.x >= 0;                                     // (a pair of a molecule that is not on this path: -1 - i)
+        gi = valid ? ra.x : 0;
+        gj = ra.y;
+        di = rb.z;
+        dj = rb.w;
     }
     if (__ballot(valid) == 0ull) return;
-    if (!valid) { di = -1; dj = -1; }
+    if (!valid) { di = -1; dj = -1; gi = 0; gj = 0; }
     const float *wp = L.wpack;
     const f32x16 g = lg_gtile(wp + M.weF, L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24, valid, lane);
     float pi_[16], rj_[16], pj_[16], ri_[16], w2[16];
@@ -529,9 +599,146 @@ __device__ __forceinline__ void lg_pairs_body(const LargeArgs &L, const PairMlpP
         if (tj >= 0) L.corrA[(size_t)tj * 32 + c] = fmaxf(bG[r], 0.f) - fmaxf(b0[r], 0.f);
     }
 }
-template <int MODE>
+// the correction tiles as a launch of their own (a process of a partition without sweep tasks; `large_fused` = 0)
 __global__ __launch_bounds__(256) void k_lg_pairs(LargeArgs L, PairMlpPack M) {
-    lg_pairs_body<MODE>(L, M, (int)blockIdx.x);
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pt * 32 < np) lg_pair_tile<false>(L, M, pt, np, nullptr);
+}
+// The sweep.  Its wavefronts first share out the step's near-pair correction tiles (both need only this step's P and R;
+// ~1 % of the work, and a launch of their own would be 10 us of latencies in front of or behind every sweep), then run their
+// sweep task.  The launch asks for as much LDS as keeps the workgroups spread evenly over the CUs (`wpc` per CU, see the
+// host side): left to itself the dispatcher put three of a 2220-atom system's 504 workgroups on some CUs and one on others,
+// and the launch lasted 103 us where its wavefronts lived 83.
+__global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, PairMlpPack Mpair, int do_pairs) {
+    extern __shared__ __attribute__((aligned(16))) float lg_smem[];
+    if (do_pairs) {
+        const int np = L.row_off[L.A];
+        if (np <= L.pcap) {
+            const int npt = (np + 31) >> 5, nw = (int)gridDim.x * 4;
+            for (int pt = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); pt < npt; pt += nw) lg_pair_tile<false>(L, Mpair, pt, np, nullptr);
+        }
+    }
+    lg_sweep_body(L, w2off, lg_smem, lg_smem + EPNN_LG_JC * 32);
+}
+
+// ------------------------------------------------------------------------------------------------ merged launches of the compact entry
+// What a forward of the compact entry can do at once goes into ONE launch, the kinds of work told apart by the block index
+// (a second stream would do the same on paper; its fork / join events cost more than these short kernels last):
+//   k_lg_first        tiles: feature rows a_eo, their hashes, first projections | near-partner counts
+//   k_lg_scan_types   prefix sums of the pair list | type table of every tiled molecule
+//   k_lg_fill_assign  fill of the pair list | every atom's type
+//   k_lg_second       pair records (link) | the first step's type sums | the first step's correction tiles
+struct LgFirst {
+    int tile_wgs, count_wgs, hash;
+};
+// the prefix sums of the pair list | the type table of every tiled molecule (from the hashes k_lg_first left)
+__global__ __launch_bounds__(1024) void k_lg_scan_types(LargeArgs L, FrontArgs F) {
+    __shared__ LgTypeShared T;
+    __shared__ int wsA[16], wsB[16];
+    __shared__ int carryA, carryB;
+    if (blockIdx.x == 0) front_scan_both_body(F, wsA, wsB, carryA, carryB);
+    else lg_types_table<1024, true>(L, T, (int)blockIdx.x - 1);
+}
+// the fill of the pair list | every tiled atom's type
+__global__ __launch_bounds__(256) void k_lg_fill_assign(LargeArgs L, FrontArgs F, int fill_wgs) {
+    __shared__ FrontFillShared Sh;
+    if ((int)blockIdx.x < fill_wgs) {
+        front_fill_body(F, Sh, (int)blockIdx.x);
+        return;
+    }
+    const int at = ((int)blockIdx.x - fill_wgs) * 256 + (int)threadIdx.x;
+    if (at >= L.A) return;
+    const int lm = L.mflag[L.mol_of[at]] - 1;                  // mflag = 1 + the molecule's place among the tiled ones
+    if (lm >= 0) lg_type_assign(L, at, lm, L.typ_hash[at]);
+}
+__global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, LgFirst W, FrontArgs F) {
+    __shared__ __attribute__((aligned(16))) float sm[4 * 32 * EPNN_AST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    int blk = (int)blockIdx.x;
+    if (blk < W.tile_wgs) {
+        // feature rows of the workgroup's (up to) four tiles: built in LDS by all threads (one slot each per trip), stored to
+        // a_eo from there, projected from there (k_lg_init + k_lg_proj without the round trip through memory)
+        const int t0 = blk * 4;
+        const int fq = L.nx + EPNN_EDIM;
+        int4 tls[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tls[w] = t0 + w < L.natiles ? L.atiles[t0 + w] : make_int4(0, 0, 0, 0);
+        for (int idx = tid; idx < 4 * 32 * EPNN_AST; idx += 256) sm[idx] = 0.f;
+        __syncthreads();
+        {   // one thread per atom and half of its inputs (x and q | h), every load of a thread in flight together
+            const int w = (tid & 127) >> 5, a = tid & 31, part = tid >> 7;
+            const int4 tl = w == 0 ? tls[0] : w == 1 ? tls[1] : w == 2 ? tls[2] : tls[3];
+            if (a < tl.y) {
+                const int at = tl.x + a, b = tl.z;
+                float *row = sm + (w * 32 + a) * EPNN_AST;
+                if (part == 0) {
+                    float xv[16];
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) xv[f] = f < L.nx ? L.xin[(size_t)at * L.nx + f] : 0.f;
+                    const float qv = L.q_in ? L.q_in[at] : L.Q[b] / (float)(L.moff[b + 1] - L.moff[b]);
+#pragma unroll
+                    for (int f = 0; f < 16; ++f)
+                        if (f < L.nx) row[epnn_aeo(f)] = xv[f];
+                    row[epnn_aeo(fq)] = qv;
+                    row[epnn_aeo(EPNN_F1)] = 1.f;                // carries the first Dense's bias (Wi row 59 = b1)
+                    L.qbuf[at] = qv;                             // the EPN stack's charges, both generations
+                    L.qbuf[(size_t)L.A + at] = qv;
+                } else if (L.h_in) {
+                    float hv[EPNN_EDIM];
+#pragma unroll
+                    for (int f = 0; f < EPNN_EDIM; ++f) hv[f] = L.h_in[(size_t)at * EPNN_EDIM + f];
+#pragma unroll
+                    for (int f = 0; f < EPNN_EDIM; ++f) row[epnn_aeo(L.nx + f)] = hv[f];
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 4 * 32 * EPNN_AST; idx += 256) {
+            const int w = idx / (32 * EPNN_AST), rem = idx - w * (32 * EPNN_AST);
+            const int a = rem / EPNN_AST;
+            const int4 tl = w == 0 ? tls[0] : w == 1 ? tls[1] : w == 2 ? tls[2] : tls[3];
+            if (a < tl.y) L.a_eo[(size_t)tl.x * EPNN_AST + rem] = sm[idx];
+        }
+        if (W.hash && tid < 128) {                             // hash of every atom's feature row (the atom types of the first step)
+            const int w = tid >> 5, a = tid & 31;
+            const int4 tl = w == 0 ? tls[0] : w == 1 ? tls[1] : w == 2 ? tls[2] : tls[3];
+            if (a < tl.y) {
+                unsigned long long hsh = 1469598103934665603ull;
+                for (int f = 0; f < L.nx; ++f) hsh = lg_hash_step(hsh, sm[(w * 32 + a) * EPNN_AST + epnn_aeo(f)]);
+                L.typ_hash[tl.x + a] = hsh | 1ull;
+            }
+        }
+        if (t0 + wave >= L.natiles) return;
+        const int4 tl = L.atiles[t0 + wave];
+        const int row = c < tl.y ? c : 0;
+        const float none[EPNN_KA] = {};
+        lg_proj_wave<3, false, false>(L, M, 1, tl, sm + (wave * 32 + row) * EPNN_AST + hh * 32, lane, none, L.P, L.R);
+        return;
+    }
+    blk -= W.tile_wgs;
+    if (blk < W.count_wgs) front_count_body(F, sm, blk);
+}
+struct LgSecond {
+    int link_wgs, tsweep_wgs;
+};
+__global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, LgSecond W, FrontArgs F) {
+    int blk = (int)blockIdx.x;
+    if (blk < W.link_wgs) {
+        front_link_body(F, blk, W.link_wgs);
+        return;
+    }
+    blk -= W.link_wgs;
+    if (blk < W.tsweep_wgs) {
+        if (threadIdx.x < 64) lg_tsweep_wave(L, M, blk);
+        return;
+    }
+    blk -= W.tsweep_wgs;
+    const int np = L.row_off[L.A];
+    if (np > L.pcap) return;
+    const int pt = blk * 4 + (int)(threadIdx.x >> 6);
+    if (pt * 32 < np) lg_pair_tile<true>(L, M, pt, np, F.nbr);
 }
 
 // ------------------------------------------------------------------------------------------------ reduction of S
@@ -731,7 +938,7 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     __shared__ __attribute__((aligned(16))) float Ss[32 * EPNN_SST];
     __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
-    if (L.row_off[L.A] > L.pcap) return;
+    const int np = L.row_off[L.A];                               // (looked at below: the loads in between do not depend on the pair list)
     const int4 tl = L.atiles[blockIdx.x];
     const float *wp = L.wpack;
     float w1[40], w2[16], w3[32], wA[EPNN_KA];
@@ -753,6 +960,7 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     }
     for (int i = tid; i < tl.y * (EPNN_AST / 4); i += 512)
         reinterpret_cast<f32x4 *>(Ai)[i] = reinterpret_cast<const f32x4 *>(L.a_eo + (size_t)tl.x * EPNN_AST)[i];
+    if (np > L.pcap) return;
     {
         const int o = tid & 31, a16 = tid >> 5, n = L.moff[tl.z + 1] - L.moff[tl.z];
         const int a[2] = {a16, a16 + 16};
@@ -801,12 +1009,12 @@ __device__ __forceinline__ void lg_handoff(const LargeArgs &L) {
 // sum of an atom's incidence row of transfers, slot order
 __device__ __forceinline__ float lg_slot_sum(const float *dl, int lo, int hi) {
     float acc = 0.f;
-    for (; lo < hi; lo += 8) {
-        float v[8];
+    for (; lo < hi; lo += 16) {
+        float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = lo + u < hi ? dl[lo + u] : 0.f;
+        for (int u = 0; u < 16; ++u) v[u] = lo + u < hi ? dl[lo + u] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (lo + u < hi) acc += v[u];
     }
     return acc;
@@ -817,18 +1025,15 @@ __device__ __forceinline__ float lg_slot_sum(const float *dl, int lo, int hi) {
 // z1 = relu(G + (Pst_i + q_i wqi) + (Rst_j + q_j wqj)) both ways, delta = 0.5 (f_ij - f_ji), deposits +w_i delta, -w_j delta.
 __global__ __launch_bounds__(256) void k_lg_epn_step(LargeArgs L, PairMlpPack M, int t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
-    const int np = L.row_off[L.A];
-    if (np > L.pcap) return;
     const int slot = (blockIdx.x * 4 + wave) * 32 + c;
-    bool valid = slot < np;
-    int4 ra = make_int4(0, 0, 0, 0), rb = make_int4(0, 0, 0, -1);
-    if (valid) {
-        ra = L.prec[2 * slot];
-        rb = L.prec[2 * slot + 1];
-        valid = L.mflag[L.mol_of[ra.x]] != 0;
-    }
+    // the pair count and the pair records travel together (the records' array is padded: any slot of the grid may be read)
+    const int np = L.row_off[L.A];
+    const int4 ra0 = L.prec[2 * slot], rb0 = L.prec[2 * slot + 1];
+    if (np > L.pcap) return;
+    bool valid = slot < np && ra0.x >= 0;                      // (a pair of a molecule that is not on this path: -1 - i)
+    const int4 ra = valid ? ra0 : make_int4(0, 0, 0, 0), rb = valid ? rb0 : make_int4(0, 0, 0, -1);
     if (__ballot(valid) == 0ull) return;
-    const int gi = ra.x, gj = ra.y;
+    const int gi = valid ? ra.x : 0, gj = valid ? ra.y : 0;
     const float *wp = L.wpack;
     const float *Pst = L.Pst + (size_t)t * L.A * 32, *Rst = L.Rst + (size_t)t * L.A * 32;
     // this half's atom: its charge of the previous step and the transfers it received there
@@ -945,6 +1150,7 @@ static int large_plan(epnn_handle *h) {
         int want;
         if (ngroup >= 512) want = std::max(1, (4096 + ngroup - 1) / ngroup);
         else want = std::max(1, (int)std::lround(512.0 * std::max(1, (int)std::lround(ngroup / 64.0)) / ngroup));
+        if (h->opt_large_chunks > 0) want = h->opt_large_chunks;
         int nchunk = std::max(1, std::min(want, (n + 15) / 16));
         int clen = (n + nchunk - 1) / nchunk;
         nchunk = (n + clen - 1) / clen;
@@ -983,7 +1189,7 @@ static int large_plan(epnn_handle *h) {
         h->l_S0.ensure((size_t)lp.maxchunk * A * 32 * 4) || h->l_csr_off.ensure((A + 1) * sizeof(int)) ||
         h->l_cnt.ensure(2 * (A + 1) * sizeof(int)) || h->l_sfin.ensure(A * 32 * 4) ||
         h->l_lmol.ensure(nl * sizeof(int)) || h->l_typrow.ensure(A * sizeof(int)) ||
-        h->l_typtab.ensure(nl * (2 * EPNN_TYPE_MAX + 1) * sizeof(int)) || h->l_stype.ensure(nl * EPNN_TYPE_MAX * 32 * 4))
+        h->l_typtab.ensure(nl * (2 * EPNN_TYPE_MAX + 1) * sizeof(int)) || h->l_typhash.ensure((A + nl * EPNN_TYPE_MAX) * 8) || h->l_stype.ensure(nl * EPNN_TYPE_MAX * 32 * 4))
         return 1;
     HIPCHK(hipMemcpyAsync(h->l_tiles.p, lp.atiles.data(), lp.atiles.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->l_lmol.p, P.large_list.data(), nl * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1003,16 +1209,23 @@ static int ensure_large_pairs(epnn_handle *h) {
 
 struct PairSource;
 // `have_inc`: the pair list came with its incidence rows (compact entry: epnn_frontend.hip.h); otherwise (dense front-end) they
-// are built here.  `lists_ev`: when not null the list is being built on the handle's second stream -- everything that needs
-// it waits for this event; what needs only the atoms (feature rows, atom types, first projections, the first step's type
-// sums) runs beside the list construction.
+// are built here.  `front`: when not null the pair list has NOT been built yet and this function drives the front-end's
+// launches itself, merged with what needs only the atoms (k_lg_first / k_lg_second above).
 static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
-                             const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn, bool have_inc, hipEvent_t lists_ev) {
+                             const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn, bool have_inc, const FrontArgs *front) {
     const Plan &P = h->plan;
-    if (P.large_list.empty()) {
-        if (lists_ev) HIPCHK(hipStreamWaitEvent(h->stream, lists_ev, 0));
+    hipStream_t st = h->stream;
+    const unsigned gLink = (unsigned)std::min<size_t>(((size_t)h->pcap + 255) / 256, 1024);
+    const unsigned rows4 = (unsigned)((P.A + 3) / 4);
+    auto front_alone = [&]() -> int {          // the front-end as four launches of its own
+        hipLaunchKernelGGL(k_front_count, dim3(rows4), dim3(256), 0, st, *front);
+        hipLaunchKernelGGL(k_front_scan_both, dim3(1), dim3(1024), 0, st, *front);
+        hipLaunchKernelGGL(k_front_fill, dim3(rows4), dim3(256), 0, st, *front);
+        hipLaunchKernelGGL(k_front_link, dim3(gLink), dim3(256), 0, st, *front);
+        HIPCHK(hipGetLastError());
         return 0;
-    }
+    };
+    if (P.large_list.empty()) return front ? front_alone() : 0;
     if (ensure_large_pairs(h) || h->d_incoff.ensure(((size_t)P.A + 1) * sizeof(int))) return 1;
     const size_t pc = (size_t)h->pcap;
     LargeArgs L{};
@@ -1075,28 +1288,30 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.typ_cnt = L.typ_rep + (size_t)L.nlarge * EPNN_TYPE_MAX;
     L.typ_n = L.typ_cnt + (size_t)L.nlarge * EPNN_TYPE_MAX;
     L.S_type = h->l_stype.as<float>();
+    L.typ_hash = h->l_typhash.as<unsigned long long>();
+    L.typ_hsh = L.typ_hash + (size_t)P.A;
     // compact entry: the forward's last kernel hands status + pair count to the host (two device-to-host copies less)
     L.host_status = (h->want_large_handoff && run_epn && h->cfg.T > 0 && h->part_world == 1) ? h->h_status : nullptr;
     h->did_large_handoff = L.host_status != nullptr;
     L.q_out = d_q;
     L.h_out = d_hout;
     L.status = h->d_status.as<int>();
-    hipStream_t st = h->stream;
     const unsigned gA = (unsigned)std::min<size_t>(((size_t)P.A * EPNN_AST + 255) / 256, 4096);
     const unsigned gP = (unsigned)std::min<size_t>((pc + 255) / 256, 4096);
     const unsigned gAt = (unsigned)std::min<size_t>(((size_t)P.A + 255) / 256, 4096);
     const unsigned gT = (unsigned)((L.natiles + 3) / 4);
     const unsigned gPT = (unsigned)((pc + 127) / 128);
+    const unsigned gES = (unsigned)((L.natiles * L.T + 3) / 4);
     const int Tg = run_gnn ? L.T : 0, Te = run_epn ? L.T : 0;
     // the first GNN step by atom types: the compact entry only (h = 0 and one q per molecule: a feature row depends on x alone)
     const bool types = Tg > 0 && h->opt_large_dedupe && !h->types_overflowed && !d_hin && !d_qin && !d_nm;
-    hipLaunchKernelGGL(k_lg_init, dim3(gA), dim3(256), 0, st, L);
-    if (types) hipLaunchKernelGGL(k_lg_types, dim3((unsigned)L.nlarge), dim3(1024), 0, st, L);
-    // Launch sequence (the single-process case): proj(0) | per GNN step: sweep + correction tiles, tail (reduce, update,
-    // next projections) | per EPN step: pair tiles; a last launch adds the final transfers.  With a partition the other
-    // processes' rows of S arrive between the reduction and the update, so those stay separate launches.
+    // Launch sequence (the single-process case): first projections | per GNN step: sweep (its waves also run the step's
+    // correction tiles), tail (reduce, update, next projections) | per EPN step: pair tiles; a last launch adds the final
+    // transfers.  With a partition the other processes' rows of S arrive between the reduction and the update, so those stay
+    // separate launches.
     const bool collective = h->part_world > 1 || h->opt_part_collective;
     const bool split = collective || !h->opt_large_fused;
+    const bool merged = front && Tg > 0 && !split;           // k_lg_first / k_lg_second
     const unsigned gTile = (unsigned)L.natiles;
     auto next_after_gnn = [&](int t) {
         LgNext X{};
@@ -1104,82 +1319,81 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
         else if (Te > 0) X.run = 2;
         return X;
     };
-    if (Tg > 0) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[0], 1);
-    else if (Te > 0) hipLaunchKernelGGL(k_lg_epn_static, dim3((unsigned)((L.natiles * L.T + 3) / 4)), dim3(256), 0, st, L);
-    bool lists_ready = false;
-    auto need_lists = [&]() -> int {           // from here on the launches read the pair list / the incidence rows
-        if (lists_ready) return 0;
-        lists_ready = true;
-        if (lists_ev) HIPCHK(hipStreamWaitEvent(st, lists_ev, 0));
-        if (!have_inc) {
+    bool step0_pairs_done = false;
+    if (merged) {
+        LgFirst W1{(int)gT, (int)rows4, types ? 1 : 0};
+        hipLaunchKernelGGL(k_lg_first, dim3((unsigned)(W1.tile_wgs + W1.count_wgs)), dim3(256), 0, st, L, h->widx.msg[0], W1, *front);
+        hipLaunchKernelGGL(k_lg_scan_types, dim3(1u + (types ? (unsigned)L.nlarge : 0u)), dim3(1024), 0, st, L, *front);
+        hipLaunchKernelGGL(k_lg_fill_assign, dim3(rows4 + (types ? (unsigned)((P.A + 255) / 256) : 0u)), dim3(256), 0, st, L, *front, (int)rows4);
+        if (types) {
+            LgSecond W2{(int)gLink, L.nlarge * 2};
+            hipLaunchKernelGGL(k_lg_second, dim3((unsigned)(W2.link_wgs + W2.tsweep_wgs) + gPT), dim3(256), 0, st, L, h->widx.msg[0], W2, *front);
+            step0_pairs_done = true;
+        } else {
+            hipLaunchKernelGGL(k_front_link, dim3(gLink), dim3(256), 0, st, *front);
+        }
+    } else {
+        if (front && front_alone()) return 1;
+        hipLaunchKernelGGL(k_lg_init, dim3(gA), dim3(256), 0, st, L);
+        if (types) hipLaunchKernelGGL(k_lg_types, dim3((unsigned)L.nlarge), dim3(1024), 0, st, L);
+        if (Tg > 0) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, h->widx.msg[0], 1);
+        else if (Te > 0) hipLaunchKernelGGL(k_lg_epn_static, dim3(gES), dim3(256), 0, st, L);
+        if (!have_inc && !front) {
             HIPCHK(hipMemsetAsync(L.dn_cnt, 0, 2 * ((size_t)P.A + 1) * sizeof(int), st));
             hipLaunchKernelGGL(k_lg_dn_count, dim3(gP), dim3(256), 0, st, L);
             hipLaunchKernelGGL(k_lg_dn_scan, dim3(1), dim3(1024), 0, st, L);
             hipLaunchKernelGGL(k_lg_dn_fill, dim3(gP), dim3(256), 0, st, L);
             hipLaunchKernelGGL(k_lg_dn_link, dim3(gP), dim3(256), 0, st, L);
         }
-        return 0;
-    };
+        if (types) hipLaunchKernelGGL(k_lg_tsweep, dim3((unsigned)L.nlarge * 2), dim3(64), 0, st, L, h->widx.msg[0]);
+    }
+    // the sweep's workgroups per CU: as many as its task count fills evenly, enforced through the launch's LDS size
+    const int wpc = L.nstasks <= 256 ? 1 : L.nstasks <= 512 ? 2 : L.nstasks <= 768 ? 3 : 4;
+    const size_t sweep_lds = std::max<size_t>((size_t)2 * EPNN_LG_JC * 32 * 4, ((size_t)163840 / wpc) & ~size_t(255));
+    if (L.nstasks > 0 && !h->sweep_attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lg_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        h->sweep_attr = true;
+    }
     for (int t = 0; t < Tg; ++t) {
         const bool ty = types && t == 0;
-        if (ty) hipLaunchKernelGGL(k_lg_tsweep, dim3((unsigned)L.nlarge * 2), dim3(64), 0, st, L, h->widx.msg[0]);
-        if (split) {
-            if (!ty && L.nstasks > 0)
-                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2);
-            if (need_lists()) return 1;
-            hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
-            hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>(), ty ? 1 : 0);
-            if (collective) {
-                // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms); everything
-                // after this point is computed by every process for every atom
-                HIPCHK(hipGetLastError());
-                if (h->part_exchange) {                       // the caller's exchange (host-staged: gloo tests, no communicator)
-                    HIPCHK(hipStreamSynchronize(st));
-                    if (h->part_exchange(h->part_ctx, h->l_sfin.as<float>(), 32, P.A, h->part_row_lo, h->part_row_hi))
-                        EPNN_FAIL("forward: the partition's exchange function reported an error");
-                } else {
-                    // all-gather of unequal row ranges on the handle's stream: every process broadcasts its own rows in
-                    // place, grouped into one RCCL operation (xGMI is point to point: `world` concurrent broadcasts use every
-                    // link at once); no host synchronisation, the update kernel simply follows on the stream
-                    if (!h->comm || h->comm_world != h->part_world) EPNN_FAIL("forward: a partition is set but neither an exchange function nor a communicator");
-                    ncclResult_t rc = ncclGroupStart();
-                    for (int r = 0; r < h->part_world && rc == ncclSuccess; ++r) {
-                        const size_t cnt = (size_t)(h->part_hi[r] - h->part_lo[r]) * 32;
-                        if (cnt == 0) continue;
-                        float *rows = h->l_sfin.as<float>() + (size_t)h->part_lo[r] * 32;
-                        rc = ncclBroadcast(rows, rows, cnt, ncclFloat, r, h->comm, st);
-                    }
-                    const ncclResult_t rc2 = ncclGroupEnd();
-                    if (rc != ncclSuccess || rc2 != ncclSuccess)
-                        EPNN_FAIL("forward: RCCL row exchange failed: %s", ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
-                }
-            }
-            hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_sfin.as<float>());
-            const LgNext X = next_after_gnn(t);
-            if (X.run == 1) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, 1);
-            else if (X.run == 2) hipLaunchKernelGGL(k_lg_epn_static, dim3((unsigned)((L.natiles * L.T + 3) / 4)), dim3(256), 0, st, L);
+        const bool sweep = !ty && L.nstasks > 0;
+        if (sweep) hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), sweep_lds, st, L, h->wvidx.g[t].w2, h->widx.msg[t], 1);
+        else if (!(ty && step0_pairs_done)) hipLaunchKernelGGL(k_lg_pairs, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
+        if (!split) {
+            hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(512), 0, st, L, h->widx.upd[t], next_after_gnn(t), ty ? 1 : 0);
             continue;
         }
-        if (ty) {
-            if (need_lists()) return 1;
-            hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
-        } else if (L.nstasks > 0 && L.nstasks <= 512 && h->opt_large_pairs_beside != 1) {
-            if (need_lists()) return 1;
-            hipLaunchKernelGGL(k_lg_sweep_pairs, dim3((unsigned)L.nstasks + gPT), dim3(256), 0, st, L, h->wvidx.g[t].w2, h->widx.msg[t]);
-        } else {
-            if (need_lists()) return 1;
-            // correction tiles beside the sweep (both need only this step's P and R): fork to the second stream, join before the tail
-            HIPCHK(hipEventRecord(h->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-            hipLaunchKernelGGL(k_lg_pairs<0>, dim3(gPT), dim3(256), 0, h->stream2, L, h->widx.msg[t]);
-            HIPCHK(hipEventRecord(h->ev_join, h->stream2));
-            if (L.nstasks > 0)
-                hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), 0, st, L, h->wvidx.g[t].w2);
-            HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+        hipLaunchKernelGGL(k_lg_reduce, dim3((unsigned)L.natiles * 4), dim3(256), 0, st, L, h->l_sfin.as<float>(), ty ? 1 : 0);
+        if (collective) {
+            // the other processes' rows of S (this one's all-pairs sums are complete only for its own atoms); everything
+            // after this point is computed by every process for every atom
+            HIPCHK(hipGetLastError());
+            if (h->part_exchange) {                       // the caller's exchange (host-staged: gloo tests, no communicator)
+                HIPCHK(hipStreamSynchronize(st));
+                if (h->part_exchange(h->part_ctx, h->l_sfin.as<float>(), 32, P.A, h->part_row_lo, h->part_row_hi))
+                    EPNN_FAIL("forward: the partition's exchange function reported an error");
+            } else {
+                // all-gather of unequal row ranges on the handle's stream: every process broadcasts its own rows in
+                // place, grouped into one RCCL operation (xGMI is point to point: `world` concurrent broadcasts use every
+                // link at once); no host synchronisation, the update kernel simply follows on the stream
+                if (!h->comm || h->comm_world != h->part_world) EPNN_FAIL("forward: a partition is set but neither an exchange function nor a communicator");
+                ncclResult_t rc = ncclGroupStart();
+                for (int r = 0; r < h->part_world && rc == ncclSuccess; ++r) {
+                    const size_t cnt = (size_t)(h->part_hi[r] - h->part_lo[r]) * 32;
+                    if (cnt == 0) continue;
+                    float *rows = h->l_sfin.as<float>() + (size_t)h->part_lo[r] * 32;
+                    rc = ncclBroadcast(rows, rows, cnt, ncclFloat, r, h->comm, st);
+                }
+                const ncclResult_t rc2 = ncclGroupEnd();
+                if (rc != ncclSuccess || rc2 != ncclSuccess)
+                    EPNN_FAIL("forward: RCCL row exchange failed: %s", ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
+            }
         }
-        hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(512), 0, st, L, h->widx.upd[t], next_after_gnn(t), ty ? 1 : 0);
+        hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_sfin.as<float>());
+        const LgNext X = next_after_gnn(t);
+        if (X.run == 1) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, 1);
+        else if (X.run == 2) hipLaunchKernelGGL(k_lg_epn_static, dim3(gES), dim3(256), 0, st, L);
     }
-    if (need_lists()) return 1;
     if (d_hout) hipLaunchKernelGGL(k_lg_export_h, dim3(gA), dim3(256), 0, st, L);
     for (int t = 0; t < Te; ++t) hipLaunchKernelGGL(k_lg_epn_step, dim3(gPT), dim3(256), 0, st, L, h->widx.pas[t], t);
     if (Te > 0) hipLaunchKernelGGL(k_lg_epn_final, dim3(gAt), dim3(256), 0, st, L);

@@ -252,6 +252,26 @@ class Engine:
         assert len(unique_id) == 128
         check(self.lib.epnn_comm_init(self.h, unique_id, rank, world), self.lib)
 
+    def debug_pairs(self, cap):
+        """(pi, pj, near weight) of the pair list the last forward built outside the fused kernel (tests)"""
+        pi, pj, w = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        n = C.c_int64(0)
+        check(self.lib.epnn_debug_pairs(self.h, iptr(pi), iptr(pj), fptr(w), cap, C.byref(n)), self.lib)
+        k = min(int(n.value), cap)
+        return pi[:k], pj[:k], w[:k], int(n.value)
+
+    def comm_count(self):
+        """ranks that joined this engine's RCCL communicator"""
+        n = C.c_int32(0)
+        check(self.lib.epnn_comm_count(self.h, C.byref(n)), self.lib)
+        return int(n.value)
+
+    def comm_allreduce(self, values, op="sum"):
+        """all-reduce of a few host doubles over the engine's RCCL communicator (barrier / MAX over ranks of a driver)"""
+        buf = (C.c_double * len(values))(*[float(v) for v in values])
+        check(self.lib.epnn_comm_allreduce(self.h, buf, len(values), {"sum": 0, "max": 1}[op]), self.lib)
+        return [float(v) for v in buf]
+
     @staticmethod
     def comm_unique_id():
         lib = _lib.load()

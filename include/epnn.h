@@ -138,6 +138,16 @@ int epnn_train_apply(epnn_handle *h);
  * communicator carries the row exchange of a partitioned large system (epnn_set_partition with exchange == NULL). */
 int epnn_comm_unique_id(char *out128);
 int epnn_comm_init(epnn_handle *h, const char *id128, int rank, int world);
+/* ranks that joined the communicator (ncclCommCount) */
+int epnn_comm_count(epnn_handle *h, int32_t *ranks_out);
+/* all-reduce of n <= 1024 host doubles over the communicator, on the handle's stream, waited for (op 0 = sum, 1 = max): the
+ * barrier and the MAX-over-ranks timing of a multi-process driver go through the same RCCL path as the product's collectives
+ * (the reference has nothing distributed; bench.py --gpus N is the caller) */
+int epnn_comm_allreduce(epnn_handle *h, double *inout, int32_t n, int32_t op);
+
+/* (tests) the pair list of the last forward that built one outside the fused kernel: first / second atom and near weight
+ * (is_near of charge_gn.py:90-94 as 1.0 / 0.0, times the mask for dense inputs) of up to `cap` pairs; *count_out = pairs listed */
+int epnn_debug_pairs(epnn_handle *h, int32_t *pi, int32_t *pj, float *pwi, int64_t cap, int64_t *count_out);
 
 /* Device memory and stream plumbing for callers that keep inputs resident (bench.py). */
 int epnn_dev_alloc(epnn_handle *h, size_t bytes, void **out);
@@ -161,9 +171,10 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * "large_dedupe" (1, default: the tiled path's first GNN step of the compact entry groups the atoms by feature row -- h = 0 and one
  * q per molecule there, so the all-pairs sum of charge_gn.py:70 takes (distinct rows)^2 pair evaluations instead of n^2; 0: the
  * all-pairs sweep; a molecule with more than 64 distinct rows switches the handle back to the sweep by itself),
- * "large_overlap" (1, default: the compact entry builds the pair list of tiled molecules on the handle's second stream beside
- * the first projections; 0: everything on one stream), "large_pairs_beside" (developer switch: 1 launches the tiled path's
- * near-pair correction tiles on the second stream even where they would ride in the sweep's launch), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
+ * "large_merge" (1, default: the compact entry launches the pair-list construction of tiled molecules merged with the work that
+ * needs only the atoms -- feature rows, atom types, first projections, the first step's type sums and correction tiles -- in
+ * two launches whose workgroups take their kind of work from the block index; 0: every kernel its own launch), "large_chunks" (developer
+ * switch: number of pieces the partner range of a tiled molecule's all-pairs sweep is cut into; 0, default: by size), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
  * "train_graph" (1: a train step's launch sequence is captured once and replayed as a hipGraph, 0, default: kernel by kernel),
  * "train_fused" (1: one workgroup per atom runs a whole pair MLP over its rows, forward and backward; 0: one launch per
  * Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS budget of 96 atoms). */

@@ -199,11 +199,19 @@ def test_bench_two_ranks_on_this_box(tmp_path, launcher):
     assert o["n_gpus"] == 2 and o["steps"] == 40 and o["unit"] == "atoms/s" and o["scaling"] == "weak" and o["dtype"] == "f32"
     assert o["config"]["workload"] == "qm9_like_b1024_N29" and o["vs_baseline"] is None
     per = o["ranks"]["atoms_per_s_per_rank"]
-    assert o["ranks"]["world_size"] == 2 and len(per) == 2 and o["ranks"]["timing_backend"] in ("gloo", "nccl")
-    # max-over-ranks time: value <= sum of the rates.  (No absolute rate here: inside the test suite the two ranks share the GPU
-    # with this process's own handles and their hardware queues; alone they reach the single-rank rate between them.)
-    assert 0.5 * sum(per) < o["value"] <= 1.001 * sum(per) and o["value"] > 1e6
-    assert 0 < o["roofline"]["frac"] < 1.3 and o["roofline"]["bound"] == "mfma"
+    assert o["ranks"]["world_size"] == 2 and len(per) == 2
+    # one GPU on this box: RCCL refuses two ranks on a device, the timing exchange goes over the rendezvous store; with two
+    # devices it is the library's communicator and both ranks must have joined it
+    if o["ranks"]["rccl_ranks"] is None:
+        assert o["ranks"]["timing_backend"].startswith("rendezvous") and o["ranks"]["ranks_per_device"] == 2
+        assert o["ranks"]["hw_queues_per_rank"] <= 4              # ranks that share a device take fewer hardware queues each
+    else:
+        assert o["ranks"]["timing_backend"].startswith("rccl") and o["ranks"]["rccl_ranks"] == 2
+    # max-over-ranks time: value <= sum of the rates; and two ranks sharing the GPU must not fall off the queue cliff of round 2
+    # (13.6 M atoms/s in total with 16 hardware queues per rank beside this process's own: gpurun_out/r2_fulltests2.log)
+    assert 0.5 * sum(per) < o["value"] <= 1.001 * sum(per) and o["value"] > 5e7
+    assert 0 < o["roofline"]["frac"] < 1.0 and o["roofline"]["bound"] == "mfma"
+    assert "torch" not in open(os.path.join(ROOT, "bench.py")).read().replace("torch.distributed.run", "")
 
 
 def test_bench_line_of_the_drivers_command(tmp_path):
@@ -218,8 +226,9 @@ def test_bench_line_of_the_drivers_command(tmp_path):
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]
     o = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_cold", "prewarm_ms"):
         assert key in o, key
+    assert 0.5 * o["value"] < o["value_cold"] <= 1.05 * o["value"] and o["prewarm_ms"] > 10     # the cold figure stands beside `value`
     assert o["n_gpus"] == 1 and o["steps"] == 20 and o["warmup"] == 5 and o["higher_is_better"] is True
     assert o["unit"] == "atoms/s" and o["dtype"] == "f32" and o["data"] == "synthetic" and o["vs_baseline"] is None
     assert o["config"]["workload"] == "qm9_like_b1024_N29" and "model" not in o["config"]

@@ -14,6 +14,8 @@ from epnn_amd import checkpoint, synth, charge_gn
 from epnn_amd.engine import Engine
 
 def main():
+    opts = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--opt=")]          # --opt=name:value (engine option)
+    sys.argv = [a for a in sys.argv if not a.startswith("--opt=")]
     argv = [a for a in sys.argv[1:] if not a.startswith("--gpus")]
     gpus = next((int(a.split("=")[1]) if "=" in a else int(sys.argv[sys.argv.index(a) + 1]) for a in sys.argv[1:] if a.startswith("--gpus")), 0)
     if gpus:
@@ -33,6 +35,8 @@ def main():
         device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
     eng = Engine(nx=9, T=5, device=device)
     eng.set_weights(w)
+    for o in opts:
+        eng.set_option(o.split(":")[0], int(o.split(":")[1]))
     if rccl:
         from epnn_amd.rendezvous import Rendezvous
         rdzv = Rendezvous(rank, world)
