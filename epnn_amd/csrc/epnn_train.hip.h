@@ -12,6 +12,7 @@
 #pragma once
 #include "epnn_host.h"
 #include "epnn_train_fused.hip.h"
+#include "epnn_train_mfma.hip.h"
 
 struct TDense {            // one Dense inside the flat parameter vector
     int offW, offB, n_in, n_out;
@@ -622,12 +623,17 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     };
     hipLaunchKernelGGL(k_t_nodemask, dim3(t_grid(BN)), dim3(256), 0, st, d_mask, nm, B, N);
     hipLaunchKernelGGL(k_t_wgt, dim3(t_grid(R)), dim3(256), 0, st, d_e, d_mask, wgt, (int)R, E, h->cfg.near_tol);
+    // forward on the matrix pipe ("train_fused" >= 2, epnn_train_mfma.hip.h): a workgroup per 16 atoms of a molecule
+    const bool mfma_fwd = h->opt_train_fused >= 2 && nx + 49 <= EPNN_TM_FS;
+    const int nblk = (N + 15) / 16;
+    const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + 4 * 16 * 33) * 4;
     // ================================================================ forward: GNN (charge_gn.py:60-74)
     const float *hcur = d_h0;
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->msg[t], hcur, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
-        hipLaunchKernelGGL(k_tf_pair_fwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
+        if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<0>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, upd_args(t, hcur), nblk);
+        else hipLaunchKernelGGL(k_tf_pair_fwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
         hcur = P(gs[t].hn);
     }
     const float *feats = hcur;
@@ -636,7 +642,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->pas[t], feats, qcur);
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.qn = P(es[t].qn);
-        hipLaunchKernelGGL(k_tf_pair_fwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
+        if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<1>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, TfUpd{}, nblk);
+        else hipLaunchKernelGGL(k_tf_pair_fwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         qcur = P(es[t].qn);
     }
     HIPCHK(hipMemcpyAsync(d_pred, qcur, (size_t)BN * 4, hipMemcpyDeviceToDevice, st));

@@ -211,7 +211,7 @@ def test_bench_two_ranks_on_this_box(tmp_path, launcher):
     # (13.6 M atoms/s in total with 16 hardware queues per rank beside this process's own: gpurun_out/r2_fulltests2.log)
     assert 0.5 * sum(per) < o["value"] <= 1.001 * sum(per) and o["value"] > 5e7
     assert 0 < o["roofline"]["frac"] < 1.0 and o["roofline"]["bound"] == "mfma"
-    assert "torch" not in open(os.path.join(ROOT, "bench.py")).read().replace("torch.distributed.run", "")
+    assert "import torch" not in open(os.path.join(ROOT, "bench.py")).read()          # the timing exchange is the library's own
 
 
 def test_bench_line_of_the_drivers_command(tmp_path):
