@@ -1591,10 +1591,18 @@ extern "C" int epnn_train_apply(epnn_handle *h) {
 // shared tail of the two train-step entry points: slot arrays are on the device
 // forward + backward of one batch: row-fused kernels when the padded size fits their LDS budget ("train_fused", default 1),
 // else (or with the option at 0) the layer-by-layer kernels
+static bool train_is_fused(const epnn_handle *h, int N) { return h->opt_train_fused && N <= EPNN_TF_NMAX; }
+// d_loss: [B][N] loss terms (the layer-by-layer path fills one per molecule and leaves the rest zero); adam_now: the fused
+// path's last launch also takes the optimizer step
 static int train_fb(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x, const float *d_h0,
-                    const float *d_q0, const float *d_y, float *d_pred, float *d_loss, bool size_only = false) {
-    if (h->opt_train_fused && N <= EPNN_TF_NMAX)
-        return train_fwd_bwd_fused(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only);
+                    const float *d_q0, const float *d_y, float *d_pred, float *d_loss, bool size_only = false, bool adam_now = false) {
+    if (train_is_fused(h, N))
+        return train_fwd_bwd_fused(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only, adam_now);
+    if (!size_only) {
+        TrainState *ts = train_state(h);
+        HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));       // its launches ADD their parts of the gradient
+        HIPCHK(hipMemsetAsync(d_loss, 0, (size_t)B * N * 4, h->stream));
+    }
     return train_fwd_bwd(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only);
 }
 
@@ -1602,8 +1610,12 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
                             const float *d_h0, const float *d_q0, const float *d_y, float *pred_host, float *loss_host, int apply) {
     TrainState *ts = train_state(h);
     if (!ts->ready) EPNN_FAIL("train step: call epnn_train_init first");
-    if (ts->loss.ensure((size_t)B * 4 + (size_t)B * N * 4)) return 1;
-    float *d_loss = ts->loss.as<float>(), *d_pred = d_loss + B;
+    const size_t BN = (size_t)B * N;
+    if (ts->loss.ensure(2 * BN * 4)) return 1;
+    float *d_loss = ts->loss.as<float>(), *d_pred = d_loss + BN;
+    // the optimizer step rides in the gradient reduction's launch when nothing has to happen between the two (no all-reduce
+    // over ranks, no graph replay: the step size changes every step and would be frozen into the graph)
+    const bool adam_now = apply && train_is_fused(h, N) && !h->opt_train_graph && !(h->comm && h->comm_world > 1);
     if (h->opt_train_graph) {
         // One molecule padded to N = 41 is ~2 Gflop spread over ~340 tiny launches: the step is launch-bound, so the
         // launch sequence is recorded once per (B, N, buffer set) and replayed as one hipGraph.
@@ -1614,8 +1626,7 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
             if (ts->gexec) { (void)hipGraphExecDestroy(ts->gexec); ts->gexec = nullptr; }
             if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
             HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            int bad = hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream) != hipSuccess;
-            bad = bad || train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss);
+            const int bad = train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss);
             const hipError_t ec = hipStreamEndCapture(h->stream, &ts->graph);
             if (bad || ec != hipSuccess) {
                 if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
@@ -1627,20 +1638,19 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
         }
         HIPCHK(hipGraphLaunch(ts->gexec, h->stream));
     } else {
-        HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));
-        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss)) return 1;
+        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, false, adam_now)) return 1;
     }
-    if (apply && train_apply(h)) return 1;
+    if (apply && !adam_now && train_apply(h)) return 1;
     // the step's loss terms and predictions are neighbours on the device: one download into page-locked memory
-    const size_t nback = (size_t)B + (pred_host ? (size_t)B * N : 0);
+    const size_t nback = BN + (pred_host ? BN : 0);
     if (h->pin_tout.ensure(nback * 4)) return 1;
     HIPCHK(hipMemcpyAsync(h->pin_tout.p, d_loss, nback * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const float *back = h->pin_tout.as<float>();
-    if (pred_host) memcpy(pred_host, back + B, (size_t)B * N * 4);
+    if (pred_host) memcpy(pred_host, back + BN, BN * 4);
     if (loss_host) {
         double s = 0;
-        for (int b = 0; b < B; ++b) s += back[b];
+        for (size_t k = 0; k < BN; ++k) s += back[k];
         *loss_host = (float)s;
     }
     return 0;

@@ -278,6 +278,14 @@ __global__ __launch_bounds__(64) void k_t_loss(const float *y, const float *q, f
         loss[b] = s;
     }
 }
+// predictions and per-atom loss terms (the row-fused forward writes them from its last pass sweep)
+__global__ __launch_bounds__(256) void k_t_loss_terms(const float *y, const float *q, float *pred, float *lterm, int BN) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < BN; i += gridDim.x * 256) {
+        const float d = y[i] - q[i];
+        pred[i] = q[i];
+        lterm[i] = d * d;
+    }
+}
 // dm_ij = gM_i  (broadcast over j);  gM = second block of dU0 * nm
 __global__ __launch_bounds__(256) void k_t_bcast_gm(const float *dU0, const float *nm, float *dm, int BN, int N, int H, int O) {
     const size_t total = (size_t)BN * N * O;
@@ -562,10 +570,13 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
     return 0;
 }
 
-// The same forward + backward with the row-fused kernels of epnn_train_fused.hip.h (N <= EPNN_TF_NMAX): ~45 launches.
+// The same forward + backward with the row-fused kernels of epnn_train_fused.hip.h (N <= EPNN_TF_NMAX).  2T forward and 2T
+// backward launches and one that sums the weight-gradient partials (and, with `adam_now`, takes the optimizer step):
+// node masks, pair weights, loss terms and the "atoms" stage between two backward sweeps ride in their neighbours (round 3;
+// they were 18 launches of their own).  d_loss receives one loss term per atom slot [B][N].
 static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
                                const float *d_h0, const float *d_q0, const float *d_y, float *d_pred, float *d_loss,
-                               bool size_only = false) {
+                               bool size_only = false, bool adam_now = false) {
     TrainState *ts = train_state(h);
     if (!ts->ready) EPNN_FAIL("training: call epnn_train_init first");
     const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, E = EPNN_EDIM, F = nx + H + 1, D = 2 * F + E, FS = F | 1;
@@ -576,6 +587,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     float *grad = ts->grad.as<float>();
     const int Pm0 = D * 32 + 32 + 1024 + 32 + 32 * 32 + 32, Pm1 = D * 32 + 32 + 1024 + 32 + 32 + 1;
     if (2 * T + 1 > EPNN_TF_MAXRED) EPNN_FAIL("training: T = %d exceeds the fused step's reduction table", T);
+    if (T < 1) EPNN_FAIL("training: T must be at least 1");
     // ---- arena
     size_t need = 0;
     auto sz = [&](size_t n) { size_t o = need; need += (n + 63) & ~size_t(63); return o; };
@@ -585,14 +597,15 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = 0; t < T; ++t)
         gs[t] = {sz(R * 32), sz(R * 32), sz((size_t)BN * 32), sz((size_t)BN * 80), sz((size_t)BN * 32), sz((size_t)BN * 32), sz((size_t)BN * H)};
     for (int t = 0; t < T; ++t) es[t] = {sz(2 * R * 32), sz(2 * R * 32), sz(BN)};
-    const size_t o_dz1 = sz(2 * R * 32), o_dU0 = sz((size_t)BN * 80), o_gh = sz((size_t)BN * H), o_gfeat = sz((size_t)BN * H), o_gq = sz(BN);
+    const size_t o_dz1a = sz(2 * R * 32), o_dz1b = sz(2 * R * 32), o_dU0 = sz((size_t)BN * 80), o_gh = sz((size_t)BN * H),
+                 o_gfeat = sz((size_t)BN * H), o_gq = sz(BN);
     size_t o_pm[EPNN_MAXT], o_pp[EPNN_MAXT];
     for (int t = 0; t < T; ++t) o_pm[t] = sz((size_t)BN * Pm0);
     for (int t = 0; t < T; ++t) o_pp[t] = sz((size_t)BN * Pm1);
     const size_t o_pu = sz((size_t)T * BN * EPNN_TF_PU);
     if (ts->arena.ensure(need * 4)) return 1;
-    const size_t lds_fwd = ((size_t)N * FS + (size_t)N * 49 + (size_t)D * 32 + 4 * (size_t)N * 33 + EPNN_TF_NG * 32 + 32 + 2 * (size_t)N) * 4;
-    const size_t lds_bwd = ((size_t)N * FS + (size_t)N * 49 + 8 * (size_t)N * 33 + 32 * 33 + 192 + N + 336) * 4;
+    const size_t lds_fwd = ((size_t)N * FS + (size_t)N * 49 + (size_t)D * 32 + 4 * (size_t)N * 33 + EPNN_TF_NG * 32 + 32 + 3 * (size_t)N) * 4;
+    const size_t lds_bwd = ((size_t)N * FS + (size_t)N * 49 + 8 * (size_t)N * 33 + 32 * 33 + 192 + N + 336 + 128) * 4;
     if (!ts->fused_attr) {
         const int cap = 160 * 1024;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -605,11 +618,14 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     float *ar = ts->arena.as<float>();
     auto P = [&](size_t off) { return ar + off; };
     float *nm = P(o_nm), *wgt = P(o_wgt);
+    float *gq = P(o_gq), *gfeat = P(o_gfeat), *gh = P(o_gh);
     auto pair_args = [&](const TDense *mlp, const float *hh, const float *qq) {
         TfPair A{};
         A.x = d_x; A.h = hh; A.q = qq; A.e = d_e; A.theta = theta;
         A.oW1 = mlp[0].offW; A.ob1 = mlp[0].offB; A.oW2 = mlp[1].offW; A.ob2 = mlp[1].offB; A.oW3 = mlp[2].offW; A.ob3 = mlp[2].offB;
-        A.N = N; A.nx = nx; A.wgt = wgt; A.nm = nm; A.dz1 = P(o_dz1);
+        A.N = N; A.nx = nx; A.wgt = wgt; A.nm = nm;
+        A.nm_w = nm; A.wgt_w = wgt; A.tol = h->cfg.near_tol; A.pmode = -1;
+        A.gfeat = gfeat; A.gh = gh; A.gqv = gq; A.gq = gq; A.dU0 = P(o_dU0);
         return A;
     };
     auto upd_args = [&](int t, const float *hh) {
@@ -618,66 +634,89 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         U.oW0 = ts->upd[0].offW; U.ob0 = ts->upd[0].offB; U.oW1 = ts->upd[1].offW; U.ob1 = ts->upd[1].offB;
         U.oW2 = ts->upd[2].offW; U.ob2 = ts->upd[2].offB;
         U.U0 = P(gs[t].U0); U.U1 = P(gs[t].U1); U.U2 = P(gs[t].U2); U.hn = P(gs[t].hn);
-        U.gh = P(o_gh); U.dU0 = P(o_dU0); U.part = P(o_pu) + (size_t)t * BN * EPNN_TF_PU;
+        U.gh = gh; U.dU0 = P(o_dU0); U.part = P(o_pu) + (size_t)t * BN * EPNN_TF_PU;
         return U;
     };
-    hipLaunchKernelGGL(k_t_nodemask, dim3(t_grid(BN)), dim3(256), 0, st, d_mask, nm, B, N);
-    hipLaunchKernelGGL(k_t_wgt, dim3(t_grid(R)), dim3(256), 0, st, d_e, d_mask, wgt, (int)R, E, h->cfg.near_tol);
-    // forward on the matrix pipe ("train_fused" >= 2, epnn_train_mfma.hip.h): a workgroup per 16 atoms of a molecule
-    const bool mfma_fwd = h->opt_train_fused >= 2 && nx + 49 <= EPNN_TM_FS;
+    // forward on the matrix pipe ("train_fused" = 2, epnn_train_mfma.hip.h): a workgroup per 16 atoms of a molecule.  Measured
+    // SLOWER than the row-fused forward at these sizes (0.66 vs 0.47 ms per step: three workgroups per molecule are a chain of
+    // dependent MFMAs where the row-fused kernels have 41 x 16 wavefronts), so it is an option, not the default.
+    const bool mfma_fwd = h->opt_train_fused == 2 && nx + 49 <= EPNN_TM_FS;
     const int nblk = (N + 15) / 16;
-    const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + 4 * 16 * 33) * 4;
+    const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + EPNN_TM_NW * 16 * 33) * 4;
+    if (mfma_fwd) {
+        hipLaunchKernelGGL(k_t_nodemask, dim3(t_grid(BN)), dim3(256), 0, st, d_mask, nm, B, N);
+        hipLaunchKernelGGL(k_t_wgt, dim3(t_grid(R)), dim3(256), 0, st, d_e, d_mask, wgt, (int)R, E, h->cfg.near_tol);
+    }
     // ================================================================ forward: GNN (charge_gn.py:60-74)
     const float *hcur = d_h0;
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->msg[t], hcur, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
+        if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the node masks
         if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<0>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, upd_args(t, hcur), nblk);
         else hipLaunchKernelGGL(k_tf_pair_fwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
         hcur = P(gs[t].hn);
     }
     const float *feats = hcur;
-    // ================================================================ forward: EPN (charge_gn.py:98-118)
+    // ================================================================ forward: EPN (charge_gn.py:98-118), loss terms (:397)
     const float *qcur = d_q0;
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->pas[t], feats, qcur);
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.qn = P(es[t].qn);
+        if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the pair weights
+        if (t == T - 1 && !mfma_fwd) { A.y = d_y; A.pred = d_pred; A.lterm = d_loss; }
         if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<1>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, TfUpd{}, nblk);
         else hipLaunchKernelGGL(k_tf_pair_fwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         qcur = P(es[t].qn);
     }
-    HIPCHK(hipMemcpyAsync(d_pred, qcur, (size_t)BN * 4, hipMemcpyDeviceToDevice, st));
-    // ================================================================ loss (charge_gn.py:397-398)
-    float *gq = P(o_gq), *gfeat = P(o_gfeat), *gh = P(o_gh);
-    hipLaunchKernelGGL(k_t_loss, dim3(B), dim3(64), 0, st, d_y, qcur, gq, d_loss, N);
-    HIPCHK(hipMemsetAsync(gfeat, 0, (size_t)BN * H * 4, st));
-    // ================================================================ backward: EPN
+    if (mfma_fwd) hipLaunchKernelGGL(k_t_loss_terms, dim3(t_grid(BN)), dim3(256), 0, st, d_y, qcur, d_pred, d_loss, BN);
+    // ================================================================ backward: EPN, then GNN.  Every launch starts with the
+    // "atoms" stage of the one before it (the gradient that reached the atoms through that sweep's first Dense); the
+    // sweeps alternate between two dz1 buffers, so a launch may still read the previous one's while it writes its own.
+    int nb = 0;
+    int pmode = -1, poW1 = 0, pfirst = 0;
+    auto chain = [&](TfPair &A) {
+        A.dz1 = P((nb & 1) ? o_dz1b : o_dz1a);
+        A.pdz1 = P((nb & 1) ? o_dz1a : o_dz1b);
+        A.pmode = pmode; A.poW1 = poW1; A.pfirst = pfirst;
+        nb += 1;
+    };
     for (int t = T - 1; t >= 0; --t) {
         TfPair A = pair_args(ts->pas[t], feats, t ? P(es[t - 1].qn) : d_q0);
-        A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.gq = gq; A.part = P(o_pp[t]); A.gacc = gfeat;
+        A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.part = P(o_pp[t]);
+        A.first = t == T - 1; A.y = d_y; A.pred = d_pred;
+        chain(A);
         hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, TfUpd{});
-        hipLaunchKernelGGL(k_tb_atoms<1>, dim3(BN), dim3(128), 0, st, A);
+        pmode = 1; poW1 = ts->pas[t][0].offW; pfirst = t == T - 1;
     }
-    // ================================================================ backward: GNN
-    HIPCHK(hipMemcpyAsync(gh, gfeat, (size_t)BN * H * 4, hipMemcpyDeviceToDevice, st));
     for (int t = T - 1; t >= 0; --t) {
         const float *hin = t ? P(gs[t - 1].hn) : d_h0;
         TfPair A = pair_args(ts->msg[t], hin, d_q0);
-        A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.dU0 = P(o_dU0); A.part = P(o_pm[t]); A.gacc = gh;
+        A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.part = P(o_pm[t]);
+        chain(A);
         hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, upd_args(t, hin));     // update backward first
-        hipLaunchKernelGGL(k_tb_atoms<0>, dim3(BN), dim3(128), 0, st, A);
+        pmode = 0; poW1 = ts->msg[t][0].offW; pfirst = 0;
     }
-    // ================================================================ gradient = sum of the workgroups' partials
+    // ================================================================ gradient = sum of the workgroups' partials (+ Adam)
     TfReduce Rd{};
     int maxlen = 0;
-    auto entry = [&](int theta_off, int len, int nblk, size_t part_off) {
-        Rd.theta_off[Rd.n] = theta_off; Rd.len[Rd.n] = len; Rd.nblk[Rd.n] = nblk; Rd.part_off[Rd.n] = part_off;
+    auto entry = [&](int theta_off, int len, int nblk_, size_t part_off) {
+        Rd.theta_off[Rd.n] = theta_off; Rd.len[Rd.n] = len; Rd.nblk[Rd.n] = nblk_; Rd.part_off[Rd.n] = part_off;
         Rd.n += 1;
         maxlen = std::max(maxlen, len);
     };
     entry(ts->upd[0].offW, EPNN_TF_PU, T * BN, o_pu);
     for (int t = 0; t < T; ++t) entry(ts->msg[t][0].offW, Pm0, BN, o_pm[t]);
     for (int t = 0; t < T; ++t) entry(ts->pas[t][0].offW, Pm1, BN, o_pp[t]);
+    if (adam_now) {
+        ts->step += 1;
+        const double tt = (double)ts->step;
+        Rd.adam = 1;
+        Rd.alpha = (float)((double)ts->lr * std::sqrt(1.0 - std::pow((double)ts->b2, tt)) / (1.0 - std::pow((double)ts->b1, tt)));
+        Rd.b1 = ts->b1; Rd.b2 = ts->b2; Rd.eps = ts->eps;
+        Rd.theta = ts->theta.as<float>(); Rd.m = ts->m.as<float>(); Rd.v = ts->v.as<float>();
+        ts->dev_newer = true;
+    }
     hipLaunchKernelGGL(k_tb_wreduce, dim3((unsigned)((maxlen + 63) / 64), (unsigned)Rd.n), dim3(256), 0, st, Rd, ar, grad);
     HIPCHK(hipGetLastError());
     return 0;

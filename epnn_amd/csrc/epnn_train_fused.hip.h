@@ -33,6 +33,20 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     float *dz1;                  // gradient at the first layer's pre-activation [dir][R][32]
     float *part;                 // weight-gradient partials [BN][Pm], Pm = D*32 + 32 + 1024 + 32 + 32*O + O (parameter order)
     float *gacc;                 // atoms kernel: pass network gfeat [BN][48] (+=), message network gh [BN][48] (=)
+    // ---- launches folded into their neighbours (round 3): the step is a chain of dependent launches of ~10 us each, so
+    // every small kernel between two pair sweeps costs as much as a sweep
+    const float *mask;           // forward, first step of a stack: [B][N][N]; the message sweep derives the node masks (nm_w),
+    float *nm_w, *wgt_w;         //   the pass sweep the pair weights mask * is_near (wgt_w), and every later launch reads them
+    float tol;
+    const float *y;              // forward, last pass step: labels -> predictions (pred) and loss terms (lterm) per atom;
+    float *pred, *lterm;         //   backward, first pass step (first != 0): gq = -2 (y - pred)
+    int first;                   // backward: this is the first launch of its stack
+    // backward: the "atoms" stage of the PREVIOUS backward launch runs as this launch's prologue (k_tb_atoms' arithmetic)
+    int pmode;                   // -1: nothing; 1: the previous launch was a pass sweep; 0: a message sweep
+    int poW1;                    // that sweep's first Dense
+    int pfirst;                  // pmode 1: that sweep was the first one (gfeat starts from it instead of adding to it)
+    const float *pdz1;           // that sweep's dz1 (the sweeps alternate between two buffers)
+    float *gfeat, *gh, *gqv;     // [BN][48], [BN][48], [BN]
 };
 
 // ---------------------------------------------------------------------------------------------- update MLP arguments
@@ -96,7 +110,34 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
              [&](int idx, float v) { const int j = idx / 48; Es[j * 49 + (idx - j * 48)] = v; });
     tf_stage(D * 32, tid, [&](int idx) { return A.theta[A.oW1 + idx]; }, [&](int idx, float v) { W1s[idx] = v; });
+    float *wl = red + EPNN_TF_NG * 32 + 32 + 2 * N;            // [N] pair weights of this atom's rows (pass network)
+    if (MODE == 0 && A.mask && tid < 64) {
+        // node mask of this atom (charge_gn.py:59): clip(sum_j mask[j][i], 0, 1); what k_t_nodemask did in a launch of its own
+        float sm = 0.f;
+        for (int j = tid; j < N; j += 64) sm += A.mask[(a0 + j) * N + i];
+        for (int dd = 32; dd >= 1; dd >>= 1) sm += __shfl_xor(sm, dd, 64);
+        if (tid == 0) {
+            const float v = fminf(fmaxf(sm, 0.f), 1.f);
+            A.nm_w[bi] = v;
+            wl[0] = v;
+        }
+    }
     __syncthreads();
+    if (MODE == 1) {
+        // pair weights mask * is_near (charge_gn.py:90-94,116): from the staged e rows on the stack's first launch, else as stored
+        for (int j = tid; j < N; j += EPNN_TF_NT) {
+            float w;
+            if (A.mask) {
+                float mx = 0.f;
+                for (int k = 0; k < 48; ++k) mx = fmaxf(mx, Es[j * 49 + k]);
+                w = mx > A.tol ? A.mask[rowbase + j] : 0.f;
+                A.wgt_w[rowbase + j] = w;
+            } else {
+                w = A.wgt[rowbase + j];
+            }
+            wl[j] = w;
+        }
+    }
     // ---- layer 1: z1 = b1 + a_i W1[0:F] + a_j W1[F:2F] + e_ij W1[2F:]   (the a_i term once per thread, not per row)
     const float b1 = A.theta[A.ob1 + o];
     const float *ai = As + i * FS;
@@ -176,7 +217,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         __syncthreads();
         float *u0 = red, *u1 = red + 80, *u2 = red + 112;       // the group sums red[0 .. NG*32) are dead by now
         const bool upd = U.theta != nullptr;
-        const float nm = upd ? U.nm[bi] : 0.f;
+        const float nm = upd ? (A.mask ? wl[0] : U.nm[bi]) : 0.f;
         if (tid < 32) {
             float mo = (float)N * A.theta[A.ob3 + tid];
             for (int k = 0; k < 32; ++k) mo = fmaf(red[EPNN_TF_NG * 32 + k], A.theta[A.oW3 + k * 32 + tid], mo);
@@ -226,8 +267,14 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         __syncthreads();
         if (tid == 0) {
             float s = 0.f;
-            for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * A.wgt[rowbase + j];
-            A.qn[bi] = A.q[bi] + s;
+            for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * wl[j];
+            const float qn = A.q[bi] + s;
+            A.qn[bi] = qn;
+            if (A.y) {                            // last step: prediction and loss term of this atom (charge_gn.py:397)
+                const float d = A.y[bi] - qn;
+                A.pred[bi] = qn;
+                A.lterm[bi] = d * d;
+            }
         }
     }
 }
@@ -253,8 +300,59 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
     float *vec = W2s + 32 * 33;               // dms [32] | vs [32] | s1 [2][32] | sb2 [32] | c2 / dw3 [32] | df [N]
     float *dms = vec, *vs = vec + 32, *s1 = vec + 64, *sb2 = vec + 128, *c2 = vec + 160, *dfs = vec + 192;
     float *ub = dfs + N;                      // MODE 0, fused update backward: u0 [80] | u1 [32] | u2 [32] | dh [48] | du2 [32] | du1 [32] | dU0 [80]
+    float *psh = ub + 336;                    // [4][32] prologue: row / column sums of the previous sweep's dz1
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
+    // ---- prologue: what the previous backward launch leaves for this atom -- the gradient that reaches a_i through the first
+    // Dense of that sweep (k_tb_atoms' arithmetic, a launch of its own before): gq / gfeat after a pass sweep, gh after a
+    // message sweep; and on the first pass sweep gq = -2 (y - pred)   (charge_gn.py:397-398)
+    if (MODE == 1 && A.first && tid == 0) A.gqv[bi] = -2.f * (A.y[bi] - A.pred[bi]);
+    if (A.pmode >= 0) {
+        if (tid < 128) {
+            const int which = tid >> 5;
+            float sacc = 0.f;
+            // which 0: listed rows (a, j), a is the first block;  1: listed rows (i, a), a is the second block;
+            //       2: swapped rows (i, a) = [a_a | a_i | e], first block;  3: swapped rows (a, j) = [a_j | a_a | e], second block
+            if (which < 2 || A.pmode == 1) {
+                const bool byrow = which == 0 || which == 3;
+                const float *p = A.pdz1 + (which >= 2 ? dstride : 0) + (byrow ? rowbase * 32 : (a0 * N + i) * 32) + o;
+                const size_t step = byrow ? 32 : (size_t)N * 32;
+                int t = 0;
+                for (; t + 8 <= N; t += 8) {          // eight loads in flight, summed in row order
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(t + u) * step];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc += v[u];
+                }
+                for (; t < N; ++t) sacc += p[(size_t)t * step];
+            }
+            psh[which * 32 + o] = sacc;
+        }
+        __syncthreads();
+        const int k = nx + tid;                   // h part: k in [nx, nx+48), q part: k = nx + 48
+        if (tid < 128 && k < F) {
+            float da = 0.f;
+            for (int oo = 0; oo < 32; ++oo) {
+                const float sP = psh[oo] + psh[64 + oo], sR = psh[32 + oo] + psh[96 + oo];
+                da = fmaf(sP, A.theta[A.poW1 + k * 32 + oo], da);
+                da = fmaf(sR, A.theta[A.poW1 + (F + k) * 32 + oo], da);
+            }
+            if (A.pmode == 1) {
+                if (tid < 48) {
+                    const float gf = (A.pfirst ? 0.f : A.gfeat[(size_t)bi * 48 + tid]) + da;
+                    A.gfeat[(size_t)bi * 48 + tid] = gf;
+                    if (MODE == 0) A.gh[(size_t)bi * 48 + tid] = gf;      // the pass stack is done: the feature gradient enters the GNN
+                } else {
+                    A.gqv[bi] += da;
+                }
+            } else if (tid < 48) {
+                A.gh[(size_t)bi * 48 + tid] = A.dU0[(size_t)bi * 80 + tid] * A.nm[bi] + da;
+            }
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
     tf_stage(N * F, tid,
              [&](int idx) {
                  const int j = idx / F, k = idx - j * F;
@@ -444,54 +542,6 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- backward, to the atoms
-// da_a = (row / column sums of dz1 in which atom a is the first block of the row) W1[0:F]^T + (... second block) W1[F:2F]^T;
-// only the h and q parts of a = [x | h | q] carry gradient.  Pass network: gfeat += da_h, gq += da_q.  Message network:
-// gh = dU0[:, :48] * nm + da_h  (the gradient w.r.t. the previous step's h; q is the frozen initial charge there).
-template <int MODE>
-__global__ __launch_bounds__(128) void k_tb_atoms(TfPair A) {
-    __shared__ float sh[4][32];
-    const int N = A.N, nx = A.nx, F = nx + 49;
-    const int bi = blockIdx.x, b = bi / N, ia = bi - b * N;
-    const int tid = threadIdx.x, o = tid & 31, which = tid >> 5;
-    const size_t dstride = (size_t)gridDim.x * N * 32;
-    const size_t rows = (size_t)bi * N, mol = (size_t)b * N;
-    float s = 0.f;
-    // which 0: listed rows (a, j), a is the first block;  1: listed rows (i, a), a is the second block;
-    //       2: swapped rows (i, a) = [a_a | a_i | e], first block;  3: swapped rows (a, j) = [a_j | a_a | e], second block
-    if (which < 2 || MODE == 1) {
-        const bool byrow = which == 0 || which == 3;
-        const float *p = A.dz1 + (which >= 2 ? dstride : 0) + (byrow ? rows * 32 : (mol * N + ia) * 32) + o;
-        const size_t step = byrow ? 32 : (size_t)N * 32;
-        int t = 0;
-        for (; t + 8 <= N; t += 8) {          // eight loads in flight, summed in row order
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(t + u) * step];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; t < N; ++t) s += p[(size_t)t * step];
-    }
-    sh[which][o] = s;
-    __syncthreads();
-    const int k = nx + tid;                   // h part: k in [nx, nx+48), q part: k = nx + 48
-    if (k < F) {
-        float da = 0.f;
-        for (int oo = 0; oo < 32; ++oo) {
-            const float sP = sh[0][oo] + sh[2][oo], sR = sh[1][oo] + sh[3][oo];
-            da = fmaf(sP, A.theta[A.oW1 + k * 32 + oo], da);
-            da = fmaf(sR, A.theta[A.oW1 + (F + k) * 32 + oo], da);
-        }
-        if (MODE == 1) {
-            if (tid < 48) A.gacc[(size_t)bi * 48 + tid] += da;
-            else A.gq[bi] += da;
-        } else if (tid < 48) {
-            A.gacc[(size_t)bi * 48 + tid] = A.dU0[(size_t)bi * 80 + tid] * A.nm[bi] + da;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- update MLP (stand-alone launches)
 __global__ __launch_bounds__(64) void k_tf_update_fwd(TfUpd U) {
     __shared__ float u0[80], u1[32], u2[32];
@@ -575,8 +625,13 @@ struct TfReduce {
     int n;
     int theta_off[EPNN_TF_MAXRED], len[EPNN_TF_MAXRED], nblk[EPNN_TF_MAXRED];
     size_t part_off[EPNN_TF_MAXRED];
+    // with `adam` set the same launch takes the optimizer step on the element it has just summed (Keras-2 Adam,
+    // charge_gn.py:419: theta -= alpha m / (sqrt(v) + eps), alpha = lr sqrt(1 - b2^t) / (1 - b1^t))
+    int adam;
+    float alpha, b1, b2, eps;
+    float *theta, *m, *v;
 };
-// grad[theta_off + idx] += sum_blk part[part_off + blk * len + idx]: four quarter sums (one per wavefront), combined in order
+// grad[theta_off + idx] = sum_blk part[part_off + blk * len + idx]: four quarter sums (one per wavefront), combined in order
 __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *part, float *grad) {
     __shared__ float sh[4][64];
     const int en = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -592,5 +647,16 @@ __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *par
     }
     sh[w][lane] = s;
     __syncthreads();
-    if (w == 0 && idx < len) grad[T.theta_off[en] + idx] += ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    if (w == 0 && idx < len) {
+        const int i = T.theta_off[en] + idx;
+        const float g = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+        grad[i] = g;
+        if (T.adam) {
+            const float mi = T.b1 * T.m[i] + (1.f - T.b1) * g;
+            const float vi = T.b2 * T.v[i] + (1.f - T.b2) * g * g;
+            T.m[i] = mi;
+            T.v[i] = vi;
+            T.theta[i] -= T.alpha * mi / (sqrtf(vi) + T.eps);
+        }
+    }
 }

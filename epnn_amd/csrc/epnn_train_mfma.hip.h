@@ -19,7 +19,8 @@
 #include "epnn_host.h"
 #include "epnn_train_fused.hip.h"
 
-#define EPNN_TM_NT 256           // four wavefronts per workgroup
+#define EPNN_TM_NT 1024          // sixteen wavefronts per workgroup (a CU's four SIMDs, four deep: the chains of dependent MFMAs overlap)
+#define EPNN_TM_NW (EPNN_TM_NT / 64)
 #define EPNN_TM_FS 60            // atom-feature row in LDS: F = nx + 49 <= 60, zero padded (15 K steps of 4)
 
 __device__ __forceinline__ f32x4 tm_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(EPNN_TM_NT) void k_tm_fwd(TfPair A, TfUpd U, int nb
     float *As = tm_sm;                           // [N][FS]  a_j = [x | h | q] of every atom of the molecule, zero padded
     float *Ps = As + N * EPNN_TM_FS;             // [N][32]  P_j
     float *Rs = Ps + N * 32;                     // [N][32]  R_j
-    float *red = Rs + N * 32;                    // [4][16][33]  the wavefronts' partial sums
+    float *red = Rs + N * 32;                    // [NW][16][33]  the wavefronts' partial sums
     const size_t a0 = (size_t)b * N;
     const float *theta = A.theta;
     // ---- the molecule's atom rows
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(EPNN_TM_NT) void k_tm_fwd(TfPair A, TfUpd U, int nb
     }
     __syncthreads();
     // ---- projections of every atom: jobs (column block, P | R) dealt to the wavefronts
-    for (int job = wave; job < 2 * nblk; job += 4) {
+    for (int job = wave; job < 2 * nblk; job += EPNN_TM_NW) {
         const int jb = job >> 1, isR = job & 1;
         const int n = jb * 16 + m;
         f32x4 acc[2];
@@ -133,18 +134,25 @@ __global__ __launch_bounds__(EPNN_TM_NT) void k_tm_fwd(TfPair A, TfUpd U, int nb
         z2[0] = tm_relu(d[0]);
         z2[1] = tm_relu(d[1]);
     };
-    for (int j = wave; j < N; j += 4) {
+    // the edge rows of a wavefront's partners are fetched one partner ahead (a trip's loads would otherwise sit in front of
+    // its MFMAs with nothing to hide behind: one wavefront per SIMD and partner)
+    auto fetch_e = [&](int j, f32x4 (&ee)[3], float &wg) {
+        const size_t row = bi * N + (j < N ? j : 0);
+        const float *er = A.e + row * 48 + 12 * q;
+        const bool ok = live && j < N;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) ee[u] = ok ? tm_ld4(er + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+        wg = (MODE && ok) ? A.wgt[row] : 0.f;
+    };
+    f32x4 en[3];
+    float wn;
+    fetch_e(wave, en, wn);
+    for (int j = wave; j < N; j += EPNN_TM_NW) {
         const size_t row = bi * N + j;           // pair row (i, j)
         // G_ij = We^T e_ij for the sixteen columns
-        float ev[12];
-        {
-            const float *er = A.e + row * 48 + 12 * q;
-            const f32x4 e0 = live ? tm_ld4(er) : f32x4{0.f, 0.f, 0.f, 0.f}, e1 = live ? tm_ld4(er + 4) : f32x4{0.f, 0.f, 0.f, 0.f},
-                        e2 = live ? tm_ld4(er + 8) : f32x4{0.f, 0.f, 0.f, 0.f};
-            ev[0] = e0[0]; ev[1] = e0[1]; ev[2] = e0[2]; ev[3] = e0[3];
-            ev[4] = e1[0]; ev[5] = e1[1]; ev[6] = e1[2]; ev[7] = e1[3];
-            ev[8] = e2[0]; ev[9] = e2[1]; ev[10] = e2[2]; ev[11] = e2[3];
-        }
+        const float ev[12] = {en[0][0], en[0][1], en[0][2], en[0][3], en[1][0], en[1][1], en[1][2], en[1][3], en[2][0], en[2][1], en[2][2], en[2][3]};
+        const float wg = wn;
+        fetch_e(j + EPNN_TM_NW, en, wn);
         f32x4 g[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < 12; ++s) {
@@ -188,10 +196,10 @@ __global__ __launch_bounds__(EPNN_TM_NT) void k_tm_fwd(TfPair A, TfUpd U, int nb
                 }
             fa = tm_sumq(fa) + b3;
             fb = tm_sumq(fb) + b3;
-            if (live) qacc += 0.5f * (fa - fb) * A.wgt[row];
+            if (live) qacc += 0.5f * (fa - fb) * wg;
         }
     }
-    // ---- the four wavefronts' sums meet (fixed order)
+    // ---- the wavefronts' sums meet (fixed order)
     float *mine = red + (wave * 16 + m) * 33;
     if (MODE == 0) {
 #pragma unroll
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(EPNN_TM_NT) void k_tm_fwd(TfPair A, TfUpd U, int nb
     if (MODE == 1) {
         if (q == 0 && live) {
             float s = 0.f;
-            for (int w = 0; w < 4; ++w) s += red[(w * 16 + m) * 33];
+            for (int w = 0; w < EPNN_TM_NW; ++w) s += red[(w * 16 + m) * 33];
             A.qn[bi] = A.q[bi] + s;
         }
         return;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(EPNN_TM_NT) void k_tm_fwd(TfPair A, TfUpd U, int nb
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = 0.f;
-            for (int w = 0; w < 4; ++w) s += red[(w * 16 + m) * 33 + 16 * rb + 4 * q + r];
+            for (int w = 0; w < EPNN_TM_NW; ++w) s += red[(w * 16 + m) * 33 + 16 * rb + 4 * q + r];
             Ssum[rb][r] = s;
         }
     // M_i = W3^T (sum_j z2_ij) + N b3                                     (charge_gn.py:68-70)

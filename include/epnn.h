@@ -176,10 +176,10 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * two launches whose workgroups take their kind of work from the block index; 0: every kernel its own launch), "large_chunks" (developer
  * switch: number of pieces the partner range of a tiled molecule's all-pairs sweep is cut into; 0, default: by size), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
  * "train_graph" (1: a train step's launch sequence is captured once and replayed as a hipGraph, 0, default: kernel by kernel),
- * "train_fused" (2, default: the forward's pair MLPs run on the matrix pipe in the factorised form of the inference kernels, a
- * workgroup per 16 atoms of a molecule, the backward on the row-fused kernels; 1: one workgroup per atom runs a whole pair MLP
- * over its rows with scalar FMAs, forward and backward; 0: one launch per Dense layer on materialised rows -- also taken when
- * N exceeds the fused kernels' LDS budget of 96 atoms). */
+ * "train_fused" (1, default: one workgroup per atom runs a whole pair MLP over its rows, forward and backward, 2T + 2T + 1
+ * launches per step; 2: the forward's pair MLPs on the matrix pipe in the factorised form of the inference kernels, a workgroup
+ * per 16 atoms of a molecule -- measured slower at N = 41; 0: one launch per Dense layer on materialised rows -- also taken
+ * when N exceeds the fused kernels' LDS budget of 96 atoms). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features
  * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative
