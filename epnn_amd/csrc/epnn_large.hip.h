@@ -72,6 +72,7 @@ struct LargeArgs {
     int natiles;
     const int4 *stasks;                     // sweep tasks: (first atile, natiles<=4, j_lo, j_hi)
     const int *stask_chunk;                 // chunk index of each sweep task
+    const float2 *stask_frac;               // share [lo, hi) of the step's correction tiles each sweep task's wavefronts run
     int nstasks;
     int pcap;
     // first GNN step by atom types (k_lg_types)
@@ -354,9 +355,9 @@ __global__ __launch_bounds__(64) void k_lg_tsweep(LargeArgs L, PairMlpPack M) { 
 // to two waves).  `wA` = the wave's weight fragments (Wi for WHAT & 1, else Wj), already in registers when PRE.
 // GNNP: projections of a GNN step (zp / Nn / Yb are wanted); ZQ: the charge feature reads as 0 and the results go to
 // `oP` / `oR` (the EPN stack's static projections).
-template <int WHAT, bool PRE, bool ZQ>
+template <int WHAT, bool PRE, bool ZQ, bool PRE2 = false>
 __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPack &M, int gnnp, const int4 tl, const float *arow, int lane,
-                                             const float (&wA)[EPNN_KA], float *oP, float *oR) {
+                                             const float (&wA)[EPNN_KA], float *oP, float *oR, const float *wB = nullptr) {
     const int c = lane & 31, hh = lane >> 5;
     const int at = tl.x + (c < tl.y ? c : 0);
     const float *wp = L.wpack;
@@ -376,7 +377,7 @@ __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPa
 #pragma unroll
     for (int s = 0; s < EPNN_KA; ++s) {
         if (WHAT & 1) accP = epnn_mfma(PRE ? wA[s] : wp[M.wiF + s * 64 + lane], bv[s], accP);
-        if (WHAT & 2) accR = epnn_mfma(PRE && !(WHAT & 1) ? wA[s] : wp[M.wjF + s * 64 + lane], bv[s], accR);
+        if (WHAT & 2) accR = epnn_mfma(PRE2 ? wB[s] : (PRE && !(WHAT & 1) ? wA[s] : wp[M.wjF + s * 64 + lane]), bv[s], accR);
     }
     if (c < tl.y) {
         if (WHAT & 1) epnn_st16(oP + (size_t)at * 32 + hh * 16, accP);
@@ -538,7 +539,7 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
 // SEARCH: the pair records do not exist yet (the first step's tiles run in the launch that also links the list): the slot
 // of the pair in its second atom's row is looked up here.
 template <bool SEARCH>
-__device__ __forceinline__ void lg_pair_tile(const LargeArgs &L, const PairMlpPack &M, int pt, int np, const int *nbr) {
+__device__ __forceinline__ void lg_pair_tile(const LargeArgs &L, const PairMlpPack &M, int pt, int np, const int *nbr, bool all_tiled = false) {
     const int lane = threadIdx.x & 63, c = lane & 31, hh = lane >> 5;
     const int slot = pt * 32 + c;
     bool valid = slot < np;
@@ -548,16 +549,16 @@ __device__ __forceinline__ void lg_pair_tile(const LargeArgs &L, const PairMlpPa
             gi = L.pi[slot];
             gj = L.pj[slot];
             di = L.dest_i[slot];
-            valid = L.mflag[L.mol_of[gi]] != 0;
+            if (!all_tiled) valid = L.mflag[L.mol_of[gi]] != 0;      // (every molecule of the batch is tiled: nothing to look up)
         }
         if (valid) {
             const int lo = L.inc_off[gj], hi = L.inc_off[gj + 1];
-            for (int k0 = lo; k0 < hi && dj < 0; k0 += 8) {
-                int v[8];
+            for (int k0 = lo; k0 < hi && dj < 0; k0 += 16) {
+                int v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = k0 + u < hi ? nbr[k0 + u] : -1;
+                for (int u = 0; u < 16; ++u) v[u] = k0 + u < hi ? nbr[k0 + u] : -1;
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 16; ++u)
                     if (v[u] == gi) dj = k0 + u;
             }
         }
@@ -616,8 +617,13 @@ __global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, PairMl
     if (do_pairs) {
         const int np = L.row_off[L.A];
         if (np <= L.pcap) {
-            const int npt = (np + 31) >> 5, nw = (int)gridDim.x * 4;
-            for (int pt = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); pt < npt; pt += nw) lg_pair_tile<false>(L, Mpair, pt, np, nullptr);
+            // this task's share of the tiles: the host deals them by how much shorter a task's partner range is than its
+            // molecule's longest (a molecule's last chunk is the short one: its wavefronts take the tiles and still finish
+            // with the others; dealt evenly, every tile was ~5 us at the end of a wavefront that had a full sweep task)
+            const int npt = (np + 31) >> 5;
+            const float2 fr = L.stask_frac[blockIdx.x];
+            const int lo = min(npt, (int)(fr.x * (float)npt)), hi = fr.y >= 1.f ? npt : min(npt, (int)(fr.y * (float)npt));
+            for (int pt = lo + (int)(threadIdx.x >> 6); pt < hi; pt += 4) lg_pair_tile<false>(L, Mpair, pt, np, nullptr);
         }
     }
     lg_sweep_body(L, w2off, lg_smem, lg_smem + EPNN_LG_JC * 32);
@@ -665,6 +671,13 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
         int4 tls[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) tls[w] = t0 + w < L.natiles ? L.atiles[t0 + w] : make_int4(0, 0, 0, 0);
+        // both projections' weight fragments are requested now: they travel while the rows are built
+        float wI[EPNN_KA], wJ[EPNN_KA];
+#pragma unroll
+        for (int s = 0; s < EPNN_KA; ++s) {
+            wI[s] = L.wpack[M.wiF + s * 64 + lane];
+            wJ[s] = L.wpack[M.wjF + s * 64 + lane];
+        }
         for (int idx = tid; idx < 4 * 32 * EPNN_AST; idx += 256) sm[idx] = 0.f;
         __syncthreads();
         {   // one thread per atom and half of its inputs (x and q | h), every load of a thread in flight together
@@ -713,15 +726,14 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
         if (t0 + wave >= L.natiles) return;
         const int4 tl = L.atiles[t0 + wave];
         const int row = c < tl.y ? c : 0;
-        const float none[EPNN_KA] = {};
-        lg_proj_wave<3, false, false>(L, M, 1, tl, sm + (wave * 32 + row) * EPNN_AST + hh * 32, lane, none, L.P, L.R);
+        lg_proj_wave<3, true, false, true>(L, M, 1, tl, sm + (wave * 32 + row) * EPNN_AST + hh * 32, lane, wI, L.P, L.R, wJ);
         return;
     }
     blk -= W.tile_wgs;
     if (blk < W.count_wgs) front_count_body(F, sm, blk);
 }
 struct LgSecond {
-    int link_wgs, tsweep_wgs;
+    int link_wgs, tsweep_wgs, all_tiled;
 };
 __global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, LgSecond W, FrontArgs F) {
     int blk = (int)blockIdx.x;
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, L
     const int np = L.row_off[L.A];
     if (np > L.pcap) return;
     const int pt = blk * 4 + (int)(threadIdx.x >> 6);
-    if (pt * 32 < np) lg_pair_tile<true>(L, M, pt, np, F.nbr);
+    if (pt * 32 < np) lg_pair_tile<true>(L, M, pt, np, F.nbr, W.all_tiled != 0);
 }
 
 // ------------------------------------------------------------------------------------------------ reduction of S
@@ -764,7 +776,7 @@ __device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, con
         for (int k = 0; k < NA; ++k) s[k] = L.S_type[(size_t)L.typ_row[at[k]] * 32 + o];
     } else {
         const size_t step = (size_t)L.A * 32;
-        constexpr int CB = 32 / NA;                            // 32 partial sums of a thread in flight
+        constexpr int CB = 32 / NA;                            // 32 partial sums of a thread in flight (64 spill in the fused tail)
         for (int ch = 0; ch < nchunk; ch += CB) {
             float v[NA][CB];
 #pragma unroll
@@ -1121,6 +1133,7 @@ __global__ __launch_bounds__(256) void k_lg_export_q(LargeArgs L) {
 struct LargePlanHost {
     std::vector<int4> atiles, stasks;
     std::vector<int> stask_chunk;
+    std::vector<float> slack;               // per sweep task: partners its range is shorter than its molecule's longest
     int maxchunk = 0;
 };
 
@@ -1153,6 +1166,15 @@ static int large_plan(epnn_handle *h) {
         if (h->opt_large_chunks > 0) want = h->opt_large_chunks;
         int nchunk = std::max(1, std::min(want, (n + 15) / 16));
         int clen = (n + nchunk - 1) / nchunk;
+        // The step's near-pair correction tiles ride on the sweep's wavefronts (k_lg_sweep): a tile costs a wavefront about
+        // as long as four partners.  Lengthen the pieces a little so that the LAST piece of the range comes out short enough
+        // for its workgroups to take the molecule's tiles (~6 pairs per atom expected) in the time the others sweep.
+        {
+            const double tiles = 1.2 * (double)n * 6.0 / 32.0;
+            while (nchunk > 1 && (double)ngroup * (double)((long long)nchunk * clen - n) < tiles &&
+                   (long long)(nchunk - 1) * (clen + 1) < n && clen < n)
+                clen += 1;
+        }
         nchunk = (n + clen - 1) / clen;
         for (int i0 = 0; i0 < n; i0 += 32) lp.atiles.push_back(make_int4(a0 + i0, std::min(32, n - i0), b, nchunk));
         lp.maxchunk = std::max(lp.maxchunk, nchunk);
@@ -1170,6 +1192,7 @@ static int large_plan(epnn_handle *h) {
                 lp.stasks.push_back(make_int4(first_tile + tg, std::min(4, ntile - tg), a0 + ch * clen,
                                               a0 + std::min(n, (ch + 1) * clen)));
                 lp.stask_chunk.push_back(ch);
+                lp.slack.push_back((float)(clen - (std::min(n, (ch + 1) * clen) - ch * clen)));
             }
         }
     }
@@ -1191,6 +1214,24 @@ static int large_plan(epnn_handle *h) {
         h->l_lmol.ensure(nl * sizeof(int)) || h->l_typrow.ensure(A * sizeof(int)) ||
         h->l_typtab.ensure(nl * (2 * EPNN_TYPE_MAX + 1) * sizeof(int)) || h->l_typhash.ensure((A + nl * EPNN_TYPE_MAX) * 8) || h->l_stype.ensure(nl * EPNN_TYPE_MAX * 32 * 4))
         return 1;
+    // shares of the correction tiles: by slack where the tasks' slack can take them all, else evenly on top
+    std::vector<float2> frac(lp.stasks.size());
+    {
+        double total = 0, tiles = 0;
+        for (float v : lp.slack) total += v;
+        for (int b : P.large_list) tiles += (double)(P.offsets[b + 1] - P.offsets[b]) * 6.0 / 32.0;
+        const double even = total >= tiles ? 0.0 : std::max(1.0, (tiles - total) / std::max<size_t>(1, lp.slack.size()));
+        double sum = 0, run = 0;
+        for (float v : lp.slack) sum += v + even;
+        for (size_t k = 0; k < frac.size(); ++k) {
+            const double w = sum > 0 ? (lp.slack[k] + even) / sum : 1.0 / frac.size();
+            frac[k].x = (float)run;
+            run += w;
+            frac[k].y = k + 1 == frac.size() ? 1.f : (float)run;
+        }
+    }
+    if (h->l_sfrac.ensure(std::max<size_t>(1, frac.size()) * sizeof(float2))) return 1;
+    if (!frac.empty()) HIPCHK(hipMemcpyAsync(h->l_sfrac.p, frac.data(), frac.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->l_tiles.p, lp.atiles.data(), lp.atiles.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->l_lmol.p, P.large_list.data(), nl * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (!lp.stasks.empty()) {
@@ -1279,6 +1320,7 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.natiles = h->l_natiles;
     L.stasks = h->l_stasks.as<int4>();
     L.stask_chunk = h->l_schunk.as<int>();
+    L.stask_frac = h->l_sfrac.as<float2>();
     L.nstasks = h->l_nstasks;
     L.pcap = h->pcap;
     L.lmol = h->l_lmol.as<int>();
@@ -1326,7 +1368,7 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
         hipLaunchKernelGGL(k_lg_scan_types, dim3(1u + (types ? (unsigned)L.nlarge : 0u)), dim3(1024), 0, st, L, *front);
         hipLaunchKernelGGL(k_lg_fill_assign, dim3(rows4 + (types ? (unsigned)((P.A + 255) / 256) : 0u)), dim3(256), 0, st, L, *front, (int)rows4);
         if (types) {
-            LgSecond W2{(int)gLink, L.nlarge * 2};
+            LgSecond W2{(int)gLink, L.nlarge * 2, P.fused_count() == 0 ? 1 : 0};
             hipLaunchKernelGGL(k_lg_second, dim3((unsigned)(W2.link_wgs + W2.tsweep_wgs) + gPT), dim3(256), 0, st, L, h->widx.msg[0], W2, *front);
             step0_pairs_done = true;
         } else {

@@ -63,18 +63,20 @@ struct TfUpd {
 
 // Staging loops: `total` elements, element idx loaded by ld(idx) and placed by st(idx, value).  Four loads of a thread are
 // in flight before the first store (a plain loop would wait for every load in front of its LDS write: the loop trip
-// counts are run-time values, the compiler does not overlap the iterations).
+// counts are run-time values, the compiler does not overlap the iterations).  (Twelve in flight measured no faster for one
+// molecule per step and 8 % slower for eight: 0.43 / 0.67 ms against 0.415 / 0.616.)
+#define EPNN_TF_SD 4
 template <typename LD, typename ST>
 __device__ __forceinline__ void tf_stage(int total, int tid, LD &&ld, ST &&st) {
-    for (int base = 0; base < total; base += 4 * EPNN_TF_NT) {
-        float v[4];
+    for (int base = 0; base < total; base += EPNN_TF_SD * EPNN_TF_NT) {
+        float v[EPNN_TF_SD];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EPNN_TF_SD; ++u) {
             const int idx = base + u * EPNN_TF_NT + tid;
             v[u] = idx < total ? ld(idx) : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < EPNN_TF_SD; ++u) {
             const int idx = base + u * EPNN_TF_NT + tid;
             if (idx < total) st(idx, v[u]);
         }

@@ -24,7 +24,9 @@ def main():
         from epnn_amd.rendezvous import launch_ranks
         sys.exit(launch_ranks(__file__, sys.argv[1:], gpus))
     what = argv[0] if len(argv) > 0 else "protein"
-    steps = int(argv[1]) if len(argv) > 1 else 5
+    # (a forward of the protein lasts 0.6 ms: the GPU's clocks need some tens of milliseconds of load to come up, 200 forwards read
+    #  3 % faster than 20 -- profiles/r03_large_systems.txt --, and the default takes a tenth of a second either way)
+    steps = int(argv[1]) if len(argv) > 1 else (200 if what == "protein" else 5)
     w = checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights"))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     device, how = 0, ""
