@@ -220,7 +220,9 @@ def main():
         args.depth = 8 if args.steps >= 200 else next((d for d in (5, 4, 6) if args.steps % d == 0), 6)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: start the rank processes from here, before this process makes any GPU call (it never makes one)
+        from epnn_amd import _lib as _l
         from epnn_amd.rendezvous import launch_ranks
+        _l.visible_gpu_count()                               # (asked once, in a child process; the ranks inherit EPNN_NDEV)
         sys.exit(launch_ranks(__file__, sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -254,7 +256,7 @@ def main():
     if world > 1:
         from epnn_amd.rendezvous import Rendezvous
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        rdzv = Rendezvous(rank, world)
+        rdzv = Rendezvous(rank, world, timeout=600)          # (a fresh box can take minutes to page the libraries in)
         ndev = _lib.load().epnn_device_count()
         if ndev < 1:
             raise SystemExit("bench.py: no HIP device visible")
@@ -272,18 +274,25 @@ def main():
     if world > 1:
         from epnn_amd.engine import Engine
         if ndev >= world:
-            # the library's own communicator on lane 0's handle: every rank joins or the run fails
-            comm_eng = pipe.engines[0]
-            comm_eng.comm_init(rdzv.broadcast(Engine.comm_unique_id() if rank == 0 else None, name="rccl_id"), rank, world)
-            rccl_ranks = comm_eng.comm_count()
-            assert rccl_ranks == world, (rccl_ranks, world)
-            assert comm_eng.comm_allreduce([1.0], "sum")[0] == float(world)
-            backend = "rccl (epnn_comm_allreduce on the library's communicator)"
+            # the library's own communicator on lane 0's handle; the ranks agree over the rendezvous store whether every one of
+            # them joined it -- if not (a node whose RCCL does not come up), all of them time over the store instead and say so
+            ok, why = True, ""
+            try:
+                comm_eng = pipe.engines[0]
+                comm_eng.comm_init(rdzv.broadcast(Engine.comm_unique_id() if rank == 0 else None, name="rccl_id"), rank, world)
+                rccl_ranks = comm_eng.comm_count()
+                ok = rccl_ranks == world and comm_eng.comm_allreduce([1.0], "sum")[0] == float(world)
+            except Exception as exc:                        # noqa: BLE001
+                ok, why = False, str(exc)
+            votes = rdzv.all_gather((bool(ok), why), name="rccl_ok")
+            if all(v[0] for v in votes):
+                backend = "rccl (epnn_comm_allreduce on the library's communicator)"
+            else:
+                print(f"[bench rank {rank}] RCCL communicator unavailable ({[v[1] for v in votes if not v[0]]}); timing exchange over the rendezvous store", file=sys.stderr)
+                comm_eng, rccl_ranks = None, None
+                backend = "rendezvous store (the RCCL communicator did not come up)"
         else:
             backend = "rendezvous store (ranks share a device: RCCL refuses two ranks on one GPU)"
-    for kv in args.opt:
-        name, value = kv.split("=")
-        pipe.set_option(name, int(value))
 
     B = args.molecules
     offsets, xyz, x, Q, N = synth.qm9_like_batch(B=B, seed=rank, N=29)

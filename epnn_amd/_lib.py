@@ -81,25 +81,27 @@ _lib = None
 
 
 def visible_gpu_count():
-    """GPUs this process will see, WITHOUT initialising HIP (the runtime reads GPU_MAX_HW_QUEUES when it starts, so a driver
-    that wants to size its queues by ranks per device must count devices first): the *_VISIBLE_DEVICES lists if set, else
-    the KFD topology's nodes with SIMDs.  0 when neither says anything (the caller then asks the library)."""
+    """GPUs this process will see, WITHOUT initialising HIP in it (the runtime reads GPU_MAX_HW_QUEUES when it starts, so a
+    driver that wants to size its queues by ranks per device must count devices first): EPNN_NDEV if a launcher exported it,
+    the *_VISIBLE_DEVICES lists if set, else the library's own answer from a short-lived child process (the KFD topology in
+    /sys also lists devices a container cannot open).  0 when nothing can be said."""
+    import subprocess
+    import sys
+    v = os.environ.get("EPNN_NDEV")
+    if v and v.isdigit():
+        return int(v)
     for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None and v.strip() != "":
             return len([t for t in v.split(",") if t.strip() != ""])
-    n = 0
-    base = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        for node in os.listdir(base):
-            try:
-                with open(os.path.join(base, node, "properties")) as f:
-                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-                n += 1 if int(props.get("simd_count", "0")) > 0 else 0
-            except (OSError, ValueError):
-                pass
-    except OSError:
+        out = subprocess.run([sys.executable, "-c",
+                              "import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); lib.epnn_device_count.restype = ctypes.c_int; print(lib.epnn_device_count())",
+                              LIB_PATH], capture_output=True, text=True, timeout=300)
+        n = int(out.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
         return 0
+    os.environ["EPNN_NDEV"] = str(n)                          # children of this process (launch_ranks) need not ask again
     return n
 
 

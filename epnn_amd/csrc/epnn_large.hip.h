@@ -759,35 +759,63 @@ __global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, L
 // element adds its own terms in the same order whatever NA is.
 template <int NA>
 __device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, const int (&a)[NA], int o, int n, int types, float (&out)[NA]) {
-    const int nchunk = tl.w;
+    const int nchunk = types ? 0 : tl.w;
     int at[NA], lo[NA], hi[NA];
     bool ok[NA];
-    float s[NA];
+    float s[NA], zpv[NA];
+    // The loads are issued in as few dependent rounds as the data allows (every round is ~1 us on data the previous launch
+    // wrote): (1) row bounds, the padded partners' term, the first partial sums (or the atom's type); (2) the LAST batch of
+    // partial sums (or the type's row) together with the first eight slots of the atom's row; (3) the rest of the row.  The order
+    // in which an element's terms are ADDED is what it always was: partial sums in piece order, slots in slot order, padding.
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         ok[k] = a[k] < tl.y;
         at[k] = tl.x + (ok[k] ? a[k] : 0);
         lo[k] = L.inc_off[at[k]];
         hi[k] = L.inc_off[at[k] + 1];
+        zpv[k] = L.zp[(size_t)at[k] * 32 + o];
         s[k] = 0.f;
     }
+    constexpr int CB = 32 / NA;                                // 32 partial sums of a thread in flight (64 spill in the fused tail)
+    constexpr int S1 = 8;
+    const size_t step = (size_t)L.A * 32;
+    int trow[NA];
     if (types) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) s[k] = L.S_type[(size_t)L.typ_row[at[k]] * 32 + o];
-    } else {
-        const size_t step = (size_t)L.A * 32;
-        constexpr int CB = 32 / NA;                            // 32 partial sums of a thread in flight (64 spill in the fused tail)
-        for (int ch = 0; ch < nchunk; ch += CB) {
-            float v[NA][CB];
+        for (int k = 0; k < NA; ++k) trow[k] = L.typ_row[at[k]];
+    }
+    int ch = 0;
+    for (; ch + CB < nchunk; ch += CB) {                       // every batch but the last
+        float v[NA][CB];
 #pragma unroll
-            for (int k = 0; k < NA; ++k)
+        for (int k = 0; k < NA; ++k)
 #pragma unroll
-                for (int u = 0; u < CB; ++u) v[k][u] = ch + u < nchunk ? L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step] : 0.f;
+            for (int u = 0; u < CB; ++u) v[k][u] = L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step];
 #pragma unroll
-            for (int k = 0; k < NA; ++k)
+        for (int k = 0; k < NA; ++k)
 #pragma unroll
-                for (int u = 0; u < CB; ++u)
-                    if (ch + u < nchunk) s[k] += v[k][u];
+            for (int u = 0; u < CB; ++u) s[k] += v[k][u];
+    }
+    {
+        float v[NA][CB], c1[NA][S1], tv[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            tv[k] = types ? L.S_type[(size_t)trow[k] * 32 + o] : 0.f;
+#pragma unroll
+            for (int u = 0; u < CB; ++u) v[k][u] = ch + u < nchunk ? L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step] : 0.f;
+#pragma unroll
+            for (int u = 0; u < S1; ++u) c1[k][u] = lo[k] + u < hi[k] ? L.corrA[(size_t)(lo[k] + u) * 32 + o] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            if (types) s[k] = tv[k];
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+                if (ch + u < nchunk) s[k] += v[k][u];
+#pragma unroll
+            for (int u = 0; u < S1; ++u)
+                if (lo[k] + u < hi[k]) s[k] += c1[k][u];
+            lo[k] += S1;
         }
     }
     int left = 0;
@@ -809,7 +837,7 @@ __device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, con
         }
     }
 #pragma unroll
-    for (int k = 0; k < NA; ++k) out[k] = ok[k] ? s[k] + (float)(L.N - n) * L.zp[(size_t)at[k] * 32 + o] : 0.f;
+    for (int k = 0; k < NA; ++k) out[k] = ok[k] ? s[k] + (float)(L.N - n) * zpv[k] : 0.f;
 }
 __global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin, int types) {
     if (L.row_off[L.A] > L.pcap) return;
