@@ -1008,3 +1008,72 @@ def test_randomised_sweeps_with_a_fixed_seed(script, seed):
     out = subprocess.run([sys.executable, os.path.join(here, script), str(seed), "25"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "fuzz ok" in out.stdout or "0 not explained by a ReLU kink" in out.stdout, out.stdout[-500:]
+
+
+def test_tiled_path_variants_agree(gpu_engine_factory, weights_full, golden_dir):
+    """The tiled path's launch variants on the 2220-atom protein with model_weights (nx = 10, non-collapsed GNN): the merged
+    launches of the compact entry (`large_merge`) and the one-kernel-per-stage form (`large_fused` = 0, what a partition runs)
+    are the SAME arithmetic as the default -- bit-identical --; the first GNN step by atom types (`large_dedupe`) is an exact
+    re-association of the all-pairs sum (count x value instead of repeated adds): float32 rounding apart."""
+    from oracle import epnn_oracle as orc
+    xyz, x, Q = orc.parse_xyz(os.path.join(golden_dir, "protein", "6qlp_capped.xyz"), 10)
+    n = x.shape[0]
+    off, Qa = np.array([0, n], np.int32), np.array([Q], np.float32)
+
+    def run(**opts):
+        eng = gpu_engine_factory(nx=10, T=5)
+        eng.set_weights(weights_full)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        q = eng.forward_xyz(off, xyz, x, Qa, N=n)
+        assert eng.last_stats()[2] == 1 and eng.last_stats()[3] == 0
+        return q
+
+    ref = run()
+    assert np.isfinite(ref).all()
+    assert np.array_equal(run(large_merge=0), ref)
+    assert np.array_equal(run(large_fused=0), ref)
+    assert np.array_equal(run(large_chunks=14), run(large_chunks=14, large_fused=0))
+    sweep = run(large_dedupe=0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    print(f"protein, model_weights: first step by types vs by sweep: max |dq| {np.abs(sweep - ref).max():.2e} (|q| up to {scale:.2f})")
+    assert np.abs(sweep - ref).max() <= 2e-4 * scale          # model_weights: |h| ~ 150, float32 noise of the algorithm itself ~1e-4
+    assert np.array_equal(run(large_dedupe=0, large_merge=0), sweep)
+
+
+def test_more_atom_types_than_the_table_holds_falls_back_to_the_sweep(gpu_engine_factory):
+    """The first GNN step groups the atoms of a tiled molecule by feature row (at most 64 distinct rows).  A molecule whose
+    rows are ALL different overflows the table: the device raises the flag, the host repeats the forward with the all-pairs
+    sweep and the handle stays on the sweep; a molecule with few types next to it does not change that.  Against the float64
+    oracle, and the repeat is counted in the stats."""
+    from oracle import epnn_oracle as orc
+    nx, T = 9, 2
+    w = random_weights(nx, T, seed=5, scale=0.3)
+    rng = np.random.default_rng(3)
+    mols = []
+    for n, distinct in ((90, True), (70, False)):
+        pts = rng.uniform(0, 9.0, size=(n, 3)).astype(np.float32)
+        x = np.zeros((n, nx), np.float32)
+        x[np.arange(n), 1 + rng.integers(0, 4, size=n)] = 1
+        x[:, 0] = np.arange(n) * 0.01 + 1.0 if distinct else rng.choice([1.0, 6.0, 8.0], size=n)
+        mols.append((pts, x, np.float32(0)))
+    off, xyz, x, Q = _batch(mols)
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+    q = eng.forward_xyz(off, xyz, x, Q, N=96)
+    st = eng.last_stats()
+    assert st[2] == 2 and st[3] >= 1, st                       # two tiled molecules, at least one repeat of the forward
+    ref = _oracle_batch(mols, w, 96)
+    ref32 = _oracle_batch(mols, w, 96, np.float32)
+    err = max(np.abs(q[off[k]:off[k + 1]] - ref[k][:len(m[0])]).max() for k, m in enumerate(mols))
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    assert err <= max(TOL, 3 * noise), (err, noise)
+    q2 = eng.forward_xyz(off, xyz, x, Q, N=96)                 # the handle now sweeps: no repeat, same bits
+    assert eng.last_stats()[3] == st[3] and np.array_equal(q2, q)
+    # few types only: the table serves, and the result agrees with the sweep's to rounding
+    eng2 = gpu_engine_factory(nx=nx, T=T)
+    eng2.set_weights(w)
+    o2 = np.array([0, 70], np.int32)
+    qa = eng2.forward_xyz(o2, mols[1][0], mols[1][1], Q[1:], N=96)
+    assert eng2.last_stats()[3] == 0
+    assert np.abs(qa - q[off[1]:off[2]]).max() <= max(TOL, 3 * noise)
