@@ -1810,6 +1810,17 @@ extern "C" int epnn_comm_allreduce(epnn_handle *h, double *inout, int32_t n, int
 
 // The pair list the separate front-end (or the dense front-end) built for the last forward: indices and near weights of up
 // to `cap` pairs (tests: the device's D < cutoff and is_near decisions against a host count).  Returns the number of pairs.
+#ifdef EPNN_TF_CLOCKS
+// development build only (tools/train_clocks.py): phase clocks of workgroup 0 of every row-fused training launch of the last step
+extern "C" int epnn_debug_train_clocks(epnn_handle *h, unsigned long long *dst, int n) {
+    if (!h || !dst || !h->train) EPNN_FAIL("epnn_debug_train_clocks: bad argument");
+    TrainState *ts = train_state(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(dst, ts->clk.p, (size_t)std::min(n, 64 * 16) * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 extern "C" int epnn_debug_pairs(epnn_handle *h, int32_t *pi, int32_t *pj, float *pwi, int64_t cap, int64_t *count_out) {
     if (!h || !pi || !pj || !pwi || !count_out || cap < 0) EPNN_FAIL("epnn_debug_pairs: bad argument");
     HIPCHK(hipSetDevice(h->device));

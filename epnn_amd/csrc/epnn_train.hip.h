@@ -340,6 +340,9 @@ struct TrainState {
     hipGraphExec_t gexec = nullptr;
     std::vector<const void *> gkey;
     bool fused_attr = false;                     // dynamic LDS limit of the row-fused kernels raised
+#ifdef EPNN_TF_CLOCKS
+    DevBuf clk;                                  // [launch][16] phase clocks of workgroup 0 (development build)
+#endif
 };
 
 static TrainState *train_state(epnn_handle *h) {
@@ -599,6 +602,9 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = 0; t < T; ++t) es[t] = {sz(2 * R * 32), sz(2 * R * 32), sz(BN)};
     const size_t o_dz1a = sz(2 * R * 32), o_dz1b = sz(2 * R * 32), o_dU0 = sz((size_t)BN * 80), o_gh = sz((size_t)BN * H),
                  o_gfeat = sz((size_t)BN * H), o_gq = sz(BN);
+    // matrix-pipe backward: second copies of what the scalar kernels update in place (several workgroups per atom read the
+    // previous launch's copy while one of them writes this launch's), and the row sums a sweep leaves for the next prologue
+    const size_t o_dU0b = sz((size_t)BN * 80), o_gfeatb = sz((size_t)BN * H), o_gqb = sz(BN), o_rsa = sz((size_t)BN * 64), o_rsb = sz((size_t)BN * 64);
     size_t o_pm[EPNN_MAXT], o_pp[EPNN_MAXT];
     for (int t = 0; t < T; ++t) o_pm[t] = sz((size_t)BN * Pm0);
     for (int t = 0; t < T; ++t) o_pp[t] = sz((size_t)BN * Pm1);
@@ -608,10 +614,14 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     const size_t lds_bwd = ((size_t)N * FS + (size_t)N * 49 + 8 * (size_t)N * 33 + 32 * 33 + 192 + N + 336 + 128) * 4;
     if (!ts->fused_attr) {
         const int cap = 160 * 1024;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd_mm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd_mm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         ts->fused_attr = true;
     }
     if (size_only) return 0;            // scratch is allocated: nothing below calls the allocator (graph capture)
@@ -619,6 +629,11 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     auto P = [&](size_t off) { return ar + off; };
     float *nm = P(o_nm), *wgt = P(o_wgt);
     float *gq = P(o_gq), *gfeat = P(o_gfeat), *gh = P(o_gh);
+#ifdef EPNN_TF_CLOCKS
+    int nclk = 0;
+    if (ts->clk.ensure(64 * 16 * 8)) return 1;
+    HIPCHK(hipMemsetAsync(ts->clk.p, 0, 64 * 16 * 8, st));
+#endif
     auto pair_args = [&](const TDense *mlp, const float *hh, const float *qq) {
         TfPair A{};
         A.x = d_x; A.h = hh; A.q = qq; A.e = d_e; A.theta = theta;
@@ -626,6 +641,9 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.N = N; A.nx = nx; A.wgt = wgt; A.nm = nm;
         A.nm_w = nm; A.wgt_w = wgt; A.tol = h->cfg.near_tol; A.pmode = -1;
         A.gfeat = gfeat; A.gh = gh; A.gqv = gq; A.gq = gq; A.dU0 = P(o_dU0);
+#ifdef EPNN_TF_CLOCKS
+        A.clk = ts->clk.as<unsigned long long>() + 16 * (nclk++);
+#endif
         return A;
     };
     auto upd_args = [&](int t, const float *hh) {
@@ -641,6 +659,11 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     // SLOWER than the row-fused forward at these sizes (0.66 vs 0.47 ms per step: three workgroups per molecule are a chain of
     // dependent MFMAs where the row-fused kernels have 41 x 16 wavefronts), so it is an option, not the default.
     const bool mfma_fwd = h->opt_train_fused == 2 && nx + 49 <= EPNN_TM_FS;
+    // hidden layers of the row-fused kernels on the matrix pipe ("train_fused" = 1, the default); 3 = the scalar FMA version
+    const bool mm = h->opt_train_fused != 3 && nx + 49 <= EPNN_TF_FMAX && ((uintptr_t)d_e & 15) == 0;
+    auto lds_bwd_mm = [&](int nd) { return ((size_t)4 * nd * N * EPNN_TB_RS + (size_t)N * EPNN_TB_ES + 1168 + (size_t)N * FS) * 4; };
+    // one molecule per step is N workgroups on 256 CUs: up to four workgroups per atom share its weight-gradient jobs
+    const int nsplit = std::max(1, std::min(4, 256 / BN));
     const int nblk = (N + 15) / 16;
     const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + EPNN_TM_NW * 16 * 33) * 4;
     if (mfma_fwd) {
@@ -654,7 +677,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
         if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the node masks
         if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<0>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, upd_args(t, hcur), nblk);
-        else hipLaunchKernelGGL(k_tf_pair_fwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
+        else if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<0, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));
+        else hipLaunchKernelGGL((k_tf_pair_fwd<0, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
         hcur = P(gs[t].hn);
     }
     const float *feats = hcur;
@@ -666,7 +690,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the pair weights
         if (t == T - 1 && !mfma_fwd) { A.y = d_y; A.pred = d_pred; A.lterm = d_loss; }
         if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<1>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, TfUpd{}, nblk);
-        else hipLaunchKernelGGL(k_tf_pair_fwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
+        else if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
+        else hipLaunchKernelGGL((k_tf_pair_fwd<1, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         qcur = P(es[t].qn);
     }
     if (mfma_fwd) hipLaunchKernelGGL(k_t_loss_terms, dim3(t_grid(BN)), dim3(256), 0, st, d_y, qcur, d_pred, d_loss, BN);
@@ -679,6 +704,14 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.dz1 = P((nb & 1) ? o_dz1b : o_dz1a);
         A.pdz1 = P((nb & 1) ? o_dz1a : o_dz1b);
         A.pmode = pmode; A.poW1 = poW1; A.pfirst = pfirst;
+        if (mm) {
+            const bool odd = nb & 1;
+            A.nsplit = nsplit;
+            A.gfeat = P(odd ? o_gfeatb : o_gfeat); A.gfeat_r = P(odd ? o_gfeat : o_gfeatb);
+            A.gqv = P(odd ? o_gqb : o_gq); A.gq_r = P(odd ? o_gq : o_gqb);
+            A.dU0_r = P(odd ? o_dU0 : o_dU0b);
+            A.rs_w = P(odd ? o_rsb : o_rsa); A.rs_r = P(odd ? o_rsa : o_rsb);
+        }
         nb += 1;
     };
     for (int t = T - 1; t >= 0; --t) {
@@ -686,7 +719,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.part = P(o_pp[t]);
         A.first = t == T - 1; A.y = d_y; A.pred = d_pred;
         chain(A);
-        hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, TfUpd{});
+        if (mm) hipLaunchKernelGGL(k_tb_pair_bwd_mm<1>, dim3(BN * nsplit), dim3(EPNN_TF_NT), lds_bwd_mm(2), st, A, TfUpd{});
+        else hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, TfUpd{});
         pmode = 1; poW1 = ts->pas[t][0].offW; pfirst = t == T - 1;
     }
     for (int t = T - 1; t >= 0; --t) {
@@ -694,7 +728,12 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         TfPair A = pair_args(ts->msg[t], hin, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.part = P(o_pm[t]);
         chain(A);
-        hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, upd_args(t, hin));     // update backward first
+        if (mm) {
+            TfUpd Ub = upd_args(t, hin);
+            Ub.dU0 = P(((nb - 1) & 1) ? o_dU0b : o_dU0);               // chain() has counted this launch
+            hipLaunchKernelGGL(k_tb_pair_bwd_mm<0>, dim3(BN * nsplit), dim3(EPNN_TF_NT), lds_bwd_mm(1), st, A, Ub);
+        }
+        else hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, upd_args(t, hin));     // update backward first
         pmode = 0; poW1 = ts->msg[t][0].offW; pfirst = 0;
     }
     // ================================================================ gradient = sum of the workgroups' partials (+ Adam)

@@ -15,6 +15,7 @@
 #define EPNN_TF_NT 512           // threads of a pair workgroup: 16 row groups x 32 outputs
 #define EPNN_TF_NG (EPNN_TF_NT / 32)
 #define EPNN_TF_JM 3             // partner rows per thread and pass of the layer-1 loop (16 row groups x 3 = 48 rows)
+#define EPNN_TF_FMAX 60         // matrix-pipe layers: F = nx + 49 <= 60 (15 K steps of 4 per atom block)
 #define EPNN_TF_KT 4             // weight rows per thread and pass of the dW1 loops
 
 struct TfPair {                  // one sweep of a pair MLP (message network of GNN step t / pass network of EPN step t)
@@ -47,7 +48,23 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     int pfirst;                  // pmode 1: that sweep was the first one (gfeat starts from it instead of adding to it)
     const float *pdz1;           // that sweep's dz1 (the sweeps alternate between two buffers)
     float *gfeat, *gh, *gqv;     // [BN][48], [BN][48], [BN]
+    // matrix-pipe backward (k_tb_pair_bwd_mm): `nsplit` workgroups per atom share its weight-gradient jobs (one molecule is 41
+    // workgroups on 256 CUs); what a launch updates in place in the scalar kernel is read from the previous launch's copy here
+    int nsplit;
+    const float *gfeat_r, *gq_r, *dU0_r; // the previous launch's gfeat / gq / dU0 (this one writes gfeat / gqv / U.dU0)
+    const float *rs_r;                   // [BN][2][32] the previous sweep's row sums of dz1 (listed, swapped rows of each atom)
+    float *rs_w;
+#ifdef EPNN_TF_CLOCKS
+    unsigned long long *clk;     // development build (tools/train_clocks.py): wall_clock64 (100 MHz) of workgroup 0 at the phase boundaries
+#endif
 };
+#ifdef EPNN_TF_CLOCKS
+#define TF_CLK_T(k, t) do { if (A.clk && blockIdx.x == 0 && threadIdx.x == (t)) A.clk[k] = wall_clock64(); } while (0)
+#define TF_CLK(k) TF_CLK_T(k, 0)
+#else
+#define TF_CLK_T(k, t) do { } while (0)
+#define TF_CLK(k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------- update MLP arguments
 struct TfUpd {
@@ -61,9 +78,17 @@ struct TfUpd {
 #define EPNN_TF_PU (80 * 32 + 32 + 32 * 32 + 32 + 32 * 48 + 48)
 
 
+// Matrix-pipe helpers (v_mfma_f32_16x16x4_f32).  Lane (q, x) = (lane >> 4, lane & 15) holds A[m = x][k = q] and B[k = q][n = x];
+// accumulator register r of that lane is D[m = 4 q + r][n = x].  Here a COLUMN n is a pair row and m an output feature, so a
+// 32-feature vector of a row is two row blocks rb x four registers: feature 16 rb + 4 q + r.
+__device__ __forceinline__ f32x4 tm_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 tm_relu(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+__device__ __forceinline__ f32x4 tm_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void tm_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
 // Staging loops: `total` elements, element idx loaded by ld(idx) and placed by st(idx, value).  Four loads of a thread are
 // in flight before the first store (a plain loop would wait for every load in front of its LDS write: the loop trip
-// counts are run-time values, the compiler does not overlap the iterations).  (Twelve in flight measured no faster for one
+// counts are run-time values, the compiler does not overlap the iterations).  The loads are unconditional, of a clamped index.  (Twelve in flight measured no faster for one
 // molecule per step and 8 % slower for eight: 0.43 / 0.67 ms against 0.415 / 0.616.)
 #define EPNN_TF_SD 4
 template <typename LD, typename ST>
@@ -71,9 +96,9 @@ __device__ __forceinline__ void tf_stage(int total, int tid, LD &&ld, ST &&st) {
     for (int base = 0; base < total; base += EPNN_TF_SD * EPNN_TF_NT) {
         float v[EPNN_TF_SD];
 #pragma unroll
-        for (int u = 0; u < EPNN_TF_SD; ++u) {
-            const int idx = base + u * EPNN_TF_NT + tid;
-            v[u] = idx < total ? ld(idx) : 0.f;
+        for (int u = 0; u < EPNN_TF_SD; ++u) {        // unconditional loads of a clamped index: a load under `if` becomes a branch
+            const int idx = base + u * EPNN_TF_NT + tid;    // with s_waitcnt vmcnt(0) in front of the next one -- one round trip EACH
+            v[u] = ld(idx < total ? idx : total - 1);
         }
 #pragma unroll
         for (int u = 0; u < EPNN_TF_SD; ++u) {
@@ -87,13 +112,43 @@ __device__ __forceinline__ void tf_stage(int total, int tid, LD &&ld, ST &&st) {
 // MODE 0: message network (out_dim 32, summed over ALL N partners); MODE 1: pass network (out_dim 1, both orders).
 // MODE 0 with U.theta set also runs the update MLP of its atom (charge_gn.py:71-74: it needs only the atom's own h and
 // summed message), which used to be a launch of its own per step.
-template <int MODE>
+//
+// MM: the two hidden layers on the matrix pipe.  A wavefront owns 16 partner rows of one order of the pair (job = tile x order;
+// N = 41 is 3 or 6 jobs on the workgroup's 8 wavefronts) and runs [a_i | a_j | e_ij] W1 as 2 F / 4 + 12 K steps of
+// v_mfma_f32_16x16x4_f32 with its W1 / W2 fragments read from L2 straight into registers -- issued before the rows are staged, so
+// the two latencies overlap and W1 (21 KB, the largest staging) never goes through LDS -- then layer 2 from the accumulators as
+// they stand.  The scalar version (MM = false) is the same arithmetic as 164 + 32 dependent FMAs per thread behind LDS reads.
+template <int MODE, bool MM>
 __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
     const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
     const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
     const int tid = threadIdx.x, o = tid & 31, g = tid >> 5;
     constexpr int ND = MODE ? 2 : 1;
+    TF_CLK(0);
+    // ---- MM: this wavefront's weight fragments (every job of a wavefront has the same order of the pair: 8 % ND == 0)
+    constexpr int KA = MM ? (EPNN_TF_FMAX + 3) / 4 : 1;       // K steps of an atom block
+    const int wave = tid >> 6, lq = (tid >> 4) & 3, lx = tid & 15;
+    const int njobs = ((N + 15) / 16) * ND, jdir = wave % ND;
+    float wi[2][KA], wj[2][KA], we[2][MM ? 12 : 1], w2f[2][MM ? 8 : 1];
+    if (MM && wave < njobs) {
+        // order 0 rows are [a_i | a_j | e_ij]: the workgroup's atom meets block 0 of W1; order 1 rows are [a_j | a_i | e_ij]
+        const float *w1 = A.theta + A.oW1, *w2 = A.theta + A.oW2;
+        const int own = jdir ? F : 0, oth = jdir ? 0 : F;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int s = 0; s < KA; ++s) {
+                const int k = 4 * s + lq;
+                wi[rb][s] = k < F ? w1[(own + k) * 32 + 16 * rb + lx] : 0.f;
+                wj[rb][s] = k < F ? w1[(oth + k) * 32 + 16 * rb + lx] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 12; ++s) we[rb][s] = w1[(2 * F + 4 * s + lq) * 32 + 16 * rb + lx];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) w2f[rb][s] = w2[(16 * (s >> 2) + 4 * lq + (s & 3)) * 32 + 16 * rb + lx];
+        }
+    }
     float *As = tf_sm;                        // [N][FS]   a_j of every atom of the molecule
     float *Es = As + N * FS;                  // [N][49]   e_ij of this atom's rows
     float *W1s = Es + N * 49;                 // [D][32]
@@ -102,16 +157,50 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     float *red = H2s + ND * N * 33;           // [NG][32] + [32]  /  [2][N]
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
-    tf_stage(N * F, tid,
-             [&](int idx) {
-                 const int j = idx / F, k = idx - j * F;
-                 const size_t at = a0 + j;
-                 return k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
-             },
-             [&](int idx, float v) { const int j = idx / F; As[j * FS + (idx - j * F)] = v; });
-    tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
-             [&](int idx, float v) { const int j = idx / 48; Es[j * 49 + (idx - j * 48)] = v; });
-    tf_stage(D * 32, tid, [&](int idx) { return A.theta[A.oW1 + idx]; }, [&](int idx, float v) { W1s[idx] = v; });
+    if (MM) {
+        // both arrays' loads of a round are in flight before the first LDS write (N = 41 is one round)
+        const int nA = N * F, nE = N * 48;
+        const int rounds = max((nA + 5 * EPNN_TF_NT - 1) / (5 * EPNN_TF_NT), (nE + 4 * EPNN_TF_NT - 1) / (4 * EPNN_TF_NT));
+        for (int rd = 0; rd < rounds; ++rd) {
+            float va[5], ve[4];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int ia = min((5 * rd + u) * EPNN_TF_NT + tid, nA - 1);
+                const int j = ia / F, k = ia - j * F;
+                const size_t at = a0 + j;
+                va[u] = *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ve[u] = A.e[rowbase * 48 + min((4 * rd + u) * EPNN_TF_NT + tid, nE - 1)];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int ia = (5 * rd + u) * EPNN_TF_NT + tid;
+                if (ia < nA) {
+                    const int j = ia / F;
+                    As[j * FS + (ia - j * F)] = va[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ie = (4 * rd + u) * EPNN_TF_NT + tid;
+                if (ie < nE) {
+                    const int j = ie / 48;
+                    Es[j * 49 + (ie - j * 48)] = ve[u];
+                }
+            }
+        }
+    } else {
+        tf_stage(N * F, tid,
+                 [&](int idx) {
+                     const int j = idx / F, k = idx - j * F;
+                     const size_t at = a0 + j;
+                     return *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));      // one load of a selected address
+                 },
+                 [&](int idx, float v) { const int j = idx / F; As[j * FS + (idx - j * F)] = v; });
+        tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
+                 [&](int idx, float v) { const int j = idx / 48; Es[j * 49 + (idx - j * 48)] = v; });
+    }
+    if (!MM) tf_stage(D * 32, tid, [&](int idx) { return A.theta[A.oW1 + idx]; }, [&](int idx, float v) { W1s[idx] = v; });
     float *wl = red + EPNN_TF_NG * 32 + 32 + 2 * N;            // [N] pair weights of this atom's rows (pass network)
     if (MODE == 0 && A.mask && tid < 64) {
         // node mask of this atom (charge_gn.py:59): clip(sum_j mask[j][i], 0, 1); what k_t_nodemask did in a launch of its own
@@ -125,6 +214,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         }
     }
     __syncthreads();
+    TF_CLK(1);
     if (MODE == 1) {
         // pair weights mask * is_near (charge_gn.py:90-94,116): from the staged e rows on the stack's first launch, else as stored
         for (int j = tid; j < N; j += EPNN_TF_NT) {
@@ -140,6 +230,56 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             wl[j] = w;
         }
     }
+    if (MM) {
+        const float *ai = As + i * FS;
+        for (int job = wave; job < njobs; job += EPNN_TF_NT / 64) {
+            const int j = (job / ND) * 16 + lx;
+            const bool jv = j < N;
+            const float *aj = As + (jv ? j : 0) * FS, *ej = Es + (jv ? j : 0) * 49;
+            f32x4 acc[2], d2[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                acc[rb] = tm_ld4(A.theta + A.ob1 + 16 * rb + 4 * lq);
+                d2[rb] = tm_ld4(A.theta + A.ob2 + 16 * rb + 4 * lq);
+            }
+#pragma unroll
+            for (int s = 0; s < KA; ++s) {
+                const int k = 4 * s + lq;
+                const float vi = k < F ? ai[k] : 0.f, vj = (k < F && jv) ? aj[k] : 0.f;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    acc[rb] = tm_mfma(wi[rb][s], vi, acc[rb]);
+                    acc[rb] = tm_mfma(wj[rb][s], vj, acc[rb]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 12; ++s) {
+                const float ve = jv ? ej[4 * s + lq] : 0.f;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb] = tm_mfma(we[rb][s], ve, acc[rb]);
+            }
+            acc[0] = tm_relu(acc[0]);
+            acc[1] = tm_relu(acc[1]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) d2[rb] = tm_mfma(w2f[rb][s], acc[s >> 2][s & 3], d2[rb]);
+            }
+            d2[0] = tm_relu(d2[0]);
+            d2[1] = tm_relu(d2[1]);
+            if (jv) {
+                float *l2 = H2s + (jdir * N + j) * 33;
+                float *g1 = A.H1 + jdir * dstride + (rowbase + j) * 32, *g2 = A.H2 + jdir * dstride + (rowbase + j) * 32;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    tm_st4(g1 + 16 * rb + 4 * lq, acc[rb]);
+                    tm_st4(g2 + 16 * rb + 4 * lq, d2[rb]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) l2[16 * rb + 4 * lq + r] = d2[rb][r];
+                }
+            }
+        }
+    } else {
     // ---- layer 1: z1 = b1 + a_i W1[0:F] + a_j W1[F:2F] + e_ij W1[2F:]   (the a_i term once per thread, not per row)
     const float b1 = A.theta[A.ob1 + o];
     const float *ai = As + i * FS;
@@ -203,7 +343,9 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 A.H2[d * dstride + (rowbase + j) * 32 + o] = h2;
             }
     }
+    }
     __syncthreads();
+    TF_CLK(2);
     // ---- layer 3 (linear) and the reduction over partners
     if (MODE == 0) {
         // sum_j (H2_j W3 + b3) = (sum_j H2_j) W3 + N b3: column sums in a fixed order (row groups, then the groups in order), then one 32x32 product
@@ -217,6 +359,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             red[EPNN_TF_NG * 32 + tid] = s;
         }
         __syncthreads();
+        TF_CLK(3);
         float *u0 = red, *u1 = red + 80, *u2 = red + 112;       // the group sums red[0 .. NG*32) are dead by now
         const bool upd = U.theta != nullptr;
         const float nm = upd ? (A.mask ? wl[0] : U.nm[bi]) : 0.f;
@@ -237,6 +380,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         }
         if (!upd) return;
         __syncthreads();
+        TF_CLK(4);
         if (tid < 32) {
             float z = U.theta[U.ob0 + tid];
             for (int k = 0; k < 80; ++k) z = fmaf(u0[k], U.theta[U.oW0 + k * 32 + tid], z);
@@ -258,6 +402,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             for (int k = 0; k < 32; ++k) z = fmaf(u2[k], U.theta[U.oW2 + k * 48 + tid], z);
             U.hn[(size_t)bi * 48 + tid] = z * nm;
         }
+        TF_CLK(5);
     } else {
         float *fs = red;                      // [2][N]
         for (int idx = tid; idx < 2 * N; idx += EPNN_TF_NT) {
@@ -267,6 +412,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             fs[idx] = f;
         }
         __syncthreads();
+        TF_CLK(3);
         if (tid == 0) {
             float s = 0.f;
             for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * wl[j];
@@ -278,6 +424,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 A.lterm[bi] = d * d;
             }
         }
+        TF_CLK(5);
     }
 }
 
@@ -308,6 +455,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
     // ---- prologue: what the previous backward launch leaves for this atom -- the gradient that reaches a_i through the first
     // Dense of that sweep (k_tb_atoms' arithmetic, a launch of its own before): gq / gfeat after a pass sweep, gh after a
     // message sweep; and on the first pass sweep gq = -2 (y - pred)   (charge_gn.py:397-398)
+    TF_CLK(0);
     if (MODE == 1 && A.first && tid == 0) A.gqv[bi] = -2.f * (A.y[bi] - A.pred[bi]);
     if (A.pmode >= 0) {
         if (tid < 128) {
@@ -355,11 +503,12 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
         __threadfence_block();
     }
     __syncthreads();
+    TF_CLK(1);
     tf_stage(N * F, tid,
              [&](int idx) {
                  const int j = idx / F, k = idx - j * F;
                  const size_t at = a0 + j;
-                 return k < nx ? A.x[at * nx + k] : (k < nx + 48 ? A.h[at * 48 + (k - nx)] : A.q[at]);
+                 return *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));      // one load of a selected address
              },
              [&](int idx, float v) { const int j = idx / F; As[j * FS + (idx - j * F)] = v; });
     tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
@@ -371,6 +520,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
                  [&](int idx, float v) { H2s[(d * N + (idx >> 5)) * 33 + (idx & 31)] = v; });
     }
     tf_stage(1024, tid, [&](int idx) { return A.theta[A.oW2 + idx]; }, [&](int idx, float v) { W2s[(idx >> 5) * 33 + (idx & 31)] = v; });
+    TF_CLK(2);
     if (MODE == 0) {
         if (U.theta != nullptr) {
             float *u0 = ub, *u1 = ub + 80, *u2 = ub + 112, *dh = ub + 144, *du2 = ub + 192, *du1 = ub + 224, *dU = ub + 256;
@@ -421,6 +571,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
         for (int j = tid; j < N; j += EPNN_TF_NT) dfs[j] = gqi * A.wgt[rowbase + j];      // df_ij; the swapped row gets -df_ij
     }
     __syncthreads();
+    TF_CLK(3);
     // ---- gradient at z2 = [H2 > 0] * (dOut W3^T)
     if (MODE == 0) {
         if (tid < 32) {
@@ -442,6 +593,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
             }
     }
     __syncthreads();
+    TF_CLK(4);
     // ---- gradient at z1 = [H1 > 0] * (dz2 W2^T); thread = (k = o, row group g)
     {
         float w2row[32];
@@ -459,6 +611,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
             }
     }
     __syncthreads();
+    TF_CLK(5);
     // ---- column sums (fixed order over j)
     if (tid < 32 * ND) {                      // s1[d][o] = sum_j dz1
         const int d = tid >> 5;
@@ -481,6 +634,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
         c2[o] = s;
     }
     __syncthreads();
+    TF_CLK(6);
     // ---- weight-gradient partials of this workgroup, in parameter order: W1 [D][32] | b1 | W2 [32][32] | b2 | W3 [32][O] | b3
     const int Pm = D * 32 + 32 + 1024 + 32 + 32 * O + O;
     float *P = A.part + (size_t)bi * Pm;
@@ -524,6 +678,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
 #pragma unroll
         for (int kk = 0; kk < EPNN_TF_KT; ++kk) P[(2 * F + k0 + kk) * 32 + o] = acc[kk];
     }
+    TF_CLK(7);
     float *Pb1 = P + D * 32, *PW2 = Pb1 + 32, *Pb2 = PW2 + 1024, *PW3 = Pb2 + 32, *Pb3 = PW3 + 32 * O;
     if (tid < 32) {
         Pb1[tid] = s1[tid] + (MODE ? s1[32 + tid] : 0.f);
@@ -542,6 +697,484 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
         if (tid < 32) PW3[tid] = c2[tid];
         if (tid == 0) Pb3[0] = 0.f;           // sum over the rows of df and of -df, each in the same order: exactly 0
     }
+    TF_CLK(8);
+}
+
+// ---------------------------------------------------------------------------------------------- backward, pair MLP, matrix pipe
+// The same arithmetic as k_tb_pair_bwd, laid out for latency (clock stamps of one workgroup, tools/train_clocks.py: the scalar
+// kernel spent 3.3 us in the prologue, 3.8 us staging, 2.6 us in the update MLP's backward, 2-3 us in dz2 / dz1 / column sums and
+// 5.5-6.5 us in the weight-gradient loops, one after the other):
+//   * wavefront 0 runs the whole serial chain -- prologue (the previous sweep's gradient at this atom), the update MLP's backward,
+//     dM W3^T / df -- with wavefront-level LDS hand-offs, WHILE wavefronts 1-7 stage the rows (float4 rows of 36 / 52 floats);
+//   * dz2 is formed in registers by the lane that needs it as the B operand of dz1 = dz2 W2^T (16 MFMAs per 16 rows);
+//   * every weight gradient is a product over the pair rows on the matrix pipe: dW[k][o] = sum_rows X[row][k] dz[row][o], 16 weight
+//     rows x 16 outputs per job, four K steps (16 pair rows) of LDS reads in flight per pass; the bias gradients are the row "1"
+//     of a padded tile (no column-sum phase), the a_i block a constant A operand.
+// Sums run in MFMA order instead of row order: fixed, so gradients stay bit-reproducible; they differ from the scalar kernel's by rounding.
+#define EPNN_TB_RS 36            // LDS row of a 32-wide array: 16-byte aligned, bank = 4 row + column
+#define EPNN_TB_ES 52            // LDS row of e_ij (48)
+__device__ __forceinline__ void tf_wave_sync() {         // LDS written by this wavefront is read by this wavefront: order only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename T, typename LD, typename ST>
+__device__ __forceinline__ void tf_stage_w(int total, int t, int nth, LD &&ld, ST &&st) {
+    for (int base = 0; base < total; base += EPNN_TF_SD * nth) {
+        T v[EPNN_TF_SD];
+#pragma unroll
+        for (int u = 0; u < EPNN_TF_SD; ++u) {
+            const int idx = base + u * nth + t;
+            v[u] = ld(idx < total ? idx : total - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < EPNN_TF_SD; ++u) {
+            const int idx = base + u * nth + t;
+            if (idx < total) st(idx, v[u]);
+        }
+    }
+}
+// sum over `rows` pair rows of a(row) b(row) [+ a2(row) b2(row)] on the matrix pipe: lane (lq, lx) supplies A[m = lx] and B[n = lx] of
+// row 4 s + lq; sixteen rows per pass, their LDS reads issued together
+template <bool TWO, typename FA, typename FB, typename FA2, typename FB2>
+__device__ __forceinline__ f32x4 tb_rows_mm(int rows, int lq, FA &&a, FB &&b, FA2 &&a2, FB2 &&b2) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        float av[4], bv[4], av2[4], bv2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 4 * u + lq;
+            const bool ok = r < rows;
+            const int rc = ok ? r : rows - 1;              // loads are unconditional (a select, not a branch, zeroes the padding rows)
+            const float ta = a(rc);
+            av[u] = ok ? ta : 0.f;
+            bv[u] = b(rc);
+            if (TWO) {
+                const float ta2 = a2(rc);
+                av2[u] = ok ? ta2 : 0.f;
+                bv2[u] = b2(rc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = tm_mfma(av[u], bv[u], acc);
+            if (TWO) acc = tm_mfma(av2[u], bv2[u], acc);
+        }
+    }
+    return acc;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U) {
+    extern __shared__ __attribute__((aligned(16))) float tf_sm[];
+    const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
+    const int S = A.nsplit, bi = blockIdx.x / S, sub = blockIdx.x - bi * S, b = bi / N, i = bi - b * N;
+    const bool own = sub == 0;                // the workgroup of this atom that writes what is not a weight-gradient job
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lx = lane & 15;
+    constexpr int ND = MODE ? 2 : 1, O = MODE ? 1 : 32, RS = EPNN_TB_RS, ES = EPNN_TB_ES;
+    const int NR = ND * N;                    // pair rows of this workgroup: row d N + j is partner j in order d
+    float *H1s = tf_sm;                       // [NR][RS]
+    float *H2s = H1s + NR * RS;
+    float *D1s = H2s + NR * RS;               // gradient at z1
+    float *D2s = D1s + NR * RS;               // gradient at z2
+    float *Es = D2s + NR * RS;                // [N][ES]
+    float *vec = Es + N * ES;                 // dms [32] | vs [32] | - [32] | df [96]
+    float *dms = vec, *vs = vec + 32, *dfs = vec + 96;
+    float *ub = vec + 192;                    // update backward: u0 [80] | u1 [32] | u2 [32] | dh [48] | du2 [32] | du1 [32] | dU0 [80]
+    float *psh = ub + 336;                    // [4][32] prologue: row / column sums of the previous sweep's dz1
+    float *pp = psh + 128;                    // [8][2][32] prologue: the column sums' partials
+    float *As = pp + 512;                     // [N][FS]
+    const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
+    const size_t dstride = (size_t)(gridDim.x / S) * N * 32;
+    const float *theta = A.theta;
+    TF_CLK(0);
+    // W2 for dz1 = dz2 W2^T: A[m = k][kk = o], K steps in "acc" order o = 16 (s >> 2) + 4 lq + (s & 3) (two float4 of a row per lane)
+    float w2f[2][8], w3v[8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w2f[rb][s] = theta[A.oW2 + (16 * rb + lx) * 32 + 16 * (s >> 2) + 4 * lq + (s & 3)];
+    if (MODE == 1) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w3v[s] = theta[A.oW3 + 16 * (s >> 2) + 4 * lq + (s & 3)];
+    }
+    const bool upd = MODE == 0 && U.theta != nullptr;
+    if (wave == 0) {
+        // ================= the serial chain of this atom, one wavefront, no workgroup barrier.  Every load whose address does not
+        // depend on the chain is issued FIRST (weights of the prologue and of the update MLP's first two layers: ~150 registers);
+        // a stage that loads its weights when it starts pays a round trip (~0.7 us) per stage.
+        const int l32 = lane & 31;
+        float wPR[64], wA[48], wB[32];
+        if (A.pmode >= 0) {
+            const int kc = nx + (lane < 49 ? lane : 0);          // h part: k in [nx, nx+48), q part: k = nx + 48
+#pragma unroll
+            for (int oo = 0; oo < 32; ++oo) {
+                wPR[2 * oo] = theta[A.poW1 + kc * 32 + oo];
+                wPR[2 * oo + 1] = theta[A.poW1 + (F + kc) * 32 + oo];
+            }
+        }
+        if (upd) {
+#pragma unroll
+            for (int oo = 0; oo < 48; ++oo) wA[oo] = U.theta[U.oW2 + l32 * 48 + oo];
+#pragma unroll
+            for (int oo = 0; oo < 32; ++oo) wB[oo] = U.theta[U.oW1 + l32 * 32 + oo];
+        }
+        float wg0 = 0.f, wg1 = 0.f, u0a = 0.f, u0b = 0.f, u12 = 0.f, pre = 0.f, rsv = 0.f;
+        const float nm = MODE == 0 ? A.nm[bi] : 0.f;
+        if (MODE == 1) {
+            wg0 = A.wgt[rowbase + min(lane, N - 1)];
+            wg1 = A.wgt[rowbase + min(64 + lane, N - 1)];
+        }
+        if (upd) {
+            u0a = U.U0[(size_t)bi * 80 + lane];
+            u0b = U.U0[(size_t)bi * 80 + 64 + (lane & 15)];
+            u12 = *(lane < 32 ? U.U1 + (size_t)bi * 32 + lane : U.U2 + (size_t)bi * 32 + lane - 32);
+        }
+        if (A.pmode == 1) {
+            pre = *(lane < 48 ? A.gfeat_r + (size_t)bi * 48 + lane : A.gq_r + bi);
+            if (lane < 48 && A.pfirst) pre = 0.f;
+        } else if (A.pmode == 0) {
+            pre = A.dU0_r[(size_t)bi * 80 + (lane < 48 ? lane : 0)] * nm;
+        } else if (MODE == 0) {
+            pre = U.gh[(size_t)bi * 48 + (lane < 48 ? lane : 0)];
+        }
+        if (A.pmode >= 0) rsv = A.rs_r[(size_t)bi * 64 + lane];
+        float gq = 0.f, ghv = pre;
+        if (MODE == 1 && A.first) gq = -2.f * (A.y[bi] - A.pred[bi]);           // charge_gn.py:397-398
+        else if (MODE == 1 && A.pmode < 0) gq = A.gq_r[bi];
+        // ---- prologue: the gradient that reaches a_i through the first Dense of the PREVIOUS sweep (k_tb_atoms' arithmetic).
+        // It needs four sums of that sweep's dz1 over N rows each:
+        //   0: listed rows (a, j), a is the first block;  1: listed rows (i, a), a is the second block;
+        //   2: swapped rows (i, a) = [a_a | a_i | e], first block;  3: swapped rows (a, j) = [a_j | a_a | e], second block
+        // 0 and 3 run over this atom's own rows: the previous launch left them (rs_r; the "1" rows of its weight-gradient
+        // tiles).  1 and 2 run down a column of the molecule's rows: float4 loads, lane = (row group of 8, float4 of the row),
+        // 2 x ceil(N / 8) loads per lane in flight at once, then the eight partials in a fixed order.
+        if (A.pmode >= 0) {
+            const int rg = lane >> 3, c4 = lane & 7;
+            const bool two = A.pmode == 1;
+            const float *pc = A.pdz1 + (a0 * N + i) * 32 + 4 * c4;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = 0; t0 < N; t0 += 48) {
+                f32x4 v0[6], v1[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int tc = min(t0 + 8 * u + rg, N - 1);
+                    v0[u] = tm_ld4(pc + (size_t)tc * N * 32);
+                    v1[u] = tm_ld4(pc + dstride + (size_t)tc * N * 32);
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const bool ok = t0 + 8 * u + rg < N;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s0[c] += ok ? v0[u][c] : 0.f;
+                        s1[c] += ok && two ? v1[u][c] : 0.f;
+                    }
+                }
+            }
+            tm_st4(pp + (rg * 2 + 0) * 32 + 4 * c4, s0);
+            tm_st4(pp + (rg * 2 + 1) * 32 + 4 * c4, s1);
+            tf_wave_sync();
+            {
+                const int half = lane >> 5;
+                float col = 0.f;
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) col += pp[(g8 * 2 + half) * 32 + l32];
+                psh[(half ? 64 : 32) + l32] = col;                    // which 1 (lanes 0-31), which 2 (lanes 32-63)
+                psh[(half ? 96 : 0) + l32] = half && !two ? 0.f : rsv;      // which 0, which 3
+            }
+            tf_wave_sync();
+            TF_CLK(4);
+            if (lane < 49) {
+                float da = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < 32; ++oo) {
+                    const float sP = psh[oo] + psh[64 + oo], sR = psh[32 + oo] + psh[96 + oo];
+                    da = fmaf(sP, wPR[2 * oo], da);
+                    da = fmaf(sR, wPR[2 * oo + 1], da);
+                }
+                if (A.pmode == 1) {
+                    if (lane < 48) {
+                        ghv = pre + da;
+                        if (own) A.gfeat[(size_t)bi * 48 + lane] = ghv;
+                        if (MODE == 0 && own) A.gh[(size_t)bi * 48 + lane] = ghv;     // the pass stack is done: the feature gradient enters the GNN
+                    } else {
+                        gq = pre + da;
+                    }
+                } else if (lane < 48) {
+                    ghv = pre + da;
+                    if (own) A.gh[(size_t)bi * 48 + lane] = ghv;
+                }
+            }
+        }
+        TF_CLK(5);
+        if (MODE == 1) {
+            if (A.pmode >= 0) gq = __shfl(gq, 48, 64);
+            if (lane == 0 && own) A.gqv[bi] = gq;
+            const float gqi = 0.5f * gq;
+            if (lane < N) dfs[lane] = gqi * wg0;                                  // df_ij; the swapped row gets -df_ij
+            if (lane + 64 < N) dfs[lane + 64] = gqi * wg1;
+        } else {
+            if (upd) {
+                float *u0 = ub, *u1 = ub + 80, *u2 = ub + 112, *dh = ub + 144, *du2 = ub + 192, *du1 = ub + 224, *dU = ub + 256;
+                // the last layer's weights (dU0 = du1 W0^T: 80 outputs on 64 lanes) follow the prologue's into the registers it freed
+                float wC[32], wD[32];
+#pragma unroll
+                for (int oo = 0; oo < 32; ++oo) {
+                    wC[oo] = U.theta[U.oW0 + lane * 32 + oo];
+                    wD[oo] = U.theta[U.oW0 + (64 + (lane & 15)) * 32 + oo];
+                }
+                u0[lane] = u0a;
+                if (lane < 16) u0[64 + lane] = u0b;
+                u1[lane] = u12;                                               // u1 | u2 are adjacent
+                if (lane < 48) dh[lane] = ghv * nm;
+                tf_wave_sync();
+                if (lane < 32) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int oo = 0; oo < 48; ++oo) sacc = fmaf(dh[oo], wA[oo], sacc);
+                    du2[lane] = u2[lane] > 0.f ? sacc : 0.f;
+                }
+                tf_wave_sync();
+                if (lane < 32) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int oo = 0; oo < 32; ++oo) sacc = fmaf(du2[oo], wB[oo], sacc);
+                    du1[lane] = u1[lane] > 0.f ? sacc : 0.f;
+                }
+                tf_wave_sync();
+                {
+                    float sc = 0.f, sd = 0.f;
+#pragma unroll
+                    for (int oo = 0; oo < 32; ++oo) {
+                        sc = fmaf(du1[oo], wC[oo], sc);
+                        sd = fmaf(du1[oo], wD[oo], sd);
+                    }
+                    dU[lane] = sc;
+                    if (own) U.dU0[(size_t)bi * 80 + lane] = sc;
+                    if (lane < 16) {
+                        dU[64 + lane] = sd;
+                        if (own) U.dU0[(size_t)bi * 80 + 64 + lane] = sd;
+                    }
+                }
+                tf_wave_sync();
+                if (lane < 32) dms[lane] = dU[48 + lane] * nm;                    // dM_i: the same for every partner row
+            } else if (lane < 32) {
+                dms[lane] = A.dU0[(size_t)bi * 80 + 48 + lane] * nm;
+            }
+            tf_wave_sync();
+            TF_CLK(6);
+            if (lane < 32) {
+                float v = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < 32; ++oo) v = fmaf(dms[oo], theta[A.oW3 + lane * 32 + oo], v);
+                vs[lane] = v;
+            }
+        }
+        TF_CLK(7);
+    } else {
+        // ================= wavefronts 1-7: the rows into LDS.  EVERY array's loads of a round are issued before the first LDS
+        // write (array after array, each is a round trip of its own: 7 of them were 4.5 us); N = 41 is one round
+        const int t = tid - 64, nth = EPNN_TF_NT - 64;
+        const int nH = NR * 8, nE = N * 12, nA = N * F;
+        const int rounds = max(max((nH + 2 * nth - 1) / (2 * nth), (nE + 2 * nth - 1) / (2 * nth)), (nA + 6 * nth - 1) / (6 * nth));
+        for (int rd = 0; rd < rounds; ++rd) {
+            f32x4 vh1[2], vh2[2], ve[2];
+            float va[6];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ih = min((2 * rd + u) * nth + t, nH - 1), ie = min((2 * rd + u) * nth + t, nE - 1);
+                const int row = ih >> 3, d = row >= N;                        // row d N + j
+                const size_t src = (d ? dstride : 0) + (rowbase + (row - d * N)) * 32 + 4 * (ih & 7);
+                vh1[u] = tm_ld4(A.H1 + src);
+                vh2[u] = tm_ld4(A.H2 + src);
+                ve[u] = tm_ld4(A.e + rowbase * 48 + (size_t)ie * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int ia = min((6 * rd + u) * nth + t, nA - 1);
+                const int j = ia / F, k = ia - j * F;
+                const size_t at = a0 + j;
+                va[u] = *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));     // one load of a selected address
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ih = (2 * rd + u) * nth + t;
+                if (ih < nH) {
+                    tm_st4(H1s + (ih >> 3) * RS + 4 * (ih & 7), vh1[u]);
+                    tm_st4(H2s + (ih >> 3) * RS + 4 * (ih & 7), vh2[u]);
+                }
+                if (ih < nE) {
+                    const int j = ih / 12;
+                    tm_st4(Es + j * ES + 4 * (ih - 12 * j), ve[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int ia = (6 * rd + u) * nth + t;
+                if (ia < nA) {
+                    const int j = ia / F;
+                    As[j * FS + (ia - j * F)] = va[u];
+                }
+            }
+        }
+        TF_CLK_T(8, 64);
+    }
+    __syncthreads();
+    TF_CLK(1);
+    // ---- dz2 = [H2 > 0] * (dOut W3^T) in registers, dz1 = [H1 > 0] * (dz2 W2^T) on the matrix pipe: a wavefront per 16 rows
+    for (int job = wave; job < ((N + 15) / 16) * ND; job += EPNN_TF_NT / 64) {
+        const int d = job % ND, j = (job / ND) * 16 + lx;
+        const bool jv = j < N;
+        const int r = d * N + (jv ? j : 0);
+        f32x4 h2[2], dz2[2];
+        h2[0] = tm_ld4(H2s + r * RS + 4 * lq);
+        h2[1] = tm_ld4(H2s + r * RS + 16 + 4 * lq);
+        if (MODE == 0) {
+            const f32x4 va = tm_ld4(vs + 4 * lq), vb = tm_ld4(vs + 16 + 4 * lq);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dz2[0][c] = jv && h2[0][c] > 0.f ? va[c] : 0.f;
+                dz2[1][c] = jv && h2[1][c] > 0.f ? vb[c] : 0.f;
+            }
+        } else {
+            const float df = d ? -dfs[jv ? j : 0] : dfs[jv ? j : 0];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dz2[0][c] = jv && h2[0][c] > 0.f ? df * w3v[c] : 0.f;
+                dz2[1][c] = jv && h2[1][c] > 0.f ? df * w3v[4 + c] : 0.f;
+            }
+        }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            acc[0] = tm_mfma(w2f[0][s], dz2[s >> 2][s & 3], acc[0]);
+            acc[1] = tm_mfma(w2f[1][s], dz2[s >> 2][s & 3], acc[1]);
+        }
+        if (jv) {
+            tm_st4(D2s + r * RS + 4 * lq, dz2[0]);
+            tm_st4(D2s + r * RS + 16 + 4 * lq, dz2[1]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const f32x4 h1 = tm_ld4(H1s + r * RS + 16 * rb + 4 * lq);
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = h1[c] > 0.f ? acc[rb][c] : 0.f;
+                tm_st4(D1s + r * RS + 16 * rb + 4 * lq, v);
+                if (own) tm_st4(A.dz1 + d * dstride + (rowbase + j) * 32 + 16 * rb + 4 * lq, v);
+            }
+        }
+    }
+    if (upd && own) {
+        // weight-gradient partials of the update MLP for this atom (rank one per layer), parameter order
+        const float *u0 = ub, *u1 = ub + 80, *u2 = ub + 112, *dh = ub + 144, *du2 = ub + 192, *du1 = ub + 224;
+        float *Pu = U.part + (size_t)bi * EPNN_TF_PU;
+        for (int idx = tid; idx < 80 * 32; idx += EPNN_TF_NT) Pu[idx] = u0[idx >> 5] * du1[idx & 31];
+        Pu += 80 * 32;
+        if (tid < 32) Pu[tid] = du1[tid];
+        Pu += 32;
+        for (int idx = tid; idx < 32 * 32; idx += EPNN_TF_NT) Pu[idx] = u1[idx >> 5] * du2[idx & 31];
+        Pu += 32 * 32;
+        if (tid < 32) Pu[tid] = du2[tid];
+        Pu += 32;
+        for (int idx = tid; idx < 32 * 48; idx += EPNN_TF_NT) Pu[idx] = u2[idx / 48] * dh[idx % 48];
+        Pu += 32 * 48;
+        if (tid < 48) Pu[tid] = dh[tid];
+    }
+    __syncthreads();
+    TF_CLK(2);
+    // ---- weight-gradient partials of this workgroup, in parameter order: W1 [D][32] | b1 | W2 [32][32] | b2 | W3 [32][O] | b3
+    const int Pm = D * 32 + 32 + 1024 + 32 + 32 * O + O;
+    float *P = A.part + (size_t)bi * Pm;
+    float *Pb1 = P + D * 32, *PW2 = Pb1 + 32, *Pb2 = PW2 + 1024, *PW3 = Pb2 + 32, *Pb3 = PW3 + 32 * O;
+    const float *ai = As + i * FS;
+    // atom-block tiles.  Block 0 carries three rows of ones behind its F weight rows: F = the sum of dz1 over the listed rows,
+    // F + 1 = over the swapped rows (the NEXT launch's prologue needs them: rs_w), F + 2 = both (the bias gradient)
+    const int KTA = (F + 18) / 16;
+    const int nA = 2 * KTA, nE = 6, nW2 = 6, nW3 = MODE ? 2 : 4;
+    const int njobs = 2 * nA + nE + nW2 + nW3;
+    auto none = [](int) { return 0.f; };
+    for (int job = wave + (EPNN_TF_NT / 64) * sub; job < njobs; job += (EPNN_TF_NT / 64) * S) {
+        f32x4 acc;
+        if (job < 2 * nA) {
+            // first Dense, atom blocks.  Block 0: listed rows carry a_i there, swapped rows a_j; block 1 the other way round
+            const int blk = job >= nA, jj = job - blk * nA, kt = jj >> 1, ob = jj & 1;
+            const int k = 16 * kt + lx, o = 16 * ob + lx;
+            const int kc = k < F ? k : 0;
+            const float aic = ai[kc], oneN = blk == 0 && (k == F || k == F + 2) ? 1.f : 0.f, oneT = blk == 0 && (k == F + 1 || k == F + 2) ? 1.f : 0.f;
+            auto dN = [&](int r) { return D1s[r * RS + o]; };
+            auto dT = [&](int r) { return D1s[(N + r) * RS + o]; };
+            if (blk == 0) {                   // a_i meets the listed rows, a_j the swapped ones
+                auto ac = [&](int) { return k < F ? aic : oneN; };
+                auto aj = [&](int r) { const float t = As[r * FS + kc]; return k < F ? t : oneT; };
+                acc = MODE == 0 ? tb_rows_mm<false>(N, lq, ac, dN, none, none) : tb_rows_mm<true>(N, lq, ac, dN, aj, dT);
+            } else {
+                auto ac = [&](int) { return k < F ? aic : 0.f; };
+                auto aj = [&](int r) { const float t = As[r * FS + kc]; return k < F ? t : 0.f; };
+                acc = MODE == 0 ? tb_rows_mm<false>(N, lq, aj, dN, none, none) : tb_rows_mm<true>(N, lq, aj, dN, ac, dT);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kk = 16 * kt + 4 * lq + c;
+                if (kk < F) P[(blk * F + kk) * 32 + o] = acc[c];
+                else if (blk == 0 && kk == F) A.rs_w[(size_t)bi * 64 + o] = acc[c];
+                else if (blk == 0 && kk == F + 1) A.rs_w[(size_t)bi * 64 + 32 + o] = acc[c];
+                else if (blk == 0 && kk == F + 2) Pb1[o] = acc[c];
+            }
+        } else if (job < 2 * nA + nE) {
+            // first Dense, edge block: the same e_ij in both orders
+            const int jj = job - 2 * nA, kt = jj >> 1, ob = jj & 1, k = 16 * kt + lx, o = 16 * ob + lx;
+            auto ae = [&](int r) { return Es[r * ES + k]; };
+            auto dS = [&](int r) { return MODE ? D1s[r * RS + o] + D1s[(N + r) * RS + o] : D1s[r * RS + o]; };
+            acc = tb_rows_mm<false>(N, lq, ae, dS, none, none);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) P[(2 * F + 16 * kt + 4 * lq + c) * 32 + o] = acc[c];
+        } else if (job < 2 * nA + nE + nW2) {
+            // second Dense over both orders; tile 2 is the row "1": b2.  The pass network's dz2 of the two orders of a pair cancel
+            // (+df w3 against -df w3 wherever both rows are active): b2 sums them pair by pair, not one order after the other
+            const int jj = job - 2 * nA - nE, kt = jj >> 1, ob = jj & 1, k = 16 * kt + lx, o = 16 * ob + lx;
+            if (kt < 2) {
+                auto ah = [&](int r) { return H1s[r * RS + k]; };
+                auto d2 = [&](int r) { return D2s[r * RS + o]; };
+                acc = tb_rows_mm<false>(NR, lq, ah, d2, none, none);
+            } else {
+                auto a1 = [&](int) { return lx == 0 ? 1.f : 0.f; };
+                auto d2 = [&](int r) { return MODE ? D2s[r * RS + o] + D2s[(N + r) * RS + o] : D2s[r * RS + o]; };
+                acc = tb_rows_mm<false>(N, lq, a1, d2, none, none);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kk = 16 * kt + 4 * lq + c;
+                if (kk < 32) PW2[kk * 32 + o] = acc[c];
+                else if (kk == 32) Pb2[o] = acc[c];
+            }
+        } else {
+            // third Dense: message network sum_j H2[j][k] dM[o]; pass network sum over both orders of H2[row][k] (+-df)
+            const int jj = job - 2 * nA - nE - nW2, kt = MODE ? jj : jj >> 1, ob = MODE ? 0 : jj & 1, k = 16 * kt + lx, o = 16 * ob + lx;
+            auto ah = [&](int r) { return H2s[r * RS + k]; };
+            if (MODE == 0) {
+                const float dmo = dms[o];
+                auto bm = [&](int) { return dmo; };
+                acc = tb_rows_mm<false>(N, lq, ah, bm, none, none);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) PW3[(16 * kt + 4 * lq + c) * 32 + o] = acc[c];
+            } else {
+                auto bd = [&](int r) { const float t = dfs[r < N ? r : r - N]; return lx == 0 ? (r < N ? t : -t) : 0.f; };
+                acc = tb_rows_mm<false>(NR, lq, ah, bd, none, none);
+                if (lx == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) PW3[16 * kt + 4 * lq + c] = acc[c];
+                }
+            }
+        }
+    }
+    if (!own) {
+    } else if (MODE == 0) {
+        if (tid < 32) Pb3[tid] = (float)N * dms[tid];
+    } else if (tid == 0) {
+        Pb3[0] = 0.f;                         // sum over the rows of df and of -df, each in the same order: exactly 0
+    }
+    TF_CLK(3);
 }
 
 // ---------------------------------------------------------------------------------------------- update MLP (stand-alone launches)

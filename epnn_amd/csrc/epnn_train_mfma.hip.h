@@ -23,10 +23,6 @@
 #define EPNN_TM_NW (EPNN_TM_NT / 64)
 #define EPNN_TM_FS 60            // atom-feature row in LDS: F = nx + 49 <= 60, zero padded (15 K steps of 4)
 
-__device__ __forceinline__ f32x4 tm_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 tm_relu(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
-__device__ __forceinline__ f32x4 tm_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
-__device__ __forceinline__ void tm_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 // sum over the four lanes q = 0..3 that share a column (v_permlane16/32_swap: no LDS), every lane gets the same bits
 __device__ __forceinline__ float tm_sumq(float v) {
     const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);

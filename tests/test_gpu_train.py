@@ -95,7 +95,7 @@ def config3_case(val_dir, val_names, golden_dir, weights_decay):
     return out
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [1, 3, 0])
 @pytest.mark.parametrize("which", ["decay_model_weights", "random"])
 def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, config3_case, which, fused):
     """BASELINE.json configs[2] shape: N = 41, T = 5, real molecules of the reference's `mixed` set (a QM9 molecule, a
@@ -119,8 +119,9 @@ def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, config3_cas
     assert abs(loss - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
     g = eng.get_gradients().astype(np.float64)
     pos, worst, worst_noise, zero_tensors, kinked = 0, 0.0, 0.0, 0, 0
-    for m in [w["upd"]] + w["msg"] + w["pas"]:
-        for W, b in m:
+    table = []
+    for mi, m in enumerate([w["upd"]] + w["msg"] + w["pas"]):
+        for li, (W, b) in enumerate(m):
             for arr in (W, b):
                 sl = slice(pos, pos + arr.size)
                 scale = np.abs(gr[sl]).max()
@@ -129,6 +130,9 @@ def test_gradients_match_oracle_at_config3_shape(gpu_engine_factory, config3_cas
                     kink = band[sl].max() / scale                          # 0 for every tensor with the shipped weights
                     err = np.abs(g[sl] - gr[sl]).max() / scale
                     kinked += kink > 0
+                    table.append((mi, li, arr.shape, float(err), float(noise)))
+                    if os.environ.get("EPNN_TEST_VERBOSE"):
+                        print(table[-1])
                     if kink == 0:
                         worst, worst_noise = max(worst, err), max(worst_noise, noise)
                     assert err <= max(2e-4, 4 * noise) + 2 * kink, (err, noise, kink)

@@ -22,8 +22,8 @@ N, T, F = 41, 5, 58
 # the reference's literal work per step (charge_gn.py:62-68, 101-111): every one of the N^2 pair rows through a 164 -> 32 -> 32 -> 32
 # message MLP and, in both orders, a 164 -> 32 -> 32 -> 1 pass MLP, T times; the backward taken as twice the forward
 fwd_flop = B * T * N * N * (2 * (164 * 32 + 32 * 32 + 32 * 32) + 2 * 2 * (164 * 32 + 32 * 32 + 32))
-names_of = {2: "matrix-pipe forward + row-fused backward", 1: "row-fused", 0: "layer by layer"}
-modes = [(int(a.split("=")[1]), 0) for a in sys.argv[2:] if a.startswith("--mode=")] or [(2, 0), (1, 0), (1, 1), (0, 0)]
+names_of = {3: "row-fused, scalar FMA layers", 2: "16-atom matrix-pipe forward + row-fused backward", 1: "row-fused, matrix-pipe layers", 0: "layer by layer"}
+modes = [(int(a.split("=")[1]), 0) for a in sys.argv[2:] if a.startswith("--mode=")] or [(1, 0), (3, 0), (2, 0), (1, 1), (0, 0)]
 best = None
 for fused, graph in modes:
     eng.set_option("train_fused", fused)
