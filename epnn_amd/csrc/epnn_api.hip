@@ -1518,13 +1518,18 @@ __global__ __launch_bounds__(256) void k_t_pad_inputs(const float *xyz, const fl
                                                       const int *moff, int B, int N, int nx, int E, double cutoff, double eta,
                                                       const double *mu, float *e, float *mask, float *xs, float *hs, float *qs,
                                                       float *ys) {
+    // a thread per (pair, four channels): one thread per pair was 48 double-precision exp in a row on 7 workgroups (13 us of a
+    // 0.27 ms one-molecule step); the distance and the cutoff are recomputed by the 12 threads of a pair
     const size_t pairs = (size_t)B * N * N;
+    const int G = (E + 3) / 4;
     const double pi_d = 3.141592653589793;
-    for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < pairs; r += (size_t)gridDim.x * 256) {
+    for (size_t it = (size_t)blockIdx.x * 256 + threadIdx.x; it < pairs * G; it += (size_t)gridDim.x * 256) {
+        const size_t r = it / G;
+        const int cg = (int)(it - r * G);
         const int j = (int)(r % N), i = (int)((r / N) % N), b = (int)(r / ((size_t)N * N));
         const int a0 = moff[b], n = moff[b + 1] - a0;
         const bool real = i < n && j < n;
-        mask[r] = real ? 1.f : 0.f;
+        if (cg == 0) mask[r] = real ? 1.f : 0.f;
         double D = 0, Cc = 0;
         if (real) {
             D = epnn_dist(xyz, a0 + i, a0 + j);
@@ -1533,11 +1538,11 @@ __global__ __launch_bounds__(256) void k_t_pad_inputs(const float *xyz, const fl
             if (D <= 0.0) Cc = 1.0;
             if (i == j) Cc = 0.0;
         }
-        for (int ch = 0; ch < E; ++ch) {
+        for (int ch = 4 * cg; ch < min(E, 4 * cg + 4); ++ch) {
             const double d = D - mu[ch];
             e[r * E + ch] = real ? (float)(Cc * exp(-eta * (d * d))) : 0.f;
         }
-        if (j == 0) {
+        if (j == 0 && cg == 0) {
             const size_t at = (size_t)b * N + i;
             for (int f = 0; f < nx; ++f) xs[at * nx + f] = i < n ? x[(size_t)(a0 + i) * nx + f] : 0.f;
             for (int f = 0; f < EPNN_EDIM; ++f) hs[at * EPNN_EDIM + f] = 0.f;
@@ -1595,9 +1600,10 @@ static bool train_is_fused(const epnn_handle *h, int N) { return h->opt_train_fu
 // d_loss: [B][N] loss terms (the layer-by-layer path fills one per molecule and leaves the rest zero); adam_now: the fused
 // path's last launch also takes the optimizer step
 static int train_fb(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x, const float *d_h0,
-                    const float *d_q0, const float *d_y, float *d_pred, float *d_loss, bool size_only = false, bool adam_now = false) {
+                    const float *d_q0, const float *d_y, float *d_pred, float *d_loss, bool size_only = false, bool adam_now = false,
+                    float *out_host = nullptr) {
     if (train_is_fused(h, N))
-        return train_fwd_bwd_fused(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only, adam_now);
+        return train_fwd_bwd_fused(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only, adam_now, out_host);
     if (!size_only) {
         TrainState *ts = train_state(h);
         HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));       // its launches ADD their parts of the gradient
@@ -1638,13 +1644,16 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
         }
         HIPCHK(hipGraphLaunch(ts->gexec, h->stream));
     } else {
-        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, false, adam_now)) return 1;
+        // the last forward launch of the row-fused path writes loss terms | predictions into page-locked host memory as well:
+        // no download (a 4 us copy kernel and its launch) between the last launch and the caller
+        if (h->pin_tout.ensure(2 * BN * 4)) return 1;
+        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, false, adam_now, h->pin_tout.as<float>())) return 1;
     }
     if (apply && !adam_now && train_apply(h)) return 1;
     // the step's loss terms and predictions are neighbours on the device: one download into page-locked memory
     const size_t nback = BN + (pred_host ? BN : 0);
     if (h->pin_tout.ensure(nback * 4)) return 1;
-    HIPCHK(hipMemcpyAsync(h->pin_tout.p, d_loss, nback * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!(ts->host_out && !h->opt_train_graph)) HIPCHK(hipMemcpyAsync(h->pin_tout.p, d_loss, nback * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const float *back = h->pin_tout.as<float>();
     if (pred_host) memcpy(pred_host, back + BN, BN * 4);
@@ -1740,7 +1749,7 @@ extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *
     memcpy(stage + o_Q, Q, (size_t)B * 4);
     memcpy(stage + o_y, y_flat, (size_t)A * 4);
     HIPCHK(hipMemcpyAsync(h->s_train.p, stage, in_bytes, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_t_pad_inputs, dim3(t_grid(pairs)), dim3(256), 0, h->stream, reinterpret_cast<const float *>(dev + o_xyz),
+    hipLaunchKernelGGL(k_t_pad_inputs, dim3(t_grid(pairs * ((h->cfg.e_dim + 3) / 4))), dim3(256), 0, h->stream, reinterpret_cast<const float *>(dev + o_xyz),
                        reinterpret_cast<const float *>(dev + o_x), reinterpret_cast<const float *>(dev + o_Q),
                        reinterpret_cast<const float *>(dev + o_y), reinterpret_cast<const int *>(dev), B, N, nx, h->cfg.e_dim,
                        (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),

@@ -340,6 +340,7 @@ struct TrainState {
     hipGraphExec_t gexec = nullptr;
     std::vector<const void *> gkey;
     bool fused_attr = false;                     // dynamic LDS limit of the row-fused kernels raised
+    bool host_out = false;                       // the last forward launch wrote loss terms | predictions into the caller's page-locked buffer
 #ifdef EPNN_TF_CLOCKS
     DevBuf clk;                                  // [launch][16] phase clocks of workgroup 0 (development build)
 #endif
@@ -579,9 +580,10 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
 // they were 18 launches of their own).  d_loss receives one loss term per atom slot [B][N].
 static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
                                const float *d_h0, const float *d_q0, const float *d_y, float *d_pred, float *d_loss,
-                               bool size_only = false, bool adam_now = false) {
+                               bool size_only = false, bool adam_now = false, float *out_host = nullptr) {
     TrainState *ts = train_state(h);
     if (!ts->ready) EPNN_FAIL("training: call epnn_train_init first");
+    ts->host_out = false;
     const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, E = EPNN_EDIM, F = nx + H + 1, D = 2 * F + E, FS = F | 1;
     const int BN = B * N;
     const size_t R = (size_t)BN * N;
@@ -662,8 +664,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     // hidden layers of the row-fused kernels on the matrix pipe ("train_fused" = 1, the default); 3 = the scalar FMA version
     const bool mm = h->opt_train_fused != 3 && nx + 49 <= EPNN_TF_FMAX && ((uintptr_t)d_e & 15) == 0;
     auto lds_bwd_mm = [&](int nd) { return ((size_t)4 * nd * N * EPNN_TB_RS + (size_t)N * EPNN_TB_ES + 1168 + (size_t)N * FS) * 4; };
-    // one molecule per step is N workgroups on 256 CUs: up to four workgroups per atom share its weight-gradient jobs
-    const int nsplit = std::max(1, std::min(4, 256 / BN));
+    // one molecule per step is N workgroups on 256 CUs: up to six workgroups per atom share its weight-gradient jobs
+    const int nsplit = std::max(1, std::min(6, 256 / BN));
     const int nblk = (N + 15) / 16;
     const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + EPNN_TM_NW * 16 * 33) * 4;
     if (mfma_fwd) {
@@ -688,7 +690,11 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         TfPair A = pair_args(ts->pas[t], feats, qcur);
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.qn = P(es[t].qn);
         if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the pair weights
-        if (t == T - 1 && !mfma_fwd) { A.y = d_y; A.pred = d_pred; A.lterm = d_loss; }
+        if (t == T - 1 && !mfma_fwd) {
+            A.y = d_y; A.pred = d_pred; A.lterm = d_loss;
+            A.out_h = out_host;
+            ts->host_out = out_host != nullptr;
+        }
         if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<1>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, TfUpd{}, nblk);
         else if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         else hipLaunchKernelGGL((k_tf_pair_fwd<1, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});

@@ -41,6 +41,7 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     float tol;
     const float *y;              // forward, last pass step: labels -> predictions (pred) and loss terms (lterm) per atom;
     float *pred, *lterm;         //   backward, first pass step (first != 0): gq = -2 (y - pred)
+    float *out_h;                // forward, last pass step: page-locked host memory for the same two (or null): no download after the step
     int first;                   // backward: this is the first launch of its stack
     // backward: the "atoms" stage of the PREVIOUS backward launch runs as this launch's prologue (k_tb_atoms' arithmetic)
     int pmode;                   // -1: nothing; 1: the previous launch was a pass sweep; 0: a message sweep
@@ -61,7 +62,9 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
 #ifdef EPNN_TF_CLOCKS
 #define TF_CLK_T(k, t) do { if (A.clk && blockIdx.x == 0 && threadIdx.x == (t)) A.clk[k] = wall_clock64(); } while (0)
 #define TF_CLK(k) TF_CLK_T(k, 0)
+#define TF_CYC(k) do { if (A.clk && blockIdx.x == 0 && threadIdx.x == 0) A.clk[k] = __builtin_readcyclecounter(); } while (0)
 #else
+#define TF_CYC(k) do { } while (0)
 #define TF_CLK_T(k, t) do { } while (0)
 #define TF_CLK(k) do { } while (0)
 #endif
@@ -85,6 +88,15 @@ __device__ __forceinline__ f32x4 tm_mfma(float a, float b, f32x4 c) { return __b
 __device__ __forceinline__ f32x4 tm_relu(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 __device__ __forceinline__ f32x4 tm_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void tm_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+// four consecutive parameters: the flat parameter vector is only 4-byte aligned at a tensor's start (the pass networks end in a
+// 32 x 1 Dense + 1 bias), global_load_dwordx4 takes any dword address
+__device__ __forceinline__ void tf_wave_sync() {         // LDS written by this wavefront is read by this wavefront: order only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4 tm_ld4u(const float *p) { return *reinterpret_cast<const f32x4u *>(p); }
 
 // Staging loops: `total` elements, element idx loaded by ld(idx) and placed by st(idx, value).  Four loads of a thread are
 // in flight before the first store (a plain loop would wait for every load in front of its LDS write: the loop trip
@@ -148,6 +160,39 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) w2f[rb][s] = w2[(16 * (s >> 2) + 4 * lq + (s & 3)) * 32 + 16 * rb + lx];
         }
+    }
+    // ---- MM, message network: the LAST wavefront (never a layer job: N <= 96 is at most 6 tiles) runs the atom's serial tail --
+    // column sums, third Dense, update MLP -- with wavefront-level hand-offs, its weights in registers since the kernel's start
+    // (a stage that loads its weights when it starts pays a round trip; the tail was 2.9 us of a 9.2 us launch).  Each sum over
+    // k is split between the two half-wavefronts (lane = (half, o)).
+    constexpr bool TAIL = MM && MODE == 0;
+    const bool updf = U.theta != nullptr;
+    float w3c[TAIL ? 16 : 1], w0c[TAIL ? 40 : 1], w1c[TAIL ? 16 : 1], w2c[TAIL ? 32 : 1], tb3 = 0.f, tb0 = 0.f, tb1 = 0.f, tb2 = 0.f, hpre = 0.f, nmpre = 0.f;
+    if (TAIL && wave == 7) {
+        const int half = (tid >> 5) & 1, oc = (tid & 63) < 48 ? (tid & 63) : 0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) w3c[kk] = A.theta[A.oW3 + (16 * half + kk) * 32 + o];
+        tb3 = A.theta[A.ob3 + o];
+        if (updf) {
+#pragma unroll
+            for (int kk = 0; kk < 40; ++kk) w0c[kk] = U.theta[U.oW0 + (40 * half + kk) * 32 + o];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) w1c[kk] = U.theta[U.oW1 + (16 * half + kk) * 32 + o];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) w2c[kk] = U.theta[U.oW2 + kk * 48 + oc];
+            tb0 = U.theta[U.ob0 + o];
+            tb1 = U.theta[U.ob1 + o];
+            tb2 = U.theta[U.ob2 + oc];
+            hpre = U.h[(size_t)bi * 48 + oc];
+            if (!A.mask) nmpre = U.nm[bi];
+        }
+    }
+    // ---- MM, pass network: the pair weights of this atom's rows are formed by the last two wavefronts; what they need from
+    // global memory is loaded here, not behind the barrier
+    float wpre = 0.f;
+    if (MM && MODE == 1 && tid >= EPNN_TF_NT - 128) {
+        const int j = min(tid - (EPNN_TF_NT - 128), N - 1);
+        wpre = A.mask ? A.mask[(size_t)bi * N + j] : A.wgt[(size_t)bi * N + j];
     }
     float *As = tf_sm;                        // [N][FS]   a_j of every atom of the molecule
     float *Es = As + N * FS;                  // [N][49]   e_ij of this atom's rows
@@ -215,8 +260,20 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     }
     __syncthreads();
     TF_CLK(1);
-    if (MODE == 1) {
+    if (MM && MODE == 1) {
         // pair weights mask * is_near (charge_gn.py:90-94,116): from the staged e rows on the stack's first launch, else as stored
+        const int j = tid - (EPNN_TF_NT - 128);
+        if (j >= 0 && j < N) {
+            float w = wpre;
+            if (A.mask) {
+                float mx = 0.f;
+                for (int k = 0; k < 48; ++k) mx = fmaxf(mx, Es[j * 49 + k]);
+                w = mx > A.tol ? wpre : 0.f;
+                A.wgt_w[rowbase + j] = w;
+            }
+            wl[j] = w;
+        }
+    } else if (MODE == 1) {
         for (int j = tid; j < N; j += EPNN_TF_NT) {
             float w;
             if (A.mask) {
@@ -346,6 +403,68 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     }
     __syncthreads();
     TF_CLK(2);
+    if (TAIL) {
+        if (wave != 7) return;
+        const int lane = tid & 63, half = lane >> 5;
+        float *S = red, *u0 = red + 32, *u1 = red + 112, *u2 = red + 144;
+        // sum_j (H2_j W3 + b3) = (sum_j H2_j) W3 + N b3: column sums (even rows, odd rows, then the two), then one 32x32 product
+        float cs = 0.f;
+#pragma unroll 8
+        for (int j = half; j < N; j += 2) cs += H2s[j * 33 + o];
+        cs += __shfl_xor(cs, 32, 64);
+        if (half == 0) S[o] = cs;
+        tf_wave_sync();
+        float mo = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) mo = fmaf(S[16 * half + kk], w3c[kk], mo);
+        mo += __shfl_xor(mo, 32, 64);
+        mo += (float)N * tb3;
+        const float nm = updf ? (A.mask ? wl[0] : nmpre) : 0.f;
+        if (half == 0) {
+            A.M[(size_t)bi * 32 + o] = mo;
+            if (updf) {
+                const float v = mo * nm;
+                u0[48 + o] = v;
+                U.U0[(size_t)bi * 80 + 48 + o] = v;
+            }
+        }
+        TF_CLK_T(3, EPNN_TF_NT - 64);
+        if (!updf) return;
+        if (lane < 48) {
+            const float v = hpre * nm;
+            u0[lane] = v;
+            U.U0[(size_t)bi * 80 + lane] = v;
+        }
+        tf_wave_sync();
+        float z = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 40; ++kk) z = fmaf(u0[40 * half + kk], w0c[kk], z);
+        z += __shfl_xor(z, 32, 64);
+        z = fmaxf(z + tb0, 0.f);
+        if (half == 0) {
+            u1[o] = z;
+            U.U1[(size_t)bi * 32 + o] = z;
+        }
+        tf_wave_sync();
+        z = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) z = fmaf(u1[16 * half + kk], w1c[kk], z);
+        z += __shfl_xor(z, 32, 64);
+        z = fmaxf(z + tb1, 0.f);
+        if (half == 0) {
+            u2[o] = z;
+            U.U2[(size_t)bi * 32 + o] = z;
+        }
+        tf_wave_sync();
+        if (lane < 48) {
+            z = tb2;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) z = fmaf(u2[kk], w2c[kk], z);
+            U.hn[(size_t)bi * 48 + lane] = z * nm;
+        }
+        TF_CLK_T(5, EPNN_TF_NT - 64);
+        return;
+    }
     // ---- layer 3 (linear) and the reduction over partners
     if (MODE == 0) {
         // sum_j (H2_j W3 + b3) = (sum_j H2_j) W3 + N b3: column sums in a fixed order (row groups, then the groups in order), then one 32x32 product
@@ -413,15 +532,26 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         }
         __syncthreads();
         TF_CLK(3);
+        if (MM && tid >= 64) return;
+        float s = 0.f;
+        if (MM) {                                 // one wavefront, a fixed butterfly, instead of a serial loop on one lane
+            for (int j = tid; j < N; j += 64) s += 0.5f * (fs[j] - fs[N + j]) * wl[j];
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd, 64);
+        }
         if (tid == 0) {
-            float s = 0.f;
-            for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * wl[j];
+            if (!MM)
+                for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * wl[j];
             const float qn = A.q[bi] + s;
             A.qn[bi] = qn;
             if (A.y) {                            // last step: prediction and loss term of this atom (charge_gn.py:397)
                 const float d = A.y[bi] - qn;
                 A.pred[bi] = qn;
                 A.lterm[bi] = d * d;
+                if (A.out_h) {                    // and straight into the caller's page-locked buffer: loss terms [BN] | predictions [BN]
+                    A.out_h[bi] = d * d;
+                    A.out_h[(size_t)gridDim.x + bi] = qn;
+                }
             }
         }
         TF_CLK(5);
@@ -713,11 +843,6 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
 // Sums run in MFMA order instead of row order: fixed, so gradients stay bit-reproducible; they differ from the scalar kernel's by rounding.
 #define EPNN_TB_RS 36            // LDS row of a 32-wide array: 16-byte aligned, bank = 4 row + column
 #define EPNN_TB_ES 52            // LDS row of e_ij (48)
-__device__ __forceinline__ void tf_wave_sync() {         // LDS written by this wavefront is read by this wavefront: order only
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 template <typename T, typename LD, typename ST>
 __device__ __forceinline__ void tf_stage_w(int total, int t, int nth, LD &&ld, ST &&st) {
     for (int base = 0; base < total; base += EPNN_TF_SD * nth) {
@@ -788,36 +913,38 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
     const size_t dstride = (size_t)(gridDim.x / S) * N * 32;
     const float *theta = A.theta;
     TF_CLK(0);
+    TF_CYC(14);
     // W2 for dz1 = dz2 W2^T: A[m = k][kk = o], K steps in "acc" order o = 16 (s >> 2) + 4 lq + (s & 3) (two float4 of a row per lane)
-    float w2f[2][8], w3v[8];
+    f32x4 w2f[2][2], w3v[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) w2f[rb][s] = theta[A.oW2 + (16 * rb + lx) * 32 + 16 * (s >> 2) + 4 * lq + (s & 3)];
+        for (int hh = 0; hh < 2; ++hh) w2f[rb][hh] = tm_ld4u(theta + A.oW2 + (16 * rb + lx) * 32 + 16 * hh + 4 * lq);
     if (MODE == 1) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) w3v[s] = theta[A.oW3 + 16 * (s >> 2) + 4 * lq + (s & 3)];
+        w3v[0] = tm_ld4u(theta + A.oW3 + 4 * lq);
+        w3v[1] = tm_ld4u(theta + A.oW3 + 16 + 4 * lq);
     }
     const bool upd = MODE == 0 && U.theta != nullptr;
     if (wave == 0) {
         // ================= the serial chain of this atom, one wavefront, no workgroup barrier.  Every load whose address does not
-        // depend on the chain is issued FIRST (weights of the prologue and of the update MLP's first two layers: ~150 registers);
-        // a stage that loads its weights when it starts pays a round trip (~0.7 us) per stage.
+        // depend on the chain is issued FIRST, as float4 (a wavefront has 63 loads in flight at most: the ~230 scalar loads of
+        // the prologue's and the update MLP's weights were four windows of it); a stage that loads its weights when it starts
+        // pays a round trip (~0.7 us) per stage.
         const int l32 = lane & 31;
-        float wPR[64], wA[48], wB[32];
+        f32x4 wP[8], wR[8], wA[12], wB[8];
         if (A.pmode >= 0) {
             const int kc = nx + (lane < 49 ? lane : 0);          // h part: k in [nx, nx+48), q part: k = nx + 48
 #pragma unroll
-            for (int oo = 0; oo < 32; ++oo) {
-                wPR[2 * oo] = theta[A.poW1 + kc * 32 + oo];
-                wPR[2 * oo + 1] = theta[A.poW1 + (F + kc) * 32 + oo];
+            for (int c = 0; c < 8; ++c) {
+                wP[c] = tm_ld4u(theta + A.poW1 + kc * 32 + 4 * c);
+                wR[c] = tm_ld4u(theta + A.poW1 + (F + kc) * 32 + 4 * c);
             }
         }
         if (upd) {
 #pragma unroll
-            for (int oo = 0; oo < 48; ++oo) wA[oo] = U.theta[U.oW2 + l32 * 48 + oo];
+            for (int c = 0; c < 12; ++c) wA[c] = tm_ld4u(U.theta + U.oW2 + l32 * 48 + 4 * c);
 #pragma unroll
-            for (int oo = 0; oo < 32; ++oo) wB[oo] = U.theta[U.oW1 + l32 * 32 + oo];
+            for (int c = 0; c < 8; ++c) wB[c] = tm_ld4u(U.theta + U.oW1 + l32 * 32 + 4 * c);
         }
         float wg0 = 0.f, wg1 = 0.f, u0a = 0.f, u0b = 0.f, u12 = 0.f, pre = 0.f, rsv = 0.f;
         const float nm = MODE == 0 ? A.nm[bi] : 0.f;
@@ -876,23 +1003,36 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             tm_st4(pp + (rg * 2 + 1) * 32 + 4 * c4, s1);
             tf_wave_sync();
             {
+                // lane (half, o): half 0 holds sum 0 (rsv) and forms sum 1, half 1 holds sum 3 and forms sum 2; the first block's
+                // gradient needs sP = 0 + 2, the second block's sR = 1 + 3: one exchange between the halves
                 const int half = lane >> 5;
                 float col = 0.f;
 #pragma unroll
                 for (int g8 = 0; g8 < 8; ++g8) col += pp[(g8 * 2 + half) * 32 + l32];
-                psh[(half ? 64 : 32) + l32] = col;                    // which 1 (lanes 0-31), which 2 (lanes 32-63)
-                psh[(half ? 96 : 0) + l32] = half && !two ? 0.f : rsv;      // which 0, which 3
+                const float row = half && !two ? 0.f : rsv;
+                const float ocol = __shfl_xor(col, 32, 64), orow = __shfl_xor(row, 32, 64);
+                if (half == 0) {
+                    psh[2 * l32] = row + ocol;                            // sP[o]
+                    psh[2 * l32 + 1] = col + orow;                        // sR[o]
+                }
             }
             tf_wave_sync();
             TF_CLK(4);
             if (lane < 49) {
-                float da = 0.f;
+                float daP = 0.f, daR = 0.f;                               // two chains of 32 instead of one of 64
 #pragma unroll
-                for (int oo = 0; oo < 32; ++oo) {
-                    const float sP = psh[oo] + psh[64 + oo], sR = psh[32 + oo] + psh[96 + oo];
-                    da = fmaf(sP, wPR[2 * oo], da);
-                    da = fmaf(sR, wPR[2 * oo + 1], da);
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 sa = tm_ld4(psh + 8 * c), sb = tm_ld4(psh + 8 * c + 4);      // sP, sR of outputs 4 c .. 4 c + 3
+                    daP = fmaf(sa[0], wP[c][0], daP);
+                    daR = fmaf(sa[1], wR[c][0], daR);
+                    daP = fmaf(sa[2], wP[c][1], daP);
+                    daR = fmaf(sa[3], wR[c][1], daR);
+                    daP = fmaf(sb[0], wP[c][2], daP);
+                    daR = fmaf(sb[1], wR[c][2], daR);
+                    daP = fmaf(sb[2], wP[c][3], daP);
+                    daR = fmaf(sb[3], wR[c][3], daR);
                 }
+                const float da = daP + daR;
                 if (A.pmode == 1) {
                     if (lane < 48) {
                         ghv = pre + da;
@@ -915,14 +1055,16 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             if (lane < N) dfs[lane] = gqi * wg0;                                  // df_ij; the swapped row gets -df_ij
             if (lane + 64 < N) dfs[lane + 64] = gqi * wg1;
         } else {
+            f32x4 w3r[8];
             if (upd) {
                 float *u0 = ub, *u1 = ub + 80, *u2 = ub + 112, *dh = ub + 144, *du2 = ub + 192, *du1 = ub + 224, *dU = ub + 256;
-                // the last layer's weights (dU0 = du1 W0^T: 80 outputs on 64 lanes) follow the prologue's into the registers it freed
-                float wC[32], wD[32];
+                // the last layer's weights (dU0 = du1 W0^T: 80 outputs on 64 lanes) and W3 follow the prologue's into the registers it freed
+                f32x4 wC[8], wD[8];
 #pragma unroll
-                for (int oo = 0; oo < 32; ++oo) {
-                    wC[oo] = U.theta[U.oW0 + lane * 32 + oo];
-                    wD[oo] = U.theta[U.oW0 + (64 + (lane & 15)) * 32 + oo];
+                for (int c = 0; c < 8; ++c) {
+                    wC[c] = tm_ld4u(U.theta + U.oW0 + lane * 32 + 4 * c);
+                    wD[c] = tm_ld4u(U.theta + U.oW0 + (64 + (lane & 15)) * 32 + 4 * c);
+                    w3r[c] = tm_ld4u(theta + A.oW3 + l32 * 32 + 4 * c);
                 }
                 u0[lane] = u0a;
                 if (lane < 16) u0[64 + lane] = u0b;
@@ -930,25 +1072,43 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
                 if (lane < 48) dh[lane] = ghv * nm;
                 tf_wave_sync();
                 if (lane < 32) {
-                    float sacc = 0.f;
+                    float sa = 0.f, sb = 0.f;                                     // even / odd float4s: two chains
 #pragma unroll
-                    for (int oo = 0; oo < 48; ++oo) sacc = fmaf(dh[oo], wA[oo], sacc);
-                    du2[lane] = u2[lane] > 0.f ? sacc : 0.f;
+                    for (int c = 0; c < 12; c += 2) {
+                        const f32x4 x0 = tm_ld4(dh + 4 * c), x1 = tm_ld4(dh + 4 * c + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sa = fmaf(x0[r], wA[c][r], sa);
+                            sb = fmaf(x1[r], wA[c + 1][r], sb);
+                        }
+                    }
+                    du2[lane] = u2[lane] > 0.f ? sa + sb : 0.f;
                 }
                 tf_wave_sync();
                 if (lane < 32) {
-                    float sacc = 0.f;
+                    float sa = 0.f, sb = 0.f;
 #pragma unroll
-                    for (int oo = 0; oo < 32; ++oo) sacc = fmaf(du2[oo], wB[oo], sacc);
-                    du1[lane] = u1[lane] > 0.f ? sacc : 0.f;
+                    for (int c = 0; c < 8; c += 2) {
+                        const f32x4 x0 = tm_ld4(du2 + 4 * c), x1 = tm_ld4(du2 + 4 * c + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sa = fmaf(x0[r], wB[c][r], sa);
+                            sb = fmaf(x1[r], wB[c + 1][r], sb);
+                        }
+                    }
+                    du1[lane] = u1[lane] > 0.f ? sa + sb : 0.f;
                 }
                 tf_wave_sync();
                 {
                     float sc = 0.f, sd = 0.f;
 #pragma unroll
-                    for (int oo = 0; oo < 32; ++oo) {
-                        sc = fmaf(du1[oo], wC[oo], sc);
-                        sd = fmaf(du1[oo], wD[oo], sd);
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x4 x0 = tm_ld4(du1 + 4 * c);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sc = fmaf(x0[r], wC[c][r], sc);
+                            sd = fmaf(x0[r], wD[c][r], sd);
+                        }
                     }
                     dU[lane] = sc;
                     if (own) U.dU0[(size_t)bi * 80 + lane] = sc;
@@ -959,16 +1119,25 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
                 }
                 tf_wave_sync();
                 if (lane < 32) dms[lane] = dU[48 + lane] * nm;                    // dM_i: the same for every partner row
-            } else if (lane < 32) {
-                dms[lane] = A.dU0[(size_t)bi * 80 + 48 + lane] * nm;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) w3r[c] = tm_ld4u(theta + A.oW3 + l32 * 32 + 4 * c);
+                if (lane < 32) dms[lane] = A.dU0[(size_t)bi * 80 + 48 + lane] * nm;
             }
             tf_wave_sync();
             TF_CLK(6);
             if (lane < 32) {
-                float v = 0.f;
+                float va = 0.f, vb = 0.f;
 #pragma unroll
-                for (int oo = 0; oo < 32; ++oo) v = fmaf(dms[oo], theta[A.oW3 + lane * 32 + oo], v);
-                vs[lane] = v;
+                for (int c = 0; c < 8; c += 2) {
+                    const f32x4 x0 = tm_ld4(dms + 4 * c), x1 = tm_ld4(dms + 4 * c + 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        va = fmaf(x0[r], w3r[c][r], va);
+                        vb = fmaf(x1[r], w3r[c + 1][r], vb);
+                    }
+                }
+                vs[lane] = va + vb;
             }
         }
         TF_CLK(7);
@@ -1041,16 +1210,17 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             const float df = d ? -dfs[jv ? j : 0] : dfs[jv ? j : 0];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                dz2[0][c] = jv && h2[0][c] > 0.f ? df * w3v[c] : 0.f;
-                dz2[1][c] = jv && h2[1][c] > 0.f ? df * w3v[4 + c] : 0.f;
+                dz2[0][c] = jv && h2[0][c] > 0.f ? df * w3v[0][c] : 0.f;
+                dz2[1][c] = jv && h2[1][c] > 0.f ? df * w3v[1][c] : 0.f;
             }
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            acc[0] = tm_mfma(w2f[0][s], dz2[s >> 2][s & 3], acc[0]);
-            acc[1] = tm_mfma(w2f[1][s], dz2[s >> 2][s & 3], acc[1]);
+            acc[0] = tm_mfma(w2f[0][s >> 2][s & 3], dz2[s >> 2][s & 3], acc[0]);
+            acc[1] = tm_mfma(w2f[1][s >> 2][s & 3], dz2[s >> 2][s & 3], acc[1]);
         }
+        TF_CLK(9);
         if (jv) {
             tm_st4(D2s + r * RS + 4 * lq, dz2[0]);
             tm_st4(D2s + r * RS + 16 + 4 * lq, dz2[1]);
@@ -1065,6 +1235,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             }
         }
     }
+    TF_CLK(10);
     if (upd && own) {
         // weight-gradient partials of the update MLP for this atom (rank one per layer), parameter order
         const float *u0 = ub, *u1 = ub + 80, *u2 = ub + 112, *dh = ub + 144, *du2 = ub + 192, *du1 = ub + 224;
@@ -1081,6 +1252,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
         Pu += 32 * 48;
         if (tid < 48) Pu[tid] = dh[tid];
     }
+    TF_CLK(11);
     __syncthreads();
     TF_CLK(2);
     // ---- weight-gradient partials of this workgroup, in parameter order: W1 [D][32] | b1 | W2 [32][32] | b2 | W3 [32][O] | b3
@@ -1094,8 +1266,10 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
     const int nA = 2 * KTA, nE = 6, nW2 = 6, nW3 = MODE ? 2 : 4;
     const int njobs = 2 * nA + nE + nW2 + nW3;
     auto none = [](int) { return 0.f; };
-    for (int job = wave + (EPNN_TF_NT / 64) * sub; job < njobs; job += (EPNN_TF_NT / 64) * S) {
+    // jobs are dealt to the atom's workgroups first, then to the wavefronts of each (two wavefronts of a SIMD share its matrix pipe)
+    for (int job = sub + S * wave; job < njobs; job += (EPNN_TF_NT / 64) * S) {
         f32x4 acc;
+        TF_CLK(12);
         if (job < 2 * nA) {
             // first Dense, atom blocks.  Block 0: listed rows carry a_i there, swapped rows a_j; block 1 the other way round
             const int blk = job >= nA, jj = job - blk * nA, kt = jj >> 1, ob = jj & 1;
@@ -1113,6 +1287,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
                 auto aj = [&](int r) { const float t = As[r * FS + kc]; return k < F ? t : 0.f; };
                 acc = MODE == 0 ? tb_rows_mm<false>(N, lq, aj, dN, none, none) : tb_rows_mm<true>(N, lq, aj, dN, ac, dT);
             }
+            TF_CLK(13);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int kk = 16 * kt + 4 * lq + c;
@@ -1175,6 +1350,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
         Pb3[0] = 0.f;                         // sum over the rows of df and of -df, each in the same order: exactly 0
     }
     TF_CLK(3);
+    TF_CYC(15);
 }
 
 // ---------------------------------------------------------------------------------------------- update MLP (stand-alone launches)

@@ -42,4 +42,6 @@ for l in range(64):
     if c[l, 0] == 0: continue
     row = c[l]; last = max(k for k in range(16) if row[k])
     kind = "msg fwd" if l < 5 else "pass fwd" if l < 10 else "pass bwd" if l < 15 else "msg bwd"
-    print(f"{l:3d} {kind:9s}", " ".join(f"{(row[k] - row[0]):6d}" if row[k] else "     -" for k in range(1, last + 1)))
+    cyc = f"  core clock {(row[15] - row[14]) / max(1, row[3] - row[0]) / 10:.2f} GHz" if row[14] and row[15] else ""
+    last = min(last, 13)
+    print(f"{l:3d} {kind:9s}", " ".join(f"{(row[k] - row[0]):6d}" if row[k] else "     -" for k in range(1, last + 1)) + cyc)
