@@ -1242,6 +1242,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
+    else if (!strcmp(name, "train_split")) { if (value < 0 || value > 8) EPNN_FAIL("epnn_set_option: train_split must be 0 (automatic) .. 8"); h->opt_train_split = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
     return 0;
 }
@@ -1626,7 +1627,7 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
         // One molecule padded to N = 41 is ~2 Gflop spread over ~340 tiny launches: the step is launch-bound, so the
         // launch sequence is recorded once per (B, N, buffer set) and replayed as one hipGraph.
         if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, true)) return 1;
-        const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, (const void *)(size_t)h->opt_train_fused, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
+        const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, (const void *)(size_t)(h->opt_train_fused + 16 * h->opt_train_split), d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
                                                d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p};
         if (!ts->gexec || key != ts->gkey) {
             if (ts->gexec) { (void)hipGraphExecDestroy(ts->gexec); ts->gexec = nullptr; }

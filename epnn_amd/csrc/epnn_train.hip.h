@@ -665,7 +665,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     const bool mm = h->opt_train_fused != 3 && nx + 49 <= EPNN_TF_FMAX && ((uintptr_t)d_e & 15) == 0;
     auto lds_bwd_mm = [&](int nd) { return ((size_t)4 * nd * N * EPNN_TB_RS + (size_t)N * EPNN_TB_ES + 1168 + (size_t)N * FS) * 4; };
     // one molecule per step is N workgroups on 256 CUs: up to six workgroups per atom share its weight-gradient jobs
-    const int nsplit = std::max(1, std::min(6, 256 / BN));
+    const int nsplit = h->opt_train_split ? h->opt_train_split : std::max(1, std::min(6, 256 / BN));
     const int nblk = (N + 15) / 16;
     const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + EPNN_TM_NW * 16 * 33) * 4;
     if (mfma_fwd) {

@@ -96,6 +96,9 @@ __device__ __forceinline__ void tf_wave_sync() {         // LDS written by this 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ f32x2 tm_ld2u(const float *p) { return *reinterpret_cast<const f32x2u *>(p); }
 __device__ __forceinline__ f32x4 tm_ld4u(const float *p) { return *reinterpret_cast<const f32x4u *>(p); }
 
 // Staging loops: `total` elements, element idx loaded by ld(idx) and placed by st(idx, value).  Four loads of a thread are
@@ -138,28 +141,48 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     const int tid = threadIdx.x, o = tid & 31, g = tid >> 5;
     constexpr int ND = MODE ? 2 : 1;
     TF_CLK(0);
-    // ---- MM: this wavefront's weight fragments (every job of a wavefront has the same order of the pair: 8 % ND == 0)
+    // ---- MM: this wavefront's weight fragments (every job of a wavefront has the same order of the pair: 8 % ND == 0).
+    // Row m of output tile rb is FEATURE 2 m + rb: a lane's two tiles are neighbours in memory (one 8-byte load per K step
+    // instead of two 4-byte ones: 35 loads per lane, inside the 63 a wavefront can have in flight; 100 were two round trips),
+    // and its eight accumulators are features 8 lq .. 8 lq + 7 of its row.
     constexpr int KA = MM ? (EPNN_TF_FMAX + 3) / 4 : 1;       // K steps of an atom block
     const int wave = tid >> 6, lq = (tid >> 4) & 3, lx = tid & 15;
     const int njobs = ((N + 15) / 16) * ND, jdir = wave % ND;
-    float wi[2][KA], wj[2][KA], we[2][MM ? 12 : 1], w2f[2][MM ? 8 : 1];
+    f32x2 wj[KA], we[MM ? 12 : 1], w2f[MM ? 8 : 1];
+    f32x4 b2v[2];
     if (MM && wave < njobs) {
-        // order 0 rows are [a_i | a_j | e_ij]: the workgroup's atom meets block 0 of W1; order 1 rows are [a_j | a_i | e_ij]
+        // order 0 rows are [a_i | a_j | e_ij]: the partner a_j meets block 1 of W1; order 1 rows are [a_j | a_i | e_ij]: block 0
         const float *w1 = A.theta + A.oW1, *w2 = A.theta + A.oW2;
-        const int own = jdir ? F : 0, oth = jdir ? 0 : F;
+        const int oth = jdir ? 0 : F;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int s = 0; s < KA; ++s) {
-                const int k = 4 * s + lq;
-                wi[rb][s] = k < F ? w1[(own + k) * 32 + 16 * rb + lx] : 0.f;
-                wj[rb][s] = k < F ? w1[(oth + k) * 32 + 16 * rb + lx] : 0.f;
-            }
-#pragma unroll
-            for (int s = 0; s < 12; ++s) we[rb][s] = w1[(2 * F + 4 * s + lq) * 32 + 16 * rb + lx];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) w2f[rb][s] = w2[(16 * (s >> 2) + 4 * lq + (s & 3)) * 32 + 16 * rb + lx];
+        for (int s = 0; s < KA; ++s) {
+            const int k = 4 * s + lq;
+            const f32x2 t = tm_ld2u(w1 + (oth + (k < F ? k : 0)) * 32 + 2 * lx);
+            wj[s] = k < F ? t : f32x2{0.f, 0.f};
         }
+#pragma unroll
+        for (int s = 0; s < 12; ++s) we[s] = tm_ld2u(w1 + (2 * F + 4 * s + lq) * 32 + 2 * lx);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w2f[s] = tm_ld2u(w2 + (8 * lq + s) * 32 + 2 * lx);     // K step s pairs lane lq with input feature 8 lq + s
+        b2v[0] = tm_ld4u(A.theta + A.ob2 + 8 * lq);
+        b2v[1] = tm_ld4u(A.theta + A.ob2 + 8 * lq + 4);
+    }
+    // ---- MM: the a_i term of the first Dense is the same for every row of a workgroup and order of the pair: b1 + a_i W1[own
+    // block] is formed ONCE (wavefront 6 for order 0, wavefront 7 for order 1 of the pass network; lane = (k mod 8, float4 of
+    // features), then the eight partials) while the job wavefronts run their rows' K steps, and added before the ReLU -- 30 of a
+    // job's 100 MFMAs were this one vector recomputed per 16 rows
+    const int bw = !MM ? -1 : MODE ? wave - 6 : (wave == 6 ? 0 : -1);
+    f32x4 wb[MM ? 8 : 1];
+    float b1v = 0.f;
+    if (MM && bw >= 0) {
+        const int kq = (tid & 63) >> 3, f4 = tid & 7;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = kq + 8 * u;
+            const f32x4 t = tm_ld4u(A.theta + A.oW1 + ((bw ? F : 0) + (k < F ? k : 0)) * 32 + 4 * f4);
+            wb[u] = k < F ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        b1v = A.theta[A.ob1 + o];
     }
     // ---- MM, message network: the LAST wavefront (never a layer job: N <= 96 is at most 6 tiles) runs the atom's serial tail --
     // column sums, third Dense, update MLP -- with wavefront-level hand-offs, its weights in registers since the kernel's start
@@ -289,50 +312,82 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     }
     if (MM) {
         const float *ai = As + i * FS;
-        for (int job = wave; job < njobs; job += EPNN_TF_NT / 64) {
+        float *pb = red;                          // [2][8][32] partials of the base vectors; the vectors end up in [d][0][.]
+        bool first = true;
+        for (int job = wave; first || job < njobs; job += EPNN_TF_NT / 64) {
+            const bool has = job < njobs;
             const int j = (job / ND) * 16 + lx;
-            const bool jv = j < N;
+            const bool jv = has && j < N;
             const float *aj = As + (jv ? j : 0) * FS, *ej = Es + (jv ? j : 0) * 49;
-            f32x4 acc[2], d2[2];
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (first && bw >= 0) {
+                const int lane = tid & 63, kq = lane >> 3, f4 = lane & 7;
+                f32x4 p = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                acc[rb] = tm_ld4(A.theta + A.ob1 + 16 * rb + 4 * lq);
-                d2[rb] = tm_ld4(A.theta + A.ob2 + 16 * rb + 4 * lq);
-            }
+                for (int u = 0; u < 8; ++u) {
+                    const int k = kq + 8 * u;
+                    const float a = ai[k < F ? k : 0];
 #pragma unroll
-            for (int s = 0; s < KA; ++s) {
-                const int k = 4 * s + lq;
-                const float vi = k < F ? ai[k] : 0.f, vj = (k < F && jv) ? aj[k] : 0.f;
+                    for (int c = 0; c < 4; ++c) p[c] = fmaf(a, wb[u][c], p[c]);             // wb is zero beyond F
+                }
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    acc[rb] = tm_mfma(wi[rb][s], vi, acc[rb]);
-                    acc[rb] = tm_mfma(wj[rb][s], vj, acc[rb]);
+                for (int c = 0; c < 4; ++c) pb[(bw * 8 + kq) * 32 + 4 * f4 + c] = p[c];
+                tf_wave_sync();
+                if (lane < 32) {
+                    float v = b1v;
+#pragma unroll
+                    for (int g8 = 0; g8 < 8; ++g8) v += pb[(bw * 8 + g8) * 32 + lane];
+                    pb[bw * 256 + lane] = v;          // a lane reads and writes its own column only
                 }
             }
+            if (has) {
 #pragma unroll
-            for (int s = 0; s < 12; ++s) {
-                const float ve = jv ? ej[4 * s + lq] : 0.f;
+                for (int s = 0; s < KA; ++s) {
+                    const int k = 4 * s + lq;
+                    const float t = aj[k < F ? k : 0], vj = (k < F && jv) ? t : 0.f;
+                    acc[0] = tm_mfma(wj[s][0], vj, acc[0]);
+                    acc[1] = tm_mfma(wj[s][1], vj, acc[1]);
+                }
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) acc[rb] = tm_mfma(we[rb][s], ve, acc[rb]);
+                for (int s = 0; s < 12; ++s) {
+                    const float t = ej[4 * s + lq], ve = jv ? t : 0.f;
+                    acc[0] = tm_mfma(we[s][0], ve, acc[0]);
+                    acc[1] = tm_mfma(we[s][1], ve, acc[1]);
+                }
             }
-            acc[0] = tm_relu(acc[0]);
-            acc[1] = tm_relu(acc[1]);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) d2[rb] = tm_mfma(w2f[rb][s], acc[s >> 2][s & 3], d2[rb]);
+            if (first) {
+                __syncthreads();                      // the base vectors are in LDS (every wavefront passes here exactly once)
+                first = false;
             }
-            d2[0] = tm_relu(d2[0]);
-            d2[1] = tm_relu(d2[1]);
-            if (jv) {
-                float *l2 = H2s + (jdir * N + j) * 33;
-                float *g1 = A.H1 + jdir * dstride + (rowbase + j) * 32, *g2 = A.H2 + jdir * dstride + (rowbase + j) * 32;
+            if (has) {
+                const float *vb = pb + jdir * 256 + 8 * lq;
+                f32x4 d2[2];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    tm_st4(g1 + 16 * rb + 4 * lq, acc[rb]);
-                    tm_st4(g2 + 16 * rb + 4 * lq, d2[rb]);
+                for (int c = 0; c < 4; ++c) {
+                    acc[0][c] = fmaxf(acc[0][c] + vb[2 * c], 0.f);
+                    acc[1][c] = fmaxf(acc[1][c] + vb[2 * c + 1], 0.f);
+                    d2[0][c] = b2v[c >> 1][2 * (c & 1)];              // feature 8 lq + 2 c
+                    d2[1][c] = b2v[c >> 1][2 * (c & 1) + 1];          // feature 8 lq + 2 c + 1
+                }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) l2[16 * rb + 4 * lq + r] = d2[rb][r];
+                for (int s = 0; s < 8; ++s) {
+                    d2[0] = tm_mfma(w2f[s][0], acc[s & 1][s >> 1], d2[0]);
+                    d2[1] = tm_mfma(w2f[s][1], acc[s & 1][s >> 1], d2[1]);
+                }
+                d2[0] = tm_relu(d2[0]);
+                d2[1] = tm_relu(d2[1]);
+                if (jv) {
+                    float *l2 = H2s + (jdir * N + j) * 33 + 8 * lq;
+                    float *g1 = A.H1 + jdir * dstride + (rowbase + j) * 32 + 8 * lq, *g2 = A.H2 + jdir * dstride + (rowbase + j) * 32 + 8 * lq;
+                    tm_st4(g1, f32x4{acc[0][0], acc[1][0], acc[0][1], acc[1][1]});
+                    tm_st4(g1 + 4, f32x4{acc[0][2], acc[1][2], acc[0][3], acc[1][3]});
+                    tm_st4(g2, f32x4{d2[0][0], d2[1][0], d2[0][1], d2[1][1]});
+                    tm_st4(g2 + 4, f32x4{d2[0][2], d2[1][2], d2[0][3], d2[1][3]});
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        l2[2 * c] = d2[0][c];
+                        l2[2 * c + 1] = d2[1][c];
+                    }
                 }
             }
         }

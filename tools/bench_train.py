@@ -13,6 +13,8 @@ mols = [charge_gn.read_xyz(os.path.join(d, "mixed_val", nm + ".xyz"), 9) for nm 
 labels = [np.load(os.path.join(d, "mixed_val", nm + ".npy")).astype(np.float32).ravel() if os.path.exists(os.path.join(d, "mixed_val", nm + ".npy")) else np.zeros(len(m[1]), np.float32) for nm, m in zip(names, mols)]
 eng = Engine(nx=9, T=5); eng.set_weights(checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights")))
 eng.train_init()
+for a in sys.argv[2:]:
+    if a.startswith("--opt="): k_, v_ = a[6:].split(":"); eng.set_option(k_, int(v_))
 def batch(k):
     ms = mols[k * B:(k + 1) * B]; ys = labels[k * B:(k + 1) * B]
     off = np.zeros(len(ms) + 1, np.int32); off[1:] = np.cumsum([len(m[1]) for m in ms])
