@@ -142,26 +142,17 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     constexpr int ND = MODE ? 2 : 1;
     TF_CLK(0);
     // ---- MM: this wavefront's weight fragments (every job of a wavefront has the same order of the pair: 8 % ND == 0).
-    // Row m of output tile rb is FEATURE 2 m + rb: a lane's two tiles are neighbours in memory (one 8-byte load per K step
-    // instead of two 4-byte ones: 35 loads per lane, inside the 63 a wavefront can have in flight; 100 were two round trips),
-    // and its eight accumulators are features 8 lq .. 8 lq + 7 of its row.
+    // Row m of output tile rb is FEATURE 2 m + rb: a lane's two tiles are neighbours in memory (one 8-byte read per K step),
+    // and its eight accumulators are features 8 lq .. 8 lq + 7 of its row.  W1 goes through LDS once per workgroup (float4
+    // staging beside the rows): as registers of every job wavefront it was 27 KB per wavefront through the CU's 64 B/clk
+    // vector memory path -- six copies for the pass network, 1 us of its launch.
     constexpr int KA = MM ? (EPNN_TF_FMAX + 3) / 4 : 1;       // K steps of an atom block
     const int wave = tid >> 6, lq = (tid >> 4) & 3, lx = tid & 15;
     const int njobs = ((N + 15) / 16) * ND, jdir = wave % ND;
-    f32x2 wj[KA], we[MM ? 12 : 1], w2f[MM ? 8 : 1];
+    f32x2 w2f[MM ? 8 : 1];
     f32x4 b2v[2];
     if (MM && wave < njobs) {
-        // order 0 rows are [a_i | a_j | e_ij]: the partner a_j meets block 1 of W1; order 1 rows are [a_j | a_i | e_ij]: block 0
-        const float *w1 = A.theta + A.oW1, *w2 = A.theta + A.oW2;
-        const int oth = jdir ? 0 : F;
-#pragma unroll
-        for (int s = 0; s < KA; ++s) {
-            const int k = 4 * s + lq;
-            const f32x2 t = tm_ld2u(w1 + (oth + (k < F ? k : 0)) * 32 + 2 * lx);
-            wj[s] = k < F ? t : f32x2{0.f, 0.f};
-        }
-#pragma unroll
-        for (int s = 0; s < 12; ++s) we[s] = tm_ld2u(w1 + (2 * F + 4 * s + lq) * 32 + 2 * lx);
+        const float *w2 = A.theta + A.oW2;
 #pragma unroll
         for (int s = 0; s < 8; ++s) w2f[s] = tm_ld2u(w2 + (8 * lq + s) * 32 + 2 * lx);     // K step s pairs lane lq with input feature 8 lq + s
         b2v[0] = tm_ld4u(A.theta + A.ob2 + 8 * lq);
@@ -228,9 +219,14 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     if (MM) {
         // both arrays' loads of a round are in flight before the first LDS write (N = 41 is one round)
         const int nA = N * F, nE = N * 48;
-        const int rounds = max((nA + 5 * EPNN_TF_NT - 1) / (5 * EPNN_TF_NT), (nE + 4 * EPNN_TF_NT - 1) / (4 * EPNN_TF_NT));
+        const int w0 = MODE ? 0 : F, nW = (D - w0) * 8;              // W1 rows the jobs read: the partner blocks and the edge block
+        const int rounds = max(max((nA + 5 * EPNN_TF_NT - 1) / (5 * EPNN_TF_NT), (nE + 4 * EPNN_TF_NT - 1) / (4 * EPNN_TF_NT)),
+                               (nW + 3 * EPNN_TF_NT - 1) / (3 * EPNN_TF_NT));
         for (int rd = 0; rd < rounds; ++rd) {
             float va[5], ve[4];
+            f32x4 vw[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) vw[u] = tm_ld4u(A.theta + A.oW1 + w0 * 32 + 4 * min((3 * rd + u) * EPNN_TF_NT + tid, nW - 1));
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
                 const int ia = min((5 * rd + u) * EPNN_TF_NT + tid, nA - 1);
@@ -255,6 +251,11 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                     const int j = ie / 48;
                     Es[j * 49 + (ie - j * 48)] = ve[u];
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int iw = (3 * rd + u) * EPNN_TF_NT + tid;
+                if (iw < nW) tm_st4(W1s + w0 * 32 + 4 * iw, vw[u]);
             }
         }
     } else {
@@ -341,18 +342,22 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 }
             }
             if (has) {
+                // order 0 rows are [a_i | a_j | e_ij]: the partner a_j meets block 1 of W1; order 1 rows are [a_j | a_i | e_ij]: block 0
+                const float *wjs = W1s + (jdir ? 0 : F) * 32 + 2 * lx, *wes = W1s + 2 * F * 32 + 2 * lx;
 #pragma unroll
                 for (int s = 0; s < KA; ++s) {
-                    const int k = 4 * s + lq;
-                    const float t = aj[k < F ? k : 0], vj = (k < F && jv) ? t : 0.f;
-                    acc[0] = tm_mfma(wj[s][0], vj, acc[0]);
-                    acc[1] = tm_mfma(wj[s][1], vj, acc[1]);
+                    const int k = 4 * s + lq, kc = k < F ? k : 0;
+                    const float t = aj[kc], vj = (k < F && jv) ? t : 0.f;
+                    const f32x2 w = *reinterpret_cast<const f32x2 *>(wjs + kc * 32);
+                    acc[0] = tm_mfma(w[0], vj, acc[0]);
+                    acc[1] = tm_mfma(w[1], vj, acc[1]);
                 }
 #pragma unroll
                 for (int s = 0; s < 12; ++s) {
                     const float t = ej[4 * s + lq], ve = jv ? t : 0.f;
-                    acc[0] = tm_mfma(we[s][0], ve, acc[0]);
-                    acc[1] = tm_mfma(we[s][1], ve, acc[1]);
+                    const f32x2 w = *reinterpret_cast<const f32x2 *>(wes + (4 * s + lq) * 32);
+                    acc[0] = tm_mfma(w[0], ve, acc[0]);
+                    acc[1] = tm_mfma(w[1], ve, acc[1]);
                 }
             }
             if (first) {

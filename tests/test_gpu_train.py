@@ -239,6 +239,37 @@ def test_fused_step_equals_layer_by_layer_at_full_size(gpu_engine_factory, val_d
     assert worst < 1e-4
 
 
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_workgroups_per_atom_do_not_change_a_bit(gpu_engine_factory, val_dir, val_names, B):
+    """The matrix-pipe backward hands an atom's weight-gradient jobs to 1..6 workgroups ("train_split"; automatic: as many as
+    fit 256 CUs -- 6 for one molecule at N = 41, 2 for three, 1 for eight).  A job is the same arithmetic whichever workgroup
+    runs it and everything else is computed by all of them from the previous launch's copies: predictions, loss, gradients
+    and the weights after two optimizer steps are bit-identical for every split, random weights (every tensor gets a gradient)."""
+    from conftest import load_molecules
+    names = [nm for nm in val_names if nm.startswith("dsgdb9nsd")][:B]
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, names, 9)
+    rng = np.random.default_rng(B)
+    y = (rng.normal(size=int(offsets[-1])) * 0.2).astype(np.float32)
+    w = random_weights(9, 5, seed=21, scale=0.4)
+    ref = None
+    for split in (0, 1, 2, 5):
+        eng = gpu_engine_factory(nx=9, T=5)
+        eng.set_option("train_split", split)
+        eng.set_weights(w)
+        eng.train_init()
+        q, loss = eng.train_step_xyz(offsets, xyz, x, Q, y, 41, apply=False)
+        g = eng.get_gradients()
+        assert np.abs(g).max() > 0
+        q1, l1 = eng.train_step_xyz(offsets, xyz, x, Q, y, 41)
+        q2, l2 = eng.train_step_xyz(offsets, xyz, x, Q, y, 41)
+        out = (q, np.float32(loss), g, q2, np.float32(l2))
+        if ref is None:
+            ref = out
+        else:
+            for a, b_ in zip(ref, out):
+                assert np.array_equal(a, b_), split
+
+
 def test_train_step_xyz_equals_dense(gpu_engine_factory, val_dir, val_names):
     from conftest import load_molecules
     from oracle import epnn_oracle as orc
