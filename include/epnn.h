@@ -177,9 +177,12 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * switch: number of pieces the partner range of a tiled molecule's all-pairs sweep is cut into; 0, default: by size), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
  * "train_graph" (1: a train step's launch sequence is captured once and replayed as a hipGraph, 0, default: kernel by kernel),
  * "train_fused" (1, default: one workgroup per atom runs a whole pair MLP over its rows, forward and backward, 2T + 2T + 1
- * launches per step; 2: the forward's pair MLPs on the matrix pipe in the factorised form of the inference kernels, a workgroup
- * per 16 atoms of a molecule -- measured slower at N = 41; 0: one launch per Dense layer on materialised rows -- also taken
- * when N exceeds the fused kernels' LDS budget of 96 atoms). */
+ * launches per step, the Dense layers and every weight gradient as 16x16x4 f32 MFMA tiles; 3: the same decomposition with
+ * scalar FMA loops -- round 2's kernels, kept as the second implementation the tests compare; 2: the forward's pair MLPs in
+ * the factorised form of the inference kernels, a workgroup per 16 atoms of a molecule -- measured slower at N = 41; 0: one
+ * launch per Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS budget of 96 atoms),
+ * "train_split" (workgroups that share one atom's weight-gradient jobs in the backward launches of "train_fused" = 1; 0,
+ * default: as many as fit 256 CUs, at most 6 -- a one-molecule step is 41 atoms; results are bit-identical for every value). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features
  * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative

@@ -55,7 +55,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 $R
 stats $OUT/train $OUT/r03_train_kernel_stats.csv
 python3 $R/tools/bench_train.py 1 2>/dev/null | grep -v "^{" >> $OUT/r03_train_step.txt
 python3 $R/tools/bench_train.py 8 2>/dev/null >> $OUT/r03_train_step.txt
+python3 $R/tools/train_clocks.py 1 > $OUT/r03_train_clocks.txt 2>/dev/null
 (cd $R/tools/micro && ./sweep_mix > $OUT/r03_micro_sweep_mix.txt 2>&1)
+(cd $R/tools/micro && ./grid_barrier > $OUT/r03_micro_grid_barrier.txt 2>&1)
 python3 $R/tools/bench_dense_latency.py > $OUT/r03_dense_latency.txt 2>/dev/null
 rm -rf $OUT/big $OUT/bench $OUT/bench20 $OUT/prot $OUT/protpmc $OUT/train
 ls -la $OUT
