@@ -1602,9 +1602,9 @@ static bool train_is_fused(const epnn_handle *h, int N) { return h->opt_train_fu
 // path's last launch also takes the optimizer step
 static int train_fb(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x, const float *d_h0,
                     const float *d_q0, const float *d_y, float *d_pred, float *d_loss, bool size_only = false, bool adam_now = false,
-                    float *out_host = nullptr) {
+                    float *out_host = nullptr, bool step_on_device = false) {
     if (train_is_fused(h, N))
-        return train_fwd_bwd_fused(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only, adam_now, out_host);
+        return train_fwd_bwd_fused(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, size_only, adam_now, out_host, step_on_device);
     if (!size_only) {
         TrainState *ts = train_state(h);
         HIPCHK(hipMemsetAsync(ts->grad.p, 0, (size_t)ts->P * 4, h->stream));       // its launches ADD their parts of the gradient
@@ -1621,20 +1621,27 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     if (ts->loss.ensure(2 * BN * 4)) return 1;
     float *d_loss = ts->loss.as<float>(), *d_pred = d_loss + BN;
     // the optimizer step rides in the gradient reduction's launch when nothing has to happen between the two (no all-reduce
-    // over ranks, no graph replay: the step size changes every step and would be frozen into the graph)
-    const bool adam_now = apply && train_is_fused(h, N) && !h->opt_train_graph && !(h->comm && h->comm_world > 1);
+    // over ranks); the last forward launch of the row-fused path writes loss terms | predictions into page-locked host memory as
+    // well: no download (a 4 us copy kernel and its launch) between the last launch and the caller
+    const bool rowfused = train_is_fused(h, N) && (h->opt_train_fused == 1 || h->opt_train_fused == 3);
+    const bool adam_now = apply && rowfused && !(h->comm && h->comm_world > 1);
+    if (h->pin_tout.ensure(2 * BN * 4)) return 1;
+    float *out_host = rowfused ? h->pin_tout.as<float>() : nullptr;
     if (h->opt_train_graph) {
-        // One molecule padded to N = 41 is ~2 Gflop spread over ~340 tiny launches: the step is launch-bound, so the
-        // launch sequence is recorded once per (B, N, buffer set) and replayed as one hipGraph.
-        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, true)) return 1;
-        const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, (const void *)(size_t)(h->opt_train_fused + 16 * h->opt_train_split), d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
-                                               d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p};
+        // The step is a chain of dependent launches a few microseconds long: recorded once per (B, N, buffer set, apply) and
+        // replayed as one hipGraph.  The step number Adam's step size depends on then lives on the device: the graph's first
+        // launch counts it, its last one reads it (the host keeps its own count in step and repairs the device's when they differ).
+        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, true, adam_now, out_host, true)) return 1;
+        const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, (const void *)(size_t)(h->opt_train_fused + 16 * h->opt_train_split + 256 * (int)adam_now), d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
+                                               d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p, out_host, ts->d_step.p};
         if (!ts->gexec || key != ts->gkey) {
             if (ts->gexec) { (void)hipGraphExecDestroy(ts->gexec); ts->gexec = nullptr; }
             if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
+            const long step_before = ts->step;
             HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            const int bad = train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss);
+            const int bad = train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, false, adam_now, out_host, true);
             const hipError_t ec = hipStreamEndCapture(h->stream, &ts->graph);
+            ts->step = step_before;
             if (bad || ec != hipSuccess) {
                 if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
                 if (!bad) EPNN_FAIL("train step: hipStreamEndCapture failed: %s", hipGetErrorString(ec));
@@ -1643,18 +1650,25 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
             HIPCHK(hipGraphInstantiate(&ts->gexec, ts->graph, nullptr, nullptr, 0));
             ts->gkey = key;
         }
+        if (adam_now && ts->dev_step != ts->step) {
+            const long long sv = ts->step;
+            HIPCHK(hipMemcpyAsync(ts->d_step.p, &sv, 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            ts->dev_step = ts->step;
+        }
         HIPCHK(hipGraphLaunch(ts->gexec, h->stream));
+        if (adam_now) {
+            ts->step += 1;
+            ts->dev_step = ts->step;
+            ts->dev_newer = true;
+        }
     } else {
-        // the last forward launch of the row-fused path writes loss terms | predictions into page-locked host memory as well:
-        // no download (a 4 us copy kernel and its launch) between the last launch and the caller
-        if (h->pin_tout.ensure(2 * BN * 4)) return 1;
-        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, false, adam_now, h->pin_tout.as<float>())) return 1;
+        if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, false, adam_now, out_host)) return 1;
     }
     if (apply && !adam_now && train_apply(h)) return 1;
     // the step's loss terms and predictions are neighbours on the device: one download into page-locked memory
     const size_t nback = BN + (pred_host ? BN : 0);
-    if (h->pin_tout.ensure(nback * 4)) return 1;
-    if (!(ts->host_out && !h->opt_train_graph)) HIPCHK(hipMemcpyAsync(h->pin_tout.p, d_loss, nback * 4, hipMemcpyDeviceToHost, h->stream));
+    if (!ts->host_out) HIPCHK(hipMemcpyAsync(h->pin_tout.p, d_loss, nback * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const float *back = h->pin_tout.as<float>();
     if (pred_host) memcpy(pred_host, back + BN, BN * 4);

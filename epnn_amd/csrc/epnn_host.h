@@ -135,8 +135,9 @@ struct epnn_handle {
     int opt_train_split = 0;          // training, matrix-pipe backward: workgroups per atom (0 = as many as fit 256 CUs, at most 6)
     int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels; 2 = the forward on the matrix pipe instead (epnn_train_mfma.hip.h;
                                       // measured slower at N = 41: three workgroups per molecule); 0 = the layer-by-layer kernels
-    int opt_train_graph = 0;          // training: 1 replays the step's launch sequence as a hipGraph (frees the host thread; not faster:
-                                      // 0.47 vs 0.45 ms per step, the kernels are latency-bound, and a new buffer set means a new capture)
+    int opt_train_graph = 1;          // training: 1 replays the step's launch sequence (optimizer step included) as a hipGraph: 0.22 vs 0.245 ms
+                                      // per one-molecule step once the kernels were short enough for the launch boundaries to show
+                                      // (round 2: 0.47 vs 0.45); a new (B, N, buffer set) means a new capture
     int opt_wave_front = 1;           // xyz entry, small molecules only: pair list built inside the wave kernel (no front-end kernels)
     int opt_wave2 = -1;               // compact entry, block-per-wavefront kernel (epnn_wave2.hip.h): molecules with at least this many
                                       // atoms (17..32) are split over two wavefronts, those of at most 16 run in pairs, the rest on

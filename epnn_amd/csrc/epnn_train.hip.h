@@ -340,6 +340,8 @@ struct TrainState {
     hipGraphExec_t gexec = nullptr;
     std::vector<const void *> gkey;
     bool fused_attr = false;                     // dynamic LDS limit of the row-fused kernels raised
+    DevBuf d_step;                               // hipGraph replay with the optimizer step inside: the step number on the device
+    long dev_step = -1;                          //   ... and the value the host last put there
     bool host_out = false;                       // the last forward launch wrote loss terms | predictions into the caller's page-locked buffer
 #ifdef EPNN_TF_CLOCKS
     DevBuf clk;                                  // [launch][16] phase clocks of workgroup 0 (development build)
@@ -580,10 +582,11 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
 // they were 18 launches of their own).  d_loss receives one loss term per atom slot [B][N].
 static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
                                const float *d_h0, const float *d_q0, const float *d_y, float *d_pred, float *d_loss,
-                               bool size_only = false, bool adam_now = false, float *out_host = nullptr) {
+                               bool size_only = false, bool adam_now = false, float *out_host = nullptr, bool step_on_device = false) {
     TrainState *ts = train_state(h);
     if (!ts->ready) EPNN_FAIL("training: call epnn_train_init first");
-    ts->host_out = false;
+    ts->host_out = out_host != nullptr && h->opt_train_fused != 2;       // (the 16-atom forward has its own loss launch)
+    if (step_on_device && ts->d_step.ensure(8)) return 1;
     const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, E = EPNN_EDIM, F = nx + H + 1, D = 2 * F + E, FS = F | 1;
     const int BN = B * N;
     const size_t R = (size_t)BN * N;
@@ -678,6 +681,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         TfPair A = pair_args(ts->msg[t], hcur, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
         if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the node masks
+        if (t == 0 && adam_now && step_on_device) A.step_p = ts->d_step.as<long long>();
         if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<0>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, upd_args(t, hcur), nblk);
         else if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<0, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));
         else hipLaunchKernelGGL((k_tf_pair_fwd<0, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
@@ -693,7 +697,6 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         if (t == T - 1 && !mfma_fwd) {
             A.y = d_y; A.pred = d_pred; A.lterm = d_loss;
             A.out_h = out_host;
-            ts->host_out = out_host != nullptr;
         }
         if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<1>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, TfUpd{}, nblk);
         else if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
@@ -754,10 +757,14 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = 0; t < T; ++t) entry(ts->msg[t][0].offW, Pm0, BN, o_pm[t]);
     for (int t = 0; t < T; ++t) entry(ts->pas[t][0].offW, Pm1, BN, o_pp[t]);
     if (adam_now) {
-        ts->step += 1;
-        const double tt = (double)ts->step;
         Rd.adam = 1;
-        Rd.alpha = (float)((double)ts->lr * std::sqrt(1.0 - std::pow((double)ts->b2, tt)) / (1.0 - std::pow((double)ts->b1, tt)));
+        if (step_on_device) {                       // captured into a hipGraph: the caller keeps ts->step and the device counter in step
+            Rd.step_p = ts->d_step.as<long long>();
+            Rd.lr = ts->lr;
+        } else {
+            ts->step += 1;
+            Rd.alpha = epnn_adam_alpha(ts->lr, ts->b1, ts->b2, ts->step);
+        }
         Rd.b1 = ts->b1; Rd.b2 = ts->b2; Rd.eps = ts->eps;
         Rd.theta = ts->theta.as<float>(); Rd.m = ts->m.as<float>(); Rd.v = ts->v.as<float>();
         ts->dev_newer = true;
@@ -774,8 +781,7 @@ static int train_apply(epnn_handle *h) {
         if (rc != ncclSuccess) EPNN_FAIL("ncclAllReduce failed: %s", ncclGetErrorString(rc));
     }
     ts->step += 1;
-    const double t = (double)ts->step;
-    const float alpha = (float)((double)ts->lr * std::sqrt(1.0 - std::pow((double)ts->b2, t)) / (1.0 - std::pow((double)ts->b1, t)));
+    const float alpha = epnn_adam_alpha(ts->lr, ts->b1, ts->b2, ts->step);
     hipLaunchKernelGGL(k_t_adam, dim3(t_grid(ts->P)), dim3(256), 0, h->stream, ts->theta.as<float>(), ts->grad.as<float>(),
                        ts->m.as<float>(), ts->v.as<float>(), ts->P, alpha, ts->b1, ts->b2, ts->eps);
     HIPCHK(hipGetLastError());

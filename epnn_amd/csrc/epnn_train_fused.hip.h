@@ -5,8 +5,10 @@
 // trace in DESIGN.md section 6b).  Here ONE workgroup owns atom i of a molecule and runs the whole pair MLP over its N
 // partner rows -- both orders of the pair for the pass network -- with the rows [a_i | a_j | e_ij] (charge_gn.py:62-66,
 // 101-108) assembled in LDS instead of HBM; the backward kernel does the same and leaves one block of weight-gradient
-// partials per workgroup, summed in a fixed order by one launch at the end of the step.  ~45 launches instead of ~340.
-// The work per launch is far too small for the matrix pipe to matter (latency-bound): plain FMA code, LDS-resident rows.
+// partials per workgroup, summed in a fixed order by one launch at the end of the step.  2T + 2T + 1 launches instead of ~340.
+// Round 2 wrote the kernels as plain FMA loops over LDS-resident rows (k_tf_pair_fwd<MODE, false>, k_tb_pair_bwd: "train_fused" = 3);
+// round 3 put the Dense layers and every weight gradient on the matrix pipe and laid each launch out for latency (MM = true,
+// k_tb_pair_bwd_mm: DESIGN.md section 6b has the measurements that asked for each change).
 // All sums have a fixed order: gradients are bit-reproducible.
 #pragma once
 #include "epnn_host.h"
@@ -41,6 +43,7 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     float tol;
     const float *y;              // forward, last pass step: labels -> predictions (pred) and loss terms (lterm) per atom;
     float *pred, *lterm;         //   backward, first pass step (first != 0): gq = -2 (y - pred)
+    long long *step_p;           // forward, first message sweep of a replayed hipGraph that also takes the optimizer step: counts the step
     float *out_h;                // forward, last pass step: page-locked host memory for the same two (or null): no download after the step
     int first;                   // backward: this is the first launch of its stack
     // backward: the "atoms" stage of the PREVIOUS backward launch runs as this launch's prologue (k_tb_atoms' arithmetic)
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     const int tid = threadIdx.x, o = tid & 31, g = tid >> 5;
     constexpr int ND = MODE ? 2 : 1;
     TF_CLK(0);
+    if (MODE == 0 && A.step_p && bi == 0 && tid == 0) *A.step_p += 1;
     // ---- MM: this wavefront's weight fragments (every job of a wavefront has the same order of the pair: 8 % ND == 0).
     // Row m of output tile rb is FEATURE 2 m + rb: a lane's two tiles are neighbours in memory (one 8-byte read per K step),
     // and its eight accumulators are features 8 lq .. 8 lq + 7 of its row.  W1 goes through LDS once per workgroup (float4
@@ -1492,6 +1496,20 @@ __global__ __launch_bounds__(64) void k_tb_update_bwd(TfUpd U) {
 
 // ---------------------------------------------------------------------------------------------- gradient = sum of partials
 #define EPNN_TF_MAXRED 24
+// Keras-2 Adam's step size lr sqrt(1 - b2^t) / (1 - b1^t) (charge_gn.py:419) with the powers by repeated squaring in double: the
+// same bits on the host and in a kernel (a replayed hipGraph reads t from device memory)
+__host__ __device__ inline float epnn_adam_alpha(float lr, float b1, float b2, long long t) {
+    double p1 = 1.0, p2 = 1.0, x1 = (double)b1, x2 = (double)b2;
+    for (long long e = t; e > 0; e >>= 1) {
+        if (e & 1) {
+            p1 *= x1;
+            p2 *= x2;
+        }
+        x1 *= x1;
+        x2 *= x2;
+    }
+    return (float)((double)lr * sqrt(1.0 - p2) / (1.0 - p1));
+}
 struct TfReduce {
     int n;
     int theta_off[EPNN_TF_MAXRED], len[EPNN_TF_MAXRED], nblk[EPNN_TF_MAXRED];
@@ -1501,6 +1519,8 @@ struct TfReduce {
     int adam;
     float alpha, b1, b2, eps;
     float *theta, *m, *v;
+    const long long *step_p;      // hipGraph replay: the step number lives on the device (the step's first launch has counted it)
+    float lr;
 };
 // grad[theta_off + idx] = sum_blk part[part_off + blk * len + idx]: four quarter sums (one per wavefront), combined in order
 __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *part, float *grad) {
@@ -1523,11 +1543,12 @@ __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *par
         const float g = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
         grad[i] = g;
         if (T.adam) {
+            const float alpha = T.step_p ? epnn_adam_alpha(T.lr, T.b1, T.b2, *T.step_p) : T.alpha;
             const float mi = T.b1 * T.m[i] + (1.f - T.b1) * g;
             const float vi = T.b2 * T.v[i] + (1.f - T.b2) * g * g;
             T.m[i] = mi;
             T.v[i] = vi;
-            T.theta[i] -= T.alpha * mi / (sqrtf(vi) + T.eps);
+            T.theta[i] -= alpha * mi / (sqrtf(vi) + T.eps);
         }
     }
 }

@@ -23,6 +23,7 @@ names = [str(n) for n in np.load(os.path.join(ROOT, "tests/golden/val_names.npy"
 mols = [charge_gn.read_xyz(os.path.join(d, "mixed_val", nm + ".xyz"), 9) for nm in names]
 eng = Engine(nx=9, T=5); eng.set_weights(checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights")))
 eng.train_init()
+eng.set_option("train_graph", 0)          # the development build allocates its clock buffer inside the step
 for a in sys.argv[1:]:
     if a.startswith("--opt="): k, v = a[6:].split(":"); eng.set_option(k, int(v))
 def batch(k):
