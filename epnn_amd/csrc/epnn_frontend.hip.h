@@ -148,8 +148,10 @@ __device__ __forceinline__ void front_scan_both_body(const FrontArgs &F, int *ws
         int va[8], vb[8], ta = 0, tb = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            va[k] = i0 + k < F.A ? F.row_cnt[i0 + k] : 0;
-            vb[k] = i0 + k < F.A ? F.deg[i0 + k] : 0;
+            const int ic = min(i0 + k, F.A - 1);                   // unconditional loads (a load under a condition is a branch
+            const int ta_ = F.row_cnt[ic], tb_ = F.deg[ic];        // and waits for the load before it), a select after
+            va[k] = i0 + k < F.A ? ta_ : 0;
+            vb[k] = i0 + k < F.A ? tb_ : 0;
             ta += va[k];
             tb += vb[k];
         }
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(256) void k_front_scan1(FrontArgs F, int *bsum) {
     int v[8], tot = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        v[k] = base + k < F.A ? F.row_cnt[base + k] : 0;
+        const int t_ = F.row_cnt[min(base + k, F.A - 1)];
+        v[k] = base + k < F.A ? t_ : 0;
         tot += v[k];
     }
     int incl = tot;
@@ -326,10 +329,10 @@ __device__ __forceinline__ void front_link_body(const FrontArgs &F, int blk, int
         for (int k0 = lo; k0 < hi && found < 0; k0 += 8) {
             int v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = k0 + u < hi ? F.nbr[k0 + u] : -1;
+            for (int u = 0; u < 8; ++u) v[u] = F.nbr[min(k0 + u, hi - 1)];       // unconditional; a repeated last entry finds nothing new
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (v[u] == i) found = k0 + u;
+                if (k0 + u < hi && v[u] == i) found = k0 + u;
         }
         const int di = F.dest_i[p];
         F.dest_j[p] = found;

@@ -132,7 +132,7 @@ struct epnn_handle {
     DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
-    int opt_train_split = 0;          // training, matrix-pipe backward: workgroups per atom (0 = as many as fit 256 CUs, at most 6)
+    int opt_train_split = 0;          // training, matrix-pipe backward: workgroups per atom (0 = as many as fit the atom's XCD, at most 6)
     int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels; 2 = the forward on the matrix pipe instead (epnn_train_mfma.hip.h;
                                       // measured slower at N = 41: three workgroups per molecule); 0 = the layer-by-layer kernels
     int opt_train_graph = 1;          // training: 1 replays the step's launch sequence (optimizer step included) as a hipGraph: 0.22 vs 0.245 ms

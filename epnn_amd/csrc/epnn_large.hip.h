@@ -689,7 +689,10 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
                 if (part == 0) {
                     float xv[16];
 #pragma unroll
-                    for (int f = 0; f < 16; ++f) xv[f] = f < L.nx ? L.xin[(size_t)at * L.nx + f] : 0.f;
+                    for (int f = 0; f < 16; ++f) {
+                        const float t = L.xin[(size_t)at * L.nx + min(f, L.nx - 1)];
+                        xv[f] = f < L.nx ? t : 0.f;
+                    }
                     const float qv = L.q_in ? L.q_in[at] : L.Q[b] / (float)(L.moff[b + 1] - L.moff[b]);
 #pragma unroll
                     for (int f = 0; f < 16; ++f)
@@ -802,9 +805,10 @@ __device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, con
         for (int k = 0; k < NA; ++k) {
             tv[k] = types ? L.S_type[(size_t)trow[k] * 32 + o] : 0.f;
 #pragma unroll
-            for (int u = 0; u < CB; ++u) v[k][u] = ch + u < nchunk ? L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step] : 0.f;
+            // (unconditional loads of a clamped index: `cond ? p[i] : 0` is a branch per load, each waiting for the one before)
+            for (int u = 0; u < CB; ++u) v[k][u] = L.S0[(size_t)at[k] * 32 + o + (size_t)max(min(ch + u, nchunk - 1), 0) * step];
 #pragma unroll
-            for (int u = 0; u < S1; ++u) c1[k][u] = lo[k] + u < hi[k] ? L.corrA[(size_t)(lo[k] + u) * 32 + o] : 0.f;
+            for (int u = 0; u < S1; ++u) c1[k][u] = L.corrA[(size_t)max(min(lo[k] + u, hi[k] - 1), 0) * 32 + o];
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
@@ -827,7 +831,7 @@ __device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, con
 #pragma unroll
         for (int k = 0; k < NA; ++k)
 #pragma unroll
-            for (int u = 0; u < SB; ++u) v[k][u] = lo[k] + u < hi[k] ? L.corrA[(size_t)(lo[k] + u) * 32 + o] : 0.f;
+            for (int u = 0; u < SB; ++u) v[k][u] = L.corrA[(size_t)max(min(lo[k] + u, hi[k] - 1), 0) * 32 + o];
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
 #pragma unroll
@@ -1052,7 +1056,7 @@ __device__ __forceinline__ float lg_slot_sum(const float *dl, int lo, int hi) {
     for (; lo < hi; lo += 16) {
         float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = lo + u < hi ? dl[lo + u] : 0.f;
+        for (int u = 0; u < 16; ++u) v[u] = dl[min(lo + u, hi - 1)];      // unconditional: a load under a condition is a branch, one round trip each
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             if (lo + u < hi) acc += v[u];

@@ -668,7 +668,9 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     const bool mm = h->opt_train_fused != 3 && nx + 49 <= EPNN_TF_FMAX && ((uintptr_t)d_e & 15) == 0;
     auto lds_bwd_mm = [&](int nd) { return ((size_t)4 * nd * N * EPNN_TB_RS + (size_t)N * EPNN_TB_ES + 1168 + (size_t)N * FS) * 4; };
     // one molecule per step is N workgroups on 256 CUs: up to six workgroups per atom share its weight-gradient jobs
-    const int nsplit = h->opt_train_split ? h->opt_train_split : std::max(1, std::min(6, 256 / BN));
+    // (an XCD has 32 CUs and a workgroup of these kernels has a CU to itself: the shares of an XCD's atoms must fit it in one round)
+    const int nsplit = h->opt_train_split ? h->opt_train_split : std::max(1, std::min(6, 32 / ((BN + 7) / 8)));
+    const unsigned bwd_grid = 8u * (unsigned)((BN + 7) / 8) * (unsigned)nsplit;          // eight XCDs, equal parts (k_tb_pair_bwd_mm)
     const int nblk = (N + 15) / 16;
     const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + EPNN_TM_NW * 16 * 33) * 4;
     if (mfma_fwd) {
@@ -715,7 +717,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.pmode = pmode; A.poW1 = poW1; A.pfirst = pfirst;
         if (mm) {
             const bool odd = nb & 1;
-            A.nsplit = nsplit;
+            A.nsplit = nsplit; A.natoms = BN;
             A.gfeat = P(odd ? o_gfeatb : o_gfeat); A.gfeat_r = P(odd ? o_gfeat : o_gfeatb);
             A.gqv = P(odd ? o_gqb : o_gq); A.gq_r = P(odd ? o_gq : o_gqb);
             A.dU0_r = P(odd ? o_dU0 : o_dU0b);
@@ -728,7 +730,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.part = P(o_pp[t]);
         A.first = t == T - 1; A.y = d_y; A.pred = d_pred;
         chain(A);
-        if (mm) hipLaunchKernelGGL(k_tb_pair_bwd_mm<1>, dim3(BN * nsplit), dim3(EPNN_TF_NT), lds_bwd_mm(2), st, A, TfUpd{});
+        if (mm) hipLaunchKernelGGL(k_tb_pair_bwd_mm<1>, dim3(bwd_grid), dim3(EPNN_TF_NT), lds_bwd_mm(2), st, A, TfUpd{});
         else hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, TfUpd{});
         pmode = 1; poW1 = ts->pas[t][0].offW; pfirst = t == T - 1;
     }
@@ -740,7 +742,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         if (mm) {
             TfUpd Ub = upd_args(t, hin);
             Ub.dU0 = P(((nb - 1) & 1) ? o_dU0b : o_dU0);               // chain() has counted this launch
-            hipLaunchKernelGGL(k_tb_pair_bwd_mm<0>, dim3(BN * nsplit), dim3(EPNN_TF_NT), lds_bwd_mm(1), st, A, Ub);
+            hipLaunchKernelGGL(k_tb_pair_bwd_mm<0>, dim3(bwd_grid), dim3(EPNN_TF_NT), lds_bwd_mm(1), st, A, Ub);
         }
         else hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, upd_args(t, hin));     // update backward first
         pmode = 0; poW1 = ts->msg[t][0].offW; pfirst = 0;

@@ -54,7 +54,7 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     float *gfeat, *gh, *gqv;     // [BN][48], [BN][48], [BN]
     // matrix-pipe backward (k_tb_pair_bwd_mm): `nsplit` workgroups per atom share its weight-gradient jobs (one molecule is 41
     // workgroups on 256 CUs); what a launch updates in place in the scalar kernel is read from the previous launch's copy here
-    int nsplit;
+    int nsplit, natoms;                  // natoms = B N (the grid is padded: see the kernel)
     const float *gfeat_r, *gq_r, *dU0_r; // the previous launch's gfeat / gq / dU0 (this one writes gfeat / gqv / U.dU0)
     const float *rs_r;                   // [BN][2][32] the previous sweep's row sums of dz1 (listed, swapped rows of each atom)
     float *rs_w;
@@ -957,7 +957,14 @@ template <int MODE>
 __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
     const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
-    const int S = A.nsplit, bi = blockIdx.x / S, sub = blockIdx.x - bi * S, b = bi / N, i = bi - b * N;
+    // The workgroups of an atom read the same rows: they sit on ONE XCD (consecutive block indices go round the eight XCDs, each
+    // with an L2 of its own -- six workgroups of an atom spread over six XCDs fetched its rows from HBM / MALL six times, 15 MB per
+    // launch at the moment every workgroup starts).  Block x runs on XCD x % 8; there it is the (x / 8)-th of that XCD's
+    // (atom, share) pairs, the XCD's atoms being xcd, xcd + 8, ...; the grid is padded to eight equal parts.
+    const int S = A.nsplit, BNa = A.natoms;
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3, bi = (kx / S) * 8 + xcd, sub = kx - (kx / S) * S;
+    if (bi >= BNa) return;
+    const int b = bi / N, i = bi - b * N;
     const bool own = sub == 0;                // the workgroup of this atom that writes what is not a weight-gradient job
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lx = lane & 15;
     constexpr int ND = MODE ? 2 : 1, O = MODE ? 1 : 32, RS = EPNN_TB_RS, ES = EPNN_TB_ES;
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
     float *pp = psh + 128;                    // [8][2][32] prologue: the column sums' partials
     float *As = pp + 512;                     // [N][FS]
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
-    const size_t dstride = (size_t)(gridDim.x / S) * N * 32;
+    const size_t dstride = (size_t)BNa * N * 32;
     const float *theta = A.theta;
     TF_CLK(0);
     TF_CYC(14);

@@ -183,7 +183,8 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * the factorised form of the inference kernels, a workgroup per 16 atoms of a molecule -- measured slower at N = 41; 0: one
  * launch per Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS budget of 96 atoms),
  * "train_split" (workgroups that share one atom's weight-gradient jobs in the backward launches of "train_fused" = 1; 0,
- * default: as many as fit 256 CUs, at most 6 -- a one-molecule step is 41 atoms; results are bit-identical for every value). */
+ * default: as many as fit the XCD the atom's workgroups are placed on, at most 6 -- 5 for a one-molecule step of 41 atoms; results
+ * are bit-identical for every value). */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features
  * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative

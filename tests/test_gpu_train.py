@@ -242,7 +242,7 @@ def test_fused_step_equals_layer_by_layer_at_full_size(gpu_engine_factory, val_d
 @pytest.mark.parametrize("B", [1, 3, 8])
 def test_workgroups_per_atom_do_not_change_a_bit(gpu_engine_factory, val_dir, val_names, B):
     """The matrix-pipe backward hands an atom's weight-gradient jobs to 1..6 workgroups ("train_split"; automatic: as many as
-    fit 256 CUs -- 6 for one molecule at N = 41, 2 for three, 1 for eight).  A job is the same arithmetic whichever workgroup
+    fit the 32 CUs of the XCD the atom's workgroups share -- 5 for one molecule at N = 41, 2 for three, 1 for eight).  A job is the same arithmetic whichever workgroup
     runs it and everything else is computed by all of them from the previous launch's copies: predictions, loss, gradients
     and the weights after two optimizer steps are bit-identical for every split, random weights (every tensor gets a gradient)."""
     from conftest import load_molecules
