@@ -1537,25 +1537,44 @@ __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *par
     if ((int)blockIdx.x * 64 >= len) return;
     const int nblk = T.nblk[en];
     const int lo = (int)((long long)nblk * w / 4), hi = (int)((long long)nblk * (w + 1) / 4);
+    // everything this thread will need is requested before the first wait: the optimizer state of its element (wavefront 0) and
+    // sixteen partials per pass, unconditional loads of a clamped block index (a remainder loop of single loads, then m / v, then
+    // theta were five round trips of the step's last 7 us)
+    const bool fin = w == 0 && idx < len;
+    const int ei = T.theta_off[en] + (idx < len ? idx : 0);
+    float m0 = 0.f, v0 = 0.f, th0 = 0.f;
+    long long stp = 0;
+    if (T.adam && fin) {
+        if (T.step_p) stp = *T.step_p;
+        m0 = T.m[ei];
+        v0 = T.v[ei];
+        th0 = T.theta[ei];
+    }
     float s = 0.f;
     if (idx < len) {
         const float *p = part + T.part_off[en] + idx;
-#pragma unroll 8
-        for (int blk = lo; blk < hi; ++blk) s += p[(size_t)blk * len];
+        for (int blk = lo; blk < hi; blk += 16) {
+            float pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pv[u] = p[(size_t)min(blk + u, hi - 1) * len];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (blk + u < hi) s += pv[u];
+        }
     }
     sh[w][lane] = s;
     __syncthreads();
-    if (w == 0 && idx < len) {
-        const int i = T.theta_off[en] + idx;
+    if (fin) {
+        const int i = ei;
         const float g = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
         grad[i] = g;
         if (T.adam) {
-            const float alpha = T.step_p ? epnn_adam_alpha(T.lr, T.b1, T.b2, *T.step_p) : T.alpha;
-            const float mi = T.b1 * T.m[i] + (1.f - T.b1) * g;
-            const float vi = T.b2 * T.v[i] + (1.f - T.b2) * g * g;
+            const float alpha = T.step_p ? epnn_adam_alpha(T.lr, T.b1, T.b2, stp) : T.alpha;
+            const float mi = T.b1 * m0 + (1.f - T.b1) * g;
+            const float vi = T.b2 * v0 + (1.f - T.b2) * g * g;
             T.m[i] = mi;
             T.v[i] = vi;
-            T.theta[i] -= alpha * mi / (sqrtf(vi) + T.eps);
+            T.theta[i] = th0 - alpha * mi / (sqrtf(vi) + T.eps);
         }
     }
 }
