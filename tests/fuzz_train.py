@@ -8,7 +8,11 @@ ulp of 0 that the two summation orders put on different sides of the ReLU kink (
 scaling the weights by 1 +- 1e-4 makes both agree with the oracle to 7e-7 again.
 Round 2 (seed 24, 1398 cases, 5 flagged): every flagged case is now checked against the oracle's kink bracket
 (relu'(z) = [z > +-tau] separately for the GNN rows and the pass network's two row sets, tau = 4e-6): a case whose
-gradient lies within the bracket is a ReLU-kink decision, anything else makes the script fail."""
+gradient lies within the bracket is a ReLU-kink decision, anything else makes the script fail.
+Round 3 (seed 31, 5016 cases after the matrix-pipe rewrite of the row-fused kernels, 6 flagged): five kink decisions and one batch
+of a one-atom and a three-atom molecule where BOTH implementations are 3.5e-4 off and the float32 oracle itself 3.1e-4 -- the
+noise floor of that problem; the tolerance is now max(2e-4, 4 x the float32 oracle's distance from the float64 one), as in
+the config-3 test."""
 import os
 import sys
 import time
@@ -61,12 +65,17 @@ def main():
                 lo = ot.flatten(ot.loss_and_grads(*batch, w, kink_shift=+4e-6, kink_where=where)[2])
                 hi = ot.flatten(ot.loss_and_grads(*batch, w, kink_shift=-4e-6, kink_where=where)[2])
                 band += np.abs(hi - lo)
+            # the float32 noise floor of the problem itself: the reference algorithm evaluated in float32 against float64 (a batch
+            # of one- and three-atom molecules has residuals and gradients so small that float32 rounding of the forward alone
+            # moves them by more than 2e-4 of the largest entry -- both implementations are then off by the same amount)
+            g32 = ot.flatten(ot.loss_and_grads(*batch, w, dtype=np.float32)[2]).astype(np.float64)
+            noise = float(np.abs(g32 - gr).max() / glob)
             out = [float(np.maximum(np.abs(v - gr) - 2 * band, 0).max() / glob) for v in (g, g0)]
-            kink = max(out) <= 2e-4
+            kink = max(out) <= max(2e-4, 4 * noise)
             unexplained += not kink
             print(f"case nx={nx} T={T} N={N} ns={ns}: fused vs oracle {err:.2e}, layer-by-layer vs oracle "
                   f"{np.abs(g0 - gr).max() / glob:.2e}, fused vs layer-by-layer {np.abs(g - g0).max() / glob:.2e}; kink bracket up to "
-                  f"{band.max() / glob:.1e} -> " + ("a ReLU-kink decision" if kink else f"NOT explained (outside by {max(out):.1e})"))
+                  f"{band.max() / glob:.1e} -> " + ("a ReLU-kink decision" if kink else f"NOT explained (outside by {max(out):.1e})") + f"; float32 oracle noise {noise:.1e}")
     print(f"train fuzz: {n} cases, {flagged} flagged, {unexplained} not explained by a ReLU kink")
     if unexplained:
         raise SystemExit(1)
