@@ -37,8 +37,12 @@ lib.epnn_debug_train_clocks.restype = C.c_int
 lib.epnn_debug_train_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 assert lib.epnn_debug_train_clocks(eng.h, buf, 64 * 16) == 0
 c = np.array(buf[:], dtype=np.uint64).reshape(64, 16).astype(np.int64)
-labels_f = ["fragments+staging", "layers 1-2", "col sums / layer 3 rows", "M, U0 / pair sum", "update MLP / -"]
-print("launch  kind   phase boundaries in units of 10 ns (wall_clock64) from the workgroup's start")
+print("""phase boundaries of workgroup 0 in units of 10 ns (wall_clock64) from the workgroup's start; '-' = not stamped in this launch
+forward  (k_tf_pair_fwd<MODE, true>):  1 rows staged (barrier)   2 both Dense layers done (barrier)   3 column sums + third Dense (message) /
+         per-row third Dense (pass)   5 end: update MLP (message, on the last wavefront) / pair sum (pass)
+backward (k_tb_pair_bwd_mm<MODE>):     1 chain and staging met (barrier)   2 dz2, dz1 done (barrier)   3 end of the weight-gradient jobs
+         4 chain: prologue's sums   5 chain: gradient at a_i   6 chain: update MLP backward (message)   7 chain: end   8 staging wavefronts: end
+         9 dz1 MFMAs   10 dz stores   11 update partials stored   12 first weight-gradient job starts   13 its K loop ends""")
 for l in range(64):
     if c[l, 0] == 0: continue
     row = c[l]; last = max(k for k in range(16) if row[k])
