@@ -152,6 +152,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     h->pin_train.release();
     h->pin_tout.release();
     h->pin_out.release();
+    h->pin_neff.release();
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     for (auto &e : h->evpool) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1241,6 +1242,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_order")) { h->opt_wave_order = value; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
+    else if (!strcmp(name, "dense_small")) { h->opt_dense_small = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else if (!strcmp(name, "train_split")) { if (value < 0 || value > 8) EPNN_FAIL("epnn_set_option: train_split must be 0 (automatic) .. 8"); h->opt_train_split = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
@@ -1306,12 +1308,33 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     D.flag = h->dn_flag.as<int>();
     D.neff = h->dn_neff.as<int>();
     D.tol = h->cfg.near_tol;
-    if (launch_dense_atoms(h, D)) return 1;
-    hipLaunchKernelGGL(k_dn_neff, dim3((unsigned)B), dim3(64), 0, h->stream, D);
-    HIPCHK(hipGetLastError());
+    // one or a few molecules: the call is made of latencies -- everything the host waits for is one launch that writes the
+    // effective atom counts into page-locked memory itself (dense entry)
+    const bool small_call = mode == 0 && h->opt_dense_small && slots * N <= 65536;
     h->dn_neff_host.resize(B);
-    HIPCHK(hipMemcpyAsync(h->dn_neff_host.data(), D.neff, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));       // the host plans tiles from the effective atom counts
+    if (small_call) {
+        if (h->pin_neff.ensure((size_t)B * 4) || h->dn_den.ensure(slots * 4)) return 1;
+        // a flag counts when it equals this call's generation number: numbers start at 2 (the general sequence writes 0 / 1 into
+        // the same array), and a new allocation or a wrapped counter starts from a cleared array
+        if (h->dn_flag.p != h->dn_flag_seen || h->dn_gen >= 0x7ffffff0) {
+            HIPCHK(hipMemsetAsync(h->dn_flag.p, 0, h->dn_flag.cap, h->stream));
+            h->dn_flag_seen = h->dn_flag.p;
+            h->dn_gen = 1;
+        }
+        h->dn_gen += 1;
+        const int fb = (N * (EPNN_EDIM + nx + 1) + 255) / 256, eb = (N * N + 255) / 256;
+        hipLaunchKernelGGL(k_dn_front_small, dim3((unsigned)(fb + eb), (unsigned)B), dim3(256), 0, h->stream, D, h->dn_den.as<float>(), h->dn_gen, fb);
+        hipLaunchKernelGGL(k_dn_neff_small, dim3((unsigned)B), dim3(64), 0, h->stream, D, h->dn_gen, h->pin_neff.as<int>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(h->dn_neff_host.data(), h->pin_neff.p, (size_t)B * 4);
+    } else {
+        if (launch_dense_atoms(h, D)) return 1;
+        hipLaunchKernelGGL(k_dn_neff, dim3((unsigned)B), dim3(64), 0, h->stream, D);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->dn_neff_host.data(), D.neff, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));       // the host plans tiles from the effective atom counts
+    }
     std::vector<int> offsets(B + 1, 0);
     for (int b = 0; b < B; ++b) offsets[b + 1] = offsets[b] + h->dn_neff_host[b];
     if (build_plan(h, B, N, offsets.data(), mode == 0)) return 1;     // both stacks: the block-per-wavefront kernel may take part
@@ -1339,24 +1362,30 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     D.pwi = h->d_pwi.as<float>();
     D.pwj = h->d_pwj.as<float>();
     D.status = h->d_status.as<int>();
-    HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     h->ctl_clean = false;
     h->last_front = false;
-    const unsigned rows = (unsigned)((P.A + 3) / 4);
-    hipLaunchKernelGGL(k_dn_pairs<0>, dim3(rows), dim3(256), 0, h->stream, D);
-    FrontArgs F{};
-    F.A = P.A;
-    F.row_cnt = h->d_rowcnt.as<int>();
-    F.row_off = h->d_rowoff.as<int>();
-    F.pcap = h->pcap;
-    F.status = h->d_status.as<int>();
-    {
-        const unsigned nsb = (unsigned)((F.A + EPNN_SCAN_ELEMS - 1) / EPNN_SCAN_ELEMS);
-        if (h->d_bsum.ensure((size_t)nsb * sizeof(int))) return 1;
-        hipLaunchKernelGGL(k_front_scan1, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
-        if (nsb > 1) hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+    if (small_call && P.A <= 1024) {
+        const unsigned rows = (unsigned)((P.A + 3) / 4);
+        hipLaunchKernelGGL(k_dn_pairs_count_small, dim3(rows), dim3(256), 0, h->stream, D);
+        hipLaunchKernelGGL(k_dn_pairs_fill_small, dim3(rows), dim3(256), 0, h->stream, D);
+    } else {
+        HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+        const unsigned rows = (unsigned)((P.A + 3) / 4);
+        hipLaunchKernelGGL(k_dn_pairs<0>, dim3(rows), dim3(256), 0, h->stream, D);
+        FrontArgs F{};
+        F.A = P.A;
+        F.row_cnt = h->d_rowcnt.as<int>();
+        F.row_off = h->d_rowoff.as<int>();
+        F.pcap = h->pcap;
+        F.status = h->d_status.as<int>();
+        {
+            const unsigned nsb = (unsigned)((F.A + EPNN_SCAN_ELEMS - 1) / EPNN_SCAN_ELEMS);
+            if (h->d_bsum.ensure((size_t)nsb * sizeof(int))) return 1;
+            hipLaunchKernelGGL(k_front_scan1, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+            if (nsb > 1) hipLaunchKernelGGL(k_front_scan2, dim3(nsb), dim3(256), 0, h->stream, F, h->d_bsum.as<int>());
+        }
+        hipLaunchKernelGGL(k_dn_pairs<1>, dim3(rows), dim3(256), 0, h->stream, D);
     }
-    hipLaunchKernelGGL(k_dn_pairs<1>, dim3(rows), dim3(256), 0, h->stream, D);
     HIPCHK(hipGetLastError());
     PairSource S;
     S.d_x = D.xf;

@@ -80,21 +80,30 @@ __global__ __launch_bounds__(256) void k_dn_feat(DenseArgs D, const float *den) 
 // The same four passes (k_dn_den, k_dn_feat<0..2>) in ONE launch for calls on one or a few molecules, where a launch costs more
 // than its work: thread = (atom k, channel c of [h | x | q]), every thread adds up the mask column of its atom itself (same
 // order over j as k_dn_den: the same bits).
-__global__ __launch_bounds__(256) void k_dn_feat_all(DenseArgs D, float *den) {
+// one (atom k, channel c of [h | x | q]) of molecule b; `mark(k)` records that atom k is non-trivial
+template <typename MARK>
+__device__ __forceinline__ void dn_feat_all_item(const DenseArgs &D, float *den, int b, int idx, MARK &&mark) {
     const int N = D.N, CT = EPNN_EDIM + D.nx + 1;
-    const int b = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= N * CT) return;
     const int k = idx / CT, c = idx - k * CT;
     const int which = c < EPNN_EDIM ? 0 : (c < EPNN_EDIM + D.nx ? 1 : 2);
     const int C = which == 0 ? EPNN_EDIM : (which == 1 ? D.nx : 1), cc = which == 0 ? c : (which == 1 ? c - EPNN_EDIM : 0);
     const float *src = (which == 0 ? D.h_in : (which == 1 ? D.x_in : D.q_in)) + (size_t)b * N * N * C + (size_t)k * C + cc;
     const float *mk = D.mask_in + (size_t)b * N * N + k;
     float s = 0.f, dn = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < N; ++j) {
-        s += src[(size_t)j * N * C];
-        dn += mk[(size_t)j * N];
+    for (int j0 = 0; j0 < N; j0 += 16) {                       // sixteen rows (32 loads) in flight, added in row order
+        float sv[16], dv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int jc = min(j0 + u, N - 1);
+            sv[u] = src[(size_t)jc * N * C];
+            dv[u] = mk[(size_t)jc * N];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (j0 + u < N) {
+                s += sv[u];
+                dn += dv[u];
+            }
     }
     const float v = dn != 0.f ? s / dn : 0.f;
     const size_t slot = (size_t)b * N + k;
@@ -104,9 +113,16 @@ __global__ __launch_bounds__(256) void k_dn_feat_all(DenseArgs D, float *den) {
     if (c == 0) {
         den[slot] = dn;
         D.nms[slot] = fminf(fmaxf(dn, 0.f), 1.f);
-        if (dn != 0.f) atomicOr(&D.flag[slot], 1);
+        if (dn != 0.f) mark(k);
     }
-    if (v != 0.f) atomicOr(&D.flag[slot], 1);
+    if (v != 0.f) mark(k);
+}
+__global__ __launch_bounds__(256) void k_dn_feat_all(DenseArgs D, float *den) {
+    const int N = D.N, CT = EPNN_EDIM + D.nx + 1;
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * CT) return;
+    dn_feat_all_item(D, den, b, idx, [&](int k) { atomicOr(&D.flag[(size_t)b * N + k], 1); });
 }
 
 // layer-level entry: per-atom tensors are given; copy and flag
@@ -124,21 +140,56 @@ __global__ __launch_bounds__(256) void k_dn_copy_atoms(DenseArgs D) {
 
 // e scan: one thread per ordered pair (b,i,j) reads its 48 channels as 12 x 16 B; a non-zero e[i][j] marks both atom i
 // and atom j (integer atomics, order-free; only the ~7 % near pairs issue any)
+__device__ __forceinline__ bool dn_e_nonzero(const DenseArgs &D, size_t r) {
+    const f32x4 *e4 = reinterpret_cast<const f32x4 *>(D.e_in + r * EPNN_EDIM);
+    bool nz = false;
+#pragma unroll
+    for (int q = 0; q < EPNN_EDIM / 4; ++q) {
+        const f32x4 v = e4[q];
+        nz |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
+    }
+    return nz;
+}
 __global__ __launch_bounds__(256) void k_dn_escan(DenseArgs D) {
     const size_t pairs = (size_t)D.B * D.N * D.N;
     for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < pairs; r += (size_t)gridDim.x * 256) {
-        const f32x4 *e4 = reinterpret_cast<const f32x4 *>(D.e_in + r * EPNN_EDIM);
-        bool nz = false;
-#pragma unroll
-        for (int q = 0; q < EPNN_EDIM / 4; ++q) {
-            const f32x4 v = e4[q];
-            nz |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
-        }
-        if (nz) {
+        if (dn_e_nonzero(D, r)) {
             const int j = (int)(r % D.N), i = (int)((r / D.N) % D.N), b = (int)(r / ((size_t)D.N * D.N));
             atomicOr(&D.flag[b * D.N + i], 1);
             atomicOr(&D.flag[b * D.N + j], 1);
         }
+    }
+}
+
+// One or a few molecules per call (B N^2 <= 65536): a call is made of latencies, so what the host needs before it can plan is
+// TWO launches instead of a memset, three kernels and a download: (1) the per-atom features and the e scan side by side (the
+// block index says which), flags written as the call's generation number (no memset: a flag counts when it equals `gen`);
+// (2) the effective atom counts, written into page-locked host memory as well.  The same loops in the same order as
+// k_dn_feat_all / k_dn_escan / k_dn_neff: the same bits.  (One workgroup per molecule was tried first: 0.116 ms instead of
+// 0.127 for a 9-atom call but 0.229 instead of 0.207 at 41 atoms -- the work is small, but it is not one CU's worth of latency.)
+__global__ __launch_bounds__(256) void k_dn_front_small(DenseArgs D, float *den, int gen, int feat_blocks) {
+    const int b = blockIdx.y, N = D.N, CT = EPNN_EDIM + D.nx + 1;
+    if ((int)blockIdx.x < feat_blocks) {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx < N * CT) dn_feat_all_item(D, den, b, idx, [&](int k) { D.flag[(size_t)b * N + k] = gen; });
+    } else {
+        const int r = (blockIdx.x - feat_blocks) * 256 + threadIdx.x;
+        if (r < N * N && dn_e_nonzero(D, (size_t)b * N * N + r)) {
+            D.flag[(size_t)b * N + r / N] = gen;
+            D.flag[(size_t)b * N + r % N] = gen;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_dn_neff_small(DenseArgs D, int gen, int *neff_host) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int last = 0;
+    for (int k = lane; k < D.N; k += 64)
+        if (D.flag[b * D.N + k] == gen) last = max(last, k);
+    for (int d = 32; d >= 1; d >>= 1) last = max(last, __shfl_xor(last, d, 64));
+    if (lane == 0) {
+        D.neff[b] = last + 1;
+        neff_host[b] = last + 1;
+        __threadfence_system();
     }
 }
 
@@ -155,16 +206,26 @@ __global__ __launch_bounds__(64) void k_dn_neff(DenseArgs D) {
 __device__ __forceinline__ int dn_classify(const DenseArgs &D, int b, int i, int j, float *wout) {
     const int N = D.N;
     const size_t mb = (size_t)b * N * N;
-    const float *eij = D.e_in + (mb + (size_t)i * N + j) * EPNN_EDIM;
-    const float *eji = D.e_in + (mb + (size_t)j * N + i) * EPNN_EDIM;
+    // both rows as 12 + 12 sixteen-byte loads, all in flight (96 four-byte loads were two windows of a wavefront's 63)
+    const f32x4 *eij = reinterpret_cast<const f32x4 *>(D.e_in + (mb + (size_t)i * N + j) * EPNN_EDIM);
+    const f32x4 *eji = reinterpret_cast<const f32x4 *>(D.e_in + (mb + (size_t)j * N + i) * EPNN_EDIM);
+    f32x4 va[EPNN_EDIM / 4], vc[EPNN_EDIM / 4];
+#pragma unroll
+    for (int q = 0; q < EPNN_EDIM / 4; ++q) {
+        va[q] = eij[q];
+        vc[q] = eji[q];
+    }
     bool nz = false, same = true;
     float mx = 0.f;
-    for (int ch = 0; ch < EPNN_EDIM; ++ch) {
-        const float a = eij[ch], c = eji[ch];
-        nz |= a != 0.f;
-        same &= __float_as_uint(a) == __float_as_uint(c);
-        mx = fmaxf(mx, a);
-    }
+#pragma unroll
+    for (int q = 0; q < EPNN_EDIM / 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = va[q][r], c = vc[q][r];
+            nz |= a != 0.f;
+            same &= __float_as_uint(a) == __float_as_uint(c);
+            mx = fmaxf(mx, a);
+        }
     const float mij = D.mask_in[mb + (size_t)i * N + j], mji = D.mask_in[mb + (size_t)j * N + i];
     same &= __float_as_uint(mij) == __float_as_uint(mji);
     *wout = mx > D.tol ? mij : 0.f;          // mask_ij * is_near_ij, is_near = max_k clip(e) != tol
@@ -175,11 +236,7 @@ __device__ __forceinline__ int dn_classify(const DenseArgs &D, int b, int i, int
 
 // one wave per flat atom row: count (fill == 0) or write (fill == 1) its entries, ascending j
 template <int FILL>
-__global__ __launch_bounds__(256) void k_dn_pairs(DenseArgs D) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= D.A) return;
-    if (FILL && D.row_off[D.A] > D.pcap) return;
+__device__ __forceinline__ void dn_pairs_row(const DenseArgs &D, int row, int lane, int base_in = -1) {
     const int b = D.mol_of[row], a0 = D.moff[b], n = D.moff[b + 1] - a0, i = row - a0;
     if (!FILL) {
         // the atom's own features, slot (b, i) -> flat row (what used to be a launch of its own): one lane per feature
@@ -190,7 +247,7 @@ __global__ __launch_bounds__(256) void k_dn_pairs(DenseArgs D) {
         else if (f == D.nx + EPNN_EDIM) D.qf[row] = D.qs[slot];
         else if (f < F) D.nmf[row] = D.nms[slot];
     }
-    int base = FILL ? D.row_off[row] : 0;
+    int base = FILL ? (base_in >= 0 ? base_in : D.row_off[row]) : 0;
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
         int kind = 0;
@@ -204,12 +261,62 @@ __global__ __launch_bounds__(256) void k_dn_pairs(DenseArgs D) {
             D.psym[s] = kind == 1;
             D.pwi[s] = (i == j) ? 0.f : w;
             D.pwj[s] = kind == 1 ? w : 0.f;
-            const float *eij = D.e_in + (((size_t)b * D.N + i) * D.N + j) * EPNN_EDIM;
-            for (int ch = 0; ch < EPNN_EDIM; ++ch) D.pe[(size_t)s * EPNN_EDIM + ch] = eij[ch];
+            const f32x4 *eij = reinterpret_cast<const f32x4 *>(D.e_in + (((size_t)b * D.N + i) * D.N + j) * EPNN_EDIM);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(D.pe + (size_t)s * EPNN_EDIM);
+            f32x4 ev[EPNN_EDIM / 4];
+#pragma unroll
+            for (int q = 0; q < EPNN_EDIM / 4; ++q) ev[q] = eij[q];
+#pragma unroll
+            for (int q = 0; q < EPNN_EDIM / 4; ++q) dst[q] = ev[q];
         }
         base += __popcll(bal);
     }
     if (!FILL && lane == 0) D.row_cnt[row] = base;
+}
+template <int FILL>
+__global__ __launch_bounds__(256) void k_dn_pairs(DenseArgs D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= D.A) return;
+    if (FILL && D.row_off[D.A] > D.pcap) return;
+    dn_pairs_row<FILL>(D, row, lane);
+}
+// The pair list of a small call (at most 1024 flat atoms) in two launches instead of a memset and three kernels: the count
+// launch clears the status words, the fill launch scans for itself -- every wavefront adds up the counts of the rows before its
+// own (at most 16 loads per lane) and the total, writes its row's offset, and fills.  Same per-row code.
+__global__ __launch_bounds__(256) void k_dn_pairs_count_small(DenseArgs D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x < 4) D.status[threadIdx.x] = 0;
+    const int row = blockIdx.x * 4 + wave;
+    if (row < D.A) dn_pairs_row<0>(D, row, lane);
+}
+__global__ __launch_bounds__(256) void k_dn_pairs_fill_small(DenseArgs D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= D.A) return;
+    int before = 0, total = 0;
+    for (int r0 = 0; r0 < D.A; r0 += 64) {
+        const int r = r0 + lane;
+        const int c = D.row_cnt[min(r, D.A - 1)];
+        if (r < D.A) {
+            total += c;
+            if (r < row) before += c;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += __shfl_xor(before, d, 64);
+        total += __shfl_xor(total, d, 64);
+    }
+    int *roff = const_cast<int *>(D.row_off);
+    if (lane == 0) {
+        roff[row] = before;
+        if (row == D.A - 1) {
+            roff[D.A] = total;
+            if (total > D.pcap) atomicOr(D.status, EPNN_ST_PAIR_OVERFLOW);
+        }
+    }
+    if (total > D.pcap) return;
+    dn_pairs_row<1>(D, row, lane, before);
 }
 
 // flat [A][C] -> padded (B,N,C), zeros beyond n_eff

@@ -132,6 +132,9 @@ struct epnn_handle {
     DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
+    int opt_dense_small = 1;          // dense entry, one or a few molecules per call: the front-end as four launches instead of two memsets, seven kernels, a download
+    int dn_gen = 1;                   //   ... whose flags are generation numbers (no memset per call)
+    void *dn_flag_seen = nullptr;
     int opt_train_split = 0;          // training, matrix-pipe backward: workgroups per atom (0 = as many as fit the atom's XCD, at most 6)
     int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels; 2 = the forward on the matrix pipe instead (epnn_train_mfma.hip.h;
                                       // measured slower at N = 41: three workgroups per molecule); 0 = the layer-by-layer kernels
@@ -182,7 +185,7 @@ struct epnn_handle {
     int64_t stats[4] = {0, 0, 0, 0};
     // page-locked staging: the plan's index arrays with, behind them, the inputs of the host entry (one upload per forward;
     // reused once ev_ctl says the previous upload has run); the charges of the asynchronous host entry
-    PinBuf pin_ctl, pin_out;
+    PinBuf pin_ctl, pin_out, pin_neff;
     PinBuf pin_train, pin_tout;       // inputs of epnn_train_step_xyz / of a small dense call (one upload); loss terms + predictions of a
                                       // train step / charges of a small dense call
     DevBuf s_train;

@@ -94,6 +94,33 @@ def test_layer_calls_vs_oracle(golden_dir):
     assert np.abs(q_gpu.sum(axis=(1, 2)) - qx.sum(axis=(1, 2))).max() < 2e-6
 
 
+def test_small_dense_calls_take_the_short_sequence_with_the_same_bits(golden_dir):
+    """model([h,e,x,q,mask]) on one or a few molecules builds its per-atom features, flags, effective atom counts and pair
+    list in four launches ("dense_small", default) instead of two memsets, seven kernels and a download; the flags are the
+    call's generation number, so no call clears them.  Same bits as the general sequence, call after call on ONE handle, a
+    large molecule followed by a small one (stale flags of an earlier generation must not count), batches of one and three."""
+    from epnn_amd import charge_gn
+    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, 9)
+    w = random_weights(9, 3, seed=5, scale=0.35)
+    N = x.shape[1]
+    sizes = [int(mask[b].sum(axis=0).max()) for b in range(x.shape[0])]
+    order = list(np.argsort(sizes)[::-1]) + list(np.argsort(sizes))        # largest first, then smallest first
+    model = charge_gn.make_model([32, 32], 48, 3, 9, N)
+    model.set_weights_dict(w)
+    eng = model.engine()
+    cases = [[b] for b in order] + [order[:3], order[-3:]]
+    outs = {0: [], 1: []}
+    for opt in (1, 0):
+        eng.set_option("dense_small", opt)
+        for sel in cases:
+            sel = np.asarray(sel)
+            outs[opt].append(model([h[sel], e[sel], x[sel], q[sel], mask[sel]]))
+    for a, b_, sel in zip(outs[1], outs[0], cases):
+        assert np.array_equal(a, b_), sel
+        for r, b in enumerate(sel):
+            assert np.all(a[r, sizes[b]:] == 0) and np.any(a[r, :sizes[b]] != 0)
+
+
 def test_arbitrary_dense_inputs(golden_dir):
     """Inputs gen_padded_init_state never produces: non-symmetric e, non-zero diagonal, fractional and
     non-symmetric masks, atoms with e but no mask.  The pair list must not assume symmetry."""
