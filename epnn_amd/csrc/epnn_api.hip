@@ -140,9 +140,16 @@ extern "C" int epnn_destroy(epnn_handle *h) {
         TrainState *ts = train_state(h);
         if (ts->gexec) (void)hipGraphExecDestroy(ts->gexec);
         if (ts->graph) (void)hipGraphDestroy(ts->graph);
-        for (DevBuf *b : {&ts->theta, &ts->grad, &ts->m, &ts->v, &ts->part, &ts->arena, &ts->loss}) b->release();
+        for (DevBuf *b : {&ts->theta, &ts->grad, &ts->m, &ts->v, &ts->part, &ts->arena, &ts->loss, &ts->d_step}) b->release();
         delete ts;
         h->train = nullptr;
+    }
+    if (h->infer_fused) {
+        InferFused *is = reinterpret_cast<InferFused *>(h->infer_fused);
+        is->theta.release();
+        is->arena.release();
+        delete is;
+        h->infer_fused = nullptr;
     }
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->h_status) (void)hipHostFree(h->h_status);
@@ -554,6 +561,7 @@ static int pack_weights(epnn_handle *h) {
     HIPCHK(hipMemcpyAsync(h->d_wpack.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));     // buf is a local
     h->weights_dirty = false;
+    h->weights_gen += 1;
     return 0;
 }
 
@@ -1243,6 +1251,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else if (!strcmp(name, "dense_small")) { h->opt_dense_small = value; }
+    else if (!strcmp(name, "dense_rowfused")) { h->opt_dense_rowfused = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else if (!strcmp(name, "train_split")) { if (value < 0 || value > 8) EPNN_FAIL("epnn_set_option: train_split must be 0 (automatic) .. 8"); h->opt_train_split = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
@@ -1337,6 +1346,19 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
     }
     std::vector<int> offsets(B + 1, 0);
     for (int b = 0; b < B; ++b) offsets[b + 1] = offsets[b] + h->dn_neff_host[b];
+    if (small_call && h->opt_dense_rowfused && (size_t)B * N <= 256 && infer_rowfused_fits(h, N) &&
+        20 * *std::max_element(h->dn_neff_host.begin(), h->dn_neff_host.end()) >= 11 * N) {
+        // a lone molecule that fills most of its padded size: one workgroup per atom slot through the row-fused forward kernels
+        // instead of one CU for the whole molecule (dense entry).  No pair list, no scatter: the kernels
+        // take the dense tensors and write (B,N,1); padded slots come out as exact zeros (q = 0, every transfer weight 0).
+        if (infer_rowfused_forward(h, B, N, d_e, d_mask, D.xs, D.hs, D.qs, d_out)) return 1;
+        h->h_status[0] = 0;
+        h->h_status[1] = 0;
+        h->last_front = false;
+        h->stats[1] = 0;                          // (neither the fused nor the tiled kernels: that is how epnn_last_stats shows this path)
+        h->stats[2] = 0;
+        return 0;
+    }
     if (build_plan(h, B, N, offsets.data(), mode == 0)) return 1;     // both stacks: the block-per-wavefront kernel may take part
     const Plan &P = h->plan;
     const size_t A = (size_t)P.A;

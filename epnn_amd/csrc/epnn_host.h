@@ -107,6 +107,8 @@ struct epnn_handle {
     // weights
     HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
     bool weights_dirty = true;
+    long weights_gen = 0;             // counts the changes of the weights (device-side copies made elsewhere compare it)
+    void *infer_fused = nullptr;      // InferFused (epnn_train.hip.h)
     WeightIndex widx{};
     WaveIndex wvidx{};
     std::vector<double> edge_B;       // [48][EPNN_ER] orthonormal basis of the edge-feature family (epnn_api.hip edge_basis)
@@ -132,6 +134,7 @@ struct epnn_handle {
     DevBuf f_pw, d_etab;              // fused kernel's own front-end: near weights of its pairs; table of B^T e(D)
     bool last_front = false;          // the last forward used the in-kernel front-end (status words come from its last wave)
     bool ctl_clean = false;           // d_status is known to be all zero (left so by the last wave of the previous wave-front forward)
+    int opt_dense_rowfused = 1;       // dense entry, small calls whose largest molecule fills > 55 % of N: the row-fused forward (a workgroup per atom slot)
     int opt_dense_small = 1;          // dense entry, one or a few molecules per call: the front-end as four launches instead of two memsets, seven kernels, a download
     int dn_gen = 1;                   //   ... whose flags are generation numbers (no memset per call)
     void *dn_flag_seen = nullptr;

@@ -353,7 +353,8 @@ static TrainState *train_state(epnn_handle *h) {
     return reinterpret_cast<TrainState *>(h->train);
 }
 
-static void train_layout(epnn_handle *h, TrainState *ts) {
+template <typename STATE>
+static void train_layout(epnn_handle *h, STATE *ts) {
     int off = 0;
     auto put = [&](TDense &d, const HostDense &hd) {
         d.n_in = hd.n_in;
@@ -372,7 +373,8 @@ static void train_layout(epnn_handle *h, TrainState *ts) {
 }
 
 // host copies <-> flat vector (Keras trainable_variables order)
-static void train_gather_host(epnn_handle *h, TrainState *ts, std::vector<float> &flat) {
+template <typename STATE>
+static void train_gather_host(epnn_handle *h, STATE *ts, std::vector<float> &flat) {
     flat.assign(ts->P, 0.f);
     auto cp = [&](const TDense &d, const HostDense &hd) {
         memcpy(flat.data() + d.offW, hd.W.data(), hd.W.size() * 4);
@@ -772,6 +774,82 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         ts->dev_newer = true;
     }
     hipLaunchKernelGGL(k_tb_wreduce, dim3((unsigned)((maxlen + 63) / 64), (unsigned)Rd.n), dim3(256), 0, st, Rd, ar, grad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ the forward alone
+// The row-fused forward kernels as an INFERENCE path for the dense entry's small calls (one or a few molecules whose largest
+// fills most of the padded size): 2T launches of B N workgroups, one per atom slot, against one molecule on 1-4 wavefronts
+// of ONE CU in the fused inference kernels (58-141 us at N = 41).  The literal arithmetic of the reference (rows
+// [a_i | a_j | e_ij], all N slots, both orders of a pair), nothing stored for a backward pass.  The weights are a flat
+// parameter vector of their own, refreshed when the handle's weights change.
+struct InferFused {
+    long gen = -1;
+    int P = 0;
+    TDense upd[3], msg[EPNN_MAXT][3], pas[EPNN_MAXT][3];
+    DevBuf theta, arena;
+    bool attr = false;
+};
+static bool infer_rowfused_fits(const epnn_handle *h, int N) { return N <= EPNN_TF_NMAX && h->cfg.nx + 49 <= EPNN_TF_FMAX && h->cfg.T >= 1; }
+static int infer_rowfused_forward(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
+                                  const float *d_h0, const float *d_q0, float *d_out) {
+    if (!h->infer_fused) h->infer_fused = new InferFused();
+    InferFused *is = reinterpret_cast<InferFused *>(h->infer_fused);
+    const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, F = nx + H + 1, D = 2 * F + H, FS = F | 1;
+    const int BN = B * N;
+    const size_t R = (size_t)BN * N;
+    hipStream_t st = h->stream;
+    if (is->gen != h->weights_gen) {
+        train_layout(h, is);
+        if (is->theta.ensure((size_t)is->P * 4)) return 1;
+        std::vector<float> flat;
+        train_gather_host(h, is, flat);
+        HIPCHK(hipMemcpyAsync(is->theta.p, flat.data(), (size_t)is->P * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));                      // (`flat` is pageable and goes out of scope)
+        is->gen = h->weights_gen;
+    }
+    size_t need = 0;
+    auto sz = [&](size_t n) { size_t o = need; need += (n + 63) & ~size_t(63); return o; };
+    const size_t o_nm = sz(BN), o_wgt = sz(R), o_ha = sz((size_t)BN * H), o_hb = sz((size_t)BN * H), o_qa = sz(BN), o_qb = sz(BN);
+    if (is->arena.ensure(need * 4)) return 1;
+    float *ar = is->arena.as<float>();
+    const size_t lds_fwd = ((size_t)N * FS + (size_t)N * 49 + (size_t)D * 32 + 4 * (size_t)N * 33 + EPNN_TF_NG * 32 + 32 + 3 * (size_t)N) * 4;
+    if (!is->attr) {
+        const int cap = 160 * 1024;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        is->attr = true;
+    }
+    const float *theta = is->theta.as<float>();
+    auto pair_args = [&](const TDense *mlp, const float *hh, const float *qq) {
+        TfPair A{};
+        A.x = d_x; A.h = hh; A.q = qq; A.e = d_e; A.theta = theta;
+        A.oW1 = mlp[0].offW; A.ob1 = mlp[0].offB; A.oW2 = mlp[1].offW; A.ob2 = mlp[1].offB; A.oW3 = mlp[2].offW; A.ob3 = mlp[2].offB;
+        A.N = N; A.nx = nx; A.wgt = ar + o_wgt; A.nm = ar + o_nm;
+        A.nm_w = ar + o_nm; A.wgt_w = ar + o_wgt; A.tol = h->cfg.near_tol; A.pmode = -1;
+        return A;
+    };
+    const float *hcur = d_h0;
+    for (int t = 0; t < T; ++t) {
+        TfPair A = pair_args(is->msg[t], hcur, d_q0);
+        if (t == 0) A.mask = d_mask;
+        TfUpd U{};
+        U.h = hcur; U.nm = ar + o_nm; U.theta = theta;
+        U.oW0 = is->upd[0].offW; U.ob0 = is->upd[0].offB; U.oW1 = is->upd[1].offW; U.ob1 = is->upd[1].offB;
+        U.oW2 = is->upd[2].offW; U.ob2 = is->upd[2].offB;
+        U.hn = ar + ((t & 1) ? o_hb : o_ha);
+        hipLaunchKernelGGL((k_tf_pair_fwd<0, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, U);
+        hcur = U.hn;
+    }
+    const float *qcur = d_q0;
+    for (int t = 0; t < T; ++t) {
+        TfPair A = pair_args(is->pas[t], hcur, qcur);
+        if (t == 0) A.mask = d_mask;
+        A.qn = t == T - 1 ? d_out : ar + ((t & 1) ? o_qb : o_qa);
+        hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
+        qcur = A.qn;
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

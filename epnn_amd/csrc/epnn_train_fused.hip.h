@@ -387,11 +387,13 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 d2[1] = tm_relu(d2[1]);
                 if (jv) {
                     float *l2 = H2s + (jdir * N + j) * 33 + 8 * lq;
-                    float *g1 = A.H1 + jdir * dstride + (rowbase + j) * 32 + 8 * lq, *g2 = A.H2 + jdir * dstride + (rowbase + j) * 32 + 8 * lq;
-                    tm_st4(g1, f32x4{acc[0][0], acc[1][0], acc[0][1], acc[1][1]});
-                    tm_st4(g1 + 4, f32x4{acc[0][2], acc[1][2], acc[0][3], acc[1][3]});
-                    tm_st4(g2, f32x4{d2[0][0], d2[1][0], d2[0][1], d2[1][1]});
-                    tm_st4(g2 + 4, f32x4{d2[0][2], d2[1][2], d2[0][3], d2[1][3]});
+                    if (A.H1) {                               // (null when nothing will run backward: the dense entry's small calls)
+                        float *g1 = A.H1 + jdir * dstride + (rowbase + j) * 32 + 8 * lq, *g2 = A.H2 + jdir * dstride + (rowbase + j) * 32 + 8 * lq;
+                        tm_st4(g1, f32x4{acc[0][0], acc[1][0], acc[0][1], acc[1][1]});
+                        tm_st4(g1 + 4, f32x4{acc[0][2], acc[1][2], acc[0][3], acc[1][3]});
+                        tm_st4(g2, f32x4{d2[0][0], d2[1][0], d2[0][1], d2[1][1]});
+                        tm_st4(g2 + 4, f32x4{d2[0][2], d2[1][2], d2[0][3], d2[1][3]});
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         l2[2 * c] = d2[0][c];
@@ -485,11 +487,11 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         mo += (float)N * tb3;
         const float nm = updf ? (A.mask ? wl[0] : nmpre) : 0.f;
         if (half == 0) {
-            A.M[(size_t)bi * 32 + o] = mo;
+            if (A.M) A.M[(size_t)bi * 32 + o] = mo;
             if (updf) {
                 const float v = mo * nm;
                 u0[48 + o] = v;
-                U.U0[(size_t)bi * 80 + 48 + o] = v;
+                if (U.U0) U.U0[(size_t)bi * 80 + 48 + o] = v;
             }
         }
         TF_CLK_T(3, EPNN_TF_NT - 64);
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         if (lane < 48) {
             const float v = hpre * nm;
             u0[lane] = v;
-            U.U0[(size_t)bi * 80 + lane] = v;
+            if (U.U0) U.U0[(size_t)bi * 80 + lane] = v;
         }
         tf_wave_sync();
         float z = 0.f;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         z = fmaxf(z + tb0, 0.f);
         if (half == 0) {
             u1[o] = z;
-            U.U1[(size_t)bi * 32 + o] = z;
+            if (U.U1) U.U1[(size_t)bi * 32 + o] = z;
         }
         tf_wave_sync();
         z = 0.f;
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         z = fmaxf(z + tb1, 0.f);
         if (half == 0) {
             u2[o] = z;
-            U.U2[(size_t)bi * 32 + o] = z;
+            if (U.U2) U.U2[(size_t)bi * 32 + o] = z;
         }
         tf_wave_sync();
         if (lane < 48) {
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * wl[j];
             const float qn = A.q[bi] + s;
             A.qn[bi] = qn;
+            if (A.pred && !A.y) A.pred[bi] = qn;      // inference: the charges, nothing else
             if (A.y) {                            // last step: prediction and loss term of this atom (charge_gn.py:397)
                 const float d = A.y[bi] - qn;
                 A.pred[bi] = qn;

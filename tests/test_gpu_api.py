@@ -108,6 +108,7 @@ def test_small_dense_calls_take_the_short_sequence_with_the_same_bits(golden_dir
     model = charge_gn.make_model([32, 32], 48, 3, 9, N)
     model.set_weights_dict(w)
     eng = model.engine()
+    eng.set_option("dense_rowfused", 0)                      # (its own test below: a different arithmetic form, not the same bits)
     cases = [[b] for b in order] + [order[:3], order[-3:]]
     outs = {0: [], 1: []}
     for opt in (1, 0):
@@ -119,6 +120,52 @@ def test_small_dense_calls_take_the_short_sequence_with_the_same_bits(golden_dir
         assert np.array_equal(a, b_), sel
         for r, b in enumerate(sel):
             assert np.all(a[r, sizes[b]:] == 0) and np.any(a[r, :sizes[b]] != 0)
+
+
+@pytest.mark.parametrize("nx,T", [(9, 5), (10, 2)])
+def test_lone_molecules_that_fill_their_padding_take_the_row_fused_forward(golden_dir, nx, T):
+    """model([h,e,x,q,mask]) on ONE molecule (or a few) whose largest fills more than 55 % of the padded size runs the
+    row-fused forward kernels of the training step -- a workgroup per atom slot, the reference's literal rows -- instead of
+    the fused inference kernel on one CU ("dense_rowfused", default).  Same answers as the float64 oracle to the tolerance of
+    the other dense tests and as the fused kernels to float32 rounding; padded atoms exactly zero; epnn_last_stats shows the
+    path (0 molecules on the fused and on the tiled kernels); a molecule that fills less takes the fused kernel as before."""
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, nx)
+    N = x.shape[1]
+    sizes = [int(mask[b].sum(axis=0).max()) for b in range(x.shape[0])]
+    big = int(np.argmax(sizes))
+    # pad the largest molecule so that it fills ~70 % of N', the smallest stays below 55 % of it
+    Np = int(np.ceil(sizes[big] / 0.7))
+    assert Np >= N
+
+    def cut(a, sel):                                         # (B, N, N, C) -> the selected molecules, zero padded to (Np, Np)
+        out = np.zeros((len(sel), Np, Np) + a.shape[3:], a.dtype)
+        out[:, :N, :N] = a[sel]
+        return out
+    w = random_weights(nx, T, seed=17, scale=0.35)
+    model = charge_gn.make_model([32, 32], 48, T, nx, Np)
+    model.set_weights_dict(w)
+    eng = model.engine()
+    small = int(np.argmin(sizes))
+    for sel, expect_rowfused in (([big], True), ([small], sizes[small] * 20 >= 11 * Np), ([big, small], True)):
+        ins = [cut(a, sel) for a in (h, e, x, q, mask)]
+        eng.set_option("dense_rowfused", 1)
+        pred = model(ins)
+        st = eng.last_stats()
+        assert (int(st[1]) + int(st[2]) == 0) == expect_rowfused, (sel, st)
+        eng.set_option("dense_rowfused", 0)
+        pred0 = model(ins)
+        st0 = eng.last_stats()
+        assert int(st0[1]) + int(st0[2]) == len(sel)
+        ref = orc.model_forward(*ins, w, dtype=np.float64)
+        ref32 = orc.model_forward(*ins, w, dtype=np.float32)
+        err, noise = np.abs(pred - ref).max(), np.abs(ref32 - ref).max()
+        print(f"row-fused dense call nx={nx} T={T} N={Np} molecules {sel}: |dq| {err:.3e} (fused kernels {np.abs(pred0 - ref).max():.3e}, float32 oracle {noise:.3e})")
+        assert err <= max(TOL, 3 * noise)
+        assert np.abs(pred - pred0).max() <= max(TOL, 3 * noise)
+        for r, b in enumerate(sel):
+            assert np.all(pred[r, sizes[b]:] == 0)
 
 
 def test_arbitrary_dense_inputs(golden_dir):

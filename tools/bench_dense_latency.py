@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Latency of ONE literal model([h,e,x,q,mask]) call per molecule (the reference's calling convention, infer.py:62-76), dense
-inputs resident in HBM, by molecule size at N = 41: the default kernels of a lone handle and ("wave2" = 0, "wave3" = 0)
-k_wave_forward / the tiled kernels.
+inputs resident in HBM, by molecule size at N = 41: the default (a molecule that fills more than 55 % of N takes the row-fused
+forward kernels, a workgroup per atom slot), the fused inference kernels only ("dense_rowfused" = 0), and with "wave2" = 0,
+"wave3" = 0 as well (k_wave_forward / the tiled kernels).
     python tools/bench_dense_latency.py
 """
 import os, sys
@@ -16,7 +17,7 @@ eng = Engine(nx=nx, T=5)
 eng.set_weights(checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights")))
 rng = np.random.default_rng(2)
 fn = eng.lib.epnn_model_forward_dense_dev
-print("n    default ms   one wavefront per molecule / tiled ms")
+print("n    default ms   fused kernels only (dense_rowfused = 0) ms   one wavefront per molecule / tiled (and wave2 = wave3 = 0) ms")
 for n in (9, 16, 18, 23, 29, 32, 35, 38, 41):
     span = 1.6 * n ** (1 / 3.0) * 1.3
     while True:
@@ -32,13 +33,13 @@ for n in (9, 16, 18, 23, 29, 32, 35, 38, 41):
     d = [eng.to_device(a) for a in (h, e, x, q, m)]
     out = eng.alloc(N * 4)
     row = []
-    for opts in ((-1, 1), (0, 0)):
-        eng.set_option("wave2", opts[0]); eng.set_option("wave3", opts[1])
+    for opts in ((-1, 1, 1), (-1, 1, 0), (0, 0, 0)):
+        eng.set_option("wave2", opts[0]); eng.set_option("wave3", opts[1]); eng.set_option("dense_rowfused", opts[2])
         def run():
             assert fn(eng.h, 1, N, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, out.ptr) == 0, eng.lib.epnn_last_error()
         for _ in range(5): run()
         eng.sync(); eng.timer_begin()
         for _ in range(50): run()
         row.append(eng.timer_end() / 50)
-    print(f"{n:2d}   {row[0]:.3f}        {row[1]:.3f}", flush=True)
+    print(f"{n:2d}   {row[0]:.3f}        {row[1]:.3f}        {row[2]:.3f}", flush=True)
     for b in d + [out]: b.free()
