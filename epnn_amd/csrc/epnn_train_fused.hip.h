@@ -627,7 +627,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
 
 // ---------------------------------------------------------------------------------------------- backward, pair MLP
 // MODE 0 with U.theta set first runs the update MLP's backward for its atom (it needs only the atom's own rows: gh, U0..U2)
-// and takes dM_i straight from LDS; the stand-alone k_tb_update_bwd is the same arithmetic.
+// and takes dM_i straight from LDS.
 template <int MODE>
 __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
@@ -1425,83 +1425,6 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
     }
     TF_CLK(3);
     TF_CYC(15);
-}
-
-// ---------------------------------------------------------------------------------------------- update MLP (stand-alone launches)
-__global__ __launch_bounds__(64) void k_tf_update_fwd(TfUpd U) {
-    __shared__ float u0[80], u1[32], u2[32];
-    const int a = blockIdx.x, tid = threadIdx.x;
-    const float nm = U.nm[a];
-    for (int k = tid; k < 80; k += 64) {
-        const float v = (k < 48 ? U.h[(size_t)a * 48 + k] : U.M[(size_t)a * 32 + (k - 48)]) * nm;
-        u0[k] = v;
-        U.U0[(size_t)a * 80 + k] = v;
-    }
-    __syncthreads();
-    if (tid < 32) {
-        float z = U.theta[U.ob0 + tid];
-        for (int k = 0; k < 80; ++k) z = fmaf(u0[k], U.theta[U.oW0 + k * 32 + tid], z);
-        z = fmaxf(z, 0.f);
-        u1[tid] = z;
-        U.U1[(size_t)a * 32 + tid] = z;
-    }
-    __syncthreads();
-    if (tid < 32) {
-        float z = U.theta[U.ob1 + tid];
-        for (int k = 0; k < 32; ++k) z = fmaf(u1[k], U.theta[U.oW1 + k * 32 + tid], z);
-        z = fmaxf(z, 0.f);
-        u2[tid] = z;
-        U.U2[(size_t)a * 32 + tid] = z;
-    }
-    __syncthreads();
-    if (tid < 48) {
-        float z = U.theta[U.ob2 + tid];
-        for (int k = 0; k < 32; ++k) z = fmaf(u2[k], U.theta[U.oW2 + k * 48 + tid], z);
-        U.hn[(size_t)a * 48 + tid] = z * nm;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_tb_update_bwd(TfUpd U) {
-    __shared__ float u0[80], u1[32], u2[32], dh[48], du2[32], du1[32];
-    const int a = blockIdx.x, tid = threadIdx.x;
-    const float nm = U.nm[a];
-    for (int k = tid; k < 80; k += 64) u0[k] = U.U0[(size_t)a * 80 + k];
-    if (tid < 32) {
-        u1[tid] = U.U1[(size_t)a * 32 + tid];
-        u2[tid] = U.U2[(size_t)a * 32 + tid];
-    }
-    if (tid < 48) dh[tid] = U.gh[(size_t)a * 48 + tid] * nm;
-    __syncthreads();
-    if (tid < 32) {
-        float s = 0.f;
-        for (int oo = 0; oo < 48; ++oo) s = fmaf(dh[oo], U.theta[U.oW2 + tid * 48 + oo], s);
-        du2[tid] = u2[tid] > 0.f ? s : 0.f;
-    }
-    __syncthreads();
-    if (tid < 32) {
-        float s = 0.f;
-        for (int oo = 0; oo < 32; ++oo) s = fmaf(du2[oo], U.theta[U.oW1 + tid * 32 + oo], s);
-        du1[tid] = u1[tid] > 0.f ? s : 0.f;
-    }
-    __syncthreads();
-    for (int k = tid; k < 80; k += 64) {
-        float s = 0.f;
-        for (int oo = 0; oo < 32; ++oo) s = fmaf(du1[oo], U.theta[U.oW0 + k * 32 + oo], s);
-        U.dU0[(size_t)a * 80 + k] = s;
-    }
-    // weight-gradient partials of this atom (rank one per layer), parameter order
-    float *P = U.part + (size_t)a * EPNN_TF_PU;
-    for (int idx = tid; idx < 80 * 32; idx += 64) P[idx] = u0[idx >> 5] * du1[idx & 31];
-    P += 80 * 32;
-    if (tid < 32) P[tid] = du1[tid];
-    P += 32;
-    for (int idx = tid; idx < 32 * 32; idx += 64) P[idx] = u1[idx >> 5] * du2[idx & 31];
-    P += 32 * 32;
-    if (tid < 32) P[tid] = du2[tid];
-    P += 32;
-    for (int idx = tid; idx < 32 * 48; idx += 64) P[idx] = u2[idx / 48] * dh[idx % 48];
-    P += 32 * 48;
-    if (tid < 48) P[tid] = dh[tid];
 }
 
 // ---------------------------------------------------------------------------------------------- gradient = sum of partials
