@@ -133,7 +133,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
                       &h->d_deg, &h->d_incoff, &h->d_nbr, &h->d_desti, &h->d_destj, &h->d_prec, &h->l_Nn, &h->l_Yb, &h->l_qbuf,
                       &h->l_Pst, &h->l_Rst, &h->l_lmol, &h->l_typrow, &h->l_typtab, &h->l_stype, &h->l_typhash,
                       &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->l_sfrac, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
-                      &h->dn_flag, &h->dn_neff, &h->dn_den, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
+                      &h->dn_flag, &h->dn_neff, &h->dn_den, &h->tr_realbuf, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
                       &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
     for (DevBuf *b : bufs) b->release();
     if (h->train) {
@@ -1252,6 +1252,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
     else if (!strcmp(name, "dense_small")) { h->opt_dense_small = value; }
     else if (!strcmp(name, "dense_rowfused")) { h->opt_dense_rowfused = value; }
+    else if (!strcmp(name, "train_skip_padded")) { h->opt_train_skip_padded = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else if (!strcmp(name, "train_split")) { if (value < 0 || value > 8) EPNN_FAIL("epnn_set_option: train_split must be 0 (automatic) .. 8"); h->opt_train_split = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
@@ -1569,7 +1570,7 @@ extern "C" int epnn_debug_stamps(epnn_handle *h, unsigned long long *out, size_t
 __global__ __launch_bounds__(256) void k_t_pad_inputs(const float *xyz, const float *x, const float *Q, const float *y,
                                                       const int *moff, int B, int N, int nx, int E, double cutoff, double eta,
                                                       const double *mu, float *e, float *mask, float *xs, float *hs, float *qs,
-                                                      float *ys) {
+                                                      float *ys, int *real_out) {
     // a thread per (pair, four channels): one thread per pair was 48 double-precision exp in a row on 7 workgroups (13 us of a
     // 0.27 ms one-molecule step); the distance and the cutoff are recomputed by the 12 threads of a pair
     const size_t pairs = (size_t)B * N * N;
@@ -1600,6 +1601,7 @@ __global__ __launch_bounds__(256) void k_t_pad_inputs(const float *xyz, const fl
             for (int f = 0; f < EPNN_EDIM; ++f) hs[at * EPNN_EDIM + f] = 0.f;
             qs[at] = i < n ? Q[b] / (float)n : 0.f;
             ys[at] = i < n ? y[a0 + i] : 0.f;
+            real_out[at] = i < n;
         }
     }
 }
@@ -1684,7 +1686,7 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
         // launch counts it, its last one reads it (the host keeps its own count in step and repairs the device's when they differ).
         if (train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, true, adam_now, out_host, true)) return 1;
         const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, (const void *)(size_t)(h->opt_train_fused + 16 * h->opt_train_split + 256 * (int)adam_now), d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
-                                               d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p, out_host, ts->d_step.p};
+                                               d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p, out_host, ts->d_step.p, h->tr_moff, h->tr_real};
         if (!ts->gexec || key != ts->gkey) {
             if (ts->gexec) { (void)hipGraphExecDestroy(ts->gexec); ts->gexec = nullptr; }
             if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
@@ -1805,7 +1807,7 @@ extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *
                  o_y = o_Q + up256((size_t)B * 4), in_bytes = o_y + (size_t)A * 4;
     if (h->pin_train.ensure(in_bytes) || h->s_train.ensure(in_bytes) || h->sd_e.ensure(pairs * EPNN_EDIM * 4) ||
         h->sd_mask.ensure(pairs * 4) || h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) ||
-        h->dn_qs.ensure(slots * 4) || h->sd_out.ensure(slots * 4))
+        h->dn_qs.ensure(slots * 4) || h->sd_out.ensure(slots * 4) || h->tr_realbuf.ensure(slots * 4))
         return 1;
     char *stage = h->pin_train.as<char>();
     const char *dev = h->s_train.as<char>();
@@ -1819,12 +1821,16 @@ extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *
                        reinterpret_cast<const float *>(dev + o_x), reinterpret_cast<const float *>(dev + o_Q),
                        reinterpret_cast<const float *>(dev + o_y), reinterpret_cast<const int *>(dev), B, N, nx, h->cfg.e_dim,
                        (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),
-                       h->dn_xs.as<float>(), h->dn_hs.as<float>(), h->dn_qs.as<float>(), h->sd_out.as<float>());
+                       h->dn_xs.as<float>(), h->dn_hs.as<float>(), h->dn_qs.as<float>(), h->sd_out.as<float>(), h->tr_realbuf.as<int>());
     HIPCHK(hipGetLastError());
     std::vector<float> pred(q_out_flat ? slots : 0);
-    if (train_step_slots(h, B, N, h->sd_e.as<float>(), h->sd_mask.as<float>(), h->dn_xs.as<float>(), h->dn_hs.as<float>(),
-                         h->dn_qs.as<float>(), h->sd_out.as<float>(), q_out_flat ? pred.data() : nullptr, loss_out, apply))
-        return 1;
+    // the padded slots of a coordinate batch are exact zeros in every input: the matrix-pipe kernels skip their workgroups
+    if (h->opt_train_skip_padded) { h->tr_moff = reinterpret_cast<const int *>(dev); h->tr_real = h->tr_realbuf.as<int>(); }
+    const int rc_step = train_step_slots(h, B, N, h->sd_e.as<float>(), h->sd_mask.as<float>(), h->dn_xs.as<float>(), h->dn_hs.as<float>(),
+                                         h->dn_qs.as<float>(), h->sd_out.as<float>(), q_out_flat ? pred.data() : nullptr, loss_out, apply);
+    h->tr_moff = nullptr;
+    h->tr_real = nullptr;
+    if (rc_step) return 1;
     if (q_out_flat)
         for (int b = 0; b < B; ++b)
             for (int i = 0; i < offsets[b + 1] - offsets[b]; ++i) q_out_flat[offsets[b] + i] = pred[(size_t)b * N + i];

@@ -138,6 +138,8 @@ struct epnn_handle {
     int opt_dense_small = 1;          // dense entry, one or a few molecules per call: the front-end as four launches instead of two memsets, seven kernels, a download
     int dn_gen = 1;                   //   ... whose flags are generation numbers (no memset per call)
     void *dn_flag_seen = nullptr;
+    int opt_train_skip_padded = 1;    // training, coordinate entry, matrix-pipe kernels: padded atom slots leave their workgroups at once (the same bits)
+    const int *tr_moff = nullptr, *tr_real = nullptr;      // ... set around the step by epnn_train_step_xyz
     int opt_train_split = 0;          // training, matrix-pipe backward: workgroups per atom (0 = as many as fit the atom's XCD, at most 6)
     int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels; 2 = the forward on the matrix pipe instead (epnn_train_mfma.hip.h;
                                       // measured slower at N = 41: three workgroups per molecule); 0 = the layer-by-layer kernels
@@ -205,7 +207,7 @@ struct epnn_handle {
     } pending;
     // dense front-end workspace (epnn_dense.hip.h)
     DevBuf dn_den;
-    DevBuf dn_xs, dn_hs, dn_qs, dn_nms, dn_flag, dn_neff, dn_xf, dn_hf, dn_qf, dn_nmf, dn_out;
+    DevBuf dn_xs, dn_hs, dn_qs, dn_nms, dn_flag, dn_neff, dn_xf, dn_hf, dn_qf, dn_nmf, dn_out, tr_realbuf;
     DevBuf sd_h, sd_e, sd_x, sd_q, sd_mask, sd_out;
     std::vector<int> dn_neff_host;
     void *train = nullptr;            // TrainState (epnn_train.hip.h)

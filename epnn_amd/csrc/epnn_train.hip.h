@@ -636,6 +636,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     auto P = [&](size_t off) { return ar + off; };
     float *nm = P(o_nm), *wgt = P(o_wgt);
     float *gq = P(o_gq), *gfeat = P(o_gfeat), *gh = P(o_gh);
+    // hidden layers of the row-fused kernels on the matrix pipe ("train_fused" = 1, the default); 3 = the scalar FMA version
+    const bool mm = h->opt_train_fused != 3 && nx + 49 <= EPNN_TF_FMAX && ((uintptr_t)d_e & 15) == 0;
 #ifdef EPNN_TF_CLOCKS
     int nclk = 0;
     if (ts->clk.ensure(64 * 16 * 8)) return 1;
@@ -648,6 +650,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.N = N; A.nx = nx; A.wgt = wgt; A.nm = nm;
         A.nm_w = nm; A.wgt_w = wgt; A.tol = h->cfg.near_tol; A.pmode = -1;
         A.gfeat = gfeat; A.gh = gh; A.gqv = gq; A.gq = gq; A.dU0 = P(o_dU0);
+        if (mm) { A.moff = h->tr_moff; A.real = h->tr_real; }
 #ifdef EPNN_TF_CLOCKS
         A.clk = ts->clk.as<unsigned long long>() + 16 * (nclk++);
 #endif
@@ -666,8 +669,6 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     // SLOWER than the row-fused forward at these sizes (0.66 vs 0.47 ms per step: three workgroups per molecule are a chain of
     // dependent MFMAs where the row-fused kernels have 41 x 16 wavefronts), so it is an option, not the default.
     const bool mfma_fwd = h->opt_train_fused == 2 && nx + 49 <= EPNN_TM_FS;
-    // hidden layers of the row-fused kernels on the matrix pipe ("train_fused" = 1, the default); 3 = the scalar FMA version
-    const bool mm = h->opt_train_fused != 3 && nx + 49 <= EPNN_TF_FMAX && ((uintptr_t)d_e & 15) == 0;
     auto lds_bwd_mm = [&](int nd) { return ((size_t)4 * nd * N * EPNN_TB_RS + (size_t)N * EPNN_TB_ES + 1168 + (size_t)N * FS) * 4; };
     // one molecule per step is N workgroups on 256 CUs: up to six workgroups per atom share its weight-gradient jobs
     // (an XCD has 32 CUs and a workgroup of these kernels has a CU to itself: the shares of an XCD's atoms must fit it in one round)
@@ -760,6 +761,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     entry(ts->upd[0].offW, EPNN_TF_PU, T * BN, o_pu);
     for (int t = 0; t < T; ++t) entry(ts->msg[t][0].offW, Pm0, BN, o_pm[t]);
     for (int t = 0; t < T; ++t) entry(ts->pas[t][0].offW, Pm1, BN, o_pp[t]);
+    if (mm && h->tr_real) { Rd.real = h->tr_real; Rd.natoms = BN; }
     if (adam_now) {
         Rd.adam = 1;
         if (step_on_device) {                       // captured into a hipGraph: the caller keeps ts->step and the device counter in step

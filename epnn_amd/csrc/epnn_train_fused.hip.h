@@ -55,6 +55,12 @@ struct TfPair {                  // one sweep of a pair MLP (message network of 
     // matrix-pipe backward (k_tb_pair_bwd_mm): `nsplit` workgroups per atom share its weight-gradient jobs (one molecule is 41
     // workgroups on 256 CUs); what a launch updates in place in the scalar kernel is read from the previous launch's copy here
     int nsplit, natoms;                  // natoms = B N (the grid is padded: see the kernel)
+    // coordinate entry (epnn_train_step_xyz): molecule b has moff[b+1] - moff[b] real atoms, the other slots of its N are exact
+    // zeros in every input.  The matrix-pipe kernels then leave a padded atom's workgroup at once (it would compute zeros for
+    // N rows: half of the 41 slots of an average `mixed` molecule), take the padded partners' h and q as the zeros they are
+    // (nobody writes them any more), and the reduction skips the padded atoms' partials (`real`).  Null: every slot is computed.
+    const int *moff;
+    const int *real;
     const float *gfeat_r, *gq_r, *dU0_r; // the previous launch's gfeat / gq / dU0 (this one writes gfeat / gqv / U.dU0)
     const float *rs_r;                   // [BN][2][32] the previous sweep's row sums of dz1 (listed, swapped rows of each atom)
     float *rs_w;
@@ -145,6 +151,20 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     constexpr int ND = MODE ? 2 : 1;
     TF_CLK(0);
     if (MODE == 0 && A.step_p && bi == 0 && tid == 0) *A.step_p += 1;
+    const int nreal = (MM && A.moff) ? A.moff[b + 1] - A.moff[b] : N;       // real atoms of this molecule (MM: see TfPair::moff)
+    if (MM && i >= nreal) {
+        // a padded slot: q = 0, every transfer weight 0, node mask 0 -- its outputs are zeros nobody reads, except the last
+        // pass step's prediction / loss term
+        if (MODE == 1 && tid == 0 && A.y) {
+            A.pred[bi] = 0.f;
+            A.lterm[bi] = A.y[bi] * A.y[bi];
+            if (A.out_h) {
+                A.out_h[bi] = A.y[bi] * A.y[bi];
+                A.out_h[(size_t)gridDim.x + bi] = 0.f;
+            }
+        }
+        return;
+    }
     // ---- MM: this wavefront's weight fragments (every job of a wavefront has the same order of the pair: 8 % ND == 0).
     // Row m of output tile rb is FEATURE 2 m + rb: a lane's two tiles are neighbours in memory (one 8-byte read per K step),
     // and its eight accumulators are features 8 lq .. 8 lq + 7 of its row.  W1 goes through LDS once per workgroup (float4
@@ -236,7 +256,8 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 const int ia = min((5 * rd + u) * EPNN_TF_NT + tid, nA - 1);
                 const int j = ia / F, k = ia - j * F;
                 const size_t at = a0 + j;
-                va[u] = *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));
+                const float t = *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));
+                va[u] = (j >= nreal && k >= nx) ? 0.f : t;               // a padded partner's h and q (x is zero as given)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) ve[u] = A.e[rowbase * 48 + min((4 * rd + u) * EPNN_TF_NT + tid, nE - 1)];
@@ -968,6 +989,8 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
     const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3, bi = (kx / S) * 8 + xcd, sub = kx - (kx / S) * S;
     if (bi >= BNa) return;
     const int b = bi / N, i = bi - b * N;
+    const int nreal = A.moff ? A.moff[b + 1] - A.moff[b] : N;
+    if (i >= nreal) return;                   // a padded slot: every gradient it would form is zero (TfPair::moff); the reduction skips its partials
     const bool own = sub == 0;                // the workgroup of this atom that writes what is not a weight-gradient job
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane >> 4, lx = lane & 15;
     constexpr int ND = MODE ? 2 : 1, O = MODE ? 1 : 32, RS = EPNN_TB_RS, ES = EPNN_TB_ES;
@@ -1055,17 +1078,17 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             const bool two = A.pmode == 1;
             const float *pc = A.pdz1 + (a0 * N + i) * 32 + 4 * c4;
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-            for (int t0 = 0; t0 < N; t0 += 48) {
+            for (int t0 = 0; t0 < nreal; t0 += 48) {
                 f32x4 v0[6], v1[6];
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
-                    const int tc = min(t0 + 8 * u + rg, N - 1);
+                    const int tc = min(t0 + 8 * u + rg, nreal - 1);
                     v0[u] = tm_ld4(pc + (size_t)tc * N * 32);
                     v1[u] = tm_ld4(pc + dstride + (size_t)tc * N * 32);
                 }
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
-                    const bool ok = t0 + 8 * u + rg < N;
+                    const bool ok = t0 + 8 * u + rg < nreal;          // (rows of padded atoms are exact zeros, or were never written)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         s0[c] += ok ? v0[u][c] : 0.f;
@@ -1238,7 +1261,8 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
                 const int ia = min((6 * rd + u) * nth + t, nA - 1);
                 const int j = ia / F, k = ia - j * F;
                 const size_t at = a0 + j;
-                va[u] = *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));     // one load of a selected address
+                const float tv = *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));     // one load of a selected address
+                va[u] = (j >= nreal && k >= nx) ? 0.f : tv;                   // a padded partner's h and q
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1454,6 +1478,8 @@ struct TfReduce {
     float *theta, *m, *v;
     const long long *step_p;      // hipGraph replay: the step number lives on the device (the step's first launch has counted it)
     float lr;
+    const int *real;              // [natoms] 0 for a padded slot whose block of partials nobody wrote (block index mod natoms), or null
+    int natoms;
 };
 // grad[theta_off + idx] = sum_blk part[part_off + blk * len + idx]: four quarter sums (one per wavefront), combined in order
 __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *part, float *grad) {
@@ -1483,6 +1509,11 @@ __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *par
             float pv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) pv[u] = p[(size_t)min(blk + u, hi - 1) * len];
+            if (T.real) {                         // (a padded atom's partials are exact zeros when they are computed: the same bits)
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (!T.real[min(blk + u, hi - 1) % T.natoms]) pv[u] = 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
                 if (blk + u < hi) s += pv[u];

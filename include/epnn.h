@@ -189,6 +189,9 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * scalar FMA loops -- round 2's kernels, kept as the second implementation the tests compare; 2: the forward's pair MLPs in
  * the factorised form of the inference kernels, a workgroup per 16 atoms of a molecule -- measured slower at N = 41; 0: one
  * launch per Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS budget of 96 atoms),
+ * "train_skip_padded" (1, default: epnn_train_step_xyz tells the "train_fused" = 1 kernels which atom slots of the padded size are
+ * real -- the workgroups of the others, which would compute zeros for N rows each, return at once; 0: every slot is computed; the
+ * same bits),
  * "train_split" (workgroups that share one atom's weight-gradient jobs in the backward launches of "train_fused" = 1; 0,
  * default: as many as fit the XCD the atom's workgroups are placed on, at most 6 -- 5 for a one-molecule step of 41 atoms; results
  * are bit-identical for every value). */

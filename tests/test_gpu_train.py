@@ -270,6 +270,39 @@ def test_workgroups_per_atom_do_not_change_a_bit(gpu_engine_factory, val_dir, va
                 assert np.array_equal(a, b_), split
 
 
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_skipping_padded_slots_does_not_change_a_bit(gpu_engine_factory, val_dir, val_names, B):
+    """train_step_xyz pads every molecule to N slots with exact zeros; the matrix-pipe kernels leave the workgroups of those
+    slots at once ("train_skip_padded", default), read the padded partners' h and q as the zeros they are and skip their
+    weight-gradient partials in the reduction.  A padded atom's partials are exact zeros when they ARE computed, so
+    predictions, loss, gradients and the weights after two optimizer steps are bit-identical either way -- molecules of 9..29
+    atoms at N = 41, random weights."""
+    from conftest import load_molecules
+    names = [nm for nm in val_names if nm.startswith("dsgdb9nsd")][3:3 + B]
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, names, 9)
+    assert max(np.diff(offsets)) < 41
+    rng = np.random.default_rng(40 + B)
+    y = (rng.normal(size=int(offsets[-1])) * 0.2).astype(np.float32)
+    w = random_weights(9, 5, seed=23, scale=0.4)
+    ref = None
+    for skip in (1, 0):
+        eng = gpu_engine_factory(nx=9, T=5)
+        eng.set_option("train_skip_padded", skip)
+        eng.set_weights(w)
+        eng.train_init()
+        q, loss = eng.train_step_xyz(offsets, xyz, x, Q, y, 41, apply=False)
+        g = eng.get_gradients()
+        assert np.abs(g).max() > 0
+        eng.train_step_xyz(offsets, xyz, x, Q, y, 41)
+        q2, l2 = eng.train_step_xyz(offsets, xyz, x, Q, y, 41)
+        out = (q, np.float32(loss), g, q2, np.float32(l2), eng.get_weights_flat() if hasattr(eng, "get_weights_flat") else q2)
+        if ref is None:
+            ref = out
+        else:
+            for a, b_ in zip(ref, out):
+                assert np.array_equal(a, b_)
+
+
 def test_train_step_xyz_equals_dense(gpu_engine_factory, val_dir, val_names):
     from conftest import load_molecules
     from oracle import epnn_oracle as orc
