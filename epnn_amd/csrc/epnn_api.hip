@@ -1333,6 +1333,20 @@ static int enqueue_dense(epnn_handle *h, int B, int N, int mode, const float *d_
         }
         h->dn_gen += 1;
         const int fb = (N * (EPNN_EDIM + nx + 1) + 255) / 256, eb = (N * N + 255) / 256;
+        if (h->opt_dense_rowfused && (size_t)B * N <= 256 && N <= 48 && infer_rowfused_fits(h, N)) {
+            // a padded size this small: the row-fused forward is at least as fast as the fused kernel on one CU whatever the
+            // molecule's real size, and it does not need the effective atom counts -- no host synchronisation in the middle of
+            // the call (the per-atom features are all it takes from the front-end: the feature blocks alone)
+            hipLaunchKernelGGL(k_dn_front_small, dim3((unsigned)fb, (unsigned)B), dim3(256), 0, h->stream, D, h->dn_den.as<float>(), h->dn_gen, fb);
+            HIPCHK(hipGetLastError());
+            if (infer_rowfused_forward(h, B, N, d_e, d_mask, D.xs, D.hs, D.qs, d_out)) return 1;
+            h->h_status[0] = 0;
+            h->h_status[1] = 0;
+            h->last_front = false;
+            h->stats[1] = 0;
+            h->stats[2] = 0;
+            return 0;
+        }
         hipLaunchKernelGGL(k_dn_front_small, dim3((unsigned)(fb + eb), (unsigned)B), dim3(256), 0, h->stream, D, h->dn_den.as<float>(), h->dn_gen, fb);
         hipLaunchKernelGGL(k_dn_neff_small, dim3((unsigned)B), dim3(64), 0, h->stream, D, h->dn_gen, h->pin_neff.as<int>());
         HIPCHK(hipGetLastError());

@@ -178,10 +178,10 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * "dense_small" (1, default: a make_model call on one or a few molecules -- B N^2 <= 65536 -- builds its per-atom features, flags,
  * effective atom counts and pair list in four launches instead of two memsets, seven kernels and a download; 0: the general sequence;
  * the same bits),
- * "dense_rowfused" (1, default: such a small call whose largest molecule fills more than 55 % of the padded size N, with B N <= 256,
- * runs the row-fused forward kernels of the training step -- a workgroup per atom slot, the reference's literal arithmetic, nothing
- * stored for a backward pass -- instead of one CU for the whole molecule; epnn_last_stats then reports 0 molecules on the fused and
- * 0 on the tiled path; 0: always the fused / tiled kernels),
+ * "dense_rowfused" (1, default: such a small call with B N <= 256 runs the row-fused forward kernels of the training step -- a
+ * workgroup per atom slot, the reference's literal arithmetic, nothing stored for a backward pass -- instead of one CU for the whole
+ * molecule: always when N <= 48 (the call then has no host synchronisation inside), beyond that when its largest molecule fills more
+ * than 55 % of N; epnn_last_stats then reports 0 molecules on the fused and 0 on the tiled path; 0: always the fused / tiled kernels),
  * "train_graph" (1, default: a train step's launch sequence, optimizer step included, is captured once per (B, N, buffer set)
  * and replayed as a hipGraph; 0: kernel by kernel -- the same bits),
  * "train_fused" (1, default: one workgroup per atom runs a whole pair MLP over its rows, forward and backward, 2T + 2T + 1

@@ -123,49 +123,77 @@ def test_small_dense_calls_take_the_short_sequence_with_the_same_bits(golden_dir
 
 
 @pytest.mark.parametrize("nx,T", [(9, 5), (10, 2)])
-def test_lone_molecules_that_fill_their_padding_take_the_row_fused_forward(golden_dir, nx, T):
-    """model([h,e,x,q,mask]) on ONE molecule (or a few) whose largest fills more than 55 % of the padded size runs the
-    row-fused forward kernels of the training step -- a workgroup per atom slot, the reference's literal rows -- instead of
-    the fused inference kernel on one CU ("dense_rowfused", default).  Same answers as the float64 oracle to the tolerance of
-    the other dense tests and as the fused kernels to float32 rounding; padded atoms exactly zero; epnn_last_stats shows the
-    path (0 molecules on the fused and on the tiled kernels); a molecule that fills less takes the fused kernel as before."""
-    from epnn_amd import charge_gn
+def test_lone_molecules_take_the_row_fused_forward(golden_dir, nx, T):
+    """model([h,e,x,q,mask]) on ONE molecule (or a few, B N <= 256) runs the row-fused forward kernels of the training step --
+    a workgroup per atom slot, the reference's literal rows -- instead of the fused inference kernel on one CU
+    ("dense_rowfused", default): always when the padded size is at most 48 (no effective atom counts needed: no host
+    synchronisation inside the call), and beyond that when the largest molecule fills more than 55 % of the padded size.
+    Same answers as the float64 oracle to the tolerance of the other dense tests and as the fused kernels to float32 rounding;
+    padded atoms exactly zero; epnn_last_stats shows the path (0 molecules on the fused and on the tiled kernels)."""
+    from epnn_amd import charge_gn, synth
     from oracle import epnn_oracle as orc
-    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, nx)
-    N = x.shape[1]
-    sizes = [int(mask[b].sum(axis=0).max()) for b in range(x.shape[0])]
-    big = int(np.argmax(sizes))
-    # pad the largest molecule so that it fills ~70 % of N', the smallest stays below 55 % of it
-    Np = int(np.ceil(sizes[big] / 0.7))
-    assert Np >= N
-
-    def cut(a, sel):                                         # (B, N, N, C) -> the selected molecules, zero padded to (Np, Np)
-        out = np.zeros((len(sel), Np, Np) + a.shape[3:], a.dtype)
-        out[:, :N, :N] = a[sel]
-        return out
     w = random_weights(nx, T, seed=17, scale=0.35)
-    model = charge_gn.make_model([32, 32], 48, T, nx, Np)
-    model.set_weights_dict(w)
-    eng = model.engine()
-    small = int(np.argmin(sizes))
-    for sel, expect_rowfused in (([big], True), ([small], sizes[small] * 20 >= 11 * Np), ([big, small], True)):
-        ins = [cut(a, sel) for a in (h, e, x, q, mask)]
+
+    def check(model, ins, sizes, expect_rowfused, tag):
+        eng = model.engine()
         eng.set_option("dense_rowfused", 1)
         pred = model(ins)
         st = eng.last_stats()
-        assert (int(st[1]) + int(st[2]) == 0) == expect_rowfused, (sel, st)
+        assert (int(st[1]) + int(st[2]) == 0) == expect_rowfused, (tag, st)
         eng.set_option("dense_rowfused", 0)
         pred0 = model(ins)
         st0 = eng.last_stats()
-        assert int(st0[1]) + int(st0[2]) == len(sel)
+        assert int(st0[1]) + int(st0[2]) == len(sizes)
         ref = orc.model_forward(*ins, w, dtype=np.float64)
         ref32 = orc.model_forward(*ins, w, dtype=np.float32)
         err, noise = np.abs(pred - ref).max(), np.abs(ref32 - ref).max()
-        print(f"row-fused dense call nx={nx} T={T} N={Np} molecules {sel}: |dq| {err:.3e} (fused kernels {np.abs(pred0 - ref).max():.3e}, float32 oracle {noise:.3e})")
+        print(f"row-fused dense call nx={nx} T={T} {tag}: |dq| {err:.3e} (fused kernels {np.abs(pred0 - ref).max():.3e}, float32 oracle {noise:.3e})")
         assert err <= max(TOL, 3 * noise)
         assert np.abs(pred - pred0).max() <= max(TOL, 3 * noise)
-        for r, b in enumerate(sel):
-            assert np.all(pred[r, sizes[b]:] == 0)
+        for r, n in enumerate(sizes):
+            assert np.all(pred[r, n:] == 0) and np.any(pred[r, :n] != 0)
+
+    # (a) the golden QM9 molecules padded to N = 26: every call takes the row-fused kernels, whatever the molecule's size
+    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, nx)
+    N = x.shape[1]
+    sizes = [int(mask[b].sum(axis=0).max()) for b in range(x.shape[0])]
+    big, small, Np = int(np.argmax(sizes)), int(np.argmin(sizes)), 26
+
+    def pad(a, sel):                                         # (B, N, N, C) -> the selected molecules, zero padded to (Np, Np)
+        out = np.zeros((len(sel), Np, Np) + a.shape[3:], a.dtype)
+        out[:, :N, :N] = a[sel]
+        return out
+    model = charge_gn.make_model([32, 32], 48, T, nx, Np)
+    model.set_weights_dict(w)
+    for sel in ([big], [small], [big, small]):
+        check(model, [pad(a, sel) for a in (h, e, x, q, mask)], [sizes[b] for b in sel], True, f"N={Np} molecules {sel}")
+
+    # (b) N = 60: a 40-atom molecule fills two thirds of it (row-fused), a 12-atom one a fifth (the fused kernel as before)
+    Nb = 60
+    rng = np.random.default_rng(8)
+    model = charge_gn.make_model([32, 32], 48, T, nx, Nb)
+    model.set_weights_dict(w)
+
+    def synth_batch(ns):
+        B = len(ns)
+        hh = np.zeros((B, Nb, Nb, 48), np.float32); ee = np.zeros((B, Nb, Nb, 48), np.float32)
+        xx = np.zeros((B, Nb, Nb, nx), np.float32); qq = np.zeros((B, Nb, Nb, 1), np.float32); mm = np.zeros((B, Nb, Nb, 1), np.float32)
+        for b, n in enumerate(ns):
+            span = 1.6 * n ** (1 / 3.0) * 1.3
+            while True:
+                pts = rng.uniform(0, span, size=(n, 3))
+                d = np.linalg.norm(pts[:, None] - pts[None], axis=-1) + np.eye(n) * 10
+                if d.min() > 0.8:
+                    break
+            ee[b, :n, :n] = charge_gn.get_init_edges(pts.astype(np.float32), np.array([]), num=48)[0]
+            f = synth.features(rng.choice(["H", "C", "N", "O"], size=n))
+            xx[b, :n, :n, :f.shape[1]] = f[None]
+            hh[b, :n, :n] = (rng.normal(size=(n, 48)) * 0.2).astype(np.float32)[None]
+            qq[b, :n, :n, 0] = np.float32(rng.integers(-1, 2)) / np.float32(n)
+            mm[b, :n, :n, 0] = 1
+        return [hh, ee, xx, qq, mm]
+    for ns, expect in (([40], True), ([12], False), ([40, 12], True)):
+        check(model, synth_batch(ns), ns, expect, f"N={Nb} sizes {ns}")
 
 
 def test_arbitrary_dense_inputs(golden_dir):
