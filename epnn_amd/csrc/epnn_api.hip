@@ -1799,7 +1799,17 @@ extern "C" int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *
     }
     D.xs = h->dn_xs.as<float>(); D.hs = h->dn_hs.as<float>(); D.qs = h->dn_qs.as<float>(); D.nms = h->dn_nms.as<float>();
     D.flag = h->dn_flag.as<int>(); D.tol = h->cfg.near_tol;
-    if (launch_dense_atoms(h, D)) return 1;                                                         // charge_gn.py:382-384
+    if (slots * N <= 65536) {
+        // a step on one or a few molecules: the per-atom reductions alone (charge_gn.py:382-384), one launch -- training needs
+        // neither the flags nor the e scan of the inference front-end
+        if (h->dn_den.ensure(slots * 4)) return 1;
+        D.model_level = 1;
+        const int fb = (N * (EPNN_EDIM + nx + 1) + 255) / 256;
+        hipLaunchKernelGGL(k_dn_front_small, dim3((unsigned)fb, (unsigned)B), dim3(256), 0, h->stream, D, h->dn_den.as<float>(), 1, fb);
+        HIPCHK(hipGetLastError());
+    } else if (launch_dense_atoms(h, D)) {
+        return 1;
+    }
     return train_step_slots(h, B, N, D.e_in, D.mask_in, D.xs, D.hs, D.qs, d_y, pred_out, loss_out, apply);
 }
 
