@@ -140,6 +140,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
         TrainState *ts = train_state(h);
         if (ts->gexec) (void)hipGraphExecDestroy(ts->gexec);
         if (ts->graph) (void)hipGraphDestroy(ts->graph);
+        for (auto &kg : ts->kept) { (void)hipGraphExecDestroy(kg.exec); (void)hipGraphDestroy(kg.graph); }
         for (DevBuf *b : {&ts->theta, &ts->grad, &ts->m, &ts->v, &ts->part, &ts->arena, &ts->loss, &ts->d_step}) b->release();
         delete ts;
         h->train = nullptr;
@@ -1702,8 +1703,27 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
         const std::vector<const void *> key = {(const void *)(size_t)B, (const void *)(size_t)N, (const void *)(size_t)(h->opt_train_fused + 16 * h->opt_train_split + 256 * (int)adam_now), d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred,
                                                d_loss, ts->arena.p, ts->part.p, ts->theta.p, ts->grad.p, out_host, ts->d_step.p, h->tr_moff, h->tr_real};
         if (!ts->gexec || key != ts->gkey) {
-            if (ts->gexec) { (void)hipGraphExecDestroy(ts->gexec); ts->gexec = nullptr; }
-            if (ts->graph) { (void)hipGraphDestroy(ts->graph); ts->graph = nullptr; }
+            // park the current capture, look for one made with this key
+            if (ts->gexec) {
+                if (ts->kept.size() >= 4) {
+                    (void)hipGraphExecDestroy(ts->kept.front().exec);
+                    (void)hipGraphDestroy(ts->kept.front().graph);
+                    ts->kept.erase(ts->kept.begin());
+                }
+                ts->kept.push_back({ts->gkey, ts->graph, ts->gexec});
+                ts->gexec = nullptr;
+                ts->graph = nullptr;
+            }
+            for (size_t k = 0; k < ts->kept.size(); ++k)
+                if (ts->kept[k].key == key) {
+                    ts->graph = ts->kept[k].graph;
+                    ts->gexec = ts->kept[k].exec;
+                    ts->gkey = key;
+                    ts->kept.erase(ts->kept.begin() + k);
+                    break;
+                }
+        }
+        if (!ts->gexec || key != ts->gkey) {
             const long step_before = ts->step;
             HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
             const int bad = train_fb(h, B, N, d_e, d_mask, d_x, d_h0, d_q0, d_y, d_pred, d_loss, false, adam_now, out_host, true);

@@ -339,6 +339,10 @@ struct TrainState {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     std::vector<const void *> gkey;
+    // the last few captures are kept (a training loop alternates between its batch size and the last, smaller batch of an epoch:
+    // re-instantiating on every change would cost more than the replay saves)
+    struct KeptGraph { std::vector<const void *> key; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<KeptGraph> kept;
     bool fused_attr = false;                     // dynamic LDS limit of the row-fused kernels raised
     DevBuf d_step;                               // hipGraph replay with the optimizer step inside: the step number on the device
     long dev_step = -1;                          //   ... and the value the host last put there

@@ -203,6 +203,35 @@ def test_graph_replay_equals_kernel_by_kernel(gpu_engine_factory):
     assert np.array_equal(ot.flatten(wa), ot.flatten(wb))
 
 
+def test_graph_replay_keeps_the_captures_of_alternating_batch_sizes(gpu_engine_factory):
+    """A training loop alternates between its batch size and the epoch's last, smaller batch, with and without the optimizer
+    step (validation): the step's hipGraph is captured once per (B, N, buffers, apply) and the last few captures are kept, the
+    device-side step counter follows the host's across them.  Losses, predictions and the weights after twelve steps of mixed
+    kinds are bit-identical to launching kernel by kernel."""
+    nx, T, N = 9, 2, 8
+    w = random_weights(nx, T, seed=6, scale=0.5)
+    kinds = [([7, 5], True), ([6], True), ([7, 5], False), ([3, 8, 4], True)]
+    batches = [(_tiny_batch(nx, N, ns, seed=10 + k), ap) for k, (ns, ap) in enumerate(kinds)]
+    order = [0, 1, 0, 2, 3, 1, 0, 3, 2, 0, 1, 3]
+    out = []
+    for graph in (1, 0):
+        eng = gpu_engine_factory(nx=nx, T=T)
+        eng.set_option("train_graph", graph)
+        eng.set_weights(w)
+        eng.train_init()
+        tr = []
+        for k in order:
+            (h, e, x, q, mask, y), ap = batches[k]
+            p, l = eng.train_step_dense(h, e, x, q, mask, y, apply=ap)
+            tr.append((p.copy(), l))
+        out.append((tr, eng.get_weights()))
+    (ta, wa), (tb, wb) = out
+    for (pa, la), (pb, lb) in zip(ta, tb):
+        assert la == lb and np.array_equal(pa, pb)
+    from oracle import epnn_oracle_train as ot
+    assert np.array_equal(ot.flatten(wa), ot.flatten(wb))
+
+
 def test_fused_step_equals_layer_by_layer_at_full_size(gpu_engine_factory, val_dir, val_names, weights_decay):
     """configs[2] shape (N = 41, T = 5, shipped checkpoint, real molecules): the row-fused kernels and the layer-by-layer
     kernels are two implementations of the same literal algorithm; predictions, loss and every gradient tensor agree
