@@ -344,6 +344,10 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             const bool has = job < njobs;
             const int j = (job / ND) * 16 + lx;
             const bool jv = has && j < N;
+            // pass network: a tile of padded partners only (TfPair::moff) -- every transfer of its rows has weight 0 and its rows
+            // get zero gradients: zeros are stored for them, nothing is computed (4 jobs instead of 6 for an average molecule: one
+            // per SIMD)
+            const bool dead = MODE == 1 && (job / ND) * 16 >= nreal;
             const float *aj = As + (jv ? j : 0) * FS, *ej = Es + (jv ? j : 0) * 49;
             f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             if (first && bw >= 0) {
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                     pb[bw * 256 + lane] = v;          // a lane reads and writes its own column only
                 }
             }
-            if (has) {
+            if (has && !dead) {
                 // order 0 rows are [a_i | a_j | e_ij]: the partner a_j meets block 1 of W1; order 1 rows are [a_j | a_i | e_ij]: block 0
                 const float *wjs = W1s + (jdir ? 0 : F) * 32 + 2 * lx, *wes = W1s + 2 * F * 32 + 2 * lx;
 #pragma unroll
@@ -391,21 +395,23 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             }
             if (has) {
                 const float *vb = pb + jdir * 256 + 8 * lq;
-                f32x4 d2[2];
+                f32x4 d2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (!dead) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[0][c] = fmaxf(acc[0][c] + vb[2 * c], 0.f);
-                    acc[1][c] = fmaxf(acc[1][c] + vb[2 * c + 1], 0.f);
-                    d2[0][c] = b2v[c >> 1][2 * (c & 1)];              // feature 8 lq + 2 c
-                    d2[1][c] = b2v[c >> 1][2 * (c & 1) + 1];          // feature 8 lq + 2 c + 1
-                }
+                    for (int c = 0; c < 4; ++c) {
+                        acc[0][c] = fmaxf(acc[0][c] + vb[2 * c], 0.f);
+                        acc[1][c] = fmaxf(acc[1][c] + vb[2 * c + 1], 0.f);
+                        d2[0][c] = b2v[c >> 1][2 * (c & 1)];              // feature 8 lq + 2 c
+                        d2[1][c] = b2v[c >> 1][2 * (c & 1) + 1];          // feature 8 lq + 2 c + 1
+                    }
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    d2[0] = tm_mfma(w2f[s][0], acc[s & 1][s >> 1], d2[0]);
-                    d2[1] = tm_mfma(w2f[s][1], acc[s & 1][s >> 1], d2[1]);
+                    for (int s = 0; s < 8; ++s) {
+                        d2[0] = tm_mfma(w2f[s][0], acc[s & 1][s >> 1], d2[0]);
+                        d2[1] = tm_mfma(w2f[s][1], acc[s & 1][s >> 1], d2[1]);
+                    }
+                    d2[0] = tm_relu(d2[0]);
+                    d2[1] = tm_relu(d2[1]);
                 }
-                d2[0] = tm_relu(d2[0]);
-                d2[1] = tm_relu(d2[1]);
                 if (jv) {
                     float *l2 = H2s + (jdir * N + j) * 33 + 8 * lq;
                     if (A.H1) {                               // (null when nothing will run backward: the dense entry's small calls)
@@ -1295,6 +1301,19 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
         const bool jv = j < N;
         const int r = d * N + (jv ? j : 0);
         f32x4 h2[2], dz2[2];
+        if (MODE == 1 && (job / ND) * 16 >= nreal) {
+            // a tile of padded partners: df = 0 for every row of it -- zeros, without the products (the forward stored zeros too)
+            if (jv) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    tm_st4(D2s + r * RS + 4 * c4, z);
+                    tm_st4(D1s + r * RS + 4 * c4, z);
+                    if (own) tm_st4(A.dz1 + d * dstride + (rowbase + j) * 32 + 4 * c4, z);
+                }
+            }
+            continue;
+        }
         h2[0] = tm_ld4(H2s + r * RS + 4 * lq);
         h2[1] = tm_ld4(H2s + r * RS + 16 + 4 * lq);
         if (MODE == 0) {
@@ -1364,6 +1383,10 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
     const int nA = 2 * KTA, nE = 6, nW2 = 6, nW3 = MODE ? 2 : 4;
     const int njobs = 2 * nA + nE + nW2 + nW3;
     auto none = [](int) { return 0.f; };
+    // pass network: the rows of padded partners are exact zeros in dz1 and dz2 (TfPair::moff): the products stop at the last tile
+    // that holds a real partner, in both orders of the pair (two passes of sixteen rows instead of three for an average molecule)
+    const int NK = MODE ? min(N, ((nreal + 15) / 16) * 16) : N;
+    auto rm = [&](int r) { return (MODE && r >= NK) ? N + (r - NK) : r; };       // row of the flat (order, partner) index over 2 NK rows
     // jobs are dealt to the atom's workgroups first, then to the wavefronts of each (two wavefronts of a SIMD share its matrix pipe)
     for (int job = sub + S * wave; job < njobs; job += (EPNN_TF_NT / 64) * S) {
         f32x4 acc;
@@ -1379,11 +1402,11 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             if (blk == 0) {                   // a_i meets the listed rows, a_j the swapped ones
                 auto ac = [&](int) { return k < F ? aic : oneN; };
                 auto aj = [&](int r) { const float t = As[r * FS + kc]; return k < F ? t : oneT; };
-                acc = MODE == 0 ? tb_rows_mm<false>(N, lq, ac, dN, none, none) : tb_rows_mm<true>(N, lq, ac, dN, aj, dT);
+                acc = MODE == 0 ? tb_rows_mm<false>(NK, lq, ac, dN, none, none) : tb_rows_mm<true>(NK, lq, ac, dN, aj, dT);
             } else {
                 auto ac = [&](int) { return k < F ? aic : 0.f; };
                 auto aj = [&](int r) { const float t = As[r * FS + kc]; return k < F ? t : 0.f; };
-                acc = MODE == 0 ? tb_rows_mm<false>(N, lq, aj, dN, none, none) : tb_rows_mm<true>(N, lq, aj, dN, ac, dT);
+                acc = MODE == 0 ? tb_rows_mm<false>(NK, lq, aj, dN, none, none) : tb_rows_mm<true>(NK, lq, aj, dN, ac, dT);
             }
             TF_CLK(13);
 #pragma unroll
@@ -1399,7 +1422,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             const int jj = job - 2 * nA, kt = jj >> 1, ob = jj & 1, k = 16 * kt + lx, o = 16 * ob + lx;
             auto ae = [&](int r) { return Es[r * ES + k]; };
             auto dS = [&](int r) { return MODE ? D1s[r * RS + o] + D1s[(N + r) * RS + o] : D1s[r * RS + o]; };
-            acc = tb_rows_mm<false>(N, lq, ae, dS, none, none);
+            acc = tb_rows_mm<false>(NK, lq, ae, dS, none, none);
 #pragma unroll
             for (int c = 0; c < 4; ++c) P[(2 * F + 16 * kt + 4 * lq + c) * 32 + o] = acc[c];
         } else if (job < 2 * nA + nE + nW2) {
@@ -1407,13 +1430,13 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
             // (+df w3 against -df w3 wherever both rows are active): b2 sums them pair by pair, not one order after the other
             const int jj = job - 2 * nA - nE, kt = jj >> 1, ob = jj & 1, k = 16 * kt + lx, o = 16 * ob + lx;
             if (kt < 2) {
-                auto ah = [&](int r) { return H1s[r * RS + k]; };
-                auto d2 = [&](int r) { return D2s[r * RS + o]; };
-                acc = tb_rows_mm<false>(NR, lq, ah, d2, none, none);
+                auto ah = [&](int r) { return H1s[rm(r) * RS + k]; };
+                auto d2 = [&](int r) { return D2s[rm(r) * RS + o]; };
+                acc = tb_rows_mm<false>(ND * NK, lq, ah, d2, none, none);
             } else {
                 auto a1 = [&](int) { return lx == 0 ? 1.f : 0.f; };
                 auto d2 = [&](int r) { return MODE ? D2s[r * RS + o] + D2s[(N + r) * RS + o] : D2s[r * RS + o]; };
-                acc = tb_rows_mm<false>(N, lq, a1, d2, none, none);
+                acc = tb_rows_mm<false>(NK, lq, a1, d2, none, none);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -1424,7 +1447,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
         } else {
             // third Dense: message network sum_j H2[j][k] dM[o]; pass network sum over both orders of H2[row][k] (+-df)
             const int jj = job - 2 * nA - nE - nW2, kt = MODE ? jj : jj >> 1, ob = MODE ? 0 : jj & 1, k = 16 * kt + lx, o = 16 * ob + lx;
-            auto ah = [&](int r) { return H2s[r * RS + k]; };
+            auto ah = [&](int r) { return H2s[rm(r) * RS + k]; };
             if (MODE == 0) {
                 const float dmo = dms[o];
                 auto bm = [&](int) { return dmo; };
@@ -1432,8 +1455,8 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd_mm(TfPair A, TfUpd U
 #pragma unroll
                 for (int c = 0; c < 4; ++c) PW3[(16 * kt + 4 * lq + c) * 32 + o] = acc[c];
             } else {
-                auto bd = [&](int r) { const float t = dfs[r < N ? r : r - N]; return lx == 0 ? (r < N ? t : -t) : 0.f; };
-                acc = tb_rows_mm<false>(NR, lq, ah, bd, none, none);
+                auto bd = [&](int r) { const float t = dfs[r < NK ? r : r - NK]; return lx == 0 ? (r < NK ? t : -t) : 0.f; };
+                acc = tb_rows_mm<false>(2 * NK, lq, ah, bd, none, none);
                 if (lx == 0) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) PW3[16 * kt + 4 * lq + c] = acc[c];
