@@ -1533,9 +1533,18 @@ __global__ __launch_bounds__(256) void k_tb_wreduce(TfReduce T, const float *par
 #pragma unroll
             for (int u = 0; u < 16; ++u) pv[u] = p[(size_t)min(blk + u, hi - 1) * len];
             if (T.real) {                         // (a padded atom's partials are exact zeros when they are computed: the same bits)
+                const int b0 = blk % T.natoms;     // block index -> atom slot: one division per pass (the update MLP's entry has T natoms blocks)
+                int rl[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    int sl = b0 + u;
+                    if (T.natoms >= 16) sl -= sl >= T.natoms ? T.natoms : 0;
+                    else sl %= T.natoms;
+                    rl[u] = T.real[sl];
+                }
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
-                    if (!T.real[min(blk + u, hi - 1) % T.natoms]) pv[u] = 0.f;
+                    if (!rl[u]) pv[u] = 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
