@@ -1935,6 +1935,15 @@ extern "C" int epnn_comm_allreduce(epnn_handle *h, double *inout, int32_t n, int
 
 // The pair list the separate front-end (or the dense front-end) built for the last forward: indices and near weights of up
 // to `cap` pairs (tests: the device's D < cutoff and is_near decisions against a host count).  Returns the number of pairs.
+#ifdef EPNN_LG_CLOCKS
+// development build only (tools/large_clocks.py): phase clocks of workgroup 0 of the tiled path's tail and EPN-step launches of the last forward
+extern "C" int epnn_debug_large_clocks(epnn_handle *h, unsigned long long *dst, int n) {
+    if (!h || !dst || !h->lg_clk.p) EPNN_FAIL("epnn_debug_large_clocks: bad argument");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(dst, h->lg_clk.p, (size_t)std::min(n, 128) * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 #ifdef EPNN_TF_CLOCKS
 // development build only (tools/train_clocks.py): phase clocks of workgroup 0 of every row-fused training launch of the last step
 extern "C" int epnn_debug_train_clocks(epnn_handle *h, unsigned long long *dst, int n) {

@@ -191,6 +191,9 @@ struct epnn_handle {
     // page-locked staging: the plan's index arrays with, behind them, the inputs of the host entry (one upload per forward;
     // reused once ev_ctl says the previous upload has run); the charges of the asynchronous host entry
     PinBuf pin_ctl, pin_out, pin_neff;
+#ifdef EPNN_LG_CLOCKS
+    DevBuf lg_clk;                    // development build: phase clocks of the tiled path's tail / EPN-step launches
+#endif
     PinBuf pin_train, pin_tout;       // inputs of epnn_train_step_xyz / of a small dense call (one upload); loss terms + predictions of a
                                       // train step / charges of a small dense call
     DevBuf s_train;

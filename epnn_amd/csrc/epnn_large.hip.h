@@ -48,7 +48,16 @@ __device__ __forceinline__ f32x16 lg_gtile(const float *__restrict__ weF, const 
     return acc;
 }
 
+#ifdef EPNN_LG_CLOCKS
+// development build (tools/large_clocks.py): 100 MHz wall clock of workgroup 0 at phase boundaries of the tail and EPN-step launches
+#define LG_CLK(base, k) do { if (L.clk && blockIdx.x == 0 && threadIdx.x == 0) L.clk[(base) + (k)] = wall_clock64(); } while (0)
+#else
+#define LG_CLK(base, k) do { } while (0)
+#endif
 struct LargeArgs {
+#ifdef EPNN_LG_CLOCKS
+    unsigned long long *clk;
+#endif
     const float *wpack;
     WeightIndex wi;
     int nx, T, N, A, B;
@@ -982,6 +991,7 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     __shared__ __attribute__((aligned(16))) float Ss[32 * EPNN_SST];
     __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
+    LG_CLK(16 * X.run, 0);
     const int np = L.row_off[L.A];                               // (looked at below: the loads in between do not depend on the pair list)
     const int4 tl = L.atiles[blockIdx.x];
     const float *wp = L.wpack;
@@ -1009,19 +1019,24 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
         const int o = tid & 31, a16 = tid >> 5, n = L.moff[tl.z + 1] - L.moff[tl.z];
         const int a[2] = {a16, a16 + 16};
         float sv[2];
+        LG_CLK(16 * X.run, 1);
         lg_reduce<2>(L, tl, a, o, n, types, sv);
+        LG_CLK(16 * X.run, 2);
         Ss[a16 * EPNN_SST + o] = sv[0];
         Ss[(a16 + 16) * EPNN_SST + o] = sv[1];
     }
     __syncthreads();
+    LG_CLK(16 * X.run, 3);
     const int row = c < tl.y ? c : 0;
     if (wave == 0) {
         const int u0 = (L.nx - hh + 1) >> 1;
         lg_update_wave<true>(L, U, w1, w2, w3, tl, Ai + row * EPNN_AST + hh * 32 + u0, Ss + c * EPNN_SST,
                              L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane);
     }
+    LG_CLK(16 * X.run, 4);
     if (!X.run) return;
     __syncthreads();                                            // the image now holds the new h
+    LG_CLK(16 * X.run, 5);
     const float *arow = Ai + row * EPNN_AST + hh * 32;
     if (X.run == 1) {
         if (wave == 1) lg_proj_wave<1, true, false>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R);
@@ -1051,8 +1066,7 @@ __device__ __forceinline__ void lg_handoff(const LargeArgs &L) {
     __threadfence_system();
 }
 // sum of an atom's incidence row of transfers, slot order
-__device__ __forceinline__ float lg_slot_sum(const float *dl, int lo, int hi) {
-    float acc = 0.f;
+__device__ __forceinline__ float lg_slot_sum(const float *dl, int lo, int hi, float acc = 0.f) {
     for (; lo < hi; lo += 16) {
         float v[16];
 #pragma unroll
@@ -1071,6 +1085,18 @@ __global__ __launch_bounds__(256) void k_lg_epn_step(LargeArgs L, PairMlpPack M,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
     const int slot = (blockIdx.x * 4 + wave) * 32 + c;
     // the pair count and the pair records travel together (the records' array is padded: any slot of the grid may be read)
+    LG_CLK(64 + 8 * t, 0);
+    // the weights do not depend on the pair record: requested first (56 loads; a wavefront has 63 in flight)
+    const float *wp = L.wpack;
+    float wg[24], w2[16], wqi[16], wqj[16], b2v[16], w3[16];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) wg[s] = wp[M.weF + s * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
+    epnn_ld16(wp + M.wqi + hh * 16, wqi);
+    epnn_ld16(wp + M.wqj + hh * 16, wqj);
+    epnn_ld16(wp + M.b2p + hh * 16, b2v);
+    epnn_ld16(wp + M.w3p + hh * 16, w3);
     const int np = L.row_off[L.A];
     const int4 ra0 = L.prec[2 * slot], rb0 = L.prec[2 * slot + 1];
     if (np > L.pcap) return;
@@ -1078,37 +1104,56 @@ __global__ __launch_bounds__(256) void k_lg_epn_step(LargeArgs L, PairMlpPack M,
     const int4 ra = valid ? ra0 : make_int4(0, 0, 0, 0), rb = valid ? rb0 : make_int4(0, 0, 0, -1);
     if (__ballot(valid) == 0ull) return;
     const int gi = valid ? ra.x : 0, gj = valid ? ra.y : 0;
-    const float *wp = L.wpack;
     const float *Pst = L.Pst + (size_t)t * L.A * 32, *Rst = L.Rst + (size_t)t * L.A * 32;
     // this half's atom: its charge of the previous step and the transfers it received there
     const int mine = hh ? gj : gi, lo = hh ? rb.x : ra.z, hi = hh ? rb.y : ra.w;
     const float *qprev = L.qbuf + (size_t)((t + 1) & 1) * L.A;          // q_{t-1} lives in generation (t-1) & 1
     float *qnext = L.qbuf + (size_t)(t & 1) * L.A;
-    float qa = 0.f;
-    if (valid) {
-        qa = t == 0 ? L.qbuf[mine] : qprev[mine];
-        if (t > 0) {
-            qa += lg_slot_sum(L.dlA + (size_t)((t + 1) & 1) * 2 * L.pcap, lo, hi);
-            const int dest = hh ? rb.w : rb.z;
-            if (dest == lo) qnext[mine] = qa;                             // the pair that opens the atom's row keeps its charge
+    const float *dlp = L.dlA + (size_t)((t + 1) & 1) * 2 * L.pcap;
+    // everything that hangs on the pair record is requested TOGETHER, unconditionally (clamped indices): the atom's charge and
+    // the first sixteen slots of its row, the pair's e row, the four P / R rows -- one round trip behind the record instead of
+    // three (charge and slots, then the e row, then the rows; clock stamps: 2.4 us of a 6 us workgroup)
+    const float qload = (t == 0 ? L.qbuf : qprev)[mine];
+    float sv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sv[u] = dlp[min(lo + u, max(hi - 1, lo))];
+    float ev[24];
+    {
+        const float *erow = L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(erow + 4 * q);
+            ev[4 * q] = valid ? v[0] : 0.f; ev[4 * q + 1] = valid ? v[1] : 0.f; ev[4 * q + 2] = valid ? v[2] : 0.f; ev[4 * q + 3] = valid ? v[3] : 0.f;
         }
     }
-    const float qo = epnn_swap32(qa);
-    const float qi = hh ? qo : qa, qj = hh ? qa : qo;
-    const f32x16 g = lg_gtile(wp + M.weF, L.pe + (size_t)(valid ? slot : 0) * EPNN_EDIM + hh * 24, valid, lane);
-    float pi_[16], rj_[16], pj_[16], ri_[16], w2[16], wqi[16], wqj[16];
+    float pi_[16], rj_[16], pj_[16], ri_[16];
     epnn_ld16(Pst + (size_t)gi * 32 + hh * 16, pi_);
     epnn_ld16(Rst + (size_t)gj * 32 + hh * 16, rj_);
     epnn_ld16(Pst + (size_t)gj * 32 + hh * 16, pj_);
     epnn_ld16(Rst + (size_t)gi * 32 + hh * 16, ri_);
-    epnn_ld16(wp + M.wqi + hh * 16, wqi);
-    epnn_ld16(wp + M.wqj + hh * 16, wqj);
+    // G = We e on the matrix pipe while the rest is still on its way
+    f32x16 g = epnn_splat16(0.f);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) w2[s] = wp[M.w2F + s * 64 + lane];
-    float b2v[16], w3[16];
-    epnn_ld16(wp + M.b2p + hh * 16, b2v);
-    epnn_ld16(wp + M.w3p + hh * 16, w3);
+    for (int s = 0; s < 24; ++s) g = epnn_mfma(wg[s], ev[s], g);
+    float qa = 0.f;
+    if (valid) {
+        qa = qload;
+        if (t > 0) {
+            float acc = 0.f;                                              // the row's sum in slot order, then added to the charge
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (lo + u < hi) acc += sv[u];
+            if (hi - lo > 16) acc = lg_slot_sum(dlp, lo + 16, hi, acc);
+            qa += acc;
+            const int dest = hh ? rb.w : rb.z;
+            if (dest == lo) qnext[mine] = qa;                             // the pair that opens the atom's row keeps its charge
+        }
+    }
+    LG_CLK(64 + 8 * t, 1);
+    const float qo = epnn_swap32(qa);
+    const float qi = hh ? qo : qa, qj = hh ? qa : qo;
     f32x16 au, av;
+    LG_CLK(64 + 8 * t, 2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { au[r] = b2v[r]; av[r] = b2v[r]; }
 #pragma unroll
@@ -1118,6 +1163,7 @@ __global__ __launch_bounds__(256) void k_lg_epn_step(LargeArgs L, PairMlpPack M,
         au = epnn_mfma(w2[s], fmaxf((g[s] + pu) + ru, 0.f), au);
         av = epnn_mfma(w2[s], fmaxf((g[s] + pv) + rv, 0.f), av);
     }
+    LG_CLK(64 + 8 * t, 3);
     float fu = 0.f, fv = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1132,6 +1178,7 @@ __global__ __launch_bounds__(256) void k_lg_epn_step(LargeArgs L, PairMlpPack M,
         if (hh == 0) out[rb.z] = L.pwi[slot] * dl;
         else if (rb.w >= 0) out[rb.w] = -(L.pwj[slot] * dl);
     }
+    LG_CLK(64 + 8 * t, 4);
 }
 // after the last step: q_T = q_{T-1} + the atom's last slot row (thread per atom), and the hand-over to the host
 __global__ __launch_bounds__(256) void k_lg_epn_final(LargeArgs L) {
@@ -1324,6 +1371,10 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.Yb = h->l_Yb.as<float>();
     L.zp = h->l_zp.as<float>();
     L.S0 = h->l_S0.as<float>();
+#ifdef EPNN_LG_CLOCKS
+    if (h->lg_clk.ensure(128 * 8)) return 1;
+    L.clk = h->lg_clk.as<unsigned long long>();
+#endif
     L.corrA = h->l_corr.as<float>();
     L.dlA = h->l_dl.as<float>();
     L.qbuf = h->l_qbuf.as<float>();

@@ -56,6 +56,7 @@ stats $OUT/train $OUT/r03_train_kernel_stats.csv
 python3 $R/tools/bench_train.py 1 2>/dev/null | grep -v "^{" >> $OUT/r03_train_step.txt
 python3 $R/tools/bench_train.py 8 2>/dev/null >> $OUT/r03_train_step.txt
 python3 $R/tools/train_clocks.py 1 > $OUT/r03_train_clocks.txt 2>/dev/null
+python3 $R/tools/large_clocks.py > $OUT/r03_large_clocks.txt 2>/dev/null
 (cd $R/tools/micro && ./sweep_mix > $OUT/r03_micro_sweep_mix.txt 2>&1)
 (cd $R/tools/micro && ./grid_barrier > $OUT/r03_micro_grid_barrier.txt 2>&1)
 python3 $R/tools/bench_dense_latency.py > $OUT/r03_dense_latency.txt 2>/dev/null

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Where the tiled path's small launches spend their time at protein size: a development build of the library (-DEPNN_LG_CLOCKS,
+built into tools/_dev/, never the shipped .so) stamps the 100 MHz wall clock of workgroup 0 at phase boundaries of the GNN
+tail launches (k_lg_gnn_tail) and the EPN-step launches (k_lg_epn_step) of one forward of the 2220-atom protein.
+    python tools/large_clocks.py [--build]"""
+import os, sys, subprocess, ctypes as C
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DEV = os.path.join(ROOT, "tools", "_dev", "libepnn_lgclocks.so")
+if "--build" in sys.argv or not os.path.exists(DEV):
+    os.makedirs(os.path.dirname(DEV), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-mllvm",
+                    "-amdgpu-mfma-vgpr-form", "-DEPNN_LG_CLOCKS", "-shared", "-fPIC", "-o", DEV, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"),
+                    "-L/opt/rocm/lib", "-lrccl"], check=True)
+    if "--build" in sys.argv: sys.exit(0)
+from epnn_amd import _lib
+_lib.LIB_PATH = DEV
+from epnn_amd import checkpoint, charge_gn
+from epnn_amd.engine import Engine
+eng = Engine(nx=9, T=5); eng.set_weights(checkpoint.load_epnn_weights(os.path.join(ROOT, "models/decay_model_weights")))
+xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(ROOT, "tests/golden/protein/6qlp_capped.xyz"), 9)
+offsets = np.array([0, len(x)], dtype=np.int32); Q = np.array([Q], dtype=np.float32); N = len(x)
+d = [eng.to_device(a) for a in (xyz, x, Q)]; dq = eng.alloc(N * 4)
+for _ in range(5): eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, N)
+eng.sync()
+lib = _lib.load()
+buf = (C.c_ulonglong * 128)()
+lib.epnn_debug_large_clocks.restype = C.c_int
+lib.epnn_debug_large_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+assert lib.epnn_debug_large_clocks(eng.h, buf, 128) == 0
+c = np.array(buf[:], dtype=np.uint64).astype(np.int64)
+print("units of 10 ns from the start of workgroup 0 (the stamps of the LAST launch of each kind in the forward)")
+print("k_lg_gnn_tail: 1 weights / image requested   2 S reduced (partials, slot rows)   3 barrier   4 update MLP done   5 barrier (then the projections)")
+for run, name in ((0, "last GNN step (no projections)"), (1, "middle steps (next step's P, R)"), (2, "hand-over to the EPN stack (static projections)")):
+    r = c[16 * run:16 * run + 8]
+    if r[0]: print(f"  {name:48s}", " ".join(f"{(r[k] - r[0]):6d}" if r[k] else "     -" for k in range(1, 6)))
+print("k_lg_epn_step: 1 q of both atoms (slot sums of the previous step)   2 G tile, P / R rows, weights in registers   3 MFMAs done   4 end")
+for t in range(5):
+    r = c[64 + 8 * t:64 + 8 * t + 8]
+    if r[0]: print(f"  step {t}", " ".join(f"{(r[k] - r[0]):6d}" if r[k] else "     -" for k in range(1, 5)))
