@@ -939,8 +939,9 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
     const bool front_small = front_ok && P.fused_count() > 0;
     const bool pure = front_small && P.large_list.empty();
     if (!pure && ensure_pairs(h, std::max(h->pcap, std::max(1024, P.A * h->pair_cap_per_atom)))) return 1;
-    if (!pure || !h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
-    h->ctl_clean = pure;
+    // (the control words are left clear by the last wavefront of a fused-only forward and by the tiled path's hand-over)
+    if (!h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
+    h->ctl_clean = false;
     h->last_front = pure;
     hipEvent_t *ev = nullptr;
     if (h->opt_profile > 0) {
@@ -979,6 +980,7 @@ static int enqueue_forward_xyz(epnn_handle *h, int B, int N, const int32_t *offs
         HIPCHK(hipMemcpyAsync(h->h_status, h->d_status.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_status + 1, h->d_rowoff.as<int>() + P.A, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
+    h->ctl_clean = pure || h->did_large_handoff;
     h->stats[1] = (int64_t)P.fused_count();
     h->stats[2] = (int64_t)P.large_list.size();
     return 0;

@@ -1063,6 +1063,7 @@ __device__ __forceinline__ void lg_handoff(const LargeArgs &L) {
     volatile int *hs = L.host_status;
     hs[0] = *L.status;
     hs[1] = L.row_off[L.A];
+    *L.status = 0;                                             // ... and leaves the word clear for the next forward (no memset in front of it)
     __threadfence_system();
 }
 // sum of an atom's incidence row of transfers, slot order
