@@ -85,8 +85,10 @@ static int create_resources(epnn_handle *h) {
     HIPCHK(hipEventCreate(&h->ev_t0));
     HIPCHK(hipEventCreateWithFlags(&h->ev_ctl, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t1));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_status), 4 * sizeof(int), hipHostMallocDefault));
-    memset(h->h_status, 0, 4 * sizeof(int));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_status_base), 8 * sizeof(int), hipHostMallocDefault));
+    memset(h->h_status_base, 0, 8 * sizeof(int));
+    h->h_status = h->h_status_base;
+    for (auto &e : h->ev_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (h->d_status.ensure(4 * sizeof(int))) return 1;
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     // mu = np.linspace(0.1, cutoff, e_dim): arange(num)*step + start, last element forced to stop
@@ -153,7 +155,8 @@ extern "C" int epnn_destroy(epnn_handle *h) {
         h->infer_fused = nullptr;
     }
     if (h->comm) (void)ncclCommDestroy(h->comm);
-    if (h->h_status) (void)hipHostFree(h->h_status);
+    if (h->h_status_base) (void)hipHostFree(h->h_status_base);
+    for (auto &e : h->ev_done) if (e) (void)hipEventDestroy(e);
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_ctl) (void)hipEventDestroy(h->ev_ctl);
     h->pin_ctl.release();
@@ -1013,18 +1016,60 @@ static int finish_forward(epnn_handle *h) {
 extern "C" int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t *offsets, const float *d_xyz,
                                     const float *d_x, const float *d_Q, float *d_q_out) {
     if (!h || !offsets || !d_xyz || !d_x || !d_Q || !d_q_out) EPNN_FAIL("epnn_forward_xyz_dev: null argument");
-    if (h->pending.active && finish_forward(h)) return 1;     // previous call may still need a regrow
-    if (enqueue_forward_xyz(h, B, N, offsets, d_xyz, d_x, d_Q, d_q_out)) return 1;
     auto &pd = h->pending;
-    if (h->last_front) {          // nothing can overflow with the in-kernel front-end: no need to look at this forward
-        pd.active = false;        // again, the caller may queue the next one right away
-        return 0;
-    }
-    pd.active = true;
+    const void *key[4] = {d_xyz, d_x, d_Q, d_q_out};
+    // The SAME forward again (same batch, same device buffers: a trajectory, a benchmark loop) while the previous one may still need
+    // a look at its status: enqueue first, check after -- nothing is (re)allocated for a plan that is reused, the two forwards
+    // report through two status slots, and a forward that did overflow is redone with its successor behind it.  (Waiting for the
+    // previous forward before enqueueing left the GPU idle for the host's 15 us between any two forwards of the tiled path.)
+    const Plan &P0 = h->plan;
+    const bool ahead = h->opt_forward_ahead && pd.active && memcmp(pd.key, key, sizeof(key)) == 0 && P0.valid && P0.B == B && P0.N == N &&
+                       (int)P0.offsets.size() == B + 1 && memcmp(P0.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0 && h->part_world == 1;
+    if (!ahead && pd.active && finish_forward(h)) return 1;     // previous call may still need a regrow
+    const int old_slot = pd.slot;
+    std::function<int()> old_redo;
+    if (ahead) old_redo = pd.redo;
+    h->st_slot = ahead ? (old_slot ^ 1) : h->st_slot;
+    h->h_status = h->h_status_base + 4 * h->st_slot;
+    if (enqueue_forward_xyz(h, B, N, offsets, d_xyz, d_x, d_Q, d_q_out)) return 1;
+    HIPCHK(hipEventRecord(h->ev_done[h->st_slot], h->stream));
+    const bool new_active = !h->last_front;   // nothing can overflow with the in-kernel front-end: no need to look at that forward again
     std::vector<int> offs(offsets, offsets + B + 1);
-    pd.redo = [h, B, N, offs, d_xyz, d_x, d_Q, d_q_out]() {
-        return enqueue_forward_xyz(h, B, N, offs.data(), d_xyz, d_x, d_Q, d_q_out);
+    auto redo = [h, B, N, offs, d_xyz, d_x, d_Q, d_q_out]() {
+        const int rc = enqueue_forward_xyz(h, B, N, offs.data(), d_xyz, d_x, d_Q, d_q_out);
+        if (!rc) (void)hipEventRecord(h->ev_done[h->st_slot], h->stream);
+        return rc;
     };
+    if (ahead) {
+        // the forward before this one: its own event, its own slot
+        HIPCHK(hipEventSynchronize(h->ev_done[old_slot]));
+        const int *os = h->h_status_base + 4 * old_slot;
+        if (os[0] != 0) {
+            // it overflowed a capacity (this one, enqueued behind it with the same capacities, gave up at its first kernel as well):
+            // wait for everything, regrow, run the old one again until it fits, then this one
+            HIPCHK(hipStreamSynchronize(h->stream));
+            const int new_slot = h->st_slot;
+            h->st_slot = old_slot;
+            h->h_status = h->h_status_base + 4 * old_slot;
+            pd.active = true;
+            pd.redo = old_redo;
+            pd.slot = old_slot;
+            h->stats[3] += 1;
+            if (os[0] & EPNN_ST_PAIR_OVERFLOW) {
+                if (ensure_pairs(h, os[1] + os[1] / 8 + 1024)) return 1;
+            }
+            if (os[0] & EPNN_ST_TYPE_OVERFLOW) h->types_overflowed = true;
+            if (pd.redo()) return 1;
+            if (finish_forward(h)) return 1;
+            h->st_slot = new_slot;
+            h->h_status = h->h_status_base + 4 * new_slot;
+            if (redo()) return 1;
+        }
+    }
+    pd.active = new_active;
+    pd.redo = redo;
+    pd.slot = h->st_slot;
+    memcpy(pd.key, key, sizeof(key));
     return 0;
 }
 
@@ -1253,6 +1298,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "wave_order")) { h->opt_wave_order = value; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "train_graph")) { h->opt_train_graph = value; }
+    else if (!strcmp(name, "forward_ahead")) { h->opt_forward_ahead = value; }
     else if (!strcmp(name, "dense_small")) { h->opt_dense_small = value; }
     else if (!strcmp(name, "dense_rowfused")) { h->opt_dense_rowfused = value; }
     else if (!strcmp(name, "train_skip_padded")) { h->opt_train_skip_padded = value; }
@@ -1458,6 +1504,7 @@ static int dense_dev(epnn_handle *h, int B, int N, int mode, const float *d_h, c
     if (h->pending.active && finish_forward(h)) return 1;
     if (enqueue_dense(h, B, N, mode, d_h, d_e, d_x, d_q, d_mask, d_out)) return 1;
     h->pending.active = true;
+    h->pending.key[0] = nullptr;                  // (not a compact forward: the next one waits for this one the usual way)
     h->pending.redo = [=]() { return enqueue_dense(h, B, N, mode, d_h, d_e, d_x, d_q, d_mask, d_out); };
     return 0;
 }

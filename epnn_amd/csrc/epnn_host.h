@@ -126,7 +126,11 @@ struct epnn_handle {
     DevBuf d_deg, d_incoff, d_nbr, d_desti, d_destj, d_prec;   // incidence rows of the pair list (epnn_frontend.hip.h)
     int pcap = 0;
     int pair_cap_per_atom = 16;
-    int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs
+    int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs -- of the forward being enqueued: one of two slots of
+    int *h_status_base = nullptr; //   this block (a repeated device-resident forward is enqueued before the one before it is checked)
+    int st_slot = 0;
+    hipEvent_t ev_done[2] = {nullptr, nullptr};                // end of the forward that used slot 0 / 1
+    int opt_forward_ahead = 1;    // 1: epnn_forward_xyz_dev on the same batch and buffers as the call before enqueues first, checks the previous one after
     bool want_large_handoff = false, did_large_handoff = false;    // the tiled path's last kernel writes h_status itself
     // staging for the host-pointer entry points
     DevBuf s_xyz, s_misc, s_gx, s_pt;
@@ -207,6 +211,8 @@ struct epnn_handle {
     struct Pending {
         bool active = false;
         std::function<int()> redo;    // re-enqueues the same forward after a capacity regrow
+        int slot = 0;                 // its status slot / completion event
+        const void *key[4] = {nullptr, nullptr, nullptr, nullptr};      // the device buffers of a device-resident compact forward
     } pending;
     // dense front-end workspace (epnn_dense.hip.h)
     DevBuf dn_den;

@@ -175,6 +175,9 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * needs only the atoms -- feature rows, atom types, first projections, the first step's type sums and correction tiles -- in
  * two launches whose workgroups take their kind of work from the block index; 0: every kernel its own launch), "large_chunks" (developer
  * switch: number of pieces the partner range of a tiled molecule's all-pairs sweep is cut into; 0, default: by size), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
+ * "forward_ahead" (1, default: epnn_forward_xyz_dev called again with the batch and the device buffers of the call before enqueues the
+ * new forward first and looks at the previous one's status after -- two status slots, a forward that overflowed a capacity is redone
+ * with its successor behind it; 0: every call waits for the one before it before it enqueues anything; the same bits),
  * "dense_small" (1, default: a make_model call on one or a few molecules -- B N^2 <= 65536 -- builds its per-atom features, flags,
  * effective atom counts and pair list in four launches instead of two memsets, seven kernels and a download; 0: the general sequence;
  * the same bits),

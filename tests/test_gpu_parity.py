@@ -236,6 +236,42 @@ def test_capacity_regrow_and_launch_variants_are_bit_identical(gpu_engine_factor
     assert np.abs(q - ref).max() <= 2e-4
 
 
+def test_repeated_device_resident_forwards_run_one_ahead(gpu_engine_factory, weights_full, val_dir, val_names):
+    """epnn_forward_xyz_dev on the same batch and device buffers again (a trajectory, a benchmark loop) enqueues the new
+    forward before it looks at the previous one's status ("forward_ahead", default): two status slots, and a forward that
+    overflowed a capacity is redone with its successor behind it.  Ten forwards in a row, with the separate front-end and
+    a pair capacity of one per atom (the first forward overflows while the second is already behind it) and with the defaults;
+    tiled path forced for a second batch: the charges are the bits of the one-at-a-time sequence every time."""
+    names = val_names[:48]
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, names, nx=10)
+    A = int(offsets[-1])
+    for opts in ({}, {"wave_front": 0}, {"wave_front": 0, "pair_cap_per_atom": 1}, {"force_path": 2}, {"force_path": 2, "pair_cap_per_atom": 1}):
+        outs = {}
+        for ahead in (1, 0):
+            eng = gpu_engine_factory(nx=10, T=5)
+            eng.set_weights(weights_full)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            eng.set_option("forward_ahead", ahead)
+            d = [eng.to_device(a) for a in (xyz, x, Q)]
+            dq = eng.alloc(A * 4)
+            res = []
+            for rep in range(10):
+                eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, 41)
+                if rep in (0, 1, 4, 9):
+                    eng.sync()
+                    res.append(dq.download((A,)))
+            eng.sync()
+            outs[ahead] = (res, eng.last_stats())
+            for b in d + [dq]:
+                b.free()
+        for a, b_ in zip(outs[1][0], outs[0][0]):
+            assert np.array_equal(a, b_), opts
+        assert np.array_equal(outs[1][0][0], outs[1][0][-1])
+        if "pair_cap_per_atom" in opts:
+            assert outs[1][1][3] >= 1 and outs[0][1][3] >= 1, (opts, outs[1][1], outs[0][1])
+
+
 def test_fused_kernel_edge_shapes_vs_oracle(gpu_engine_factory):
     """Shapes at the limits of the one-wavefront-per-molecule kernel: single atom (no pairs), two atoms, 31 and 32 atoms
     (every lane owns an atom), and dense clusters in which EVERY pair is under the cutoff (496 near pairs for n = 32:
