@@ -46,7 +46,9 @@ with open(sys.argv[2], "w") as out:
     out.write("rocprofv3 --pmc ... -- python3 tools/bench_large.py protein 5: k_lg_sweep, mean per launch over %d launches\n" % (len(df) // max(1, df.Counter_Name.nunique())))
     out.write(df.groupby("Counter_Name").Counter_Value.mean().to_string() + "\n")
 PY
-python3 $R/tools/bench_large.py protein 50 2>/dev/null | grep "protein:" > $OUT/r03_large_systems.txt
+python3 $R/tools/bench_large.py protein 200 2>/dev/null | grep "protein:" | sed 's/^/[200 forwards] /' > $OUT/r03_large_systems.txt
+python3 $R/tools/bench_large.py protein 50 2>/dev/null | grep "protein:" >> $OUT/r03_large_systems.txt
+python3 $R/tools/bench_large.py protein 200 --opt=forward_ahead:0 2>/dev/null | grep "protein:" | sed 's/^/[200 forwards, forward_ahead=0] /' >> $OUT/r03_large_systems.txt
 python3 $R/tools/bench_large.py protein 50 --opt=large_dedupe:0 2>/dev/null | grep "protein:" | sed 's/^/[large_dedupe=0] /' >> $OUT/r03_large_systems.txt
 python3 $R/tools/bench_large.py protein 50 --opt=large_merge:0 2>/dev/null | grep "protein:" | sed 's/^/[large_merge=0] /' >> $OUT/r03_large_systems.txt
 python3 $R/tools/bench_large.py box10k 10 2>/dev/null | grep "box10k:" >> $OUT/r03_large_systems.txt
