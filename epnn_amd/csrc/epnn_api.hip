@@ -1302,6 +1302,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "dense_small")) { h->opt_dense_small = value; }
     else if (!strcmp(name, "dense_rowfused")) { h->opt_dense_rowfused = value; }
     else if (!strcmp(name, "train_skip_padded")) { h->opt_train_skip_padded = value; }
+    else if (!strcmp(name, "train_inline")) { h->opt_train_inline = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else if (!strcmp(name, "train_split")) { if (value < 0 || value > 8) EPNN_FAIL("epnn_set_option: train_split must be 0 (automatic) .. 8"); h->opt_train_split = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
@@ -1631,25 +1632,31 @@ extern "C" int epnn_debug_stamps(epnn_handle *h, unsigned long long *out, size_t
 
 // ------------------------------------------------------------------------------------------------ training
 // dense (B,N,N,.) make_model inputs from a flat coordinate batch: what gen_padded_init_state builds on the host
-__global__ __launch_bounds__(256) void k_t_pad_inputs(const float *xyz, const float *x, const float *Q, const float *y,
-                                                      const int *moff, int B, int N, int nx, int E, double cutoff, double eta,
-                                                      const double *mu, float *e, float *mask, float *xs, float *hs, float *qs,
-                                                      float *ys, int *real_out) {
+// the body: `in(k)` reads word k of the staged block  offsets | xyz | x | Q | y  (word offsets o_*), wherever that block is
+template <typename IN>
+__device__ __forceinline__ void t_pad_inputs_body(IN &&in, int o_xyz, int o_x, int o_Q, int o_y, int B, int N, int nx, int E, double cutoff,
+                                                  double eta, const double *mu, float *e, float *mask, float *xs, float *hs, float *qs,
+                                                  float *ys, int *real_out, int *moff_out) {
     // a thread per (pair, four channels): one thread per pair was 48 double-precision exp in a row on 7 workgroups (13 us of a
     // 0.27 ms one-molecule step); the distance and the cutoff are recomputed by the 12 threads of a pair
     const size_t pairs = (size_t)B * N * N;
     const int G = (E + 3) / 4;
     const double pi_d = 3.141592653589793;
+    if (moff_out && blockIdx.x == 0 && (int)threadIdx.x <= B) moff_out[threadIdx.x] = __float_as_int(in((int)threadIdx.x));
     for (size_t it = (size_t)blockIdx.x * 256 + threadIdx.x; it < pairs * G; it += (size_t)gridDim.x * 256) {
         const size_t r = it / G;
         const int cg = (int)(it - r * G);
         const int j = (int)(r % N), i = (int)((r / N) % N), b = (int)(r / ((size_t)N * N));
-        const int a0 = moff[b], n = moff[b + 1] - a0;
+        const int a0 = __float_as_int(in(b)), n = __float_as_int(in(b + 1)) - a0;
         const bool real = i < n && j < n;
         if (cg == 0) mask[r] = real ? 1.f : 0.f;
         double D = 0, Cc = 0;
         if (real) {
-            D = epnn_dist(xyz, a0 + i, a0 + j);
+            // distance exactly as scipy.spatial.distance_matrix on float32 coordinates promoted to float64 (epnn_dist)
+            const int pi_ = o_xyz + 3 * (a0 + i), pj_ = o_xyz + 3 * (a0 + j);
+            const double dx = (double)in(pj_) - (double)in(pi_), dy = (double)in(pj_ + 1) - (double)in(pi_ + 1),
+                         dz = (double)in(pj_ + 2) - (double)in(pi_ + 2);
+            D = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
             Cc = (cos(pi_d * (D - 0.0) / cutoff) + 1.0) / 2.0;
             if (D >= cutoff) Cc = 0.0;
             if (D <= 0.0) Cc = 1.0;
@@ -1661,13 +1668,29 @@ __global__ __launch_bounds__(256) void k_t_pad_inputs(const float *xyz, const fl
         }
         if (j == 0 && cg == 0) {
             const size_t at = (size_t)b * N + i;
-            for (int f = 0; f < nx; ++f) xs[at * nx + f] = i < n ? x[(size_t)(a0 + i) * nx + f] : 0.f;
+            for (int f = 0; f < nx; ++f) xs[at * nx + f] = i < n ? in(o_x + (a0 + i) * nx + f) : 0.f;
             for (int f = 0; f < EPNN_EDIM; ++f) hs[at * EPNN_EDIM + f] = 0.f;
-            qs[at] = i < n ? Q[b] / (float)n : 0.f;
-            ys[at] = i < n ? y[a0 + i] : 0.f;
+            qs[at] = i < n ? in(o_Q + b) / (float)n : 0.f;
+            ys[at] = i < n ? in(o_y + a0 + i) : 0.f;
             real_out[at] = i < n;
         }
     }
+}
+// the staged block in device memory (uploaded before the launch)
+__global__ __launch_bounds__(256) void k_t_pad_inputs(const float *blk, int o_xyz, int o_x, int o_Q, int o_y, int B, int N, int nx, int E,
+                                                      double cutoff, double eta, const double *mu, float *e, float *mask, float *xs,
+                                                      float *hs, float *qs, float *ys, int *real_out) {
+    t_pad_inputs_body([&](int k) { return blk[k]; }, o_xyz, o_x, o_Q, o_y, B, N, nx, E, cutoff, eta, mu, e, mask, xs, hs, qs, ys, real_out, nullptr);
+}
+// ... or riding in the kernel's own argument block (up to 3.6 KB: one molecule of up to ~69 atoms): no upload, i.e. no copy kernel
+// and no launch boundary in front of the step (5 us of a 0.22 ms one-molecule step); the offsets are left in device memory for the
+// step's kernels (moff_out)
+#define EPNN_PAD_INLINE_WORDS 900
+struct PadInline { float w[EPNN_PAD_INLINE_WORDS]; };
+__global__ __launch_bounds__(256) void k_t_pad_inputs_inline(const PadInline P, int o_xyz, int o_x, int o_Q, int o_y, int B, int N, int nx,
+                                                             int E, double cutoff, double eta, const double *mu, float *e, float *mask,
+                                                             float *xs, float *hs, float *qs, float *ys, int *real_out, int *moff_out) {
+    t_pad_inputs_body([&](int k) { return P.w[k]; }, o_xyz, o_x, o_Q, o_y, B, N, nx, E, cutoff, eta, mu, e, mask, xs, hs, qs, ys, real_out, moff_out);
 }
 
 extern "C" int epnn_train_init(epnn_handle *h, float lr, float beta1, float beta2, float eps) {
@@ -1904,17 +1927,34 @@ extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *
         return 1;
     char *stage = h->pin_train.as<char>();
     const char *dev = h->s_train.as<char>();
-    memcpy(stage, offsets, (size_t)(B + 1) * 4);             // (the previous step ended with a stream synchronisation)
-    memcpy(stage + o_xyz, xyz, (size_t)A * 3 * 4);
-    memcpy(stage + o_x, x, (size_t)A * nx * 4);
-    memcpy(stage + o_Q, Q, (size_t)B * 4);
-    memcpy(stage + o_y, y_flat, (size_t)A * 4);
-    HIPCHK(hipMemcpyAsync(h->s_train.p, stage, in_bytes, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_t_pad_inputs, dim3(t_grid(pairs * ((h->cfg.e_dim + 3) / 4))), dim3(256), 0, h->stream, reinterpret_cast<const float *>(dev + o_xyz),
-                       reinterpret_cast<const float *>(dev + o_x), reinterpret_cast<const float *>(dev + o_Q),
-                       reinterpret_cast<const float *>(dev + o_y), reinterpret_cast<const int *>(dev), B, N, nx, h->cfg.e_dim,
-                       (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),
-                       h->dn_xs.as<float>(), h->dn_hs.as<float>(), h->dn_qs.as<float>(), h->sd_out.as<float>(), h->tr_realbuf.as<int>());
+    const int w_xyz = (int)(o_xyz / 4), w_x = (int)(o_x / 4), w_Q = (int)(o_Q / 4), w_y = (int)(o_y / 4);
+    const unsigned pgrid = t_grid(pairs * ((h->cfg.e_dim + 3) / 4));
+    // one molecule (or two small ones): the inputs are few enough to ride in the padding kernel's argument block, packed (no 256-byte
+    // sections) -- no upload; otherwise ONE upload of the staged block
+    const size_t packed_words = (size_t)(B + 1) + (size_t)A * (3 + nx + 1) + B;
+    if (h->opt_train_inline && packed_words <= EPNN_PAD_INLINE_WORDS) {
+        PadInline P;
+        int k = 0;
+        memcpy(P.w + k, offsets, (size_t)(B + 1) * 4); k += B + 1;
+        const int p_xyz = k; memcpy(P.w + k, xyz, (size_t)A * 3 * 4); k += A * 3;
+        const int p_x = k; memcpy(P.w + k, x, (size_t)A * nx * 4); k += A * nx;
+        const int p_Q = k; memcpy(P.w + k, Q, (size_t)B * 4); k += B;
+        const int p_y = k; memcpy(P.w + k, y_flat, (size_t)A * 4); k += A;
+        hipLaunchKernelGGL(k_t_pad_inputs_inline, dim3(pgrid), dim3(256), 0, h->stream, P, p_xyz, p_x, p_Q, p_y, B, N, nx, h->cfg.e_dim,
+                           (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),
+                           h->dn_xs.as<float>(), h->dn_hs.as<float>(), h->dn_qs.as<float>(), h->sd_out.as<float>(), h->tr_realbuf.as<int>(),
+                           reinterpret_cast<int *>(h->s_train.p));
+    } else {
+        memcpy(stage, offsets, (size_t)(B + 1) * 4);             // (the previous step ended with a stream synchronisation)
+        memcpy(stage + o_xyz, xyz, (size_t)A * 3 * 4);
+        memcpy(stage + o_x, x, (size_t)A * nx * 4);
+        memcpy(stage + o_Q, Q, (size_t)B * 4);
+        memcpy(stage + o_y, y_flat, (size_t)A * 4);
+        HIPCHK(hipMemcpyAsync(h->s_train.p, stage, in_bytes, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_t_pad_inputs, dim3(pgrid), dim3(256), 0, h->stream, reinterpret_cast<const float *>(dev), w_xyz, w_x, w_Q, w_y, B, N, nx,
+                           h->cfg.e_dim, (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), h->sd_e.as<float>(), h->sd_mask.as<float>(),
+                           h->dn_xs.as<float>(), h->dn_hs.as<float>(), h->dn_qs.as<float>(), h->sd_out.as<float>(), h->tr_realbuf.as<int>());
+    }
     HIPCHK(hipGetLastError());
     std::vector<float> pred(q_out_flat ? slots : 0);
     // the padded slots of a coordinate batch are exact zeros in every input: the matrix-pipe kernels skip their workgroups
