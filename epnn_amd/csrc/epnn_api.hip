@@ -143,6 +143,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
         if (ts->gexec) (void)hipGraphExecDestroy(ts->gexec);
         if (ts->graph) (void)hipGraphDestroy(ts->graph);
         for (auto &kg : ts->kept) { (void)hipGraphExecDestroy(kg.exec); (void)hipGraphDestroy(kg.graph); }
+        if (ts->ev_fwd) (void)hipEventDestroy(ts->ev_fwd);
         for (DevBuf *b : {&ts->theta, &ts->grad, &ts->m, &ts->v, &ts->part, &ts->arena, &ts->loss, &ts->d_step}) b->release();
         delete ts;
         h->train = nullptr;
@@ -329,6 +330,10 @@ extern "C" int epnn_get_weights(epnn_handle *h, int which, int t, int layer, flo
 
 // Re-lay the Keras kernels into MFMA fragment order (see epnn_common.h) and upload.
 static int pack_weights(epnn_handle *h) {
+    if (h->train && train_state(h)->inflight) {   // a training step's backward pass may still be running: inference (re)allocates shared buffers
+        HIPCHK(hipStreamSynchronize(h->stream));
+        train_state(h)->inflight = false;
+    }
     if (train_sync_to_host(h)) return 1;          // weights trained on the device are the current ones
     if (!h->weights_dirty) return 0;
     const int nx = h->cfg.nx, F = nx + EPNN_EDIM + 1, T = h->cfg.T;
@@ -1303,6 +1308,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "dense_rowfused")) { h->opt_dense_rowfused = value; }
     else if (!strcmp(name, "train_skip_padded")) { h->opt_train_skip_padded = value; }
     else if (!strcmp(name, "train_inline")) { h->opt_train_inline = value; }
+    else if (!strcmp(name, "train_async")) { h->opt_train_async = value; }
     else if (!strcmp(name, "train_fused")) { h->opt_train_fused = value; }
     else if (!strcmp(name, "train_split")) { if (value < 0 || value > 8) EPNN_FAIL("epnn_set_option: train_split must be 0 (automatic) .. 8"); h->opt_train_split = value; }
     else EPNN_FAIL("epnn_set_option: unknown option '%s'", name);
@@ -1693,10 +1699,20 @@ __global__ __launch_bounds__(256) void k_t_pad_inputs_inline(const PadInline P, 
     t_pad_inputs_body([&](int k) { return P.w[k]; }, o_xyz, o_x, o_Q, o_y, B, N, nx, E, cutoff, eta, mu, e, mask, xs, hs, qs, ys, real_out, moff_out);
 }
 
+// A step may have returned while its backward pass was still running ("train_async"): before anything it reads can be reallocated
+// or destroyed, wait for it
+static int train_quiesce(epnn_handle *h) {
+    if (h->train && train_state(h)->inflight) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        train_state(h)->inflight = false;
+    }
+    return 0;
+}
 extern "C" int epnn_train_init(epnn_handle *h, float lr, float beta1, float beta2, float eps) {
     if (!h) EPNN_FAIL("epnn_train_init: null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->pending.active && finish_forward(h)) return 1;
+    if (train_quiesce(h)) return 1;
     return train_init(h, lr, beta1, beta2, eps);
 }
 extern "C" int epnn_param_count(epnn_handle *h, int64_t *out) {
@@ -1758,6 +1774,10 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     TrainState *ts = train_state(h);
     if (!ts->ready) EPNN_FAIL("train step: call epnn_train_init first");
     const size_t BN = (size_t)B * N;
+    if ((B != ts->last_B || N != ts->last_N) && train_quiesce(h)) return 1;      // buffers may grow: nothing of the previous step may still be running
+    ts->last_B = B;
+    ts->last_N = N;
+    if (!ts->ev_fwd) HIPCHK(hipEventCreateWithFlags(&ts->ev_fwd, hipEventDisableTiming));
     if (ts->loss.ensure(2 * BN * 4)) return 1;
     float *d_loss = ts->loss.as<float>(), *d_pred = d_loss + BN;
     // the optimizer step rides in the gradient reduction's launch when nothing has to happen between the two (no all-reduce
@@ -1767,7 +1787,11 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     const bool adam_now = apply && rowfused && !(h->comm && h->comm_world > 1);
     if (h->pin_tout.ensure(2 * BN * 4)) return 1;
     float *out_host = rowfused ? h->pin_tout.as<float>() : nullptr;
-    if (h->opt_train_graph) {
+    // "train_async": the step returns behind its forward pass.  That needs an event the host can wait for between the forward and the
+    // backward launches -- an event recorded inside a replayed graph is not one (measured: the wait returns at once) -- so such a
+    // step is launched kernel by kernel (the replay was worth 1 %, returning early is worth 8 %).
+    const bool early_ok = h->opt_train_async && rowfused && h->opt_train_fused != 2 && (adam_now || !apply);
+    if (h->opt_train_graph && !early_ok) {
         // The step is a chain of dependent launches a few microseconds long: recorded once per (B, N, buffer set, apply) and
         // replayed as one hipGraph.  The step number Adam's step size depends on then lives on the device: the graph's first
         // launch counts it, its last one reads it (the host keeps its own count in step and repairs the device's when they differ).
@@ -1778,6 +1802,7 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
             // park the current capture, look for one made with this key
             if (ts->gexec) {
                 if (ts->kept.size() >= 4) {
+                    if (train_quiesce(h)) return 1;                       // (the capture that goes may be the one still running)
                     (void)hipGraphExecDestroy(ts->kept.front().exec);
                     (void)hipGraphDestroy(ts->kept.front().graph);
                     ts->kept.erase(ts->kept.begin());
@@ -1828,7 +1853,18 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     // the step's loss terms and predictions are neighbours on the device: one download into page-locked memory
     const size_t nback = BN + (pred_host ? BN : 0);
     if (!ts->host_out) HIPCHK(hipMemcpyAsync(h->pin_tout.p, d_loss, nback * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // What the caller gets back -- loss terms, predictions -- is on the host when the FORWARD is done.  The backward pass and the
+    // optimizer step run on behind the return: the next step's launches queue up behind them on the stream, everything that looks at
+    // gradients or weights synchronises first (epnn_get_gradients, the host copies of the weights, any inference call).  A loop of
+    // steps then costs its GPU time, not GPU time + the host's wake-up and launch latencies.
+    const bool early = early_ok && ts->host_out && ts->ev_fwd;
+    if (early) {
+        HIPCHK(hipEventSynchronize(ts->ev_fwd));
+        ts->inflight = true;
+    } else {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        ts->inflight = false;
+    }
     const float *back = h->pin_tout.as<float>();
     if (pred_host) memcpy(pred_host, back + BN, BN * 4);
     if (loss_host) {
@@ -1848,6 +1884,7 @@ extern "C" int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *
     if (B < 1 || N < 1) EPNN_FAIL("epnn_train_step_dense: B and N must be positive");
     HIPCHK(hipSetDevice(h->device));
     if (h->pending.active && finish_forward(h)) return 1;
+    if (train_quiesce(h)) return 1;               // (this entry re-uploads the tensors the previous step's kernels read)
     const int nx = h->cfg.nx;
     const size_t pairs = (size_t)B * N * N, slots = (size_t)B * N;
     if (h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) || h->dn_qs.ensure(slots * 4) ||
@@ -1921,6 +1958,11 @@ extern "C" int epnn_train_step_xyz(epnn_handle *h, int B, int N, const int32_t *
     auto up256 = [](size_t bytes) { return (bytes + 255) & ~size_t(255); };
     const size_t o_xyz = up256((size_t)(B + 1) * 4), o_x = o_xyz + up256((size_t)A * 3 * 4), o_Q = o_x + up256((size_t)A * nx * 4),
                  o_y = o_Q + up256((size_t)B * 4), in_bytes = o_y + (size_t)A * 4;
+    if (h->train) {
+        // the previous step's backward pass may still be running ("train_async"): it reads the buffers below
+        TrainState *ts0 = train_state(h);
+        if ((B != ts0->last_B || N != ts0->last_N || in_bytes > h->s_train.cap || in_bytes > h->pin_train.cap) && train_quiesce(h)) return 1;
+    }
     if (h->pin_train.ensure(in_bytes) || h->s_train.ensure(in_bytes) || h->sd_e.ensure(pairs * EPNN_EDIM * 4) ||
         h->sd_mask.ensure(pairs * 4) || h->dn_xs.ensure(slots * nx * 4) || h->dn_hs.ensure(slots * EPNN_EDIM * 4) ||
         h->dn_qs.ensure(slots * 4) || h->sd_out.ensure(slots * 4) || h->tr_realbuf.ensure(slots * 4))

@@ -142,6 +142,7 @@ struct epnn_handle {
     int opt_dense_small = 1;          // dense entry, one or a few molecules per call: the front-end as four launches instead of two memsets, seven kernels, a download
     int dn_gen = 1;                   //   ... whose flags are generation numbers (no memset per call)
     void *dn_flag_seen = nullptr;
+    int opt_train_async = 1;          // training: a step returns when its forward is done (loss, predictions); backward + optimizer run on behind it
     int opt_train_inline = 1;         // training, coordinate entry: the inputs of a one-molecule step ride in the padding kernel's argument block (no upload)
     int opt_train_skip_padded = 1;    // training, coordinate entry, matrix-pipe kernels: padded atom slots leave their workgroups at once (the same bits)
     const int *tr_moff = nullptr, *tr_real = nullptr;      // ... set around the step by epnn_train_step_xyz

@@ -344,6 +344,9 @@ struct TrainState {
     struct KeptGraph { std::vector<const void *> key; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<KeptGraph> kept;
     bool fused_attr = false;                     // dynamic LDS limit of the row-fused kernels raised
+    hipEvent_t ev_fwd = nullptr;                 // recorded behind the step's last forward launch: loss terms and predictions are on the host
+    bool inflight = false;                       //   ... the caller was handed them while the backward pass and the optimizer step were still running
+    int last_B = 0, last_N = 0;
     DevBuf d_step;                               // hipGraph replay with the optimizer step inside: the step number on the device
     long dev_step = -1;                          //   ... and the value the host last put there
     bool host_out = false;                       // the last forward launch wrote loss terms | predictions into the caller's page-locked buffer
@@ -713,6 +716,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         qcur = P(es[t].qn);
     }
     if (mfma_fwd) hipLaunchKernelGGL(k_t_loss_terms, dim3(t_grid(BN)), dim3(256), 0, st, d_y, qcur, d_pred, d_loss, BN);
+    if (ts->host_out && ts->ev_fwd) HIPCHK(hipEventRecord(ts->ev_fwd, st));        // (an event-record node when the step is being captured)
     // ================================================================ backward: EPN, then GNN.  Every launch starts with the
     // "atoms" stage of the one before it (the gradient that reached the atoms through that sweep's first Dense); the
     // sweeps alternate between two dz1 buffers, so a launch may still read the previous one's while it writes its own.

@@ -195,6 +195,9 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * "train_skip_padded" (1, default: epnn_train_step_xyz tells the "train_fused" = 1 kernels which atom slots of the padded size are
  * real -- the workgroups of the others, which would compute zeros for N rows each, return at once; 0: every slot is computed; the
  * same bits),
+ * "train_async" (1, default: a training step returns as soon as its forward pass is done -- the loss and the predictions it returns are
+ * on the host then; the backward pass and the optimizer step keep running, the next step queues up behind them and every call that
+ * reads gradients or weights waits for them first; 0: a step returns when all of it is done; the same bits),
  * "train_inline" (1, default: the inputs of an epnn_train_step_xyz step of up to ~69 atoms travel in the argument block of the kernel
  * that pads them -- no upload, no copy kernel in front of the step; 0: always staged in page-locked memory and uploaded; the same bits),
  * "train_split" (workgroups that share one atom's weight-gradient jobs in the backward launches of "train_fused" = 1; 0,

@@ -332,6 +332,48 @@ def test_skipping_padded_slots_does_not_change_a_bit(gpu_engine_factory, val_dir
                 assert np.array_equal(a, b_)
 
 
+def test_a_step_that_returns_behind_its_forward_pass_is_the_same_step(gpu_engine_factory, val_dir, val_names):
+    """train_step_xyz returns when its forward pass is done ("train_async", default): loss and predictions are on the host
+    then, the backward pass and the optimizer step run on and everything that looks at gradients or weights, changes the
+    batch shape or runs inference on the handle waits for them first.  A sequence that mixes all of that -- steps on two
+    batch shapes, a gradient read-out without an optimizer step, a forward between two steps, the weights at the end --
+    returns the same bits as with every step waiting for its own end."""
+    from conftest import load_molecules
+    qm9 = [nm for nm in val_names if nm.startswith("dsgdb9nsd")]
+    b1 = load_molecules(val_dir, qm9[:3], 9)
+    b2 = load_molecules(val_dir, qm9[3:4], 9)
+    rng = np.random.default_rng(4)
+    ys = [(rng.normal(size=int(b[1][-1])) * 0.2).astype(np.float32) for b in (b1, b2)]
+    w = random_weights(9, 5, seed=29, scale=0.4)
+    outs = []
+    for asyn in (1, 0):
+        eng = gpu_engine_factory(nx=9, T=5)
+        eng.set_option("train_async", asyn)
+        eng.set_weights(w)
+        eng.train_init()
+        log = []
+
+        def step(b, y, N, apply=True):
+            mols, offsets, xyz, x, Q = b
+            q, loss = eng.train_step_xyz(offsets, xyz, x, Q, y, N, apply=apply)
+            log.append((q.copy(), np.float32(loss)))
+        for _ in range(3):
+            step(b1, ys[0], 41)
+        step(b2, ys[1], 30)                               # another batch shape: buffers are re-made
+        step(b1, ys[0], 41, apply=False)
+        log.append((eng.get_gradients(),))
+        step(b1, ys[0], 41)
+        mols, offsets, xyz, x, Q = b2
+        log.append((eng.forward_xyz(offsets, xyz, x, Q, 30),))      # inference with the weights trained so far
+        for _ in range(2):
+            step(b2, ys[1], 30)
+        log.append((np.concatenate([np.ravel(a) for m in ([eng.get_weights()["upd"]] + eng.get_weights()["msg"] + eng.get_weights()["pas"]) for W, b in m for a in (W, b)]),))
+        outs.append(log)
+    for a, b_ in zip(*outs):
+        for u, v in zip(a, b_):
+            assert np.array_equal(u, v)
+
+
 def test_train_step_xyz_equals_dense(gpu_engine_factory, val_dir, val_names):
     from conftest import load_molecules
     from oracle import epnn_oracle as orc

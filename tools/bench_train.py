@@ -25,25 +25,29 @@ N, T, F = 41, 5, 58
 # message MLP and, in both orders, a 164 -> 32 -> 32 -> 1 pass MLP, T times; the backward taken as twice the forward
 fwd_flop = B * T * N * N * (2 * (164 * 32 + 32 * 32 + 32 * 32) + 2 * 2 * (164 * 32 + 32 * 32 + 32))
 names_of = {3: "row-fused, scalar FMA layers", 2: "16-atom matrix-pipe forward + row-fused backward", 1: "row-fused, matrix-pipe layers", 0: "layer by layer"}
-# --mode=F[:G]: "train_fused" = F, "train_graph" = G (default 1, the library's default)
-modes = [tuple(int(v) for v in (a.split("=")[1] + ":1").split(":")[:2]) for a in sys.argv[2:] if a.startswith("--mode=")] or [(1, 1), (1, 0), (3, 0), (2, 0), (0, 0)]
+# --mode=F[:G[:A]]: "train_fused" = F, "train_graph" = G, "train_async" = A (defaults 1, 1: the library's defaults; a step that returns
+# behind its forward pass is launched kernel by kernel whatever G says)
+modes = [tuple(int(v) for v in (a.split("=")[1] + ":1:1").split(":")[:3]) for a in sys.argv[2:] if a.startswith("--mode=")] or [(1, 1, 1), (1, 1, 0), (1, 0, 0), (3, 0, 0), (2, 0, 0), (0, 0, 0)]
 best = None
-for fused, graph in modes:
+for fused, graph, asyn in modes:
     eng.set_option("train_fused", fused)
     eng.set_option("train_graph", graph)
+    eng.set_option("train_async", asyn)
     nb = 64 // B                                              # distinct batches; a run cycles through them
     for k in range(30): eng.train_step_xyz(*batch(k % nb), 41)         # (the first ~20 steps of a process run 5-8 % slower)
     t0 = time.perf_counter(); nst = 200; tot = 0.0
     for k in range(nst):
         q, loss = eng.train_step_xyz(*batch(k % nb), 41); tot += loss
+    eng.sync()                                                # (the last step's backward pass and optimizer step may still be running)
     dt = (time.perf_counter() - t0) / nst
-    print(f"train step ({names_of[fused]}, {'hipGraph replay' if graph else 'kernel by kernel'}): B={B} molecule(s) per step, N=41: {dt*1e3:.3f} ms/step "
+    how = "returns behind its forward pass" if asyn and fused in (1, 3) else ("hipGraph replay" if graph else "kernel by kernel")
+    print(f"train step ({names_of[fused]}, {how}): B={B} molecule(s) per step, N=41: {dt*1e3:.3f} ms/step "
           f"({1/dt:.1f} steps/s, {B/dt:.1f} molecules/s); mean loss {tot/nst:.4f}", flush=True)
-    if best is None: best = (fused, dt)
-fused, dt = best
+    if best is None: best = (fused, dt, how)
+fused, dt, how = best
 print(json.dumps({"metric": "train steps/sec (one optimizer step: forward, backward, Adam), configs[2] shape per GPU", "value": 1 / dt, "unit": "steps/s",
                   "ms_per_step": dt * 1e3, "molecules_per_step": B, "molecules_per_s": B / dt, "dtype": "f32",
-                  "config": {"workload": f"mixed_val molecules, N={N}, T={T}, B={B}", "path": names_of[fused], "weights": "decay_model_weights"},
+                  "config": {"workload": f"mixed_val molecules, N={N}, T={T}, B={B}", "path": names_of[fused] + ", " + how, "weights": "decay_model_weights"},
                   "roofline": {"bound": "mfma", "achieved": 3 * fwd_flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": 3 * fwd_flop / dt / 1e12 / 157.3,
                                "algorithmic_gflop_per_step": 3 * fwd_flop / 1e9, "traffic": None,
                                "note": "flops of the reference's literal form (N^2 rows x three Dense layers, forward + 2x for the backward); a one-molecule step is "
