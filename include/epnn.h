@@ -185,8 +185,8 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * workgroup per atom slot, the reference's literal arithmetic, nothing stored for a backward pass -- instead of one CU for the whole
  * molecule: always when N <= 48 (the call then has no host synchronisation inside), beyond that when its largest molecule fills more
  * than 55 % of N; epnn_last_stats then reports 0 molecules on the fused and 0 on the tiled path; 0: always the fused / tiled kernels),
- * "train_graph" (1, default: a train step's launch sequence, optimizer step included, is captured once per (B, N, buffer set)
- * and replayed as a hipGraph; 0: kernel by kernel -- the same bits),
+ * "train_graph" (1, default: a train step that waits for its own end -- "train_async" = 0, or several ranks -- has its launch sequence,
+ * optimizer step included, captured once per (B, N, buffer set) and replayed as a hipGraph; 0: kernel by kernel -- the same bits),
  * "train_fused" (1, default: one workgroup per atom runs a whole pair MLP over its rows, forward and backward, 2T + 2T + 1
  * launches per step, the Dense layers and every weight gradient as 16x16x4 f32 MFMA tiles; 3: the same decomposition with
  * scalar FMA loops -- round 2's kernels, kept as the second implementation the tests compare; 2: the forward's pair MLPs in
