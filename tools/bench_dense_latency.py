@@ -37,7 +37,7 @@ for n in (9, 16, 18, 23, 29, 32, 35, 38, 41):
         eng.set_option("wave2", opts[0]); eng.set_option("wave3", opts[1]); eng.set_option("dense_rowfused", opts[2])
         def run():
             assert fn(eng.h, 1, N, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, d[4].ptr, out.ptr) == 0, eng.lib.epnn_last_error()
-        for _ in range(5): run()
+        for _ in range(20): run()                      # (the first calls of a process load kernels and bring the clocks up)
         eng.sync(); eng.timer_begin()
         for _ in range(50): run()
         row.append(eng.timer_end() / 50)
