@@ -1037,8 +1037,12 @@ extern "C" int epnn_forward_xyz_dev(epnn_handle *h, int B, int N, const int32_t 
     h->st_slot = ahead ? (old_slot ^ 1) : h->st_slot;
     h->h_status = h->h_status_base + 4 * h->st_slot;
     if (enqueue_forward_xyz(h, B, N, offsets, d_xyz, d_x, d_Q, d_q_out)) return 1;
+    if (h->last_front && !ahead) {            // nothing can overflow with the in-kernel front-end: no need to look at this forward
+        pd.active = false;                    // again, the caller may queue the next one right away (the headline loop: nothing else
+        return 0;                             // is done per call)
+    }
     HIPCHK(hipEventRecord(h->ev_done[h->st_slot], h->stream));
-    const bool new_active = !h->last_front;   // nothing can overflow with the in-kernel front-end: no need to look at that forward again
+    const bool new_active = !h->last_front;
     std::vector<int> offs(offsets, offsets + B + 1);
     auto redo = [h, B, N, offs, d_xyz, d_x, d_Q, d_q_out]() {
         const int rc = enqueue_forward_xyz(h, B, N, offs.data(), d_xyz, d_x, d_Q, d_q_out);
