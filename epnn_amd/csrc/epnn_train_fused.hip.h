@@ -240,6 +240,15 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     float *red = H2s + ND * N * 33;           // [NG][32] + [32]  /  [2][N]
     const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
     const size_t dstride = (size_t)gridDim.x * N * 32;
+    // MM, pass network: a 16-row tile whose partners all carry transfer weight 0 (mask = 0 on the stack's first launch, mask * is_near
+    // after it: the padding of a molecule, whoever padded it) contributes nothing forward and gets zero gradients: flagged here by the
+    // wavefronts that hold the weights, before the staging barrier, and stored as zeros instead of computed (H1s is free in this form)
+    int *deadt = reinterpret_cast<int *>(H1s);
+    if (MM && MODE == 1 && tid >= EPNN_TF_NT - 128) {
+        const int jj = tid - (EPNN_TF_NT - 128), ln = tid & 63;
+        const unsigned long long nzb = __ballot(jj < N && wpre != 0.f);
+        if (ln < 4) deadt[(jj >> 6) * 4 + ln] = ((nzb >> (16 * ln)) & 0xFFFFull) == 0ull;
+    }
     if (MM) {
         // both arrays' loads of a round are in flight before the first LDS write (N = 41 is one round)
         const int nA = N * F, nE = N * 48;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             // pass network: a tile of padded partners only (TfPair::moff) -- every transfer of its rows has weight 0 and its rows
             // get zero gradients: zeros are stored for them, nothing is computed (4 jobs instead of 6 for an average molecule: one
             // per SIMD)
-            const bool dead = MODE == 1 && (job / ND) * 16 >= nreal;
+            const bool dead = MODE == 1 && has && ((job / ND) * 16 >= nreal || deadt[job / ND] != 0);
             const float *aj = As + (jv ? j : 0) * FS, *ej = Es + (jv ? j : 0) * 49;
             f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             if (first && bw >= 0) {
