@@ -269,6 +269,9 @@ def main():
     pipe = Pipeline(depth=args.depth, nx=9, T=5, device=device)
     pipe.set_weights(weights)
     pipe.set_option("wave2", 0)          # the throughput kernel at every depth (Pipeline does this itself above depth 1)
+    for o in args.opt:                   # developer switches, e.g. --opt wave_lds=18432
+        k, v = o.split("=")
+        pipe.set_option(k, int(v))
     comm_eng = None
     rccl_ranks = None
     if world > 1:

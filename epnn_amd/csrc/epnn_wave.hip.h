@@ -128,6 +128,16 @@ __device__ __forceinline__ float w16_sumq(float v) {
 __device__ __forceinline__ f32x4 w16_ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void w16_st(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
+// LDS through explicit 32-bit addresses: a running address costs one v_add per tile, constant offsets ride in the instruction
+typedef __attribute__((address_space(3))) const f32x4 w16_lds_cf4;
+typedef __attribute__((address_space(3))) const unsigned short w16_lds_cu16;
+__device__ __forceinline__ unsigned w16_lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p; }
+__device__ __forceinline__ f32x4 w16_lds_ld4(unsigned a) { return *(w16_lds_cf4 *)(size_t)a; }
+__device__ __forceinline__ unsigned w16_lds_ldu16(unsigned a) { return *(w16_lds_cu16 *)(size_t)a; }
+__device__ __forceinline__ f32x2 w16_lo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 w16_hi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x4 w16_cat(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+
 // fragment loads: [nrb][stride][64 lanes], steps s0 .. s0+cnt-1 of every row block.  One address per row block, the steps
 // as immediate offsets of the load (256 bytes apart, at most 16 of them: inside the 4 KB immediate range).  With the step
 // inside the index every load beyond that range cost three VALU instructions of address arithmetic -- and f32 MFMA and
@@ -139,7 +149,9 @@ __device__ __forceinline__ void w16_st(float *p, f32x4 v) { *reinterpret_cast<f3
     }
 #define W16_LD(dst, off, nrb, steps) W16_LDX(dst, off, nrb, steps, steps, 0)
 
-// D[rb][CB] += sum_s W[rb][s] * in[s]  for one column block (dependent chain of S MFMAs per row block)
+// D[rb] += sum_s W[rb][s] * in[s]  for one column block (dependent chain of S MFMAs per row block).  Interleaving the row
+// blocks' chains (a dependent v_mfma_f32_16x16x4_f32 can issue 40 cycles after its predecessor, the pipe takes one every 32)
+// was measured in round 4: no gain with two wavefronts per SIMD, and it costs registers (spills in the block-per-wavefront kernels).
 template <int NRB, int S>
 __device__ __forceinline__ void w16_mm(const float (&w)[NRB][S], const float (&in)[S], f32x4 (&d)[NRB]) {
 #pragma unroll
@@ -186,6 +198,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     const float *wp = A.wpack;
     int nstamp = 0;
     (void)nstamp;
+#ifdef EPNN_STAMPS
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz: with s_memtime it gives the shader clock this wavefront saw
+#endif
     WAVE_STAMP();
     // Column block 0 holds atoms 0..15.  Block 1 holds the m = n - 16 atoms beyond them, C = 16 / m COPIES of each (column
     // n16 = atom 16 + n16 % m, copy n16 / m): every per-atom chain computes all 16 columns anyway, so the copies come for
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     // ---- LDS layout of THIS molecule inside the wave's fixed budget.  The two stacks need different tables, and the G
     //      rows are recomputed by every step anyway, so each stack has its own layout behind the common part:
     //        common  eij [pairs] | R [n][PST]
-    //        GNN     pair map [n][32] u16 | G rows ... | zero row        (the sweep reads every G row n times: all in LDS
+    //        GNN     pair map [n][NPM] u16 | zero row | G rows ...       (the sweep reads every G row n times: all in LDS
     //                                                                     for molecules up to ~24 atoms)
     //        EPN     P [n][PST] | transfer matrix [n][DST]              (its G term never leaves the registers: computed per
     //                                                                     block of 16 pairs right where it is used)
@@ -209,12 +224,21 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     const int o_r = EPN ? ((((eij_n + 1) >> 1) + 3) & ~3) : 0;
     float *Rl = sm + o_r;                                  // [n][PST]   R_j rows (natural feature order)
     const int o_x = o_r + n * EPNN_PST;
-    unsigned short *pm = reinterpret_cast<unsigned short *>(sm + o_x);    // [j][32]  near-pair slot of (i, j), 0xFFFF = none
+    // Pair map [column][NPM] u16: where the pair tile "partner jp of every atom" finds the G row of column i's pair (i, jp): the
+    // row's byte offset from `sm` (the zero row's for a far pair and for jp >= n: the padded partner), or 1 | slot << 1 for a
+    // row that did not fit the LDS budget (gx).  NPM >= n + 8 (entries a tile behind the last partner may be read), = 2 mod 4
+    // (odd dword stride: the 16 columns of a tile read 16 banks).
+    unsigned short *pm = reinterpret_cast<unsigned short *>(sm + o_x);
+    const int NPM = ((n + 9) & ~3) + 2;
     float *Pl = sm + o_x;                                  // [n][PST]   P_i rows
     float *Dm = sm + o_x + n * EPNN_PST;                   // [n][DST]   weighted transfers: Dm[i][j] = what i receives from j
-    const int o_gg = o_x + ((n * 16 + 3) & ~3);
+    const int o_gg = o_x + ((((n * NPM + 1) >> 1) + 3) & ~3);
     const int grows_g = (A.lds_words - o_gg) / EPNN_PST - 1;
-    float *Gl = sm + o_gg;                                 // GNN: G rows [glds + 1][PST]; row glds is all zeros
+    float *Gl = sm + o_gg;                                 // GNN: row 0 all zeros, row 1 + s = G row of pair slot s < glds
+    const unsigned zent = 4u * (unsigned)o_gg;             // the zero row's entry
+    auto pm_ent = [&](int slot) -> unsigned short {
+        return (unsigned short)(slot < grows_g ? 4u * (unsigned)(o_gg + (slot + 1) * EPNN_PST) : (1u | (unsigned)slot << 1));
+    };
     int glds = min(np, grows_g);
     bool gover = np > glds;                                // some G rows live in HBM
     int ngt = (np + 31) >> 5;
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
 
     // ---- LDS init
     if (GNN)
-        for (int i = lane; i < n * 16; i += 64) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
+        for (int i = lane; i < (n * NPM + 1) >> 1; i += 64) reinterpret_cast<unsigned *>(pm)[i] = zent | zent << 16;
     wave_sync_lds();
     if (FRONT) {
         // ---- slots in row-major order (rows i0, i0+1 per step; the lower row's pairs first)
@@ -307,8 +331,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             if (near) {
                 const int slot = base + (hh ? __popc(lo) : 0) + __popc((hh ? hi : lo) & ((1u << c) - 1u));
                 eij[slot] = (unsigned short)(i | (c << 8));
-                pm[c * 32 + i] = (unsigned short)slot;                 // e is symmetric: both directions share the entry
-                pm[i * 32 + c] = (unsigned short)slot;
+                pm[c * NPM + i] = pm_ent(slot);                        // e is symmetric: both directions share the row
+                pm[i * NPM + c] = pm_ent(slot);
             }
             base += __popc(lo) + __popc(hi);
         }
@@ -363,8 +387,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         if (GNN)
             for (int p = lane; p < np; p += 64) {
                 const int li = A.pi[p0 + p] - a0, lj = A.pj[p0 + p] - a0;
-                pm[lj * 32 + li] = (unsigned short)p;                   // message into i = li from j = lj
-                if (A.psym[p0 + p]) pm[li * 32 + lj] = (unsigned short)p;
+                pm[li * NPM + lj] = pm_ent(p);                          // message into i = li from j = lj
+                if (A.psym[p0 + p]) pm[lj * NPM + li] = pm_ent(p);
             }
         if (EPN)
             for (int p = lane; p < np; p += 64) {
@@ -373,7 +397,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             }
     }
     if (GNN)
-        for (int i = lane; i < EPNN_PST; i += 64) Gl[glds * EPNN_PST + i] = 0.f;        // the sweep's zero row
+        for (int i = lane; i < EPNN_PST; i += 64) Gl[i] = 0.f;                          // the sweep's zero row
     wave_sync_lds();
 
     WAVE_STAMP();   // init done
@@ -387,7 +411,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
         w16_mm<2, KE>(gw, e0, d0);
         // two separate predicated stores per target (LDS / HBM): merged into one pointer they become flat stores
-        if (s0 < min(np, glds)) { w16_st(Gl + s0 * EPNN_PST + fo, d0[0]); w16_st(Gl + s0 * EPNN_PST + 16 + fo, d0[1]); }
+        if (s0 < min(np, glds)) { w16_st(Gl + (s0 + 1) * EPNN_PST + fo, d0[0]); w16_st(Gl + (s0 + 1) * EPNN_PST + 16 + fo, d0[1]); }
         if (gover) {
             asm volatile("" ::: "memory");
             if (s0 >= glds && s0 < np) { w16_st(A.gx + (size_t)(p0 + s0) * 32 + fo, d0[0]); w16_st(A.gx + (size_t)(p0 + s0) * 32 + 16 + fo, d0[1]); }
@@ -395,7 +419,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         if (gt * 32 + 16 < np) {                            // the second 16 pairs of the tile exist
             f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
             w16_mm<2, KE>(gw, e1, d1);
-            if (s1 < min(np, glds)) { w16_st(Gl + s1 * EPNN_PST + fo, d1[0]); w16_st(Gl + s1 * EPNN_PST + 16 + fo, d1[1]); }
+            if (s1 < min(np, glds)) { w16_st(Gl + (s1 + 1) * EPNN_PST + fo, d1[0]); w16_st(Gl + (s1 + 1) * EPNN_PST + 16 + fo, d1[1]); }
             if (gover) {
                 asm volatile("" ::: "memory");
                 if (s1 >= glds && s1 < np) { w16_st(A.gx + (size_t)(p0 + s1) * 32 + fo, d1[0]); w16_st(A.gx + (size_t)(p0 + s1) * 32 + 16 + fo, d1[1]); }
@@ -473,6 +497,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         wave_sync_all();
         WAVE_STAMP();   // step-0 G tiles + projections
 
+        // addresses of the sweep's LDS operands (bytes): this lane's 16-byte piece of a row starts at 4 fo
+        const unsigned lbase = w16_lds_addr(sm) + 16u * (unsigned)q;
+        const unsigned rbase = w16_lds_addr(Rl) + 16u * (unsigned)q, pbase = w16_lds_addr(pm);
 #pragma unroll 1
         for (int t = 0; t < Tg; ++t) {
             const WaveGnnPack &M = X.g[t];
@@ -480,119 +507,120 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             f32x4 S0[2] = {w16_splat(0.f), w16_splat(0.f)}, S1[2] = {w16_splat(0.f), w16_splat(0.f)};
             float u1s[2][8];
             {
-                // ---- partner tiles.  Partner index jp in [0, n]: atom jp, or (jp == n) the reference's zero-padded partner
-                //      (R = 0, G = 0, charge_gn.py:70), counted N - n times; beyond n nothing (weight 0).  Tile t gives block 0
-                //      partner t and copy k of block 1 partner t*C + k: block 1 is finished after nt1 tiles.
-                const float *zrow = Gl + glds * EPNN_PST;
-                const int nt0 = n + 1, nt1 = two ? (n + C1) / C1 : 0;
+                // ---- partner tiles.  Tile k of a block gives column i the partner jp = j0 + k * step: block 0 takes the
+                //      partners one by one (j0 = 0, step 1), copy c of block 1 every C1-th from c on -- block 1 is finished
+                //      after n / C1 + 1 tiles.  Tiles k < ntr hold real partners only (weight 1); the block's last tile holds
+                //      what is left: real partners, the reference's zero-padded partner (jp == n: R = 0, G = 0,
+                //      charge_gn.py:70), counted N - n times, and nothing (jp > n, weight 0).
+                //      Per tile and lane: the R row (a broadcast in block 0), the pair map's entry (read two tiles ahead)
+                //      and the G row it points to; one v_add per running address.
                 auto sweep = [&](auto over_tag) {
                     constexpr bool OVER = decltype(over_tag)::value;
-                    struct Ops { f32x4 r[2], g[2]; float w; };
-                    auto grow = [&](int sl, f32x4 (&g)[2]) {
-                        const float *gp = Gl + min(sl, glds) * EPNN_PST;         // 0xFFFF / overflow -> the zero row
-                        g[0] = w16_ld(gp + fo);
-                        g[1] = w16_ld(gp + 16 + fo);
-                        if (OVER && sl >= glds && sl != 0xFFFF) {
-                            g[0] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + fo);
-                            g[1] = w16_ld(A.gx + (size_t)(p0 + sl) * 32 + 16 + fo);
+                    struct Ops { f32x4 r0, r1, g0, g1; };
+                    auto load_rg = [&](Ops &o_, unsigned ra, unsigned ent) {
+                        o_.r0 = w16_lds_ld4(ra);
+                        o_.r1 = w16_lds_ld4(ra + 64);
+                        if (!OVER) {
+                            const unsigned ga = lbase + ent;
+                            o_.g0 = w16_lds_ld4(ga);
+                            o_.g1 = w16_lds_ld4(ga + 64);
+                        } else {
+                            const bool ov = (ent & 1u) != 0;
+                            const unsigned ga = lbase + (ov ? zent : ent);
+                            o_.g0 = w16_lds_ld4(ga);
+                            o_.g1 = w16_lds_ld4(ga + 64);
+                            if (ov) {
+                                const float *gp = A.gx + (size_t)(p0 + (int)(ent >> 1)) * 32 + fo;
+                                o_.g0 = w16_ld(gp);
+                                o_.g1 = w16_ld(gp + 16);
+                            }
                         }
                     };
-                    // operands of tile t of block CB: partner row, G row of the lane's column, weight of the tile
-                    auto load_ops = [&](auto cb_tag, int t, Ops &o_) {
-                        constexpr int CB = decltype(cb_tag)::value;
-                        const int jp = CB == 0 ? t : t * C1 + copy1;
-                        const bool real = jp < n && (CB == 0 || cat1);
-                        const float *rrow = real ? Rl + jp * EPNN_PST : zrow;
-                        o_.r[0] = w16_ld(rrow + fo);
-                        o_.r[1] = w16_ld(rrow + 16 + fo);
-                        grow(real ? (int)pm[jp * 32 + (CB == 0 ? n16 : col1)] : 0xFFFF, o_.g);
-                        o_.w = jp < n ? 1.f : (jp == n ? padw : 0.f);
-                    };
-                    auto tile = [&](const f32x4 (&Pc)[2], f32x4 (&Sc)[2], const Ops &o_) {
-                        // four-wide adds (v_pk_add_f32): every VALU instruction here competes with the matrix pipe's issue
-                        const f32x4 za = w16_relu((Pc[0] + o_.r[0]) + o_.g[0]), zb = w16_relu((Pc[1] + o_.r[1]) + o_.g[1]);
+                    // z1 = relu((P + R) + G), acc = W2^T z1 + b2, relu(acc)  (charge_gn.py:66-68)
+                    auto mlp = [&](const f32x2 (&Pc)[4], const Ops &o_, f32x4 (&zz)[2]) {
+                        const f32x4 za = w16_relu((w16_cat(Pc[0], Pc[1]) + o_.r0) + o_.g0), zb = w16_relu((w16_cat(Pc[2], Pc[3]) + o_.r1) + o_.g1);
                         const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
                         f32x4 d[2] = {b2v[0], b2v[1]};
                         w16_mm<2, 8>(pb, z, d);
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) Sc[rb] += o_.w * w16_relu(d[rb]);
+                        zz[0] = w16_relu(d[0]);
+                        zz[1] = w16_relu(d[1]);
                     };
-                    // one block after the other; operands of tile t+1 are fetched while tile t is in the matrix pipe
-                    auto run = [&](auto cb_tag, int nt, const f32x4 (&Pc)[2], f32x4 (&Sc)[2], bool last_block) {
+                    auto tile = [&](const f32x2 (&Pc)[4], f32x4 (&Sc)[2], const Ops &o_) {
+                        f32x4 zz[2];
+                        mlp(Pc, o_, zz);
+                        Sc[0] += zz[0];
+                        Sc[1] += zz[1];
+                    };
+                    auto tile_w = [&](const f32x2 (&Pc)[4], f32x4 (&Sc)[2], const Ops &o_, float w) {
+                        f32x4 zz[2];
+                        mlp(Pc, o_, zz);
+                        Sc[0] += w * zz[0];
+                        Sc[1] += w * zz[1];
+                    };
+#pragma unroll 1
+                    for (int blk = two ? 1 : 0; blk >= 0; --blk) {           // block 1 first, then block 0
+                        const bool b1 = blk == 1;
+                        f32x2 Pc[4];
+                        f32x4 Sc[2] = {w16_splat(0.f), w16_splat(0.f)};
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            Pc[2 * rb] = b1 ? w16_lo(P1[rb]) : w16_lo(P0[rb]);
+                            Pc[2 * rb + 1] = b1 ? w16_hi(P1[rb]) : w16_hi(P0[rb]);
+                        }
+                        const int step = b1 ? C1 : 1, ntr = b1 ? n / C1 : n;
+                        const int j0 = b1 && cat1 ? copy1 : 0;
+                        const int col = b1 ? col1 : (cat0 ? n16 : 0);
+                        const unsigned rs = 4u * EPNN_PST * (unsigned)step, ps = 2u * (unsigned)step;
+                        unsigned ra = rbase + 4u * EPNN_PST * (unsigned)j0, pa = pbase + 2u * (unsigned)(col * NPM + j0);
+                        // the last tile's operands: partner jl of this lane
+                        const int jl = j0 + ntr * step;
+                        const bool rl = jl < n;
+                        const float wl = rl ? 1.f : (jl == n ? padw : 0.f);
+                        const unsigned ral = rl ? rbase + 4u * EPNN_PST * (unsigned)jl : lbase + zent;
+                        const unsigned entl = w16_lds_ldu16(pbase + 2u * (unsigned)(col * NPM + min(jl, n)));
                         Ops oa, ob;
-                        load_ops(cb_tag, 0, oa);
-                        int t = 0;
+                        unsigned en = w16_lds_ldu16(pa);          // entry of tile 0
+                        pa += ps;
+                        load_rg(oa, ra, en);
+                        ra += rs;
+                        en = w16_lds_ldu16(pa);                   // entry of tile 1
+                        pa += ps;
+                        int k = 0;
 #pragma unroll 1
-                        for (; t + 2 < nt; t += 2) {                           // tiles t, t+1: neither is the last one
-                            load_ops(cb_tag, t + 1, ob);
+                        for (; k + 3 <= ntr; k += 2) {            // tiles k, k + 1; tile k + 2 is a real one too
+                            load_rg(ob, ra, en);
+                            ra += rs;
+                            en = w16_lds_ldu16(pa);
+                            pa += ps;
                             WAVE_FENCE();
                             tile(Pc, Sc, oa);
-                            load_ops(cb_tag, t + 2, oa);
+                            load_rg(oa, ra, en);
+                            ra += rs;
+                            en = w16_lds_ldu16(pa);
+                            pa += ps;
                             WAVE_FENCE();
                             tile(Pc, Sc, ob);
                         }
-                        if (last_block) { W16_LD(u1s, M.u1s, 2, 8); }         // first operand of the update MLP
-                        if (t + 1 < nt) {                                      // two tiles left
-                            load_ops(cb_tag, t + 1, ob);
+                        if (!b1) { W16_LD(u1s, M.u1s, 2, 8); }   // first operand of the update MLP
+                        if (ntr - k == 2) {                       // real tiles k, k + 1, then the last tile
+                            load_rg(ob, ra, en);
                             WAVE_FENCE();
                             tile(Pc, Sc, oa);
+                            load_rg(oa, ral, entl);
+                            WAVE_FENCE();
                             tile(Pc, Sc, ob);
-                        } else {
+                            tile_w(Pc, Sc, oa, wl);
+                        } else {                                  // real tile k, then the last tile
+                            load_rg(ob, ral, entl);
                             WAVE_FENCE();
                             tile(Pc, Sc, oa);
+                            tile_w(Pc, Sc, ob, wl);
                         }
-                    };
-                    // molecules with 25+ atoms (one copy per block-1 atom): both blocks share the partner, one tile does both
-                    auto run_both = [&]() {
-                        struct Ops2 { f32x4 r[2], g0[2], g1[2]; };
-                        auto load2 = [&](int t, Ops2 &o_) {
-                            const bool real = t < n;
-                            const float *rrow = real ? Rl + t * EPNN_PST : zrow;
-                            o_.r[0] = w16_ld(rrow + fo);
-                            o_.r[1] = w16_ld(rrow + 16 + fo);
-                            grow(real ? (int)pm[t * 32 + n16] : 0xFFFF, o_.g0);
-                            grow(real && cat1 ? (int)pm[t * 32 + col1] : 0xFFFF, o_.g1);
-                        };
-                        auto tile2 = [&](int t, const Ops2 &o_) {
-                            const f32x4 za0 = w16_relu((P0[0] + o_.r[0]) + o_.g0[0]), zb0 = w16_relu((P0[1] + o_.r[1]) + o_.g0[1]);
-                            const f32x4 za1 = w16_relu((P1[0] + o_.r[0]) + o_.g1[0]), zb1 = w16_relu((P1[1] + o_.r[1]) + o_.g1[1]);
-                            const float z0[8] = {za0[0], za0[1], za0[2], za0[3], zb0[0], zb0[1], zb0[2], zb0[3]};
-                            const float z1[8] = {za1[0], za1[1], za1[2], za1[3], zb1[0], zb1[1], zb1[2], zb1[3]};
-                            f32x4 d0[2] = {b2v[0], b2v[1]}, d1[2] = {b2v[0], b2v[1]};
-                            w16_mm<2, 8>(pb, z0, d0);
-                            w16_mm<2, 8>(pb, z1, d1);
-                            const float w = t < n ? 1.f : padw;
 #pragma unroll
-                            for (int rb = 0; rb < 2; ++rb) { S0[rb] += w * w16_relu(d0[rb]); S1[rb] += w * w16_relu(d1[rb]); }
-                        };
-                        Ops2 oa, ob;
-                        load2(0, oa);
-                        int t = 0;
-#pragma unroll 1
-                        for (; t + 2 < nt0; t += 2) {
-                            load2(t + 1, ob);
-                            WAVE_FENCE();
-                            tile2(t, oa);
-                            load2(t + 2, oa);
-                            WAVE_FENCE();
-                            tile2(t + 1, ob);
+                        for (int rb = 0; rb < 2; ++rb) {
+                            if (b1) S1[rb] = Sc[rb];
+                            else S0[rb] = Sc[rb];
                         }
-                        W16_LD(u1s, M.u1s, 2, 8);
-                        if (t + 1 < nt0) {
-                            load2(t + 1, ob);
-                            WAVE_FENCE();
-                            tile2(t, oa);
-                            tile2(t + 1, ob);
-                        } else {
-                            WAVE_FENCE();
-                            tile2(t, oa);
-                        }
-                    };
-                    if (two && C1 == 1) {
-                        run_both();
-                    } else {
-                        if (two) run(std::integral_constant<int, 1>{}, nt1, P1, S1, false);
-                        run(std::integral_constant<int, 0>{}, nt0, P0, S0, true);
                     }
                 };
                 if (gover) sweep(std::true_type{});
@@ -614,7 +642,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     S1[0] = t0_;
                     S1[1] = t1_;
                     wave_sync_lds();
-                    if (lane < EPNN_PST) Gl[glds * EPNN_PST + lane] = 0.f;      // the scratch may have covered the zero row
+                    if (lane < EPNN_PST) Gl[lane] = 0.f;                        // the scratch covered the zero row
                 }
             }
             if (t < 2) WAVE_STAMP();   // pair tiles
@@ -877,6 +905,11 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     WAVE_STAMP();
 #ifdef EPNN_STAMPS
     if (lane == 0 && A.stamps) {
+        // where the wavefront ran: HW_ID (wave slot, SIMD, CU, shader array / engine) and the XCD (tools/wave_clocks.py)
+        A.stamps[(size_t)blockIdx.x * 64 + 61] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
+                                                 ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);
+        A.stamps[(size_t)blockIdx.x * 64 + 59] = rt0;
+        A.stamps[(size_t)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memrealtime();
         A.stamps[(size_t)blockIdx.x * 64 + 62] = (unsigned long long)nstamp;
         A.stamps[(size_t)blockIdx.x * 64 + 63] = ((unsigned long long)n << 32) | (unsigned)np;
     }
