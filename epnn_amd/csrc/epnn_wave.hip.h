@@ -291,10 +291,19 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     // 16-dimensional subspace to 5e-10 (epnn_api.hip edge_basis): it projects every pair once (pt = B^T e) and all 2T
     // G products run with K = 16, lane (q, n16) taking coefficients 4q..4q+3.
     constexpr int KE = FRONT ? EPNN_ER / 4 : 12;
+    // In-kernel front-end: the pairs' edge coordinates pt[np][16] stay in the wavefront's LDS as far as they fit: row r sits
+    // 64 (r + 1) bytes below the END of the wavefront's budget, the first `ptl` rows are there.  During the GNN stack that is what
+    // the G rows leave free (all rows up to ~18 atoms: no trip through HBM at all), the others go to A.pt; the EPN stack's tables
+    // are smaller, so most of those come into LDS for its T steps (round 4: the 15.9 MB of pair scratch per launch were mostly
+    // these rows, written once and read 2T times).
+    int ptl = 0;
+    const unsigned pt_top = w16_lds_addr(sm + A.lds_words) + 16u * (unsigned)q;     // (this lane's 16-byte piece of a row)
     auto load_e1 = [&](int slot, float (&e)[KE]) {
         const int sl = slot < np ? slot : 0;
         if (FRONT) {
-            const f32x4 v = w16_ld(A.pt + (size_t)(p0 + sl) * EPNN_ER + 4 * q);
+            f32x4 v;
+            if (sl < ptl) v = w16_lds_ld4(pt_top - 64u * (unsigned)(sl + 1));  // the pair's row in the wavefront's own LDS
+            else v = w16_ld(A.pt + (size_t)(p0 + sl) * EPNN_ER + 4 * q);
             e[0] = v[0]; e[1] = v[1]; e[2] = v[2]; e[3] = v[3];
         } else {
             const float *r = A.pe + (size_t)(p0 + sl) * EPNN_EDIM + 12 * q;
@@ -340,6 +349,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         glds = min(np, grows_g);                            // the in-kernel front-end always runs both stacks: GNN first
         gover = np > glds;
         ngt = (np + 31) >> 5;
+        // above the G rows AND above the EPN stack's tables, so that the rows survive the change of layout
+        ptl = min(np, max(0, A.lds_words - max(o_gg + (glds + 1) * EPNN_PST, o_x + n * (EPNN_PST + EPNN_DST))) / EPNN_ER);
         wave_sync_lds();
         // ---- edge coefficients of every pair, one lane per pair: pt[pair] = B^T e(D), the 16 coordinates of the pair's Gaussian
         //      features (charge_gn.py:148-161) in the edge basis.  They are smooth functions of the one variable D: cubic
@@ -363,8 +374,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     }
                     w = (float)(C * exp(-A.eta * best)) > A.tol ? 1.0f : 0.0f;
                 }
-                A.pwi[p0 + s0 + lane] = w;
-                A.pwj[p0 + s0 + lane] = w;
+                if (w != 0.f) eij[s0 + lane] = (unsigned short)(ij | 0x80);   // the near flag (charge_gn.py:90-94) rides in the pair's record
                 const double tt = D * A.tab_inv_h;
                 const int i0 = min(max((int)tt - 1, 0), A.tab_n - 4);
                 const float u = (float)(tt - (double)i0);                    // position among the nodes i0 .. i0+3, normally in [1, 2)
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 const float w0 = -(um1 * um2 * um3) * (1.f / 6.f), w1 = (u * um2 * um3) * 0.5f;
                 const float w2 = -(u * um1 * um3) * 0.5f, w3 = (u * um1 * um2) * (1.f / 6.f);
                 const float *trow = A.etab + (size_t)i0 * EPNN_ER;
-                float *prow = A.pt + (size_t)(p0 + s0 + lane) * EPNN_ER;
+                float *prow = s0 + lane < ptl ? sm + A.lds_words - (size_t)(s0 + lane + 1) * EPNN_ER : A.pt + (size_t)(p0 + s0 + lane) * EPNN_ER;
 #pragma unroll
                 for (int g = 0; g < EPNN_ER / 4; ++g) {
                     const f32x4 v = w0 * w16_ld(trow + 4 * g) + w1 * w16_ld(trow + EPNN_ER + 4 * g) +
@@ -746,6 +756,16 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     if (EPN) {
         wave_sync_lds();                                    // the GNN's tables are dead: switch to the EPN layout
         for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
+        if (FRONT && ptl < np) {
+            // edge coordinates that went through HBM (no room beside the G rows): the EPN stack's layout has room for more of them
+            const int pte = min(np, (A.lds_words - (o_x + n * (EPNN_PST + EPNN_DST))) / EPNN_ER);
+            for (int i = lane; i < (pte - ptl) * (EPNN_ER / 4); i += 64) {
+                const int r = ptl + (i >> 2), k = i & 3;
+                w16_st(sm + A.lds_words - (size_t)(r + 1) * EPNN_ER + 4 * k, w16_ld(A.pt + (size_t)(p0 + r) * EPNN_ER + 4 * k));
+            }
+            ptl = max(ptl, pte);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         wave_sync_lds();
         const int qs = (nx + 1) >> 2, ql = (nx + 1) & 3;    // step / lane group of xq that holds q
 #pragma unroll 1
@@ -796,8 +816,13 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 auto load_rec = [&](int blk, Rec &r_) {
                     const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;
                     r_.ij = eij[sl];
-                    r_.wi = A.pwi[p0 + sl];
-                    r_.wj = A.pwj[p0 + sl];
+                    if (FRONT) {
+                        r_.wi = r_.wj = (r_.ij & 0x80) ? 1.f : 0.f;
+                        r_.ij &= 0xFF7F;
+                    } else {
+                        r_.wi = A.pwi[p0 + sl];
+                        r_.wj = A.pwj[p0 + sl];
+                    }
                 };
                 auto load_rows = [&](int blk, const Rec &r_, Rows &w_) {
                     const int sl = blk * 16 + n16 < np ? blk * 16 + n16 : 0;

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512) void k_tile(float *out, unsigned long long *cy
     for (int s = 0; s < 4; ++s) { P[s] = f32x2{lane * 0.001f + s * 0.01f, 0.02f}; S[s] = f32x2{0.f, 0.f}; }
     for (int s = 0; s < 8; ++s) { w[0][s] = 0.01f + 0.001f * s; w[1][s] = 0.02f - 0.001f * s; }
     const f32x4 bias = f32x4{0.01f, 0.01f, 0.01f, 0.01f};
-    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     int row = lane;
     for (int t = 0; t < tiles; ++t) {
         const f32x4 *pr = reinterpret_cast<const f32x4 *>(lds + ((t * 36) & 1023) + 4 * (lane >> 4));
@@ -89,11 +89,11 @@ __global__ __launch_bounds__(512) void k_tile(float *out, unsigned long long *cy
             }
         }
     }
-    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float res = 0.f;
     for (int s = 0; s < 4; ++s) res += S[s][0] + S[s][1];
     out[blockIdx.x * blockDim.x + threadIdx.x] = res;
-    if (lane == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+    if (lane == 0) { cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0; if (blockIdx.x == 0 && threadIdx.x == 0) { cyc[gridDim.x * 8] = t1 - t0; cyc[gridDim.x * 8 + 1] = r1 - r0; } }
 }
 
 template <int FORM>
@@ -102,7 +102,7 @@ void run(const char *name, int threads, int blocks = 256, int lds_bytes = 32768)
     float *out;
     unsigned long long *cyc;
     (void)hipMalloc(&out, (size_t)blocks * 512 * 4);
-    (void)hipMalloc(&cyc, blocks * 8 * 8);
+    (void)hipMalloc(&cyc, blocks * 8 * 8 + 16);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<FORM>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     k_tile<FORM><<<blocks, threads, lds_bytes>>>(out, cyc, 10, lds_bytes / 4);
     (void)hipDeviceSynchronize();
@@ -115,7 +115,7 @@ void run(const char *name, int threads, int blocks = 256, int lds_bytes = 32768)
     (void)hipDeviceSynchronize();
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(blocks * 8);
+    std::vector<unsigned long long> h(blocks * 8 + 2);
     (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     double avg = 0;
     const int waves = threads / 64;
@@ -124,8 +124,9 @@ void run(const char *name, int threads, int blocks = 256, int lds_bytes = 32768)
     avg /= (double)blocks * waves * tiles;
     const double per_simd = waves * (blocks / 256.0) / 4.0;
     const double flop = (double)blocks * waves * tiles * 16 * 2048.0;
-    printf("%-28s %4d x %3d threads, %5d B LDS, %d wave(s)/SIMD: %7.1f ticks per tile per wave, %7.1f ticks of SIMD time per tile (16 MFMAs = 512), %6.1f TFLOP/s\n",
-           name, blocks, threads, lds_bytes, (int)per_simd, avg, avg / per_simd, flop / (ms * 1e-3) / 1e12);
+    printf("%-28s %4d x %3d threads, %5d B LDS, %d wave(s)/SIMD: %7.1f ticks per tile per wave, %7.1f ticks of SIMD time per tile (16 MFMAs = 512), %6.1f TFLOP/s (hipEvent), clock %.3f GHz, %6.1f TFLOP/s by the in-kernel 100 MHz clock\n",
+           name, blocks, threads, lds_bytes, (int)per_simd, avg, avg / per_simd, flop / (ms * 1e-3) / 1e12, (double)h[blocks * 8] / (double)h[blocks * 8 + 1] * 0.1,
+           flop / ((double)h[blocks * 8 + 1] * 1e-8) / 1e12);
     (void)hipFree(out);
     (void)hipFree(cyc);
 }

@@ -27,7 +27,7 @@ int main() {
         for (int rep = 0; rep < 2; ++rep) {
             (void)hipEventRecord(e0);
             if (mode == 0) k_spin<<<1, 64>>>(o, 2000000ull, 0);
-            else k_spin<<<256, 512>>>(o, 2000000ull, 1);
+            else k_spin<<<256, 512>>>(o, rep == 0 ? 2000000ull : 50000000ull, 1);
             (void)hipEventRecord(e1);
             (void)hipDeviceSynchronize();
             float ms;

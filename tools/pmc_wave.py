@@ -22,6 +22,8 @@ PASSES = [
     "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS",
     "SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_FLAT SQ_LDS_UNALIGNED_STALL",
     "GRBM_GUI_ACTIVE",
+    "FETCH_SIZE",
+    "WRITE_SIZE",
 ]
 
 
@@ -88,6 +90,11 @@ def main():
               g("SQC_ICACHE_MISSES_DUPLICATE", 0) / g("SQC_ICACHE_REQ")))
     if g("SQ_LDS_IDX_ACTIVE"):
         print("LDS bank conflict share %.3f" % (g("SQ_LDS_BANK_CONFLICT", 0) / g("SQ_LDS_IDX_ACTIVE")))
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        # rocprofv3 reports KiB; gfx950's FETCH_SIZE counts half of the bytes (MI355X_MICROARCH.md, calibrated in profiles/r01_fetch_calibration.txt)
+        print("HBM traffic per launch: %.2f MB (2 x FETCH_SIZE %.2f + WRITE_SIZE %.2f); per molecule %.0f B" % (
+            (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / 1e6, 2 * g("FETCH_SIZE") * 1024 / 1e6, g("WRITE_SIZE") * 1024 / 1e6,
+            (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / mol))
     if out:
         with open(out, "w") as f:
             json.dump({"molecules": mol, "lib": lib, "counters_per_launch": vals}, f, indent=1)

@@ -39,6 +39,10 @@ offs = np.concatenate([[0], np.cumsum(np.tile(ns, copies))]).astype(np.int32)
 eng = Engine()
 eng.set_weights(checkpoint.load_epnn_weights(os.path.join(ROOT, "models", "decay_model_weights")))
 eng.set_option("wave2", 0)
+for a_ in args:                     # developer switches: --opt=name:value
+    if a_.startswith("--opt="):
+        k_, v_ = a_[6:].split(":")
+        eng.set_option(k_, int(v_))
 for _ in range(3):
     q = eng.forward_xyz(offs, np.tile(xyz, (copies, 1)), np.tile(x, (copies, 1)), np.tile(Q, copies), N)
 lib = _lib.load()
