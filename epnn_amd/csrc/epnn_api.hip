@@ -448,13 +448,14 @@ static int pack_weights(epnn_handle *h) {
             for (int k = 0; k < len; ++k) buf[off + k] = (float)fn(k);
             return off;
         };
-        // [nrb][steps][64]: lane (q,m) of (rb, step s) = fn(s, q, 16rb + m)  (input selector, output feature)
+        // [nrb][steps / 4][64][4]: lane (q,m) of (rb, step s) = fn(s, q, 16rb + m)  (input selector, output feature); a lane's
+        // four consecutive steps are 16 contiguous bytes (one dwordx4 load, W16_LDX in epnn_wave.hip.h)
         auto frag = [&](int nrb, int steps, auto &&fn) {
             const int off = alloc((size_t)nrb * steps * 64);
             for (int rb = 0; rb < nrb; ++rb)
                 for (int s = 0; s < steps; ++s)
                     for (int l = 0; l < 64; ++l)
-                        buf[off + (rb * steps + s) * 64 + l] = (float)fn(s, l >> 4, 16 * rb + (l & 15));
+                        buf[off + ((rb * (steps / 4) + s / 4) * 64 + l) * 4 + (s & 3)] = (float)fn(s, l >> 4, 16 * rb + (l & 15));
             return off;
         };
         auto accf = [](int s, int q) { return 16 * (s >> 2) + 4 * q + (s & 3); };       // "acc" K order

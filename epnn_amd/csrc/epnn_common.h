@@ -61,7 +61,8 @@ struct WeightIndex {
 // (q,n) then owns columns n and 16+n and, of each, the 8 features 16rb + 4q + r.  K steps are ordered so that an
 // accumulator set feeds the next product directly: step s = 4rb' + r' pairs lane q with input feature
 // 16rb' + 4q + r' ("acc" order).  Other K orders: "xq" feature 4s + q;  "e" channel 12q + s.
-// Fragment = [rb][step][64 lanes]: lane (q,m) holds W[in(step,q)][16rb + m].  Vectors are in natural feature order.
+// Fragment = [rb][step / 4][64 lanes][4]: lane (q,m) holds W[in(step,q)][16rb + m], its four consecutive steps in 16 contiguous
+// bytes (one global_load_dwordx4, W16_LDX).  Vectors are in natural feature order.
 #define EPNN_XS 4            // K-steps of the xq block: nx + 3 <= 16
 #define EPNN_ER 16           // dimension of the edge-feature subspace used by the fused kernel's own front-end
 #define EPNN_ETAB_N 2049     // grid points of the table of B^T e(D) over [0, cutoff]

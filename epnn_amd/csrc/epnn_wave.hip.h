@@ -138,14 +138,19 @@ __device__ __forceinline__ f32x2 w16_lo(f32x4 v) { return __builtin_shufflevecto
 __device__ __forceinline__ f32x2 w16_hi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
 __device__ __forceinline__ f32x4 w16_cat(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
 
-// fragment loads: [nrb][stride][64 lanes], steps s0 .. s0+cnt-1 of every row block.  One address per row block, the steps
-// as immediate offsets of the load (256 bytes apart, at most 16 of them: inside the 4 KB immediate range).  With the step
-// inside the index every load beyond that range cost three VALU instructions of address arithmetic -- and f32 MFMA and
-// VALU share the SIMD's issue cycles.
-#define W16_LDX(dst, off, nrb, cnt, stride, s0)                                                   \
-    _Pragma("unroll") for (int rb_ = 0; rb_ < (nrb); ++rb_) {                                     \
-        const float *fp_ = wp + (size_t)(unsigned)((off) + (rb_ * (stride) + (s0)) * 64 + lane);  \
-        _Pragma("unroll") for (int s_ = 0; s_ < (cnt); ++s_)(dst)[rb_][s_] = fp_[s_ * 64];        \
+// fragment loads: [nrb][stride / 4][64 lanes][4], steps s0 .. s0+cnt-1 of every row block (s0, cnt, stride multiples of 4).
+// A lane's four consecutive K steps are 16 contiguous bytes: ONE global_load_dwordx4 per four steps (1 KB per wavefront
+// instruction, fully coalesced) instead of four global_load_dword -- the kernel issued 1160 vector loads per molecule, nearly
+// all of them weights, and every vector-memory instruction costs issue slots beside the matrix pipe (round 4).  One address
+// per row block, the step groups as immediate offsets of the load (1 KB apart: inside the 4 KB immediate range).
+#define W16_LDX(dst, off, nrb, cnt, stride, s0)                                                                   \
+    _Pragma("unroll") for (int rb_ = 0; rb_ < (nrb); ++rb_) {                                                     \
+        const f32x4 *fp_ = reinterpret_cast<const f32x4 *>(wp + (size_t)(unsigned)(off)) +                        \
+                           (size_t)(unsigned)((rb_ * ((stride) / 4) + (s0) / 4) * 64 + lane);                     \
+        _Pragma("unroll") for (int g_ = 0; g_ < (cnt) / 4; ++g_) {                                                \
+            const f32x4 v_ = fp_[g_ * 64];                                                                        \
+            (dst)[rb_][4 * g_] = v_[0]; (dst)[rb_][4 * g_ + 1] = v_[1]; (dst)[rb_][4 * g_ + 2] = v_[2]; (dst)[rb_][4 * g_ + 3] = v_[3]; \
+        }                                                                                                         \
     }
 #define W16_LD(dst, off, nrb, steps) W16_LDX(dst, off, nrb, steps, steps, 0)
 
