@@ -1788,14 +1788,14 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     // the optimizer step rides in the gradient reduction's launch when nothing has to happen between the two (no all-reduce
     // over ranks); the last forward launch of the row-fused path writes loss terms | predictions into page-locked host memory as
     // well: no download (a 4 us copy kernel and its launch) between the last launch and the caller
-    const bool rowfused = train_is_fused(h, N) && (h->opt_train_fused == 1 || h->opt_train_fused == 3);
+    const bool rowfused = train_is_fused(h, N);
     const bool adam_now = apply && rowfused && !(h->comm && h->comm_world > 1);
     if (h->pin_tout.ensure(2 * BN * 4)) return 1;
     float *out_host = rowfused ? h->pin_tout.as<float>() : nullptr;
     // "train_async": the step returns behind its forward pass.  That needs an event the host can wait for between the forward and the
     // backward launches -- an event recorded inside a replayed graph is not one (measured: the wait returns at once) -- so such a
     // step is launched kernel by kernel (the replay was worth 1 %, returning early is worth 8 %).
-    const bool early_ok = h->opt_train_async && rowfused && h->opt_train_fused != 2 && (adam_now || !apply);
+    const bool early_ok = h->opt_train_async && rowfused && (adam_now || !apply);
     if (h->opt_train_graph && !early_ok) {
         // The step is a chain of dependent launches a few microseconds long: recorded once per (B, N, buffer set, apply) and
         // replayed as one hipGraph.  The step number Adam's step size depends on then lives on the device: the graph's first

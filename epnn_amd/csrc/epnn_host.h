@@ -147,8 +147,9 @@ struct epnn_handle {
     int opt_train_skip_padded = 1;    // training, coordinate entry, matrix-pipe kernels: padded atom slots leave their workgroups at once (the same bits)
     const int *tr_moff = nullptr, *tr_real = nullptr;      // ... set around the step by epnn_train_step_xyz
     int opt_train_split = 0;          // training, matrix-pipe backward: workgroups per atom (0 = as many as fit the atom's XCD, at most 6)
-    int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels; 2 = the forward on the matrix pipe instead (epnn_train_mfma.hip.h;
-                                      // measured slower at N = 41: three workgroups per molecule); 0 = the layer-by-layer kernels
+    int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels, Dense layers and weight gradients on the matrix pipe; 3 = the same
+                                      // decomposition as scalar FMA loops (also what 1 runs when nx + 49 > 60 features or the e rows are not
+                                      // 16-byte aligned); 0 = the layer-by-layer kernels
     int opt_train_graph = 1;          // training: 1 replays the step's launch sequence (optimizer step included) as a hipGraph: 0.22 vs 0.245 ms
                                       // per one-molecule step once the kernels were short enough for the launch boundaries to show
                                       // (round 2: 0.47 vs 0.45); a new (B, N, buffer set) means a new capture

@@ -12,7 +12,6 @@
 #pragma once
 #include "epnn_host.h"
 #include "epnn_train_fused.hip.h"
-#include "epnn_train_mfma.hip.h"
 
 struct TDense {            // one Dense inside the flat parameter vector
     int offW, offB, n_in, n_out;
@@ -594,7 +593,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
                                bool size_only = false, bool adam_now = false, float *out_host = nullptr, bool step_on_device = false) {
     TrainState *ts = train_state(h);
     if (!ts->ready) EPNN_FAIL("training: call epnn_train_init first");
-    ts->host_out = out_host != nullptr && h->opt_train_fused != 2;       // (the 16-atom forward has its own loss launch)
+    ts->host_out = out_host != nullptr;
     if (step_on_device && ts->d_step.ensure(8)) return 1;
     const int T = h->cfg.T, nx = h->cfg.nx, H = EPNN_EDIM, E = EPNN_EDIM, F = nx + H + 1, D = 2 * F + E, FS = F | 1;
     const int BN = B * N;
@@ -672,30 +671,19 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         U.gh = gh; U.dU0 = P(o_dU0); U.part = P(o_pu) + (size_t)t * BN * EPNN_TF_PU;
         return U;
     };
-    // forward on the matrix pipe ("train_fused" = 2, epnn_train_mfma.hip.h): a workgroup per 16 atoms of a molecule.  Measured
-    // SLOWER than the row-fused forward at these sizes (0.66 vs 0.47 ms per step: three workgroups per molecule are a chain of
-    // dependent MFMAs where the row-fused kernels have 41 x 16 wavefronts), so it is an option, not the default.
-    const bool mfma_fwd = h->opt_train_fused == 2 && nx + 49 <= EPNN_TM_FS;
     auto lds_bwd_mm = [&](int nd) { return ((size_t)4 * nd * N * EPNN_TB_RS + (size_t)N * EPNN_TB_ES + 1168 + (size_t)N * FS) * 4; };
     // one molecule per step is N workgroups on 256 CUs: up to six workgroups per atom share its weight-gradient jobs
     // (an XCD has 32 CUs and a workgroup of these kernels has a CU to itself: the shares of an XCD's atoms must fit it in one round)
     const int nsplit = h->opt_train_split ? h->opt_train_split : std::max(1, std::min(6, 32 / ((BN + 7) / 8)));
     const unsigned bwd_grid = 8u * (unsigned)((BN + 7) / 8) * (unsigned)nsplit;          // eight XCDs, equal parts (k_tb_pair_bwd_mm)
-    const int nblk = (N + 15) / 16;
-    const size_t lds_tm = ((size_t)N * (EPNN_TM_FS + 64) + EPNN_TM_NW * 16 * 33) * 4;
-    if (mfma_fwd) {
-        hipLaunchKernelGGL(k_t_nodemask, dim3(t_grid(BN)), dim3(256), 0, st, d_mask, nm, B, N);
-        hipLaunchKernelGGL(k_t_wgt, dim3(t_grid(R)), dim3(256), 0, st, d_e, d_mask, wgt, (int)R, E, h->cfg.near_tol);
-    }
     // ================================================================ forward: GNN (charge_gn.py:60-74)
     const float *hcur = d_h0;
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->msg[t], hcur, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
-        if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the node masks
+        if (t == 0) A.mask = d_mask;                                    // ... and the node masks
         if (t == 0 && adam_now && step_on_device) A.step_p = ts->d_step.as<long long>();
-        if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<0>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, upd_args(t, hcur), nblk);
-        else if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<0, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));
+        if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<0, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));
         else hipLaunchKernelGGL((k_tf_pair_fwd<0, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
         hcur = P(gs[t].hn);
     }
@@ -705,17 +693,15 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     for (int t = 0; t < T; ++t) {
         TfPair A = pair_args(ts->pas[t], feats, qcur);
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.qn = P(es[t].qn);
-        if (t == 0 && !mfma_fwd) A.mask = d_mask;                       // ... and the pair weights
-        if (t == T - 1 && !mfma_fwd) {
+        if (t == 0) A.mask = d_mask;                                    // ... and the pair weights
+        if (t == T - 1) {
             A.y = d_y; A.pred = d_pred; A.lterm = d_loss;
             A.out_h = out_host;
         }
-        if (mfma_fwd) hipLaunchKernelGGL(k_tm_fwd<1>, dim3((unsigned)(B * nblk)), dim3(EPNN_TM_NT), lds_tm, st, A, TfUpd{}, nblk);
-        else if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
+        if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         else hipLaunchKernelGGL((k_tf_pair_fwd<1, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         qcur = P(es[t].qn);
     }
-    if (mfma_fwd) hipLaunchKernelGGL(k_t_loss_terms, dim3(t_grid(BN)), dim3(256), 0, st, d_y, qcur, d_pred, d_loss, BN);
     if (ts->host_out && ts->ev_fwd) HIPCHK(hipEventRecord(ts->ev_fwd, st));        // (an event-record node when the step is being captured)
     // ================================================================ backward: EPN, then GNN.  Every launch starts with the
     // "atoms" stage of the one before it (the gradient that reached the atoms through that sweep's first Dense); the

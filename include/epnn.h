@@ -189,9 +189,9 @@ int epnn_timing_at(epnn_handle *h, int idx, float *out4);
  * optimizer step included, captured once per (B, N, buffer set) and replayed as a hipGraph; 0: kernel by kernel -- the same bits),
  * "train_fused" (1, default: one workgroup per atom runs a whole pair MLP over its rows, forward and backward, 2T + 2T + 1
  * launches per step, the Dense layers and every weight gradient as 16x16x4 f32 MFMA tiles; 3: the same decomposition with
- * scalar FMA loops -- round 2's kernels, kept as the second implementation the tests compare; 2: the forward's pair MLPs in
- * the factorised form of the inference kernels, a workgroup per 16 atoms of a molecule -- measured slower at N = 41; 0: one
- * launch per Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS budget of 96 atoms),
+ * scalar FMA loops -- what 1 itself runs for models with more than 60 atom features (nx > 11), and the second implementation
+ * the tests compare; 0: one launch per Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS
+ * budget of 96 atoms),
  * "train_skip_padded" (1, default: epnn_train_step_xyz tells the "train_fused" = 1 kernels which atom slots of the padded size are
  * real -- the workgroups of the others, which would compute zeros for N rows each, return at once; 0: every slot is computed; the
  * same bits),
