@@ -1795,7 +1795,9 @@ static int train_step_slots(epnn_handle *h, int B, int N, const float *d_e, cons
     // "train_async": the step returns behind its forward pass.  That needs an event the host can wait for between the forward and the
     // backward launches -- an event recorded inside a replayed graph is not one (measured: the wait returns at once) -- so such a
     // step is launched kernel by kernel (the replay was worth 1 %, returning early is worth 8 %).
-    const bool early_ok = h->opt_train_async && rowfused && (adam_now || !apply);
+    // (several ranks: the all-reduce and the optimizer step are enqueued behind the backward pass on the same stream -- every rank
+    // enqueues the same sequence --, so such a step returns behind its forward pass too)
+    const bool early_ok = h->opt_train_async && rowfused;
     if (h->opt_train_graph && !early_ok) {
         // The step is a chain of dependent launches a few microseconds long: recorded once per (B, N, buffer set, apply) and
         // replayed as one hipGraph.  The step number Adam's step size depends on then lives on the device: the graph's first

@@ -113,10 +113,13 @@ def make_row_exchange(engine, dist, rank, world):
 
 
 # --------------------------------------------------------------------------------------------- data-parallel training
-def dp_step_molecules(order, world, step):
-    """Molecules of optimizer step `step` when `world` ranks each take one molecule (train.py): rank r gets
-    order[step*world + r].  Returns the `world` indices (the global batch of that step)."""
-    return [int(order[step * world + r]) for r in range(world)]
+def dp_step_molecules(order, world, step, per_rank=1):
+    """Molecules of optimizer step `step` when `world` ranks each take `per_rank` molecules (train.py): rank r gets
+    order[(step*world + r)*per_rank : (step*world + r + 1)*per_rank].  Returns one entry per rank: the molecule's index
+    (per_rank == 1, the reference's batch of one per device) or the list of its `per_rank` indices."""
+    if per_rank == 1:
+        return [int(order[step * world + r]) for r in range(world)]
+    return [[int(i) for i in order[(step * world + r) * per_rank:(step * world + r + 1) * per_rank]] for r in range(world)]
 
 
 def allreduce_sum_host(vec, dist):

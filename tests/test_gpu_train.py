@@ -489,14 +489,16 @@ def _merged_split_dir(tmp_path, train_dir, val_dir):
     return str(d)
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_train_script_on_the_recorded_split(tmp_path, golden_dir, train_dir, val_dir, train_names, world):
+@pytest.mark.parametrize("world,per", [(1, 1), (2, 1), (1, 3), (2, 2)])
+def test_train_script_on_the_recorded_split(tmp_path, golden_dir, train_dir, val_dir, train_names, world, per):
     """train.py --names on the reference's recorded split (BASELINE.json configs[2]; models/model_systems/train_names.npy,
     val_names.npy), N = 41: six optimizer steps from the shipped checkpoint, at world size 1 and with two rank processes
     started by `--gpus 2` (they share this box's one GPU, so the gradient sum goes through the host; one GPU per rank
     uses the RCCL all-reduce).  Row k of train_pred_charges / train_lab_charges must belong to training molecule k of
-    the recorded order -- whichever rank computed it: the labels are that molecule's, the prediction has exactly its
-    atoms and sums to its total charge.  The validation arrays cover all 871 systems in the recorded order."""
+    the recorded order -- whichever rank computed it, and whichever of the `per` molecules of that rank's step it was
+    (`--molecules-per-rank`, the form of data parallelism that scales: DESIGN.md section 6): the labels are that molecule's, the
+    prediction has exactly its atoms and sums to its total charge.  The validation arrays cover all 871 systems in the recorded
+    order."""
     import subprocess, sys
     from conftest import ROOT
     from epnn_amd import charge_gn
@@ -507,15 +509,18 @@ def test_train_script_on_the_recorded_split(tmp_path, golden_dir, train_dir, val
            "--names", os.path.join(golden_dir, "train_names.npy"), os.path.join(golden_dir, "val_names.npy"), "--max-steps", str(steps)]
     if world > 1:
         cmd += ["--gpus", str(world)]
+    if per > 1:
+        cmd += ["--molecules-per-rank", str(per)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     res = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     assert len([l for l in res.stdout.splitlines() if l.startswith("Epoch 0, Loss:")]) == 1
+    assert len([l for l in res.stdout.splitlines() if "molecules/s" in l and f"{world} rank(s) x {per} molecule(s)" in l]) == 1
     arr = tmp_path / "arr"
     assert [str(n) for n in np.load(arr / "train_names.npy", allow_pickle=True)] == train_names
     pred, lab = np.load(arr / "train_pred_charges.npy"), np.load(arr / "train_lab_charges.npy")
-    assert pred.shape == lab.shape == (steps * world, 41)
-    for k in range(steps * world):
+    assert pred.shape == lab.shape == (steps * world * per, 41)
+    for k in range(steps * world * per):
         xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(train_dir, train_names[k] + ".xyz"), 9)
         y = np.load(os.path.join(train_dir, train_names[k] + ".npy")).ravel()
         n = len(y)

@@ -21,6 +21,23 @@ def test_partition_is_exact_cover_balanced_and_deterministic():
         assert all(np.array_equal(a, b) for a, b in zip(parts, again))
 
 
+def test_data_parallel_step_molecules_cover_the_order_once():
+    """shard.dp_step_molecules: the molecules of optimizer step s, one entry per rank -- one molecule each (the reference's batch
+    of one per device) or `per_rank` of them (train.py --molecules-per-rank); over the steps every position of the order is
+    taken exactly once, in order."""
+    from epnn_amd import shard
+    order = np.arange(100, 148)
+    for world, per in ((1, 1), (2, 1), (8, 1), (2, 3), (4, 2)):
+        seen = []
+        for s in range(len(order) // (world * per)):
+            parts = shard.dp_step_molecules(order, world, s, per)
+            assert len(parts) == world
+            for p in parts:
+                seen += [p] if per == 1 else p
+                assert per == 1 or len(p) == per
+        assert seen == [int(v) for v in order[:len(seen)]] and len(seen) == (len(order) // (world * per)) * world * per
+
+
 def test_take_molecules_round_trip():
     from epnn_amd import shard, synth
     offsets, xyz, x, Q, N = synth.qm9_like_batch(B=16, seed=1)

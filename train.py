@@ -12,12 +12,21 @@ summed with ONE RCCL all-reduce of the flat 296 KB gradient on the GPU (the 128-
 trajectories are comparable only at world size 1.  With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks
 share devices, RCCL cannot join two ranks of one device, and the gradient sum goes through the host instead.
 
+One molecule per GPU and step is LATENCY-bound by construction (a step is ~21 dependent launches of ~8 us, DESIGN.md
+section 6): eight GPUs at one molecule each take an optimizer step in about the time one GPU does, i.e. at best ~1.15x the
+molecules/s of one GPU that puts eight molecules into its step.  ``--molecules-per-rank B`` is the form that scales: every rank
+sums the gradients of B molecules in its step (the arithmetic of tests/test_shard_synth.py::
+test_data_parallel_gradient_sum_world2_gloo), the all-reduce stays one per step.  Rank 0 prints the molecules/s of every epoch's
+training pass, to be compared with the expectation in DESIGN.md.
+
     python train.py xyz_dir/ [--epochs E] [--n-elems 10] [--init PREFIX] [--out models/model_weights] [--limit M]
                              [--names train_names.npy val_names.npy] [--gpus N] [--max-steps S] [--outdir DIR]
+                             [--molecules-per-rank B]
 """
 import argparse
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -40,6 +49,8 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=0, help="start this many rank processes (one per GPU)")
     ap.add_argument("--max-steps", type=int, default=0, help="optimizer steps per epoch (0: the whole training split)")
     ap.add_argument("--outdir", default=".", help="where the names / predictions / labels arrays go (the reference: cwd)")
+    ap.add_argument("--molecules-per-rank", type=int, default=1,
+                    help="molecules whose gradients a rank sums in one optimizer step (1: the reference's batch of one per device)")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -121,7 +132,8 @@ def main(argv=None):
     train_loss, train_acc = charge_gn.Mean("train_loss"), charge_gn.MeanAbsoluteError("train_acc")
     test_loss, test_acc = charge_gn.Mean("test_loss"), charge_gn.MeanAbsoluteError("test_acc")
     best = np.inf
-    nsteps = len(it) // world
+    per = max(1, args.molecules_per_rank)
+    nsteps = len(it) // (world * per)
     if args.max_steps:
         nsteps = min(nsteps, args.max_steps)
     my_val = [int(i) for i in ie[rank::world]]                      # validation molecules are independent: sharded
@@ -129,20 +141,26 @@ def main(argv=None):
         for m in (train_loss, train_acc, test_loss, test_acc):
             m.reset_states()
         train_rows = []                                             # (position in `it`, prediction padded to N) of this rank
+        t_epoch = time.perf_counter()
         for s in range(nsteps):
-            pos = s * world + rank
-            i = shard.dp_step_molecules(it, world, s)[rank]
-            off, xyz, x, Q = batch_of([i])
+            mine = shard.dp_step_molecules(it, world, s, per)[rank]
+            mine = [mine] if per == 1 else mine
+            off, xyz, x, Q = batch_of(mine)
+            y = np.concatenate([labels[i] for i in mine])
             if world > 1 and not rccl:
-                q, _ = eng.train_step_xyz(off, xyz, x, Q, labels[i], N, apply=False)
+                q, _ = eng.train_step_xyz(off, xyz, x, Q, y, N, apply=False)
                 g = rdzv.all_gather(eng.get_gradients(), name="grad")
                 eng.set_gradients(np.sum(np.stack(g).astype(np.float64), axis=0).astype(np.float32))      # rank order: same bits everywhere
                 eng.train_apply()
             else:
-                q, _ = eng.train_step_xyz(off, xyz, x, Q, labels[i], N, apply=True)       # all-reduce (RCCL) + Adam on the device
-            train_rows.append((pos, padded(q)))
-            train_loss((padded(labels[i]) - padded(q)) ** 2)                               # charge_gn.py:400-401
-            train_acc(padded(q), padded(labels[i]))
+                q, _ = eng.train_step_xyz(off, xyz, x, Q, y, N, apply=True)               # all-reduce (RCCL) + Adam on the device
+            for k, i in enumerate(mine):
+                qk = padded(q[off[k]:off[k + 1]])
+                train_rows.append(((s * world + rank) * per + k, qk))
+                train_loss((padded(labels[i]) - qk) ** 2)                                  # charge_gn.py:400-401
+                train_acc(qk, padded(labels[i]))
+        eng.sync()
+        t_epoch = time.perf_counter() - t_epoch
         val_rows = []
         if my_val:
             off, xyz, x, Q = batch_of(my_val)
@@ -169,6 +187,8 @@ def main(argv=None):
         if rank == 0:
             template = 'Epoch {}, Loss: {}, Acc: {}, Test Loss: {}, Test Acc: {}'
             print(template.format(epoch, train_loss.result(), train_acc.result(), test_loss.result(), test_acc.result()), flush=True)
+            print(f"  training pass: {nsteps} optimizer steps of {world} rank(s) x {per} molecule(s) in {t_epoch:.3f} s = "
+                  f"{nsteps * world * per / t_epoch:.0f} molecules/s ({t_epoch / max(1, nsteps) * 1e3:.3f} ms per step)", flush=True)
     if rdzv is not None:
         rdzv.barrier("end")
         rdzv.close()
