@@ -50,7 +50,17 @@ int epnn_version(void);
 /* number of HIP devices visible (0 when there is none; never initialises a context beyond the count). */
 int epnn_device_count(void);
 
-/* make_model (charge_gn.py:369-391): creates the layer stack on `device`.  Weights start at zero. */
+/* make_model (charge_gn.py:369-391): creates the layer stack on `device`.  Weights start at zero.
+ *
+ * CONTRACT -- what of the reference's constructor arguments is free and what is fixed.  The reference sizes every MLP from
+ * `layers` and every width from `h_dim` (charge_gn.py:369-374, MLP_layer(nodes, ...) :31-39); every checkpoint it ships and both
+ * of its scripts use layers = [32, 32], h_dim = e_dim = 48 (charge_gn.py:413-417, infer.py:47-50).  This library implements THAT
+ * shape and nothing wider -- the kernels hold a 32-wide hidden layer in one MFMA accumulator set and 48 = 3 x 16 edge channels:
+ *   free :  nx in 1..10 (atom feature columns; 9 and 10 are the reference's two tables), T in 1..8, cutoff, eta, near_tol,
+ *           the padded size N and the batch size of every call, every weight value;
+ *   fixed:  hidden == 32 (`layers` == [32, 32] for the message, pass and update MLPs alike), h_dim == e_dim == 48.
+ * epnn_create FAILS (returns non-zero, epnn_last_error says which field) for any other value; the Python layer raises
+ * EpnnError from make_model / MLP_layer for `layers` != [32, 32].  A model of another width is not run on a slower path. */
 int epnn_create(const epnn_config *cfg, int device, epnn_handle **out);
 int epnn_destroy(epnn_handle *h);
 
