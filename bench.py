@@ -31,7 +31,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
                       the timed region / f32 MFMA peak; `pipe_frac` the same with the flops the kernel really executes
                       (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); `single_launch` = a launch with the GPU to itself
                       (65536 molecules, depth 1: flops / hipEvent duration IS its fraction, reproducible from
-                      profiles/r03_big_launch_kernel_stats.csv)
+                      profiles/r04_big_launch_kernel_stats.csv)
   parity              max |dq| of the reference's 871 validation systems against the TensorFlow predictions it stored for them
   real_data           atoms/s on that batch (real molecules of 3..38 atoms, N = 41), device-resident, pipelined
   host_to_host        the same forward from host arrays to host arrays (Pipeline.map, a DIFFERENT batch every call)
@@ -56,15 +56,18 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
 KNAME = "k_wave_forward<true,true,true>"
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
 
 
 def kernel_source_sha():
-    """Identity of the fused kernel's source: PMC figures recorded for another revision are not quoted."""
+    """Identity of the fused kernel's build: its sources (with the front-end it includes) and the compile flags.  PMC figures
+    recorded for another revision or another set of flags are not quoted."""
     hsh = hashlib.sha256()
-    for f in ("epnn_wave.hip.h", "epnn_common.h"):
+    for f in ("epnn_wave.hip.h", "epnn_common.h", "epnn_frontend.hip.h"):
         with open(os.path.join(ROOT, "epnn_amd", "csrc", f), "rb") as fh:
             hsh.update(fh.read())
+    import __graft_entry__ as entry
+    hsh.update(" ".join(entry.BUILD_FLAGS).encode())
     return hsh.hexdigest()[:16]
 
 
@@ -149,7 +152,7 @@ def collect_pmc(args):
     gfx950 correction: FETCH_SIZE x 2, MI355X_MICROARCH.md), the SQ counters at depth 1 (a launch alone).  Writes PMC_JSON."""
     import glob
     import pandas as pd
-    base = os.path.join(ROOT, "gpurun_out", "pmc_r03")
+    base = os.path.join(ROOT, "gpurun_out", "pmc_r04")
     passes = [("fetch", "FETCH_SIZE", args.depth), ("write", "WRITE_SIZE", args.depth),
               ("mops", "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE", 1),
               ("lds", "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY", 1)]
@@ -207,13 +210,14 @@ def main():
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-launch and host-to-host measurements")
-    ap.add_argument("--pmc", action="store_true", help="first run the rocprofv3 counter passes of this workload (writes profiles/r03_pmc_bench.json)")
+    ap.add_argument("--pmc", action="store_true", help="first run the rocprofv3 counter passes of this workload (writes profiles/r04_pmc_bench.json)")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight per GPU (handles/streams used round robin); 0 = by run "
                     "length: 8 for long runs (steady state: 7-10 deep measured 213-215 M atoms/s, 6 deep 207 M on the same box), for short ones the divisor of --steps among 5, 4, 6 -- the last "
                     "round of launches then fills every lane (a launch takes ~0.3 ms whatever shares the GPU with it, so a short run "
                     "that ends with two of six lanes busy pays for it: K = 20 runs at 184 M atoms/s five deep, 175 M six deep)")
     ap.add_argument("--sleep-ms", type=float, default=0.0, help="(experiment, profiles/r02_warm_sweep.txt) idle time between the warm-up steps and the timed region; negative: the host busy-waits instead of sleeping")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
+    ap.add_argument("--real-depth", type=int, default=8, help="batches in flight of the real-data measurement")
     args = ap.parse_args()
 
     if args.depth <= 0:
@@ -302,6 +306,7 @@ def main():
     A = int(offsets[-1])
     # every lane keeps its own resident copy of the (identical) inputs and its own output buffer
     lanes = [(e, e.to_device(xyz), e.to_device(x), e.to_device(Q), e.alloc(A * 4)) for e in pipe.engines]
+    n_lanes = len(lanes)
 
     def step(k):
         e, d_xyz, d_x, d_Q, d_q = lanes[k % len(lanes)]
@@ -514,23 +519,37 @@ def main():
 
     if real is not None:
         # (4) the real-data rate: the validation batch of (1), device-resident, through every lane of the pipeline
+        # Eight batches in flight whatever the timed region used: the 22 systems of 33..38 atoms of this batch run as a launch of
+        # their own (three wavefronts each, 0.12 ms of latency on 66 wavefronts) in front of the lane's main launch, so a lane is
+        # busy ~0.4 ms per batch with little work in a third of it and the LANES, not the machine, limit the rate (round 4: the
+        # 849 systems of <= 32 atoms alone run at the synthetic batch's rate at any depth; with the 22 others 147 / 171 M atoms/s
+        # at 5 / 8 lanes; a second stream per lane and a merged launch were both measured slower)
         v_off, v_xyz, v_x, v_Q = real
-        vl = [(e, e.to_device(v_xyz), e.to_device(v_x), e.to_device(v_Q), e.alloc(int(v_off[-1]) * 4)) for e in pipe.engines]
+        for lane in lanes:                                  # the timed region's lanes give their hardware queues back first
+            for d in lane[1:]:
+                d.free()
+        pipe.close()
+        pipe = None
+        rpipe = Pipeline(depth=args.real_depth, nx=9, T=5, device=device)
+        rpipe.set_weights(weights)
+        rpipe.set_option("wave2", 0)
+        vl = [(e, e.to_device(v_xyz), e.to_device(v_x), e.to_device(v_Q), e.alloc(int(v_off[-1]) * 4)) for e in rpipe.engines]
         for k in range(30 * len(vl)):                       # ~20 ms of load first (clocks)
             e, a_, b_, c_, d_ = vl[k % len(vl)]
             e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
-        pipe.sync()
+        rpipe.sync()
         nrep = 25 * len(vl)
         t1 = time.perf_counter()
         for k in range(nrep):
             e, a_, b_, c_, d_ = vl[k % len(vl)]
             e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
-        pipe.sync()
+        rpipe.sync()
         v_dt = (time.perf_counter() - t1) / nrep
         v_flops = synth.algorithmic_flops(np.diff(v_off), int(vl[0][0].last_stats()[0]))
         for lane in vl:
             for d in lane[1:]:
                 d.free()
+        rpipe.close()
         extras["real_data"] = {"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
                                "algorithmic_gflop_per_batch": v_flops / 1e9,
                                "frac": v_flops / v_dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
@@ -552,7 +571,7 @@ def main():
         roof = {"bound": "mfma", "kernel": KNAME, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "frac_basis": "algorithmic flops (SURVEY section 8d); the matrix pipe's own utilisation (executed MFMA flops, PMC) is pipe_frac",
                 "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
-                "traffic_source": (pmc["command"] + f"; kernel source {pmc['kernel_source_sha']}; profiles/r03_pmc_bench.json") if pmc else None,
+                "traffic_source": (pmc["command"] + f"; kernel source {pmc['kernel_source_sha']}; profiles/r04_pmc_bench.json") if pmc else None,
                 "algorithmic_gflop_per_launch": flops / 1e9,
                 "executed_gflop_per_launch": executed,
                 "pipe_frac": (executed * 1e9 / (k_ms / in_flight * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if executed else None,
@@ -584,10 +603,10 @@ def main():
             "config": {"workload": workload, "molecules_per_gpu": B, "atoms_per_gpu": A, "N": N,
                        "pairs_under_cutoff_per_gpu": int(stats[0]), "entry": "epnn_forward_xyz_dev (coordinates in HBM)",
                        "weights": "decay_model_weights", "parallelism": f"molecule-sharded x{world}",
-                       "batches_in_flight_per_gpu": len(lanes)},
+                       "batches_in_flight_per_gpu": n_lanes},
             "roofline": roof,
             "order": ("one forward + checks, " + ("" if args.no_extras else "0.3 s idle + warm-up + timed steps (value_cold), parity on the reference's stored outputs, single-launch measurement (+2 launches of it unmeasured, no idle gap: prewarm_ms of GPU load), ")
-                      + f"{max(args.warmup, len(lanes))} warm-up steps, {args.steps} timed steps, the same steps again with hipEvents"
+                      + f"{max(args.warmup, n_lanes)} warm-up steps, {args.steps} timed steps, the same steps again with hipEvents"
                       + ("" if args.no_extras else ", host-to-host, real-data rate")),
         }
         if world > 1:
@@ -602,12 +621,14 @@ def main():
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
 
-    for lane in lanes:
-        for d in lane[1:]:
-            d.free()
+    if pipe is not None:
+        for lane in lanes:
+            for d in lane[1:]:
+                d.free()
     if rdzv is not None:
         rdzv.barrier("end")
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
     if rdzv is not None:
         rdzv.close()
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "epnn_device_count": (C.c_int, []),
     "epnn_create": (C.c_int, [C.POINTER(EpnnConfig), C.c_int, C.POINTER(_vp)]),
     "epnn_destroy": (C.c_int, [_vp]),
+    "epnn_skip_hw_queues": (C.c_int, [C.c_int, C.c_int]),
     "epnn_set_weights": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "epnn_get_weights": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "epnn_weight_shape": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip]),

@@ -48,6 +48,20 @@ static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, 
 static int create_resources(epnn_handle *h);
 extern "C" int epnn_destroy(epnn_handle *h);
 
+// The HIP runtime maps a process's streams round-robin onto its hardware queues (GPU_MAX_HW_QUEUES of them) in the order the
+// streams are created, and which queues a pipeline's lanes sit on matters: eight lanes on every other queue run the bench batch at
+// 220 M atoms/s, on eight consecutive queues at 213 M (round 4, measured both ways several times).  A caller that builds several
+// handles can therefore leave queues out between them: n streams are created here and kept until the process ends.
+extern "C" int epnn_skip_hw_queues(int device, int n) {
+    if (n < 0 || n > 64) EPNN_FAIL("epnn_skip_hw_queues: n must be in 0..64");
+    HIPCHK(hipSetDevice(device));
+    for (int k = 0; k < n; ++k) {
+        hipStream_t s;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));      // (never used, never destroyed: it only holds its place)
+    }
+    return 0;
+}
+
 extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out) {
     if (!cfg || !out) EPNN_FAIL("epnn_create: null argument");
     if (cfg->h_dim != EPNN_EDIM || cfg->e_dim != EPNN_EDIM)
@@ -79,7 +93,6 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
 static int create_resources(epnn_handle *h) {
     const epnn_config *cfg = &h->cfg;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_t0));
@@ -832,6 +845,9 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         }
         side_mid = h->opt_wave2 != 0 && (P.pair_wgs > 0 || !P.small_order.empty());     // a lone handle (engine.Pipeline sets 0 on its
                                                                                         // lanes) with a launch to run beside
+        // (the second stream is created when a handle first needs it: every stream takes one of the process's hardware queues,
+        // and a pipeline of many handles wants them for its lanes)
+        if (side_mid && !h->stream2) HIPCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         hipStream_t st = side_mid ? h->stream2 : h->stream;
         if (side_mid) {
             HIPCHK(hipEventRecord(h->ev_fork, h->stream));
@@ -2078,7 +2094,7 @@ extern "C" int epnn_comm_allreduce(epnn_handle *h, double *inout, int32_t n, int
 extern "C" int epnn_debug_large_clocks(epnn_handle *h, unsigned long long *dst, int n) {
     if (!h || !dst || !h->lg_clk.p) EPNN_FAIL("epnn_debug_large_clocks: bad argument");
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(dst, h->lg_clk.p, (size_t)std::min(n, 128) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, h->lg_clk.p, (size_t)std::min(n, 128 + 4 * 1024) * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -99,7 +99,8 @@ struct epnn_handle {
     epnn_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;    // side stream of the tiled path (correction tiles beside the sweep), forked / joined by events
+    hipStream_t stream2 = nullptr;    // side stream of a lone handle (the launch of the 33..64-atom molecules beside the others'), forked / joined by
+                                      // events; created at its first use
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)

@@ -635,7 +635,19 @@ __global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, PairMl
             for (int pt = lo + (int)(threadIdx.x >> 6); pt < hi; pt += 4) lg_pair_tile<false>(L, Mpair, pt, np, nullptr);
         }
     }
+#ifdef EPNN_LG_CLOCKS
+    // development build: shader clock (s_memtime) and 100 MHz clock (s_memrealtime) at the start and the end of this workgroup's
+    // sweep task -- their ratio is the shader clock the sweep ran at, the starts and ends show the launch's ramp and drain
+    unsigned long long c0 = 0, r0 = 0;
+    if (threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     lg_sweep_body(L, w2off, lg_smem, lg_smem + EPNN_LG_JC * 32);
+#ifdef EPNN_LG_CLOCKS
+    if (threadIdx.x == 0 && L.clk && blockIdx.x < 1024) {
+        unsigned long long *o = L.clk + 128 + 4 * (size_t)blockIdx.x;
+        o[0] = c0; o[1] = r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ merged launches of the compact entry
@@ -1373,7 +1385,7 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     L.zp = h->l_zp.as<float>();
     L.S0 = h->l_S0.as<float>();
 #ifdef EPNN_LG_CLOCKS
-    if (h->lg_clk.ensure(128 * 8)) return 1;
+    if (h->lg_clk.ensure((128 + 4 * 1024) * 8)) return 1;
     L.clk = h->lg_clk.as<unsigned long long>();
 #endif
     L.corrA = h->l_corr.as<float>();

@@ -63,6 +63,10 @@ int epnn_device_count(void);
  * EpnnError from make_model / MLP_layer for `layers` != [32, 32].  A model of another width is not run on a slower path. */
 int epnn_create(const epnn_config *cfg, int device, epnn_handle **out);
 int epnn_destroy(epnn_handle *h);
+/* Leaves out `n` of the process's hardware queues: the HIP runtime deals a process's streams onto its hardware queues in the order
+ * they are created (every handle owns one stream), and a pipeline of several handles runs faster with its lanes on every other
+ * queue (engine.Pipeline calls this between two handles; no counterpart in the reference, which runs one model call at a time). */
+int epnn_skip_hw_queues(int device, int n);
 
 /* model.load_weights / layer.set_weights (infer.py:57): one Dense layer of one MLP.
  * which = EPNN_W_MSG (message_fns[t], charge_gn.py:52), EPNN_W_UPD (update_fn, t ignored, charge_gn.py:371),

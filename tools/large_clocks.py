@@ -22,13 +22,15 @@ eng = Engine(nx=9, T=5); eng.set_weights(checkpoint.load_epnn_weights(os.path.jo
 xyz, x, Q, _ = charge_gn.read_xyz(os.path.join(ROOT, "tests/golden/protein/6qlp_capped.xyz"), 9)
 offsets = np.array([0, len(x)], dtype=np.int32); Q = np.array([Q], dtype=np.float32); N = len(x)
 d = [eng.to_device(a) for a in (xyz, x, Q)]; dq = eng.alloc(N * 4)
-for _ in range(5): eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, N)
+nfw = int(sys.argv[sys.argv.index("--forwards") + 1]) if "--forwards" in sys.argv else 5
+for _ in range(nfw): eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, N)
 eng.sync()
 lib = _lib.load()
-buf = (C.c_ulonglong * 128)()
+NB = 128 + 4 * 1024
+buf = (C.c_ulonglong * NB)()
 lib.epnn_debug_large_clocks.restype = C.c_int
 lib.epnn_debug_large_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-assert lib.epnn_debug_large_clocks(eng.h, buf, 128) == 0
+assert lib.epnn_debug_large_clocks(eng.h, buf, NB) == 0
 c = np.array(buf[:], dtype=np.uint64).astype(np.int64)
 print("units of 10 ns from the start of workgroup 0 (the stamps of the LAST launch of each kind in the forward)")
 print("k_lg_gnn_tail: 1 weights / image requested   2 S reduced (partials, slot rows)   3 barrier   4 update MLP done   5 barrier (then the projections)")
@@ -39,3 +41,24 @@ print("k_lg_epn_step: 1 q of both atoms (slot sums of the previous step)   2 G t
 for t in range(5):
     r = c[64 + 8 * t:64 + 8 * t + 8]
     if r[0]: print(f"  step {t}", " ".join(f"{(r[k] - r[0]):6d}" if r[k] else "     -" for k in range(1, 5)))
+
+# k_lg_sweep (the LAST sweep launch of the forward): per workgroup s_memtime / s_memrealtime at the start and the end of its task
+sw = c[128:].reshape(1024, 4)
+sw = sw[sw[:, 0] > 0]
+if len(sw):
+    dt, dr = (sw[:, 2] - sw[:, 0]).astype(float), (sw[:, 3] - sw[:, 1]).astype(float)
+    ghz = dt / np.maximum(dr, 1) * 0.1
+    t0 = sw[:, 1].min()
+    st, en = (sw[:, 1] - t0) * 0.01, (sw[:, 3] - t0) * 0.01
+    print(f"k_lg_sweep, last launch of the forward ({nfw} forwards in a row): {len(sw)} workgroups; shader clock seen by them "
+          f"(s_memtime / s_memrealtime) mean {ghz.mean():.3f} GHz, 5 % .. 95 %: {np.percentile(ghz, 5):.3f} .. {np.percentile(ghz, 95):.3f}")
+    print(f"  task length {dr.mean() * 0.01:.1f} us (min {dr.min() * 0.01:.1f}, max {dr.max() * 0.01:.1f}); starts after the first workgroup's: "
+          f"median {np.median(st):.1f} us, 95 % {np.percentile(st, 95):.1f}, last {st.max():.1f}; ends: first {en.min():.1f} us, median {np.median(en):.1f}, last {en.max():.1f}")
+    # which tasks are the slow ones: 18 tile groups x 28 j-chunks on the protein (block = group * nchunk + chunk)
+    if "--detail" in sys.argv:
+        dur = dr * 0.01
+        nchunk = 28 if len(sw) == 504 else 1
+        g = dur[:len(dur) // nchunk * nchunk].reshape(-1, nchunk)
+        print("  mean task length by tile group:", " ".join(f"{v:.0f}" for v in g.mean(axis=1)))
+        print("  mean task length by j-chunk:   ", " ".join(f"{v:.0f}" for v in g.mean(axis=0)))
+        print("  histogram of task lengths (us):", np.histogram(dur, bins=[0, 30, 60, 75, 80, 85, 90, 95, 100, 110, 200])[0].tolist(), "bins 0,30,60,75,80,85,90,95,100,110+")
