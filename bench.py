@@ -190,6 +190,46 @@ def collect_pmc(args):
     return out
 
 
+def real_data_rate(depth, device=0):
+    """`--real-only` (child of the main run): atoms/s on the reference's 871-system validation split, N = 41, device-resident,
+    `depth` batches in flight.  Prints one JSON object."""
+    import tarfile
+    import tempfile
+    from epnn_amd import charge_gn, checkpoint, synth
+    from epnn_amd.engine import Pipeline
+    gdir = os.path.join(ROOT, "tests", "golden")
+    names = [str(nm) for nm in np.load(os.path.join(gdir, "val_names.npy"), allow_pickle=True)]
+    with tempfile.TemporaryDirectory() as tmp:
+        with tarfile.open(os.path.join(gdir, "mixed_val.tar.gz")) as tf:
+            tf.extractall(tmp)
+        mols = [charge_gn.read_xyz(os.path.join(tmp, "mixed_val", nm + ".xyz"), 9) for nm in names]
+    v_off = np.zeros(len(mols) + 1, np.int32)
+    v_off[1:] = np.cumsum([len(m[1]) for m in mols])
+    v_xyz, v_x = np.concatenate([m[0] for m in mols]), np.concatenate([m[1] for m in mols])
+    v_Q = np.array([m[2] for m in mols], np.float32)
+    rpipe = Pipeline(depth=depth, nx=9, T=5, device=device)
+    rpipe.set_weights(checkpoint.load_epnn_weights(os.path.join(ROOT, "models", "decay_model_weights")))
+    rpipe.set_option("wave2", 0)
+    vl = [(e, e.to_device(v_xyz), e.to_device(v_x), e.to_device(v_Q), e.alloc(int(v_off[-1]) * 4)) for e in rpipe.engines]
+    for k in range(60 * len(vl)):                           # ~50 ms of load first (clocks)
+        e, a_, b_, c_, d_ = vl[k % len(vl)]
+        e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
+    rpipe.sync()
+    nrep = 50 * len(vl)
+    t1 = time.perf_counter()
+    for k in range(nrep):
+        e, a_, b_, c_, d_ = vl[k % len(vl)]
+        e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
+    rpipe.sync()
+    v_dt = (time.perf_counter() - t1) / nrep
+    v_flops = synth.algorithmic_flops(np.diff(v_off), int(vl[0][0].last_stats()[0]))
+    rpipe.close()
+    print(json.dumps({"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
+                      "algorithmic_gflop_per_batch": v_flops / 1e9, "frac": v_flops / v_dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                      "workload": f"the reference's {len(mols)}-system validation split of `mixed` (3..38 atoms, {int(v_off[-1])} atoms), "
+                                  f"N = 41, device-resident, {len(vl)} batches in flight, in a process of its own"}))
+
+
 def committed_pmc(workload):
     try:
         with open(PMC_JSON) as f:
@@ -217,9 +257,14 @@ def main():
                     "that ends with two of six lanes busy pays for it: K = 20 runs at 184 M atoms/s five deep, 175 M six deep)")
     ap.add_argument("--sleep-ms", type=float, default=0.0, help="(experiment, profiles/r02_warm_sweep.txt) idle time between the warm-up steps and the timed region; negative: the host busy-waits instead of sleeping")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (developer switch)")
-    ap.add_argument("--real-depth", type=int, default=8, help="batches in flight of the real-data measurement")
+    ap.add_argument("--real-depth", type=int, default=14, help="batches in flight of the real-data measurement")
+    ap.add_argument("--real-only", action="store_true", help="(child of the main run) only the real-data rate, as one JSON object")
     args = ap.parse_args()
 
+    if args.real_only:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        real_data_rate(args.real_depth, int(os.environ.get("LOCAL_RANK", "0")))
+        return
     if args.depth <= 0:
         args.depth = 8 if args.steps >= 200 else next((d for d in (5, 4, 6) if args.steps % d == 0), 6)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -519,42 +564,25 @@ def main():
 
     if real is not None:
         # (4) the real-data rate: the validation batch of (1), device-resident, through every lane of the pipeline
-        # Eight batches in flight whatever the timed region used: the 22 systems of 33..38 atoms of this batch run as a launch of
+        # Fourteen batches in flight whatever the timed region used: the 22 systems of 33..38 atoms of this batch run as a launch of
         # their own (three wavefronts each, 0.12 ms of latency on 66 wavefronts) in front of the lane's main launch, so a lane is
-        # busy ~0.4 ms per batch with little work in a third of it and the LANES, not the machine, limit the rate (round 4: the
-        # 849 systems of <= 32 atoms alone run at the synthetic batch's rate at any depth; with the 22 others 147 / 171 M atoms/s
-        # at 5 / 8 lanes; a second stream per lane and a merged launch were both measured slower)
-        v_off, v_xyz, v_x, v_Q = real
-        for lane in lanes:                                  # the timed region's lanes give their hardware queues back first
+        # busy ~0.4 ms per batch with little work in a third of it and the LANES, not the machine, limit the rate (round 4, fresh
+        # process: 176 / 184 / 192 M atoms/s at 8 / 12 / 14 lanes; the 849 systems of <= 32 atoms alone run at the synthetic batch's
+        # rate at any depth; a second stream per lane and a merged launch were both measured slower).
+        # It runs in a CHILD process (this script with --real-only), after this process has closed its own lanes: which hardware
+        # queues a pipeline's lanes land on depends on every stream the process created before (129 .. 175 M atoms/s for the same
+        # eight lanes behind different histories), a fresh process has a defined one.
+        for lane in lanes:
             for d in lane[1:]:
                 d.free()
         pipe.close()
         pipe = None
-        rpipe = Pipeline(depth=args.real_depth, nx=9, T=5, device=device)
-        rpipe.set_weights(weights)
-        rpipe.set_option("wave2", 0)
-        vl = [(e, e.to_device(v_xyz), e.to_device(v_x), e.to_device(v_Q), e.alloc(int(v_off[-1]) * 4)) for e in rpipe.engines]
-        for k in range(30 * len(vl)):                       # ~20 ms of load first (clocks)
-            e, a_, b_, c_, d_ = vl[k % len(vl)]
-            e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
-        rpipe.sync()
-        nrep = 25 * len(vl)
-        t1 = time.perf_counter()
-        for k in range(nrep):
-            e, a_, b_, c_, d_ = vl[k % len(vl)]
-            e.forward_xyz_dev(v_off, a_, b_, c_, d_, 41)
-        rpipe.sync()
-        v_dt = (time.perf_counter() - t1) / nrep
-        v_flops = synth.algorithmic_flops(np.diff(v_off), int(vl[0][0].last_stats()[0]))
-        for lane in vl:
-            for d in lane[1:]:
-                d.free()
-        rpipe.close()
-        extras["real_data"] = {"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
-                               "algorithmic_gflop_per_batch": v_flops / 1e9,
-                               "frac": v_flops / v_dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                               "workload": f"the reference's {len(mols)}-system validation split of `mixed` (3..38 atoms, "
-                                           f"{int(v_off[-1])} atoms), N = 41, device-resident, {len(vl)} batches in flight"}
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--real-only", "--real-depth", str(args.real_depth)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        try:
+            extras["real_data"] = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
+        except (IndexError, ValueError):
+            print(f"[bench] real-data child failed: {child.stderr[-400:]}", file=sys.stderr)
 
     if rank == 0:
         k_ms = float(stage[:, 1].mean())                   # duration of one launch (hipEvents on its stream)

@@ -1,7 +1,11 @@
-// Microbenchmark: what an instruction costs beside f32 MFMAs once the chip is POWER-limited (round 4 finding: under dense
-// v_mfma_f32_16x16x4_f32 work MI355X clocks down to ~2.0-2.2 GHz; at that point throughput follows energy per tile, not
-// cycles per tile).  One tile = 16 MFMAs (two interleaved accumulation chains) + N extra instructions of ONE class, all 256
-// CUs, two wavefronts per SIMD.  Prints MFMA TFLOP/s, cycles per tile and the shader clock (s_memtime / s_memrealtime).
+// Microbenchmark: what an instruction costs in SIMD time beside f32 MFMAs (round 4).  One tile = 16 v_mfma_f32_16x16x4_f32 (two
+// interleaved accumulation chains) + N extra instructions of ONE class, all 256 CUs, two wavefronts per SIMD.  Prints the MFMA
+// rate (hipEvent wall time: it carries ~0.4 ms of launch overhead per kernel, so compare rows, not absolute TFLOP/s), the cycles
+// of SIMD time per tile (s_memtime inside the kernel: the reliable column) and the shader clock the wavefronts saw
+// (s_memtime / s_memrealtime).  Findings: an independent VALU instruction costs 1.4-2.6 cycles beside the matrix pipe, a
+// ds_read_b128 whose data is used a tile later ~27, a global load (any width) ~27 per 256 bytes when the window misses the L1;
+// loads that are waited for at once cost their latency.  In the fused kernel every vector-memory instruction saved was worth
+// more than ten VALU instructions (weights as dwordx4: 1160 -> 348 loads per molecule, +1.5 % atoms/s).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
