@@ -475,6 +475,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    t_enq = time.perf_counter() - t0                        # (host time of the K calls; the rest of dt is the wait for the GPU)
     barrier()
     dt = time.perf_counter() - t0
     # Kernel durations for the roofline: the same steps again (up to 600), right after the timed region, this time with
@@ -623,6 +624,7 @@ def main():
             "ms_per_step": dt_max / args.steps * 1e3,
             "value_cold": (atoms_total * args.steps / cold_max) if cold_max else None,
             "prewarm_ms": None if args.no_extras else prewarm_ms,
+            "enqueue_ms": t_enq * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -134,6 +134,49 @@ static int create_resources(epnn_handle *h) {
         }
         h->dsafe = lo;
     }
+    {   // Beyond dsafe the near flag (float)(C(D) exp(-eta min_k (D - mu_k)^2)) > tol (charge_gn.py:90-94 on get_init_edges' rows) is a
+        // function of the ONE variable D: the fused kernels' own front-end does not evaluate cos / exp per pair, it counts how many
+        // of the function's flips lie below D.  The flips are found here, in float64 with the reference's expression: a scan of
+        // (dsafe, cutoff) in 20 000 steps, every change bisected down to two adjacent doubles (flip = the last D of the old value).
+        // With the reference's parameters there is exactly one, 6.0e-3 below the cutoff.
+        const double eta = (double)cfg->eta;
+        const float tol = cfg->near_tol;
+        const int E = cfg->e_dim;
+        auto nearf = [&](double D) -> bool {
+            if (D >= stop) return false;
+            const double C = (cos(3.141592653589793 * (D - 0.0) / stop) + 1.0) / 2.0;
+            double best = 1e300;
+            for (int k = 0; k < E; ++k) best = std::min(best, (D - mu[k]) * (D - mu[k]));
+            return (float)(C * exp(-eta * best)) > tol;
+        };
+        std::vector<double> flips;
+        bool prev = true;                                   // (every D <= dsafe is near by the bound above)
+        double xprev = h->dsafe;
+        if (!nearf(xprev)) { flips.push_back(xprev); prev = false; }
+        const int M = 20000;
+        for (int i = 1; i <= M && flips.size() <= EPNN_NFLIP_MAX; ++i) {
+            const double xi = i == M ? stop : h->dsafe + (stop - h->dsafe) * (double)i / (double)M;
+            const bool cur = nearf(xi);
+            if (cur != prev) {
+                double a = xprev, b = xi;
+                for (;;) {
+                    const double mid = a + (b - a) * 0.5;
+                    if (!(mid > a && mid < b)) break;
+                    if (nearf(mid) == prev) a = mid; else b = mid;
+                }
+                flips.push_back(a);
+                prev = cur;
+            }
+            xprev = xi;
+        }
+        if (flips.size() > EPNN_NFLIP_MAX) h->edge_res = 1.0;      // (needle-like Gaussians: the in-kernel front-end is not used at all)
+        else {
+            h->nflip = (int)flips.size();
+            flips.resize(EPNN_NFLIP_MAX, 1e300);
+            if (h->d_flip.ensure(flips.size() * sizeof(double))) return 1;
+            HIPCHK(hipMemcpy(h->d_flip.p, flips.data(), flips.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     return 0;
 }
 
@@ -141,7 +184,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_mu_ex, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
+    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_flip, &h->d_mu_ex, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_train, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
@@ -816,16 +859,13 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     A.stamps = h->l_nm.as<unsigned long long>();
 #endif
     A.xyz = S.d_xyz;
-    A.mu = h->d_mu.as<double>();
-    A.cutoff = (double)h->cfg.cutoff;
-    A.eta = (double)h->cfg.eta;
-    A.cut2 = cutoff_squared(A.cutoff);       // D < cutoff decided without the sqrt
-    A.tol = h->cfg.near_tol;
+    A.cut2 = cutoff_squared((double)h->cfg.cutoff);       // D < cutoff decided without the sqrt
     A.host_status = h->h_status;          // pinned, device-visible
     A.etab = h->d_etab.as<float>();
     A.tab_n = EPNN_ETAB_N;
-    A.tab_inv_h = (double)(EPNN_ETAB_N - 1) / A.cutoff;
-    A.dsafe = h->dsafe;
+    A.tab_inv_h = (double)(EPNN_ETAB_N - 1) / (double)h->cfg.cutoff;
+    A.flip = h->d_flip.as<double>();
+    A.nflip = h->nflip;
     const dim3 grid((unsigned)P.small_order.size());
     const WaveIndex &X = h->wvidx;
     A.total_waves = (int)P.fused_count();          // reports to the hand-off: one per molecule

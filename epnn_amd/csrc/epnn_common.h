@@ -66,6 +66,7 @@ struct WeightIndex {
 #define EPNN_XS 4            // K-steps of the xq block: nx + 3 <= 16
 #define EPNN_ER 16           // dimension of the edge-feature subspace used by the fused kernel's own front-end
 #define EPNN_ETAB_N 2049     // grid points of the table of B^T e(D) over [0, cutoff]
+#define EPNN_NFLIP_MAX 128   // changes of the near flag as a function of the distance beyond dsafe that the fused front-end can hold
 #define EPNN_DST 33          // LDS row stride (floats) of the per-molecule charge-transfer matrix
 struct WaveGnnPack {           // GNN step t
     int we;               // [2][12][64]  e order       We_t

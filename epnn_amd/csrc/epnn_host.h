@@ -116,6 +116,8 @@ struct epnn_handle {
     double edge_res = 1.0;            // its residual max |e - B B^T e| over D in [0, cutoff]
     DevBuf d_wpack;
     DevBuf d_mu;
+    DevBuf d_flip;                    // [EPNN_NFLIP_MAX] the near flag's flips beyond dsafe (epnn_create), padded with 1e300
+    int nflip = 0;
     // plan + workspace
     Plan plan;
     DevBuf d_mu_ex;                   // Gaussian centres of an epnn_edges_ex call with its own num / cutoff

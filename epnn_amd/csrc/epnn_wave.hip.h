@@ -54,13 +54,12 @@ struct WaveArgs {
     int lds_words;         // LDS budget of one wave (floats)
     // in-kernel front-end (FRONT): the wave builds its molecule's near-pair list itself (get_init_edges, charge_gn.py:122-163)
     const float *xyz;      // [A][3]
-    const double *mu;      // [48]
-    double cutoff, eta;
     double cut2;           // smallest float64 t with sqrt(t) >= cutoff: D < cutoff  <=>  D*D (before the sqrt) < cut2
-    float tol;
     float *pt;             // [pcap][16] in-kernel front-end: the pairs' edge features in the 16-dimensional basis (B^T e)
     const float *etab;     // [tab_n][16] B^T e(D) on the grid D = i / tab_inv_h, i = 0 .. tab_n - 1 (last point = cutoff)
-    double tab_inv_h, dsafe;
+    double tab_inv_h;
+    const double *flip;    // [nflip] distances beyond dsafe at which the near flag changes (epnn_create): near = even number of them below D
+    int nflip;
     int tab_n;
     int total_waves;       // wavefronts of this forward over all its launches of this kernel (the last one to finish hands off)
     int prio_n;            // molecules with at least this many atoms run at raised wave priority (0: off), see k_wave_forward
@@ -79,6 +78,11 @@ struct WaveArgs {
     } while (0)
 #else
 #define WAVE_STAMP() do { } while (0)
+#endif
+#ifdef EPNN_STAMPS_INIT            // (with EPNN_STAMPS) four more stamps inside the front-end: tools/wave_clocks.py --init-detail
+#define WAVE_STAMP_I() WAVE_STAMP()
+#else
+#define WAVE_STAMP_I() do { } while (0)
 #endif
 
 // order LDS / global traffic between lanes of the wave (the compiler sees no dependence between different lanes)
@@ -102,6 +106,20 @@ __device__ __forceinline__ double wave_dist(const double *xs, int i, int j) {
 __device__ __forceinline__ double wave_dist2(const double *xs, int i, int j) {
     const double dx = xs[3 * j + 0] - xs[3 * i + 0], dy = xs[3 * j + 1] - xs[3 * i + 1], dz = xs[3 * j + 2] - xs[3 * i + 2];
     return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// the same with the partner's coordinates already in registers (cx, cy, cz = atom j)
+__device__ __forceinline__ double wave_dist2c(const double *xs, int i, double cx, double cy, double cz) {
+    const double dx = cx - xs[3 * i + 0], dy = cy - xs[3 * i + 1], dz = cz - xs[3 * i + 2];
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+// Near flag of a pair at distance D < cutoff (charge_gn.py:90-94 applied to get_init_edges' rows: max_k e_k > tol).  As a function
+// of D it is 1 up to dsafe and changes `nflip` times beyond (normally once, 6e-3 below the cutoff): epnn_create found the changes
+// with the reference's float64 expression, float32 cast included, so no cos / exp is evaluated per pair here.
+__device__ __forceinline__ bool wave_near(const double *flip, int nflip, double D) {
+    int cnt = 0;
+    for (int k = 0; k < nflip; ++k) cnt += D > flip[k] ? 1 : 0;
+    return !(cnt & 1);
 }
 
 #ifndef EPNN_WAVES_PER_SIMD
@@ -217,6 +235,41 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     const bool cat0 = n16 < n, cat1 = two && copy1 < C1;
     const bool own1 = cat1 && copy1 == 0;                   // the copy that stores the atom's rows / results
 
+    // ---- the molecule's inputs, requested in ONE round trip behind the record (coordinates, features, charge, mask, h): every lane
+    //      loads from clamped rows and selects afterwards -- a load under a condition is a branch with its own wait, and with the
+    //      consumers right behind their loads this part of the front-end was four dependent round trips.  The per-column
+    //      registers are assembled from these values where the front-end ends.
+    const int ia0 = a0 + min(n16, n - 1), ia1 = a0 + (two ? col1 : 0);
+    float cxyz[3] = {0.f, 0.f, 0.f};
+    if (FRONT) {
+        const float *xr = A.xyz + 3 * (size_t)(a0 + min(c, n - 1));
+        cxyz[0] = xr[0]; cxyz[1] = xr[1]; cxyz[2] = xr[2];
+    }
+    float nmv0 = 1.f, nmv1 = 1.f, qa0, qa1, Qb = 0.f;
+    if (A.nm_in) { nmv0 = A.nm_in[ia0]; nmv1 = A.nm_in[ia1]; }
+    if (A.q_in) { qa0 = A.q_in[ia0]; qa1 = A.q_in[ia1]; }
+    else Qb = A.Q[b];
+    float xv0[EPNN_XS], xv1[EPNN_XS];
+#pragma unroll
+    for (int s = 0; s < EPNN_XS; ++s) {
+        const int xi = min(max(4 * s + q - 1, 0), A.nx - 1);
+        xv0[s] = A.xin[(size_t)ia0 * A.nx + xi];
+        xv1[s] = A.xin[(size_t)ia1 * A.nx + xi];
+    }
+    f32x4 hk0[3], hk1[3];                                  // h: features 16*rb + 4*q + r of the two columns
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb) { hk0[rb] = w16_splat(0.f); hk1[rb] = w16_splat(0.f); }
+    const bool have_h = A.h_in != nullptr;
+    if (have_h) {
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const f32x4 v0 = w16_ld(A.h_in + (size_t)ia0 * EPNN_EDIM + 16 * rb + 4 * q), v1 = w16_ld(A.h_in + (size_t)ia1 * EPNN_EDIM + 16 * rb + 4 * q);
+            if (cat0) hk0[rb] = v0;
+            if (cat1) hk1[rb] = v1;
+        }
+    }
+    WAVE_FENCE();
+
     // ---- LDS layout of THIS molecule inside the wave's fixed budget.  The two stacks need different tables, and the G
     //      rows are recomputed by every step anyway, so each stack has its own layout behind the common part:
     //        common  eij [pairs] | R [n][PST]
@@ -252,45 +305,13 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     double *xs = reinterpret_cast<double *>(Rl);           // [n][3] float32 coordinates promoted like SciPy does (R rows come later)
     if (FRONT) {
         if (hh == 0 && c < n) {
-            xs[3 * c + 0] = (double)A.xyz[3 * (size_t)(a0 + c) + 0];
-            xs[3 * c + 1] = (double)A.xyz[3 * (size_t)(a0 + c) + 1];
-            xs[3 * c + 2] = (double)A.xyz[3 * (size_t)(a0 + c) + 2];
+            xs[3 * c + 0] = (double)cxyz[0];
+            xs[3 * c + 1] = (double)cxyz[1];
+            xs[3 * c + 2] = (double)cxyz[2];
         }
         wave_sync_lds();
+        WAVE_STAMP_I();   // coordinates in LDS
     }
-    // ---- per-column registers (cb = 0: column n16, cb = 1: column 16 + n16)
-    const float nm0 = cat0 ? (A.nm_in ? A.nm_in[a0 + n16] : 1.f) : 0.f;
-    const float nm1 = cat1 ? (A.nm_in ? A.nm_in[a0 + col1] : 1.f) : 0.f;
-    float xq0[EPNN_XS], xq1[EPNN_XS];
-    {
-        const float qv0 = cat0 ? (A.q_in ? A.q_in[a0 + n16] : A.Q[b] / (float)n) : 0.f;   // charge_gn.py:337-338
-        const float qv1 = cat1 ? (A.q_in ? A.q_in[a0 + col1] : A.Q[b] / (float)n) : 0.f;
-#pragma unroll
-        for (int s = 0; s < EPNN_XS; ++s) {
-            const int phi = 4 * s + q;
-            float v0 = 0.f, v1 = 0.f;
-            if (phi == 0) { v0 = nm0; v1 = nm1; }
-            else if (phi <= nx) {
-                if (cat0) v0 = A.xin[(size_t)(a0 + n16) * nx + phi - 1];
-                if (cat1) v1 = A.xin[(size_t)(a0 + col1) * nx + phi - 1];
-            } else if (phi == nx + 1) { v0 = qv0; v1 = qv1; }
-            else if (phi == nx + 2) { v0 = cat0 ? 1.f : 0.f; v1 = cat1 ? 1.f : 0.f; }
-            xq0[s] = v0;
-            xq1[s] = v1;
-        }
-    }
-    f32x4 hk0[3], hk1[3];                                  // h: features 16*rb + 4*q + r of the two columns
-#pragma unroll
-    for (int rb = 0; rb < 3; ++rb) { hk0[rb] = w16_splat(0.f); hk1[rb] = w16_splat(0.f); }
-    const bool have_h = A.h_in != nullptr;
-    if (have_h) {
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-            if (cat0) hk0[rb] = w16_ld(A.h_in + (size_t)(a0 + n16) * EPNN_EDIM + 16 * rb + 4 * q);
-            if (cat1) hk1[rb] = w16_ld(A.h_in + (size_t)(a0 + col1) * EPNN_EDIM + 16 * rb + 4 * q);
-        }
-    }
-
     // Edge operand of the G products.  Pair lists from outside carry arbitrary e rows: K = 48, lane (q, n16) takes channels
     // 12q..12q+11 of its pair.  The in-kernel front-end knows its e rows are Gaussians of a distance, which live in a
     // 16-dimensional subspace to 5e-10 (epnn_api.hip edge_basis): it projects every pair once (pt = B^T e) and all 2T
@@ -335,20 +356,32 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         for (int i = lane; i < (n * NPM + 1) >> 1; i += 64) reinterpret_cast<unsigned *>(pm)[i] = zent | zent << 16;
     wave_sync_lds();
     if (FRONT) {
+        WAVE_STAMP_I();   // per-atom inputs requested, pair map cleared
         // ---- slots in row-major order (rows i0, i0+1 per step; the lower row's pairs first)
         int base = 0;
-        for (int i0 = 0; i0 + 1 < n; i0 += 2) {
-            const int i = i0 + hh;
-            const bool near = c > i && c < n && wave_dist2(xs, i, c) < A.cut2;
-            const unsigned long long bal = __ballot(near);
-            const unsigned lo = (unsigned)bal, hi = (unsigned)(bal >> 32);
-            if (near) {
-                const int slot = base + (hh ? __popc(lo) : 0) + __popc((hh ? hi : lo) & ((1u << c) - 1u));
-                eij[slot] = (unsigned short)(i | (c << 8));
-                pm[c * NPM + i] = pm_ent(slot);                        // e is symmetric: both directions share the row
-                pm[i * NPM + c] = pm_ent(slot);
+        const double cx = (double)cxyz[0], cy = (double)cxyz[1], cz = (double)cxyz[2];   // this lane's partner c
+        // (four rows per trip, two per half-wave: the two distance chains overlap; rows beyond the last pair of rows give no pairs)
+        for (int i0 = 0; i0 + 1 < n; i0 += 4) {
+            const int iA = i0 + hh, iB = min(i0 + 2 + hh, n - 1);
+            const double dA = wave_dist2c(xs, iA, cx, cy, cz), dB = wave_dist2c(xs, iB, cx, cy, cz);
+            const bool nearA = c > iA && c < n && dA < A.cut2;
+            const bool nearB = i0 + 3 < n && c > iB && c < n && dB < A.cut2;
+            const unsigned long long balA = __ballot(nearA), balB = __ballot(nearB);
+            const unsigned loA = (unsigned)balA, hiA = (unsigned)(balA >> 32), loB = (unsigned)balB, hiB = (unsigned)(balB >> 32);
+            const int baseB = base + __popc(loA) + __popc(hiA);
+            if (nearA) {
+                const int slot = base + (hh ? __popc(loA) : 0) + __popc((hh ? hiA : loA) & ((1u << c) - 1u));
+                eij[slot] = (unsigned short)(iA | (c << 8));
+                pm[c * NPM + iA] = pm_ent(slot);                       // e is symmetric: both directions share the row
+                pm[iA * NPM + c] = pm_ent(slot);
             }
-            base += __popc(lo) + __popc(hi);
+            if (nearB) {
+                const int slot = baseB + (hh ? __popc(loB) : 0) + __popc((hh ? hiB : loB) & ((1u << c) - 1u));
+                eij[slot] = (unsigned short)(iB | (c << 8));
+                pm[c * NPM + iB] = pm_ent(slot);
+                pm[iB * NPM + c] = pm_ent(slot);
+            }
+            base = baseB + __popc(loB) + __popc(hiB);
         }
         np = base;
         glds = min(np, grows_g);                            // the in-kernel front-end always runs both stacks: GNN first
@@ -357,29 +390,16 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         // above the G rows AND above the EPN stack's tables, so that the rows survive the change of layout
         ptl = min(np, max(0, A.lds_words - max(o_gg + (glds + 1) * EPNN_PST, o_x + n * (EPNN_PST + EPNN_DST))) / EPNN_ER);
         wave_sync_lds();
+        WAVE_STAMP_I();   // pair slots
         // ---- edge coefficients of every pair, one lane per pair: pt[pair] = B^T e(D), the 16 coordinates of the pair's Gaussian
         //      features (charge_gn.py:148-161) in the edge basis.  They are smooth functions of the one variable D: cubic
         //      Lagrange interpolation in a table of 4097 points over [0, cutoff] (built in float64 by epnn_create, error
-        //      < 1e-9, part of epnn_edge_basis_residual).  The near flag max_k e_k > tol (charge_gn.py:90-94) is 1 up to
-        //      dsafe (where a lower bound of max_k e_k is already > 2 tol) and evaluated exactly, float32 cast included, beyond it.
-        const double pi_d = 3.141592653589793;
-        const double mu0 = A.mu[0], dmu = (A.mu[EPNN_EDIM - 1] - A.mu[0]) / (double)(EPNN_EDIM - 1);
+        //      < 1e-9, part of epnn_edge_basis_residual).  The near flag max_k e_k > tol (charge_gn.py:90-94): wave_near.
         for (int s0 = 0; s0 < np; s0 += 64) {
             if (s0 + lane < np) {
                 const int ij = eij[s0 + lane];
                 const double D = wave_dist(xs, ij & 0xFF, ij >> 8);
-                float w = 1.0f;
-                if (D > A.dsafe) {
-                    double C = (cos(pi_d * (D - 0.0) / A.cutoff) + 1.0) / 2.0;
-                    const int kb = min(EPNN_EDIM - 1, max(0, (int)((D - mu0) / dmu + 0.5)));
-                    double best = 1e300;
-                    for (int k = max(0, kb - 1); k <= min(EPNN_EDIM - 1, kb + 1); ++k) {
-                        const double d = D - A.mu[k];
-                        best = d * d < best ? d * d : best;
-                    }
-                    w = (float)(C * exp(-A.eta * best)) > A.tol ? 1.0f : 0.0f;
-                }
-                if (w != 0.f) eij[s0 + lane] = (unsigned short)(ij | 0x80);   // the near flag (charge_gn.py:90-94) rides in the pair's record
+                if (wave_near(A.flip, A.nflip, D)) eij[s0 + lane] = (unsigned short)(ij | 0x80);   // the near flag (charge_gn.py:90-94) rides in the pair's record
                 const double tt = D * A.tab_inv_h;
                 const int i0 = min(max((int)tt - 1, 0), A.tab_n - 4);
                 const float u = (float)(tt - (double)i0);                    // position among the nodes i0 .. i0+3, normally in [1, 2)
@@ -387,16 +407,30 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 const float w0 = -(um1 * um2 * um3) * (1.f / 6.f), w1 = (u * um2 * um3) * 0.5f;
                 const float w2 = -(u * um1 * um3) * 0.5f, w3 = (u * um1 * um2) * (1.f / 6.f);
                 const float *trow = A.etab + (size_t)i0 * EPNN_ER;
-                float *prow = s0 + lane < ptl ? sm + A.lds_words - (size_t)(s0 + lane + 1) * EPNN_ER : A.pt + (size_t)(p0 + s0 + lane) * EPNN_ER;
+                f32x4 tv[4][EPNN_ER / 4];                                    // the four nodes' rows: sixteen requests, ONE round trip
 #pragma unroll
-                for (int g = 0; g < EPNN_ER / 4; ++g) {
-                    const f32x4 v = w0 * w16_ld(trow + 4 * g) + w1 * w16_ld(trow + EPNN_ER + 4 * g) +
-                                    w2 * w16_ld(trow + 2 * EPNN_ER + 4 * g) + w3 * w16_ld(trow + 3 * EPNN_ER + 4 * g);
-                    w16_st(prow + 4 * g, v);
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int g = 0; g < EPNN_ER / 4; ++g) tv[k][g] = w16_ld(trow + k * EPNN_ER + 4 * g);
+                f32x4 v[EPNN_ER / 4];
+#pragma unroll
+                for (int g = 0; g < EPNN_ER / 4; ++g) v[g] = w0 * tv[0][g] + w1 * tv[1][g] + w2 * tv[2][g] + w3 * tv[3][g];
+                // two separate predicated stores (LDS / HBM): through one merged pointer they become flat stores
+                if (s0 + lane < ptl) {
+                    float *prow = sm + A.lds_words - (size_t)(s0 + lane + 1) * EPNN_ER;
+#pragma unroll
+                    for (int g = 0; g < EPNN_ER / 4; ++g) w16_st(prow + 4 * g, v[g]);
+                }
+                asm volatile("" ::: "memory");
+                if (s0 + lane >= ptl) {
+                    float *prow = A.pt + (size_t)(p0 + s0 + lane) * EPNN_ER;
+#pragma unroll
+                    for (int g = 0; g < EPNN_ER / 4; ++g) w16_st(prow + 4 * g, v[g]);
                 }
             }
         }
         wave_sync_all();
+        WAVE_STAMP_I();   // edge coordinates
         if (ngt > 0) load_e(0, ge0, ge1);
     } else {
         if (GNN)
@@ -414,6 +448,24 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     if (GNN)
         for (int i = lane; i < EPNN_PST; i += 64) Gl[i] = 0.f;                          // the sweep's zero row
     wave_sync_lds();
+    // ---- per-column registers (cb = 0: column n16, cb = 1: column 16 + n16) from the values requested at the top
+    const float nm0 = cat0 ? nmv0 : 0.f, nm1 = cat1 ? nmv1 : 0.f;
+    float xq0[EPNN_XS], xq1[EPNN_XS];
+    {
+        if (!A.q_in) qa0 = qa1 = Qb / (float)n;                                            // charge_gn.py:337-338
+        const float qv0 = cat0 ? qa0 : 0.f, qv1 = cat1 ? qa1 : 0.f;
+#pragma unroll
+        for (int s = 0; s < EPNN_XS; ++s) {
+            const int phi = 4 * s + q;
+            float v0 = 0.f, v1 = 0.f;
+            if (phi == 0) { v0 = nm0; v1 = nm1; }
+            else if (phi <= nx) { v0 = cat0 ? xv0[s] : 0.f; v1 = cat1 ? xv1[s] : 0.f; }
+            else if (phi == nx + 1) { v0 = qv0; v1 = qv1; }
+            else if (phi == nx + 2) { v0 = cat0 ? 1.f : 0.f; v1 = cat1 ? 1.f : 0.f; }
+            xq0[s] = v0;
+            xq1[s] = v1;
+        }
+    }
 
     WAVE_STAMP();   // init done
     const float Nf = (float)A.N, padw = (float)(A.N - n);

@@ -199,23 +199,11 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
         ngt = (np + 31) >> 5;
         wave_sync_lds();
         // ---- edge coefficients of every pair, one lane per pair (see k_wave_forward); the two wavefronts take alternate groups of 64
-        const double pi_d = 3.141592653589793;
-        const double mu0 = A.mu[0], dmu = (A.mu[EPNN_EDIM - 1] - A.mu[0]) / (double)(EPNN_EDIM - 1);
         for (int s0 = 64 * doff; s0 < np; s0 += 64 * dstep) {
             if (s0 + lane < np) {
                 const int ij = eij[s0 + lane];
                 const double D = wave_dist(xs, ij & 0xFF, ij >> 8);
-                float wgt = 1.0f;
-                if (D > A.dsafe) {
-                    double C = (cos(pi_d * (D - 0.0) / A.cutoff) + 1.0) / 2.0;
-                    const int kb = min(EPNN_EDIM - 1, max(0, (int)((D - mu0) / dmu + 0.5)));
-                    double best = 1e300;
-                    for (int k = max(0, kb - 1); k <= min(EPNN_EDIM - 1, kb + 1); ++k) {
-                        const double d = D - A.mu[k];
-                        best = d * d < best ? d * d : best;
-                    }
-                    wgt = (float)(C * exp(-A.eta * best)) > A.tol ? 1.0f : 0.0f;
-                }
+                const float wgt = wave_near(A.flip, A.nflip, D) ? 1.0f : 0.0f;
                 A.pwi[p0 + s0 + lane] = wgt;
                 A.pwj[p0 + s0 + lane] = wgt;
                 const double tt = D * A.tab_inv_h;

@@ -330,7 +330,7 @@ def test_bench_line_of_the_drivers_command(tmp_path):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_cold", "prewarm_ms"):
         assert key in o, key
-    assert 0.5 * o["value"] < o["value_cold"] <= 1.05 * o["value"] and o["prewarm_ms"] > 10     # the cold figure stands beside `value`
+    assert 0.5 * o["value"] < o["value_cold"] <= 1.25 * o["value"] and o["prewarm_ms"] > 10     # the cold figure stands beside `value`
     assert o["n_gpus"] == 1 and o["steps"] == 20 and o["warmup"] == 5 and o["higher_is_better"] is True
     assert o["unit"] == "atoms/s" and o["dtype"] == "f32" and o["data"] == "synthetic" and o["vs_baseline"] is None
     assert o["config"]["workload"] == "qm9_like_b1024_N29" and "model" not in o["config"]

@@ -2,7 +2,7 @@
 """Where the fused kernel's wavefronts spend their cycles: a development build of the library (-DEPNN_STAMPS, built HERE into
 tools/_dev/, never the shipped .so) lets lane 0 of every wavefront of k_wave_forward stamp s_memtime (shader clocks) at its
 phase boundaries.  The bench batch is launched `copies` times over in ONE launch so that every SIMD holds its two wavefronts.
-Usage: python tools/wave_clocks.py [--lib path/to/stamps/build.so] [--copies 4]"""
+Usage: python tools/wave_clocks.py [--lib path/to/stamps/build.so] [--copies 4] [--init-detail]"""
 import ctypes as C
 import os
 import subprocess
@@ -12,14 +12,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-DEV = os.path.join(ROOT, "tools", "_dev", "libepnn_stamps.so")
 args = sys.argv[1:]
+INIT = "--init-detail" in args          # four more stamps inside the front-end (-DEPNN_STAMPS_INIT)
+DEV = os.path.join(ROOT, "tools", "_dev", "libepnn_stamps_init.so" if INIT else "libepnn_stamps.so")
 if "--lib" in args:
     DEV = os.path.abspath(args[args.index("--lib") + 1])
 elif "--build" in args or not os.path.exists(DEV):
     os.makedirs(os.path.dirname(DEV), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-mllvm",
-                    "-amdgpu-mfma-vgpr-form", "-DEPNN_STAMPS", "-shared", "-fPIC", "-o", DEV, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"),
+                    "-amdgpu-mfma-vgpr-form", "-DEPNN_STAMPS"] + (["-DEPNN_STAMPS_INIT"] if INIT else []) + ["-shared", "-fPIC", "-o", DEV, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"),
                     "-L/opt/rocm/lib", "-lrccl"], check=True)
     if "--build" in args:
         sys.exit(0)
@@ -55,6 +56,9 @@ st = np.frombuffer(buf, dtype=np.uint64).reshape(W, 64).astype(np.int64)
 names = ["init (front-end)", "G tiles + projections 0", "sweep 0", "update 0", "G tiles 1", "projections 1", "sweep 1", "update 1",
          "G tiles 2", "projections 2", "GNN steps 2.. + h", "EPN P,R 0", "EPN blocks 0", "charge update 0", "EPN P,R 1", "EPN blocks 1",
          "charge update 1", "EPN steps 2.."]
+if INIT:
+    names = ["init: record, coordinates -> LDS", "init: inputs requested, pair map cleared", "init: pair slots (f64 cutoff compare)",
+             "init: edge coordinates (table)", "init: zero row, first e rows"] + names[1:]
 nst = st[:, 62]
 wn = (st[:, 63] >> 32).astype(int)
 npair = (st[:, 63] & 0xFFFFFFFF).astype(int)
