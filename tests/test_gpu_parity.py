@@ -489,6 +489,34 @@ def test_other_edge_constants_vs_oracle(gpu_engine_factory, val_dir, val_names, 
         assert worst <= TOL
 
 
+@pytest.mark.parametrize("eta,near_tol", [(2.0, 1e-2), (2.0, 0.3), (1.2, 0.05)])
+def test_near_flag_at_other_tolerances_fused_front_end_vs_pair_list(gpu_engine_factory, val_dir, val_names, eta, near_tol):
+    """`near_tol` is a free constructor argument (the reference hard-codes 1e-5, charge_gn.py:89).  The fused kernel's own
+    front-end does not evaluate max_k e_k per pair: epnn_create finds, with the reference's float64 expression, the distances at
+    which the flag changes and the kernel counts how many lie below D.  With a large tolerance the change sits well inside the
+    cutoff (1.9 .. 2.8 A), where QM9 molecules have many pairs: the charges must equal those of the 48-channel front-end,
+    which forms the e rows and takes their maximum like the reference does."""
+    nx, T, N = 9, 3, 33
+    w = random_weights(nx, T, seed=23, scale=0.35)
+    names = [nm for nm in val_names if nm.startswith("dsgdb9nsd")][:40]
+    mols, offsets, xyz, x, Q = load_molecules(val_dir, names, nx)
+    q = []
+    for front in (1, 0):
+        eng = gpu_engine_factory(nx=nx, T=T, eta=eta, near_tol=near_tol)
+        assert float(eng.lib.epnn_edge_basis_residual(eng.h)) < 1e-8      # (otherwise the kernel's own front-end would not run)
+        eng.set_weights(w)
+        eng.set_option("wave_front", front)
+        q.append(eng.forward_xyz(offsets, xyz, x, Q, N=N))
+        assert eng.last_stats()[1] == len(mols)
+    # the same run with the reference's tolerance differs by far more than rounding: the flag matters on this input
+    eng = gpu_engine_factory(nx=nx, T=T, eta=eta)
+    eng.set_weights(w)
+    q_ref_tol = eng.forward_xyz(offsets, xyz, x, Q, N=N)
+    print(f"eta {eta} near_tol {near_tol}: fused vs pair-list front-end {np.abs(q[0] - q[1]).max():.2e}; effect of the tolerance {np.abs(q[0] - q_ref_tol).max():.2e}")
+    assert np.abs(q[0] - q_ref_tol).max() > 1e-3
+    assert np.abs(q[0] - q[1]).max() <= 5e-6
+
+
 _PART_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
