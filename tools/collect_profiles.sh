@@ -27,8 +27,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench20 -- python3 
 stats $OUT/bench20 $OUT/r04_bench20_kernel_stats.csv
 # 4. PMC passes (bench.py --pmc runs them as children before touching the GPU) + the un-profiled lines
 cd $R
-python3 bench.py --steps 20 --warmup 5 > $OUT/r04_bench20_line.json 2> $OUT/pmc.err
-python3 bench.py --pmc > $OUT/r04_bench_line.json 2>> $OUT/pmc.err
+python3 bench.py --pmc > $OUT/r04_bench_line.json 2> $OUT/pmc.err       # (first: it rewrites profiles/r04_pmc_bench.json, which the next line quotes)
+python3 bench.py --steps 20 --warmup 5 > $OUT/r04_bench20_line.json 2>> $OUT/pmc.err
 cp profiles/r04_pmc_bench.json $OUT/ 2>/dev/null
 echo "pmc done"
 cd /tmp
