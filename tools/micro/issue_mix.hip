@@ -12,7 +12,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { BASE, VALU16, PK16, LDS4B, LDS4G, GL4_L1, GL4_L2, GLX4_L2, VALU32, LDS8G, GL16_L2, P_LDS4G, P_GL4_L2, P_GL16_L2, P_GLX4_L2, P_GLX16_L2 };
+enum { BASE, VALU16, PK16, LDS4B, LDS4G, GL4_L1, GL4_L2, GLX4_L2, VALU32, LDS8G, GL16_L2, P_LDS4G, P_GL4_L2, P_GL16_L2, P_GLX4_L2, P_GLX16_L2, DPP16, P_LDS2B, P_LDS4B, P_U16 };
 
 template <int KIND>
 __global__ __launch_bounds__(512) void k_mix(float *out, unsigned long long *cyc, const float *wts, int tiles) {
@@ -48,6 +48,10 @@ __global__ __launch_bounds__(512) void k_mix(float *out, unsigned long long *cyc
                 asm volatile("v_max_f32_e32 %0, %1, %0\n\tv_add_f32_e32 %0, %1, %0" : "+v"(v[s][0]) : "v"(z[s]));
                 asm volatile("v_max_f32_e32 %0, %1, %0\n\tv_add_f32_e32 %0, %1, %0" : "+v"(v[s][1]) : "v"(z[s]));
             }
+            if (KIND == DPP16) {      // the partner's row broadcast out of a register of the lane that owns it: folded into the add
+                v[s][0] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, z[s]), 0x150 + 5, 0xf, 0xf, true));
+                v[s][1] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, z[(s + 1) & 7]), 0x150 + 11, 0xf, 0xf, true));
+            }
             if (KIND == PK16) {
                 asm volatile("v_pk_add_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1" : "+v"(v[s]) : "v"(v[(s + 1) & 7]));
             }
@@ -67,6 +71,18 @@ __global__ __launch_bounds__(512) void k_mix(float *out, unsigned long long *cyc
                 pl[k] = *reinterpret_cast<const f32x4 *>(lds + 4096 + ((row * 36) & 4095 & ~3) + 4 * (lane >> 4));
                 row = (row * 5 + 7) & 127;
             }
+        }
+        if (KIND == P_LDS2B || KIND == P_LDS4B) {
+#pragma unroll
+            for (int k = 0; k < (KIND == P_LDS2B ? 2 : 4); ++k) {
+                la += pl[k];
+                pl[k] = *reinterpret_cast<const f32x4 *>(lds + ((t * 36 + k * 72) & 4095 & ~3) + 4 * (lane >> 4));
+            }
+        }
+        if (KIND == P_U16) {
+            la[0] += pl[0][0];
+            pl[0][0] = (float)reinterpret_cast<const unsigned short *>(lds)[(row * 29 + t) & 8191];
+            row = (row * 5 + 7) & 127;
         }
         if (KIND == P_GL4_L2 || KIND == P_GL16_L2) {
 #pragma unroll
@@ -135,6 +151,10 @@ int main() {
         run<GL4_L2>("+ 4 global_load_dword, 128 KB window (L2)", wts);
         run<GL16_L2>("+ 16 global_load_dword, 128 KB window (L2)", wts);
         run<GLX4_L2>("+ 1 global_load_dwordx4, 128 KB window (L2)", wts);
+        run<DPP16>("+ 16 v_add_f32_dpp row_newbcast", wts);
+        run<P_LDS2B>("+ 2 ds_read_b128, one address per 16 lanes, used a tile later", wts);
+        run<P_LDS4B>("+ 4 ds_read_b128, one address per 16 lanes, used a tile later", wts);
+        run<P_U16>("+ 1 ds_read_u16 per lane, used a tile later", wts);
         run<P_LDS4G>("+ 4 ds_read_b128 a row per lane, used a tile later", wts);
         run<P_GL4_L2>("+ 4 global_load_dword (L2), used a tile later", wts);
         run<P_GL16_L2>("+ 16 global_load_dword (L2), used a tile later", wts);
