@@ -364,9 +364,13 @@ __global__ __launch_bounds__(64) void k_lg_tsweep(LargeArgs L, PairMlpPack M) { 
 // to two waves).  `wA` = the wave's weight fragments (Wi for WHAT & 1, else Wj), already in registers when PRE.
 // GNNP: projections of a GNN step (zp / Nn / Yb are wanted); ZQ: the charge feature reads as 0 and the results go to
 // `oP` / `oR` (the EPN stack's static projections).
-template <int WHAT, bool PRE, bool ZQ, bool PRE2 = false>
+// PREW2: `w2pre` = 16 fragments of W2 + b2[c] in element 16, requested by the caller long before: the zp / Yb chains then start
+// without a round trip of their own.
+__device__ static const float lg_none17[17] = {};
+template <int WHAT, bool PRE, bool ZQ, bool PRE2 = false, bool PREW2 = false>
 __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPack &M, int gnnp, const int4 tl, const float *arow, int lane,
-                                             const float (&wA)[EPNN_KA], float *oP, float *oR, const float *wB = nullptr) {
+                                             const float (&wA)[EPNN_KA], float *oP, float *oR, const float *wB = nullptr,
+                                             const float (&w2pre)[17] = lg_none17) {
     const int c = lane & 31, hh = lane >> 5;
     const int at = tl.x + (c < tl.y ? c : 0);
     const float *wp = L.wpack;
@@ -400,9 +404,9 @@ __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPa
     }
     if ((WHAT & 1) && gnnp) {
         // padded partner: R = 0, G = 0  ->  zp_i = relu(W2^T relu(P_i) + b2); rows = atoms, cols = out
-        f32x16 acc = epnn_splat16(wp[M.b2 + c]);
+        f32x16 acc = epnn_splat16(PREW2 ? w2pre[16] : wp[M.b2 + c]);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = epnn_mfma(fmaxf(accP[s], 0.f), wp[M.w2F + s * 64 + lane], acc);
+        for (int s = 0; s < 16; ++s) acc = epnn_mfma(fmaxf(accP[s], 0.f), PREW2 ? w2pre[s] : wp[M.w2F + s * 64 + lane], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = epnn_kappa(hh, r);
@@ -411,9 +415,9 @@ __device__ __forceinline__ void lg_proj_wave(const LargeArgs &L, const PairMlpPa
     }
     if ((WHAT & 2) && gnnp) {
         // the partner's share of the sweep's second Dense: Yb_j = b2 + W2^T R_j; rows = atoms, cols = out
-        f32x16 acc = epnn_splat16(wp[M.b2 + c]);
+        f32x16 acc = epnn_splat16(PREW2 ? w2pre[16] : wp[M.b2 + c]);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = epnn_mfma(accR[s], wp[M.w2F + s * 64 + lane], acc);
+        for (int s = 0; s < 16; ++s) acc = epnn_mfma(accR[s], PREW2 ? w2pre[s] : wp[M.w2F + s * 64 + lane], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = epnn_kappa(hh, r);
@@ -693,12 +697,15 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
 #pragma unroll
         for (int w = 0; w < 4; ++w) tls[w] = t0 + w < L.natiles ? L.atiles[t0 + w] : make_int4(0, 0, 0, 0);
         // both projections' weight fragments are requested now: they travel while the rows are built
-        float wI[EPNN_KA], wJ[EPNN_KA];
+        float wI[EPNN_KA], wJ[EPNN_KA], w2n[17];
 #pragma unroll
         for (int s = 0; s < EPNN_KA; ++s) {
             wI[s] = L.wpack[M.wiF + s * 64 + lane];
             wJ[s] = L.wpack[M.wjF + s * 64 + lane];
         }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) w2n[s] = L.wpack[M.w2F + s * 64 + lane];
+        w2n[16] = L.wpack[M.b2 + c];
         for (int idx = tid; idx < 4 * 32 * EPNN_AST; idx += 256) sm[idx] = 0.f;
         __syncthreads();
         {   // one thread per atom and half of its inputs (x and q | h), every load of a thread in flight together
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
         if (t0 + wave >= L.natiles) return;
         const int4 tl = L.atiles[t0 + wave];
         const int row = c < tl.y ? c : 0;
-        lg_proj_wave<3, true, false, true>(L, M, 1, tl, sm + (wave * 32 + row) * EPNN_AST + hh * 32, lane, wI, L.P, L.R, wJ);
+        lg_proj_wave<3, true, false, true, true>(L, M, 1, tl, sm + (wave * 32 + row) * EPNN_AST + hh * 32, lane, wI, L.P, L.R, wJ, w2n);
         return;
     }
     blk -= W.tile_wgs;
@@ -881,10 +888,12 @@ __global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin, int
 // sum from `srow` ([32] out-major).  New h goes to `dst` (a full even/odd row; global a_eo, and `dst2` when not null).
 // LATE: only w1 is in registers at entry; the other two layers' fragments are requested here and travel under the first layer's
 // forty MFMAs (the fused tail keeps its registers for the reduction that runs before this).
+// `bs` (optional): the five bias vectors staged by the caller as [cb3p 32 | bu1p 32 | bu2p 32 | bu3p 64] (LDS): read from the
+// weight pack they are three round trips in the middle of a chain of dependent MFMAs.
 template <bool LATE>
 __device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack &U, const float (&w1)[40], float (&w2)[16],
                                                float (&w3)[32], const int4 tl, const float *arow, const float *srow,
-                                               float *dst, float *dst2, int lane) {
+                                               float *dst, float *dst2, int lane, const float *bs = nullptr) {
     const int c = lane & 31, hh = lane >> 5;
     if (LATE) {
         const float *wq = L.wpack;
@@ -903,8 +912,8 @@ __device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack
 #pragma unroll
     for (int s = 0; s < 16; ++s) sv[s] = srow[2 * s + hh];
     float cb[16], b1[16];
-    epnn_ld16(wp + U.cb3p + hh * 16, cb);
-    epnn_ld16(wp + U.bu1p + hh * 16, b1);
+    epnn_ld16(bs ? bs + hh * 16 : wp + U.cb3p + hh * 16, cb);
+    epnn_ld16(bs ? bs + 32 + hh * 16 : wp + U.bu1p + hh * 16, b1);
     const float Nf = (float)L.N;
     f32x16 acc;
 #pragma unroll
@@ -918,7 +927,7 @@ __device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack
     const float nmc = L.nm_in ? L.nm_in[at] : 1.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) u1[r] = fmaxf(nmc * acc[r] + b1[r], 0.f);
-    epnn_ld16(wp + U.bu2p + hh * 16, b2v);
+    epnn_ld16(bs ? bs + 64 + hh * 16 : wp + U.bu2p + hh * 16, b2v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = b2v[r];
 #pragma unroll
@@ -926,8 +935,8 @@ __device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack
     float u2[16], b3a[16], b3b[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) u2[r] = fmaxf(acc[r], 0.f);
-    epnn_ld16(wp + U.bu3p + hh * 16, b3a);
-    epnn_ld16(wp + U.bu3p + 32 + hh * 16, b3b);
+    epnn_ld16(bs ? bs + 96 + hh * 16 : wp + U.bu3p + hh * 16, b3a);
+    epnn_ld16(bs ? bs + 128 + hh * 16 : wp + U.bu3p + 32 + hh * 16, b3b);
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = b3a[r]; o1[r] = b3b[r]; }
@@ -1002,6 +1011,7 @@ struct LgNext {
 __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgNext X, int types) {
     __shared__ __attribute__((aligned(16))) float Ss[32 * EPNN_SST];
     __shared__ __attribute__((aligned(16))) float Ai[32 * EPNN_AST];
+    __shared__ __attribute__((aligned(16))) float Bs[160];     // the update MLP's biases: [cb3p | bu1p | bu2p | bu3p]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
     LG_CLK(16 * X.run, 0);
     const int np = L.row_off[L.A];                               // (looked at below: the loads in between do not depend on the pair list)
@@ -1012,11 +1022,19 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
 #pragma unroll
         for (int s = 0; s < 40; ++s) w1[s] = wp[U.u1F + s * 64 + lane];
     }
+    if (tid >= 352) {                                            // (waves 5..7: nothing else to request)
+        const int k = tid - 352;
+        Bs[k] = wp[(k < 32 ? U.cb3p : k < 64 ? U.bu1p - 32 : k < 96 ? U.bu2p - 64 : U.bu3p - 96) + k];
+    }
     int job = -1;                                                // EPN static projections: job = 2 t + (0: P, 1: R)
+    float w2n[17];                                               // next sweep: W2 fragments + b2[c] for the zp / Yb chains of waves 1 / 2
     if (X.run == 1 && (wave == 1 || wave == 2)) {
         const int off = wave == 1 ? X.M.wiF : X.M.wjF;
 #pragma unroll
         for (int s = 0; s < EPNN_KA; ++s) wA[s] = wp[off + s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) w2n[s] = wp[X.M.w2F + s * 64 + lane];
+        w2n[16] = wp[X.M.b2 + c];
     } else if (X.run == 2 && wave >= 1 && wave - 1 < 2 * L.T) {
         job = wave - 1;
         const PairMlpPack &M = L.wi.pas[job >> 1];
@@ -1043,7 +1061,7 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     if (wave == 0) {
         const int u0 = (L.nx - hh + 1) >> 1;
         lg_update_wave<true>(L, U, w1, w2, w3, tl, Ai + row * EPNN_AST + hh * 32 + u0, Ss + c * EPNN_SST,
-                             L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane);
+                             L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane, Bs);
     }
     LG_CLK(16 * X.run, 4);
     if (!X.run) return;
@@ -1051,8 +1069,8 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     LG_CLK(16 * X.run, 5);
     const float *arow = Ai + row * EPNN_AST + hh * 32;
     if (X.run == 1) {
-        if (wave == 1) lg_proj_wave<1, true, false>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R);
-        if (wave == 2) lg_proj_wave<2, true, false>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R);
+        if (wave == 1) lg_proj_wave<1, true, false, false, true>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R, nullptr, w2n);
+        if (wave == 2) lg_proj_wave<2, true, false, false, true>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R, nullptr, w2n);
         return;
     }
     for (; job >= 0 && job < 2 * L.T; job += 7) {
