@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_lg_epn_static(LargeArgs L) {
 // interleaved.
 template <bool TWO>
 __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const float (&pb)[2][8],
-                                              const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
+                                              const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2], int jg, int flip) {
     auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
     auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
         nn[0] = w16_ld(Ns + j * 32 + po);
@@ -497,6 +497,13 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
     fetch(0, na, ya);
     int j = 0;
     for (; j + 2 <= nj; j += 2) {
+        // the two wavefronts of a SIMD (one of each of the CU's two workgroups) take turns at the higher issue priority, eight
+        // partners at a time: with equal priorities the older one is always served first and finishes 17 us before the other
+        // (protein: tasks end at 84 / 91 us instead of 76 / 92, the launch 1.3 us earlier; r04_protein_sweep_clocks.txt)
+        if ((j & 7) == 0) {
+            if ((((jg + j) >> 3) & 1) ^ flip) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         fetch(j + 1, nb, yb);
         partner(na, ya);
         fetch(min(j + 2, nj - 1), na, ya);
@@ -535,8 +542,9 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
         }
         __syncthreads();
         if (active) {
-            if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
-            else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
+            const int flip = 2 * blockIdx.x >= gridDim.x ? 1 : 0;
+            if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - tk.z, flip);
+            else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - tk.z, flip);
         }
     }
     if (!active) return;

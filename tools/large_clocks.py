@@ -2,12 +2,13 @@
 """Where the tiled path's small launches spend their time at protein size: a development build of the library (-DEPNN_LG_CLOCKS,
 built into tools/_dev/, never the shipped .so) stamps the 100 MHz wall clock of workgroup 0 at phase boundaries of the GNN
 tail launches (k_lg_gnn_tail) and the EPN-step launches (k_lg_epn_step) of one forward of the 2220-atom protein.
-    python tools/large_clocks.py [--build]"""
+    python tools/large_clocks.py [--build] [--lib path] [--forwards n] [--detail]"""
 import os, sys, subprocess, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 DEV = os.path.join(ROOT, "tools", "_dev", "libepnn_lgclocks.so")
+if "--lib" in sys.argv: DEV = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])      # another development build (-DEPNN_LG_CLOCKS)
 if "--build" in sys.argv or not os.path.exists(DEV):
     os.makedirs(os.path.dirname(DEV), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-mllvm",
