@@ -40,6 +40,7 @@ SIGNATURES = {
     "epnn_set_weights": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "epnn_get_weights": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "epnn_weight_shape": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip]),
+    "epnn_set_update_layers": (C.c_int, [_vp, C.c_int, _ip]),
     "epnn_edges": (C.c_int, [_vp, C.c_int, _fp, _fp]),
     "epnn_edges_ex": (C.c_int, [_vp, C.c_int, _fp, C.c_int, C.c_double, C.c_double, _fp, C.POINTER(C.c_double)]),
     "epnn_forward_xyz": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _fp, _fp, _fp, _fp]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "epnn_gnn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_epn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_mlp_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "epnn_mlp_forward_layers": (C.c_int, [_vp, C.c_int, C.c_int, _ip, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp]),
     "epnn_train_init": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     "epnn_param_count": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "epnn_train_step_dense": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int]),

@@ -89,10 +89,11 @@ class MLP_layer:
         x = np.asarray(x, dtype=np.float32)
         lead = x.shape[:-1]
         self.build(x.shape[-1])
-        if self.nodes != [32, 32]:
-            raise EpnnError("MLP_layer.call: only nodes=[32,32] is built (charge_gn.py:52,84,415)")
         eng = _scratch_engine()
-        out = eng.mlp_forward(x.reshape(-1, x.shape[-1]), self.get_weights())
+        if self.nodes == [32, 32]:
+            out = eng.mlp_forward(x.reshape(-1, x.shape[-1]), self.get_weights())           # the matrix-pipe kernel
+        else:
+            out = eng.mlp_forward_layers(x.reshape(-1, x.shape[-1]), self.get_weights())    # any widths (generic Dense stack)
         return out.reshape(lead + (self.out_dim,))
 
     __call__ = call
@@ -134,6 +135,7 @@ def _push(eng, msg, upd, pas, nx):
             eng.set_layer("msg", t, l, k, b)
     if upd is not None:
         upd.build(80)
+        eng.set_update_layers(upd.nodes)          # make_model(layers, ...): any hidden widths ([32, 32]: the tuned kernels)
         for l, (k, b) in enumerate(upd.get_weights()):
             eng.set_layer("upd", 0, l, k, b)
     for t, m in enumerate(pas or []):
@@ -270,8 +272,9 @@ class EPNNModel(_Stack):
         self.update_fn = MLP_layer(layers, out_dim=h_dim)
         self.graph_net = GNN_layer(MLP_layer, self.update_fn, T)
         self.electron_net = EPN_layer(MLP_layer, T=T)
-        if list(layers) != [32, 32]:
-            raise EpnnError("make_model: layers must be [32, 32] (charge_gn.py:415)")
+        if not 1 <= len(list(layers)) <= 7 or any(not 1 <= int(w) <= 256 for w in layers):
+            raise EpnnError("make_model: layers must be 1..7 hidden widths of 1..256 units (charge_gn.py:371; [32, 32] is the "
+                            "reference's own choice and the shape the tuned kernels and the training step are built for)")
         F = n_elems + h_dim + 1
         self.update_fn.build(h_dim + 32)
         for m in self.graph_net.message_fns + self.electron_net.pass_fns:

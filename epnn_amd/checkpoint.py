@@ -299,7 +299,7 @@ def _build_block(items, restart_interval=16) -> bytes:
     return bytes(buf)
 
 
-def keras_object_graph(T: int, n_plain_layers: int = 14) -> bytes:
+def keras_object_graph(T: int, n_plain_layers: int = 14, n_upd: int = 3) -> bytes:
     """The ``TrackableObjectGraph`` proto Keras writes for the reference's ``make_model`` (``charge_gn.py:369-391``).
 
     TensorFlow restores by walking this graph, so a file without the real layout cannot be loaded by the reference's
@@ -315,7 +315,8 @@ def keras_object_graph(T: int, n_plain_layers: int = 14) -> bytes:
 
     Keras variable names follow creation order in ``make_model`` (``:371-374``): ``dense .. dense_2`` update MLP,
     then the T message MLPs, then the T pass MLPs.  Checked byte for byte against the graph strings of all three shipped
-    checkpoints (``tests/test_checkpoint.py``).
+    checkpoints (``tests/test_checkpoint.py``).  ``n_upd``: Dense layers of the update MLP (``len(layers) + 1`` of
+    ``make_model(layers, ...)``; 3 for the reference's ``[32, 32]``) -- the same tree with a longer or shorter ``layer_set``.
     """
     class Obj:
         def __init__(self):
@@ -324,11 +325,11 @@ def keras_object_graph(T: int, n_plain_layers: int = 14) -> bytes:
 
     dense_counter = [0]
 
-    def mlp():
+    def mlp(n_dense=3):
         m = Obj()
         m.children.append(("nodes", Obj()))
         ls = Obj()
-        for l in range(3):
+        for l in range(n_dense):
             d = Obj()
             stem = "dense" if dense_counter[0] == 0 else f"dense_{dense_counter[0]}"
             dense_counter[0] += 1
@@ -340,7 +341,7 @@ def keras_object_graph(T: int, n_plain_layers: int = 14) -> bytes:
         m.children.append(("layer_set", ls))
         return m
 
-    upd = mlp()
+    upd = mlp(n_upd)
     msgs = [mlp() for _ in range(T)]
     pas = [mlp() for _ in range(T)]
     gnn, epn = Obj(), Obj()
@@ -489,7 +490,7 @@ def write_bundle(prefix: str, tensors, graph_bytes: bytes):
         f.write(bytes(data))
 
 
-def epnn_weight_keys(T: int):
+def epnn_weight_keys(T: int, n_upd: int = 3):
     """Checkpoint key stems (no suffix) in the reference's naming, per (group, step, layer, kind)."""
     keys = {}
     g, p = "layer_with_weights-0", "layer_with_weights-1"
@@ -500,7 +501,7 @@ def epnn_weight_keys(T: int):
             for kind in ("kernel", "bias"):
                 keys[("msg", t, l, kind)] = f"{mroot}/layer_set/{l}/{kind}"
                 keys[("pas", t, l, kind)] = f"{proot}/layer_set/{l}/{kind}"
-    for l in range(3):
+    for l in range(n_upd):
         for kind in ("kernel", "bias"):
             keys[("upd", 0, l, kind)] = f"{g}/update_fn/layer_set/{l}/{kind}"
     return keys
@@ -509,7 +510,8 @@ def epnn_weight_keys(T: int):
 def save_epnn_weights(prefix: str, weights, graph_bytes: bytes | None = None):
     """Inverse of :func:`load_epnn_weights` (reference ``charge_gn.py:462``)."""
     T = len(weights["msg"])
-    keys = epnn_weight_keys(T)
+    n_upd = len(weights["upd"])
+    keys = epnn_weight_keys(T, n_upd)
     tensors = {}
     for t in range(T):
         for l in range(3):
@@ -517,8 +519,8 @@ def save_epnn_weights(prefix: str, weights, graph_bytes: bytes | None = None):
             tensors[keys[("msg", t, l, "bias")]] = weights["msg"][t][l][1]
             tensors[keys[("pas", t, l, "kernel")]] = weights["pas"][t][l][0]
             tensors[keys[("pas", t, l, "bias")]] = weights["pas"][t][l][1]
-    for l in range(3):
+    for l in range(n_upd):
         tensors[keys[("upd", 0, l, "kernel")]] = weights["upd"][l][0]
         tensors[keys[("upd", 0, l, "bias")]] = weights["upd"][l][1]
     # message_fns/T-1 and message_fn are the same node of the object graph: one tensor, stored under message_fn
-    write_bundle(prefix, tensors, graph_bytes if graph_bytes is not None else keras_object_graph(T))
+    write_bundle(prefix, tensors, graph_bytes if graph_bytes is not None else keras_object_graph(T, n_upd=n_upd))

@@ -7,9 +7,9 @@
 #include "epnn_frontend.hip.h"
 #include "epnn_wave.hip.h"
 #include "epnn_wave2.hip.h"
+#include "epnn_mlp.hip.h"
 #include "epnn_large.hip.h"
 #include "epnn_dense.hip.h"
-#include "epnn_mlp.hip.h"
 #include "epnn_train.hip.h"
 
 thread_local std::string g_epnn_err;
@@ -184,7 +184,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->d_wpack, &h->d_mu, &h->d_flip, &h->d_mu_ex, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
+    DevBuf *bufs[] = {&h->d_wpack, &h->d_updgen, &h->d_mu, &h->d_flip, &h->d_mu_ex, &h->d_ctl, &h->d_rowcnt, &h->d_rowoff,
                       &h->d_status, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_train, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
@@ -349,12 +349,43 @@ static double edge_basis(const epnn_config &cfg, const std::vector<double> &mu, 
 
 // ------------------------------------------------------------------------------------------------ weights
 static HostDense *find_layer(epnn_handle *h, int which, int t, int layer) {
-    if (!h || layer < 0 || layer > 2) return nullptr;
+    if (!h || layer < 0) return nullptr;
+    if (which == EPNN_W_UPD && h->upd_generic) return layer < (int)h->updg.size() ? &h->updg[layer] : nullptr;
+    if (layer > 2) return nullptr;
     if (which == EPNN_W_UPD) return &h->upd[layer];
     if (t < 0 || t >= h->cfg.T) return nullptr;
     if (which == EPNN_W_MSG) return &h->msg[t][layer];
     if (which == EPNN_W_PAS) return &h->pas[t][layer];
     return nullptr;
+}
+
+static int finish_forward(epnn_handle *h);
+extern "C" int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_t *widths) {
+    if (!h || !widths) EPNN_FAIL("epnn_set_update_layers: null argument");
+    if (n_hidden < 1 || n_hidden + 1 > EPNN_GMLP_LMAX) EPNN_FAIL("epnn_set_update_layers: %d hidden layers (1 .. %d are built)", n_hidden, EPNN_GMLP_LMAX - 1);
+    for (int l = 0; l < n_hidden; ++l)
+        if (widths[l] < 1 || widths[l] > EPNN_GMLP_WMAX) EPNN_FAIL("epnn_set_update_layers: width %d of layer %d (1 .. %d are built)", widths[l], l, EPNN_GMLP_WMAX);
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    if (h->train) EPNN_FAIL("epnn_set_update_layers: the handle holds training state (the training step is built for layers == [32, 32] only)");
+    const int H = h->cfg.hidden;
+    h->upd_generic = !(n_hidden == 2 && widths[0] == H && widths[1] == H);
+    h->updg.clear();
+    if (h->upd_generic) {
+        int n_in = h->cfg.h_dim + H;                       // [h | summed messages] (charge_gn.py:71)
+        for (int l = 0; l <= n_hidden; ++l) {
+            HostDense d;
+            d.n_in = n_in;
+            d.n_out = l < n_hidden ? widths[l] : h->cfg.h_dim;
+            d.W.assign((size_t)d.n_in * d.n_out, 0.f);
+            d.b.assign(d.n_out, 0.f);
+            n_in = d.n_out;
+            h->updg.push_back(std::move(d));
+        }
+    }
+    h->weights_dirty = true;
+    h->plan.valid = false;
+    return 0;
 }
 
 extern "C" int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, int32_t *n_in, int32_t *n_out) {
@@ -623,9 +654,33 @@ static int pack_weights(epnn_handle *h) {
             E.wjf = folded(W1, nullptr, F);
         }
     }
+    std::vector<float> gbuf;
+    if (h->upd_generic) {
+        // the generic update stage takes its kernels as they are: [W3_t | b3_t] of every message MLP, then the update MLP's layers
+        auto put = [&](const std::vector<float> &v) {
+            const int off = (int)gbuf.size();
+            gbuf.insert(gbuf.end(), v.begin(), v.end());
+            return off;
+        };
+        for (int t = 0; t < T; ++t) {
+            h->gen_w3[t] = put(h->msg[t][2].W);
+            h->gen_b3[t] = put(h->msg[t][2].b);
+        }
+        GenMlp &G = h->gen_upd;
+        G.n = (int)h->updg.size();
+        G.dims[0] = h->updg[0].n_in;
+        for (int l = 0; l < G.n; ++l) {
+            G.dims[l + 1] = h->updg[l].n_out;
+            G.offW[l] = put(h->updg[l].W);
+            G.offB[l] = put(h->updg[l].b);
+        }
+        G.w = nullptr;
+        if (h->d_updgen.ensure(gbuf.size() * sizeof(float))) return 1;
+        HIPCHK(hipMemcpyAsync(h->d_updgen.p, gbuf.data(), gbuf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
     if (h->d_wpack.ensure(buf.size() * sizeof(float))) return 1;
     HIPCHK(hipMemcpyAsync(h->d_wpack.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));     // buf is a local
+    HIPCHK(hipStreamSynchronize(h->stream));     // buf / gbuf are locals
     h->weights_dirty = false;
     h->weights_gen += 1;
     return 0;
@@ -644,7 +699,7 @@ static size_t plan_payload_offset(int B, int A) { return (plan_ctl_ints(B, A) * 
 static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
                       bool *ctl_fresh = nullptr) {
     Plan &P = h->plan;
-    allow_mid = allow_mid && h->opt_force_path == 0;
+    allow_mid = allow_mid && h->opt_force_path == 0 && !h->upd_generic;
     if (ctl_fresh) *ctl_fresh = false;
     if (P.valid && P.B == B && P.N == N && P.allow_mid == allow_mid && (int)P.offsets.size() == B + 1 &&
         memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0 &&
@@ -690,7 +745,9 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
     for (int b = 0; b < B; ++b) {
         const int n = offsets[b + 1] - offsets[b];
         for (int a = offsets[b]; a < offsets[b + 1]; ++a) c_molof[a] = b;
-        const bool small = (h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok);
+        // (an update MLP of other widths than [32, 32]: the fused kernels are not built for it, everything is tiled)
+        const bool small = !h->upd_generic && ((h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok));
+        if (h->upd_generic && h->opt_force_path == 1) EPNN_FAIL("forward: force_path=1 with an update MLP other than [32, 32] (tiled path only)");
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
         const bool mid = !small && allow_mid && h->opt_wave3 && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX4;
@@ -1683,6 +1740,42 @@ extern "C" int epnn_mlp_forward(epnn_handle *h, int rows, int n_in, int n_out, c
     hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, h->stream, M);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, M.out, no * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int epnn_mlp_forward_layers(epnn_handle *h, int rows, int n_layers, const int32_t *dims, const float *const *W,
+                                       const float *const *b, const float *x, float *out) {
+    if (!h || !dims || !W || !b || !x || !out) EPNN_FAIL("epnn_mlp_forward_layers: null argument");
+    if (rows < 1 || n_layers < 1 || n_layers > EPNN_GMLP_LMAX) EPNN_FAIL("epnn_mlp_forward_layers: rows >= 1 and 1 .. %d Dense layers", EPNN_GMLP_LMAX);
+    for (int l = 0; l <= n_layers; ++l)
+        if (dims[l] < 1 || dims[l] > EPNN_GMLP_WMAX) EPNN_FAIL("epnn_mlp_forward_layers: width %d (1 .. %d are built)", dims[l], EPNN_GMLP_WMAX);
+    for (int l = 0; l < n_layers; ++l)
+        if (!W[l] || !b[l]) EPNN_FAIL("epnn_mlp_forward_layers: null kernel / bias of layer %d", l);
+    HIPCHK(hipSetDevice(h->device));
+    if (h->pending.active && finish_forward(h)) return 1;
+    GenMlp G{};
+    G.n = n_layers;
+    size_t nw = 0;
+    for (int l = 0; l <= n_layers; ++l) G.dims[l] = dims[l];
+    for (int l = 0; l < n_layers; ++l) {
+        G.offW[l] = (int)nw;
+        nw += (size_t)dims[l] * dims[l + 1];
+        G.offB[l] = (int)nw;
+        nw += (size_t)dims[l + 1];
+    }
+    const size_t nxs = (size_t)rows * dims[0], no = (size_t)rows * dims[n_layers];
+    if (h->s_misc.ensure((nw + nxs + no) * 4)) return 1;
+    float *d = h->s_misc.as<float>();
+    for (int l = 0; l < n_layers; ++l) {
+        (void)hipMemcpyAsync(d + G.offW[l], W[l], (size_t)dims[l] * dims[l + 1] * 4, hipMemcpyHostToDevice, h->stream);
+        (void)hipMemcpyAsync(d + G.offB[l], b[l], (size_t)dims[l + 1] * 4, hipMemcpyHostToDevice, h->stream);
+    }
+    (void)hipMemcpyAsync(d + nw, x, nxs * 4, hipMemcpyHostToDevice, h->stream);
+    G.w = d;
+    hipLaunchKernelGGL(k_mlp_generic, dim3((unsigned)((rows + EPNN_GMLP_ROWS - 1) / EPNN_GMLP_ROWS)), dim3(256), 0, h->stream, G, d + nw, d + nw + nxs, rows);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d + nw + nxs, no * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }

@@ -96,6 +96,19 @@ struct WaveIndex {
     int bu3;              // [48]
 };
 
+// A Dense stack of any widths (MLP_layer with other `nodes` than [32, 32], charge_gn.py:30-45): rows x dims[0] -> relu dims[1] ->
+// ... -> dims[n] (the last Dense linear).  Kernels in Keras layout [in][out].  Used by epnn_mlp_forward_layers and by the update
+// stage of the tiled path when make_model was given other `layers` (epnn_set_update_layers); plain f32 FMA loops, not the hot path.
+#define EPNN_GMLP_ROWS 16     // rows per workgroup
+#define EPNN_GMLP_WMAX 256    // widest layer
+#define EPNN_GMLP_LMAX 8      // Dense layers
+struct GenMlp {
+    int n;
+    int dims[EPNN_GMLP_LMAX + 1];
+    int offW[EPNN_GMLP_LMAX], offB[EPNN_GMLP_LMAX];     // floats from `w`
+    const float *w;
+};
+
 __host__ __device__ static inline int epnn_kappa(int hh, int r) { return 4 * hh + (r & 3) + 8 * (r >> 2); }
 
 // position of atom feature f inside the even/odd image row: half (f&1), slot f>>1

@@ -107,6 +107,14 @@ struct epnn_handle {
     int ev_next = 0;                  // forwards recorded since the option was set
     // weights
     HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
+    // make_model(layers != [32, 32]) / MLP_layer(nodes) as update_fn (charge_gn.py:369-371): the update MLP with any hidden widths
+    // (epnn_set_update_layers).  Every molecule then takes the tiled path with one kernel per stage, whose update stage is the
+    // generic Dense stack of epnn_mlp.hip.h; `upd` above keeps its standard shapes (zeros) so that the fragment packers run unchanged.
+    std::vector<HostDense> updg;
+    bool upd_generic = false;
+    DevBuf d_updgen;                  // raw kernels / biases of updg + the message MLPs' last Dense (W3_t, b3_t), see pack_weights
+    GenMlp gen_upd{};                 // offsets into d_updgen
+    int gen_w3[EPNN_MAXT] = {0}, gen_b3[EPNN_MAXT] = {0};
     bool weights_dirty = true;
     long weights_gen = 0;             // counts the changes of the weights (device-side copies made elsewhere compare it)
     void *infer_fused = nullptr;      // InferFused (epnn_train.hip.h)

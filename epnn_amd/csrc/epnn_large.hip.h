@@ -1007,6 +1007,49 @@ __global__ __launch_bounds__(256) void k_lg_update(LargeArgs L, UpdPack U, const
                           L.a_eo + (size_t)at * EPNN_AST, nullptr, lane);
 }
 
+// The update stage for an update MLP of other widths than [32, 32] (make_model(layers), charge_gn.py:369-371; always with one
+// kernel per stage): workgroup = 16 atoms of a tile.  messages = W3^T S + N b3 (the message MLP's last Dense, summed over all N
+// partners, :68-70), masked_input = [h | messages] * node_mask (:71-72), h = update_fn(masked_input) * node_mask (:73-74).
+__global__ __launch_bounds__(256) void k_lg_update_generic(LargeArgs L, GenMlp G, int offW3, int offb3, const float *Sfin) {
+    __shared__ float a0[EPNN_GMLP_ROWS * EPNN_GMLP_ST], a1[EPNN_GMLP_ROWS * EPNN_GMLP_ST];
+    if (L.row_off[L.A] > L.pcap) return;
+    const int4 tl = L.atiles[blockIdx.x >> 1];
+    const int r0 = (blockIdx.x & 1) * EPNN_GMLP_ROWS, tid = threadIdx.x;
+    if (r0 >= tl.y) return;
+    const float *W3 = G.w + offW3, *b3 = G.w + offb3;
+    const float Nf = (float)L.N;
+    // S rows -> a1, then [h | messages] * node_mask -> a0
+    for (int idx = tid; idx < EPNN_GMLP_ROWS * 32; idx += 256) {
+        const int r = idx >> 5, k = idx & 31;
+        a1[r * EPNN_GMLP_ST + k] = r0 + r < tl.y ? Sfin[(size_t)(tl.x + r0 + r) * 32 + k] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < EPNN_GMLP_ROWS * (EPNN_EDIM + 32); idx += 256) {
+        const int r = idx % EPNN_GMLP_ROWS, f = idx / EPNN_GMLP_ROWS;
+        const bool live = r0 + r < tl.y;
+        const int at = tl.x + (live ? r0 + r : 0);
+        const float nmc = L.nm_in ? L.nm_in[at] : 1.f;
+        float v;
+        if (f < EPNN_EDIM) v = L.a_eo[(size_t)at * EPNN_AST + epnn_aeo(L.nx + f)];
+        else {
+            const int o = f - EPNN_EDIM;
+            float acc = Nf * b3[o];
+            for (int k = 0; k < 32; ++k) acc = fmaf(a1[r * EPNN_GMLP_ST + k], W3[k * 32 + o], acc);
+            v = acc;
+        }
+        a0[r * EPNN_GMLP_ST + f] = live ? nmc * v : 0.f;
+    }
+    __syncthreads();
+    const float *res = gmlp_rows(G, a0, a1);
+    for (int idx = tid; idx < EPNN_GMLP_ROWS * EPNN_EDIM; idx += 256) {
+        const int r = idx % EPNN_GMLP_ROWS, f = idx / EPNN_GMLP_ROWS;
+        if (r0 + r >= tl.y) continue;
+        const int at = tl.x + r0 + r;
+        const float nmc = L.nm_in ? L.nm_in[at] : 1.f;
+        L.a_eo[(size_t)at * EPNN_AST + epnn_aeo(L.nx + f)] = nmc * res[r * EPNN_GMLP_ST + f];
+    }
+}
+
 // ---- one launch for everything between two sweeps: workgroup (eight waves) = one 32-atom tile.  All 512 threads reduce the
 // tile's S -- one output of two atoms each, every partial sum of a thread in flight at once: three dependent round trips
 // (bounds, partials, slot rows) --, wave 0 runs the update MLP, then the NEXT thing's projections from an LDS image of the
@@ -1474,7 +1517,7 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
     // transfers.  With a partition the other processes' rows of S arrive between the reduction and the update, so those stay
     // separate launches.
     const bool collective = h->part_world > 1 || h->opt_part_collective;
-    const bool split = collective || !h->opt_large_fused;
+    const bool split = collective || !h->opt_large_fused || h->upd_generic;
     const bool merged = front && Tg > 0 && !split;           // k_lg_first / k_lg_second
     const unsigned gTile = (unsigned)L.natiles;
     auto next_after_gnn = [&](int t) {
@@ -1553,7 +1596,12 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
                     EPNN_FAIL("forward: RCCL row exchange failed: %s", ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
             }
         }
-        hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_sfin.as<float>());
+        if (h->upd_generic) {
+            GenMlp G = h->gen_upd;
+            G.w = h->d_updgen.as<float>();
+            hipLaunchKernelGGL(k_lg_update_generic, dim3(2u * (unsigned)L.natiles), dim3(256), 0, st, L, G, h->gen_w3[t], h->gen_b3[t], h->l_sfin.as<float>());
+        } else
+            hipLaunchKernelGGL(k_lg_update, dim3(gT), dim3(256), 0, st, L, h->widx.upd[t], h->l_sfin.as<float>());
         const LgNext X = next_after_gnn(t);
         if (X.run == 1) hipLaunchKernelGGL(k_lg_proj, dim3(gT), dim3(256), 0, st, L, X.M, 1);
         else if (X.run == 2) hipLaunchKernelGGL(k_lg_epn_static, dim3(gES), dim3(256), 0, st, L);

@@ -54,3 +54,40 @@ __global__ __launch_bounds__(256) void k_mlp_forward(MlpArgs M) {
         }
     }
 }
+
+// ---- any widths (GenMlp, epnn_common.h).  EPNN_GMLP_ROWS rows of activations live in LDS (row stride WMAX + 1: the rows of one output
+// column sit in different banks); thread (row r, output o) runs the dot product over the layer's inputs.
+#define EPNN_GMLP_ST (EPNN_GMLP_WMAX + 1)
+// the stack on the rows held in `a0`; the result is in the returned buffer (a0 or a1).  All threads of the workgroup call it.
+__device__ __forceinline__ float *gmlp_rows(const GenMlp &G, float *a0, float *a1) {
+    float *src = a0, *dst = a1;
+    for (int l = 0; l < G.n; ++l) {
+        const int ni = G.dims[l], no = G.dims[l + 1];
+        const float *W = G.w + G.offW[l], *b = G.w + G.offB[l];
+        const bool act = l + 1 < G.n;
+        for (int idx = threadIdx.x; idx < EPNN_GMLP_ROWS * no; idx += blockDim.x) {
+            const int r = idx % EPNN_GMLP_ROWS, o = idx / EPNN_GMLP_ROWS;
+            const float *in = src + r * EPNN_GMLP_ST;
+            float acc = b[o];
+            for (int i = 0; i < ni; ++i) acc = fmaf(in[i], W[(size_t)i * no + o], acc);
+            dst[r * EPNN_GMLP_ST + o] = act ? fmaxf(acc, 0.f) : acc;
+        }
+        __syncthreads();
+        float *t = src; src = dst; dst = t;
+    }
+    return src;
+}
+__global__ __launch_bounds__(256) void k_mlp_generic(GenMlp G, const float *x, float *out, int rows) {
+    __shared__ float a0[EPNN_GMLP_ROWS * EPNN_GMLP_ST], a1[EPNN_GMLP_ROWS * EPNN_GMLP_ST];
+    const int row0 = blockIdx.x * EPNN_GMLP_ROWS, ni = G.dims[0], no = G.dims[G.n];
+    for (int idx = threadIdx.x; idx < EPNN_GMLP_ROWS * ni; idx += blockDim.x) {
+        const int r = idx / ni, i = idx - r * ni;
+        a0[r * EPNN_GMLP_ST + i] = row0 + r < rows ? x[(size_t)(row0 + r) * ni + i] : 0.f;
+    }
+    __syncthreads();
+    const float *res = gmlp_rows(G, a0, a1);
+    for (int idx = threadIdx.x; idx < EPNN_GMLP_ROWS * no; idx += blockDim.x) {
+        const int r = idx / no, o = idx - r * no;
+        if (row0 + r < rows) out[(size_t)(row0 + r) * no + o] = res[r * EPNN_GMLP_ST + o];
+    }
+}

@@ -415,6 +415,7 @@ static int train_sync_to_host(epnn_handle *h) {
 }
 
 static int train_init(epnn_handle *h, float lr, float b1, float b2, float eps) {
+    if (h->upd_generic) EPNN_FAIL("train: the training step is built for an update MLP of layers == [32, 32] only (epnn_set_update_layers gave others)");
     TrainState *ts = train_state(h);
     if (train_sync_to_host(h)) return 1;
     train_layout(h, ts);
@@ -787,7 +788,7 @@ struct InferFused {
     DevBuf theta, arena;
     bool attr = false;
 };
-static bool infer_rowfused_fits(const epnn_handle *h, int N) { return N <= EPNN_TF_NMAX && h->cfg.nx + 49 <= EPNN_TF_FMAX && h->cfg.T >= 1; }
+static bool infer_rowfused_fits(const epnn_handle *h, int N) { return N <= EPNN_TF_NMAX && h->cfg.nx + 49 <= EPNN_TF_FMAX && h->cfg.T >= 1 && !h->upd_generic; }
 static int infer_rowfused_forward(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x,
                                   const float *d_h0, const float *d_q0, float *d_out) {
     if (!h->infer_fused) h->infer_fused = new InferFused();

@@ -52,6 +52,7 @@ class Engine:
         h = C.c_void_p()
         check(self.lib.epnn_create(C.byref(self.cfg), device, C.byref(h)), self.lib)
         self.h = h
+        self._upd_layers = [hidden, hidden]              # hidden widths of the update MLP (set_update_layers)
 
     def close(self):
         if getattr(self, "h", None):
@@ -85,20 +86,30 @@ class Engine:
         check(self.lib.epnn_get_weights(self.h, _WHICH[group], t, layer, fptr(k), fptr(b)), self.lib)
         return k, b
 
+    def set_update_layers(self, widths):
+        """make_model(layers, ...): hidden widths of the update MLP (charge_gn.py:371); [32, 32] is the default and the tuned shape."""
+        widths = [int(w) for w in widths]
+        if widths != self._upd_layers:
+            arr = np.ascontiguousarray(widths, dtype=np.int32)
+            check(self.lib.epnn_set_update_layers(self.h, len(widths), iptr(arr)), self.lib)
+            self._upd_layers = widths
+
     def set_weights(self, weights):
-        """weights = {"msg": [T][3](W,b), "upd": [3](W,b), "pas": [T][3](W,b)} (checkpoint.load_epnn_weights)."""
+        """weights = {"msg": [T][3](W,b), "upd": [n_hidden + 1](W,b), "pas": [T][3](W,b)} (checkpoint.load_epnn_weights); the update
+        MLP's hidden widths follow the kernels' shapes."""
         if len(weights["msg"]) != self.T or len(weights["pas"]) != self.T:
             raise EpnnError(f"checkpoint has T={len(weights['msg'])}, engine was built with T={self.T}")
+        self.set_update_layers([np.asarray(k).shape[1] for k, _ in weights["upd"][:-1]])
         for t in range(self.T):
             for l in range(3):
                 self.set_layer("msg", t, l, *weights["msg"][t][l])
                 self.set_layer("pas", t, l, *weights["pas"][t][l])
-        for l in range(3):
+        for l in range(len(weights["upd"])):
             self.set_layer("upd", 0, l, *weights["upd"][l])
 
     def get_weights(self):
         return {"msg": [[self.get_layer("msg", t, l) for l in range(3)] for t in range(self.T)],
-                "upd": [self.get_layer("upd", 0, l) for l in range(3)],
+                "upd": [self.get_layer("upd", 0, l) for l in range(len(self._upd_layers) + 1)],
                 "pas": [[self.get_layer("pas", t, l) for l in range(3)] for t in range(self.T)]}
 
     # ------------------------------------------------------------------ compute
@@ -188,6 +199,23 @@ class Engine:
 
     def epn_forward(self, h, e, x, q, mask):
         return self._layer(self.lib.epnn_epn_forward, h, e, x, q, mask, 1)
+
+    def mlp_forward_layers(self, rows, layers):
+        """MLP_layer(nodes, out_dim).call for any `nodes`: rows (R, n_in) through [(W,b), ...], ReLU after all but the last."""
+        rows = _f32(rows)
+        ws = [(_f32(k), _f32(b)) for k, b in layers]
+        dims = [rows.shape[1]] + [k.shape[1] for k, _ in ws]
+        for l, (k, b) in enumerate(ws):
+            if k.shape != (dims[l], dims[l + 1]) or b.shape != (dims[l + 1],):
+                raise EpnnError(f"mlp_forward_layers: layer {l} has kernel {k.shape} / bias {b.shape}, expected {(dims[l], dims[l + 1])}")
+        n = len(ws)
+        FP = C.POINTER(C.c_float)
+        Wp = (FP * n)(*[fptr(k) for k, _ in ws])
+        bp = (FP * n)(*[fptr(b) for _, b in ws])
+        darr = np.ascontiguousarray(dims, dtype=np.int32)
+        out = np.empty((rows.shape[0], dims[-1]), dtype=np.float32)
+        check(self.lib.epnn_mlp_forward_layers(self.h, rows.shape[0], n, iptr(darr), Wp, bp, fptr(rows), fptr(out)), self.lib)
+        return out
 
     def mlp_forward(self, rows, layers):
         """MLP_layer.call: rows (R, n_in) through [(W1,b1),(W2,b2),(W3,b3)] with hidden width 32."""

@@ -52,15 +52,19 @@ int epnn_device_count(void);
 
 /* make_model (charge_gn.py:369-391): creates the layer stack on `device`.  Weights start at zero.
  *
- * CONTRACT -- what of the reference's constructor arguments is free and what is fixed.  The reference sizes every MLP from
- * `layers` and every width from `h_dim` (charge_gn.py:369-374, MLP_layer(nodes, ...) :31-39); every checkpoint it ships and both
- * of its scripts use layers = [32, 32], h_dim = e_dim = 48 (charge_gn.py:413-417, infer.py:47-50).  This library implements THAT
- * shape and nothing wider -- the kernels hold a 32-wide hidden layer in one MFMA accumulator set and 48 = 3 x 16 edge channels:
+ * CONTRACT -- what of the reference's constructor arguments is free and what is fixed.  In the reference `layers` sizes the UPDATE
+ * MLP only (make_model: MLP_layer(layers, out_dim=h_dim), charge_gn.py:371); the message and pass MLPs are ([32, 32], 32) and
+ * ([32, 32], 1) by its own constants (:52, :84), and every width follows h_dim (:369-374).  Every checkpoint it ships and both of
+ * its scripts use layers = [32, 32], h_dim = e_dim = 48 (:413-417, infer.py:47-50).
  *   free :  nx in 1..10 (atom feature columns; 9 and 10 are the reference's two tables), T in 1..8, cutoff, eta, near_tol,
- *           the padded size N and the batch size of every call, every weight value;
- *   fixed:  hidden == 32 (`layers` == [32, 32] for the message, pass and update MLPs alike), h_dim == e_dim == 48.
- * epnn_create FAILS (returns non-zero, epnn_last_error says which field) for any other value; the Python layer raises
- * EpnnError from make_model / MLP_layer for `layers` != [32, 32].  A model of another width is not run on a slower path. */
+ *           the padded size N and the batch size of every call, every weight value; `layers` of the update MLP (1..7 hidden
+ *           layers of 1..256 units each: epnn_set_update_layers) for every INFERENCE entry;
+ *   fixed:  hidden == 32 (the reference's own constant for the message / pass MLPs), h_dim == e_dim == 48; the training step
+ *           (epnn_train_*) additionally needs layers == [32, 32].
+ * epnn_create FAILS (returns non-zero, epnn_last_error says which field) for any other value.  `layers` == [32, 32] runs the
+ * kernels DESIGN.md describes; any other `layers` runs every molecule through the tiled kernels with one launch per stage and a
+ * generic (f32 FMA) Dense stack as the update stage -- the same results to float32 rounding, several times slower per small
+ * molecule: a correctness path, not a tuned one. */
 int epnn_create(const epnn_config *cfg, int device, epnn_handle **out);
 int epnn_destroy(epnn_handle *h);
 /* Leaves out `n` of the process's hardware queues: the HIP runtime deals a process's streams onto its hardware queues in the order
@@ -70,11 +74,17 @@ int epnn_skip_hw_queues(int device, int n);
 
 /* model.load_weights / layer.set_weights (infer.py:57): one Dense layer of one MLP.
  * which = EPNN_W_MSG (message_fns[t], charge_gn.py:52), EPNN_W_UPD (update_fn, t ignored, charge_gn.py:371),
- * EPNN_W_PAS (pass_fns[t], charge_gn.py:84); layer = 0..2; kernel is Keras layout [in][out]. */
+ * EPNN_W_PAS (pass_fns[t], charge_gn.py:84); layer = 0..2 (EPNN_W_UPD: 0..n_hidden after epnn_set_update_layers); kernel is Keras
+ * layout [in][out]. */
 int epnn_set_weights(epnn_handle *h, int which, int t, int layer, const float *kernel, const float *bias);
 /* model.trainable_variables / save_weights (charge_gn.py:462). */
 int epnn_get_weights(epnn_handle *h, int which, int t, int layer, float *kernel, float *bias);
 int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, int32_t *n_in, int32_t *n_out);
+/* make_model(layers, ...) / GNN_layer(message_fn, update_fn = MLP_layer(layers, out_dim = h_dim), T) (charge_gn.py:369-371): the
+ * hidden widths of the update MLP, widths[n_hidden].  The default is {32, 32}.  Afterwards EPNN_W_UPD has n_hidden + 1 layers
+ * (layer 0: h_dim + 32 -> widths[0]; the last: widths[n_hidden - 1] -> h_dim), all zero until epnn_set_weights fills them.
+ * Fails on a handle that holds training state (see the CONTRACT above). */
+int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_t *widths);
 
 /* get_init_edges (charge_gn.py:122-163): xyz[n][3] float32 -> e[n][n][e_dim] float32, host pointers. */
 int epnn_edges(epnn_handle *h, int n, const float *xyz, float *e_out);
@@ -126,6 +136,11 @@ int epnn_gnn_forward(epnn_handle *h, int B, int N, const float *hin, const float
 int epnn_epn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,
                      const float *q, const float *mask, float *q_out);
 
+/* MLP_layer(nodes, out_dim).call (charge_gn.py:31-45) for ANY `nodes`: n_layers Dense layers, dims[n_layers + 1] = n_in, nodes...,
+ * out_dim (each 1..256; ReLU after every layer but the last), W[l] in Keras layout [dims[l]][dims[l + 1]], b[l][dims[l + 1]].
+ * x[rows][dims[0]] -> out[rows][dims[n_layers]].  Host pointers. */
+int epnn_mlp_forward_layers(epnn_handle *h, int rows, int n_layers, const int32_t *dims, const float *const *W,
+                            const float *const *b, const float *x, float *out);
 /* MLP_layer.call (charge_gn.py:41-45) as a stand-alone operator: x[rows][n_in] -> relu 32 -> relu 32 -> out[rows][n_out];
  * kernels in Keras layout [in][out].  Host pointers. */
 int epnn_mlp_forward(epnn_handle *h, int rows, int n_in, int n_out, const float *W1, const float *b1,

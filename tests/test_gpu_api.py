@@ -511,3 +511,111 @@ def test_make_model_every_size_class_on_the_block_per_wave_kernel():
     print(f"dense model, sizes {sizes}: |dq| {err:.3e} (float32 oracle noise {noise:.3e}); |block-per-wave - other kernels| {np.abs(pred - other).max():.2e}")
     assert err <= max(TOL, 4 * noise)
     assert np.abs(other - ref).max() <= max(TOL, 4 * noise) and np.abs(pred - other).max() <= max(2e-6, 4 * noise)
+
+
+def _upd_layers(widths, seed):
+    """Glorot kernels + biases of an update MLP 80 -> widths... -> 48 (charge_gn.py:371)."""
+    rng = np.random.default_rng(seed)
+    dims = [80] + list(widths) + [48]
+    out = []
+    for i, o in zip(dims[:-1], dims[1:]):
+        lim = 0.35 * np.sqrt(6.0 / (i + o))
+        out.append((rng.uniform(-lim, lim, (i, o)).astype(np.float32), rng.uniform(-0.1, 0.1, (o,)).astype(np.float32)))
+    return out
+
+
+@pytest.mark.parametrize("nodes,out_dim", [([16], 5), ([64, 32], 7), ([20, 30, 40], 3), ([], 48), ([256], 1)])
+def test_mlp_layer_call_with_any_nodes(nodes, out_dim):
+    """MLP_layer(nodes, out_dim).call for other `nodes` than the reference's own [32, 32] (charge_gn.py:31-45): the generic
+    Dense stack (epnn_mlp_forward_layers) vs the float64 oracle; `nodes = []` is a single linear Dense."""
+    from epnn_amd import charge_gn
+    from oracle import epnn_oracle as orc
+    rng = np.random.default_rng(len(nodes) + out_dim)
+    rows = rng.normal(size=(3, 37, 23)).astype(np.float32)
+    m = charge_gn.MLP_layer(nodes, out_dim=out_dim)
+    dims = [23] + list(nodes) + [out_dim]
+    ws = [((rng.normal(size=(i, o)) / np.sqrt(i)).astype(np.float32), (0.1 * rng.normal(size=(o,))).astype(np.float32))
+          for i, o in zip(dims[:-1], dims[1:])]
+    m.build(23)
+    m.set_weights(ws)
+    got = m.call(rows)
+    ref = orc.mlp(rows.reshape(-1, 23).astype(np.float64), orc._cast_layers(ws, np.float64)).reshape(3, 37, out_dim)
+    assert got.shape == (3, 37, out_dim) and got.dtype == np.float32
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("layers", [[16], [64, 32], [8, 24, 40]])
+def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp_path, layers):
+    """make_model(layers, ...) sizes the update MLP from `layers` (charge_gn.py:369-371; the message / pass MLPs are [32, 32] by
+    the reference's own constants).  Other widths than [32, 32] run the tiled kernels with the generic update stage: the literal
+    dense call, the compact entry on molecules of 3..38 atoms and a 150-atom box, and GNN_layer.call, each vs the float64
+    oracle; the checkpoint writer / reader round trip keeps the layer count; the training step refuses such a model."""
+    from epnn_amd import charge_gn, synth
+    from epnn_amd._lib import EpnnError
+    from epnn_amd.engine import Engine
+    from oracle import epnn_oracle as orc
+    from conftest import load_molecules
+    nx, T = 9, 3
+    w = random_weights(nx, T, seed=31, scale=0.35)
+    w["upd"] = _upd_layers(layers, seed=len(layers))
+    # (1) the literal make_model call
+    x, h, q, e, Q, y, mask, names = _small_state(golden_dir, nx)
+    model = charge_gn.make_model(layers, 48, T, nx, x.shape[1])
+    model.set_weights_dict(w)
+    pred = model([h, e, x, q, mask])
+    ref = orc.model_forward(h, e, x, q, mask, w, dtype=np.float64)
+    ref32 = orc.model_forward(h, e, x, q, mask, w, dtype=np.float32)
+    err, noise = np.abs(pred - ref).max(), np.abs(ref32 - ref).max()
+    print(f"layers {layers}: dense call |dq| {err:.3e} (float32 oracle noise {noise:.3e})")
+    assert err <= max(TOL, 3 * noise)
+    # (2) checkpoint round trip: len(layers) + 1 Dense layers under update_fn/layer_set
+    model.save_weights(str(tmp_path / "m"))
+    again = charge_gn.make_model(layers, 48, T, nx, x.shape[1])
+    again.load_weights(str(tmp_path / "m"))
+    w2 = again.weights_dict()
+    assert len(w2["upd"]) == len(layers) + 1
+    for (k0, b0), (k1, b1) in zip(w["upd"], w2["upd"]):
+        assert np.array_equal(k0, k1) and np.array_equal(b0, b1)
+    assert np.array_equal(again([h, e, x, q, mask]), pred)
+    # (3) the compact entry: QM9-like molecules of every path's sizes + a 150-atom box in one batch
+    mnames = [nm for nm in val_names][:30]
+    mols, offsets, xyz, xx, QQ = load_molecules(val_dir, mnames, nx)
+    _, bxyz, bx, bQ, _ = synth.box_system(n_atoms=150, seed=9)
+    offsets = np.concatenate([offsets, [offsets[-1] + 150]]).astype(np.int32)
+    xyz, xx, QQ = np.concatenate([xyz, bxyz]), np.concatenate([xx, bx]), np.concatenate([QQ, bQ]).astype(np.float32)
+    N = 150
+    eng = Engine(nx=nx, T=T)
+    eng.set_weights(w)
+    got = eng.forward_xyz(offsets, xyz, xx, QQ, N)
+    assert eng.last_stats()[1] == 0                              # nothing went through the fused kernels
+    worst = 0.0
+    for k in range(len(offsets) - 1):
+        sl = slice(offsets[k], offsets[k + 1])
+        r = orc.forward_xyz(xyz[sl], xx[sl], QQ[k], w, N=N, dtype=np.float64)
+        worst = max(worst, float(np.abs(got[sl] - r[:offsets[k + 1] - offsets[k]]).max()))
+    print(f"layers {layers}: compact entry worst |dq| {worst:.3e} over {len(offsets) - 1} systems")
+    assert worst <= TOL
+    # the same handle back on the reference's layers: the tuned kernels again
+    w32 = random_weights(nx, T, seed=31, scale=0.35)
+    eng.set_weights(w32)
+    got32 = eng.forward_xyz(offsets[:-1], xyz[:offsets[-2]], xx[:offsets[-2]], QQ[:-1], 41)
+    eng_ref = Engine(nx=nx, T=T)
+    eng_ref.set_weights(w32)
+    assert np.array_equal(got32, eng_ref.forward_xyz(offsets[:-1], xyz[:offsets[-2]], xx[:offsets[-2]], QQ[:-1], 41))
+    assert eng.last_stats()[1] > 0
+    eng.close(); eng_ref.close()
+    # (4) GNN_layer with such an update_fn
+    rng = np.random.default_rng(2)
+    hx, x1, qx, m4 = orc.model_reduce(h, x, q, mask)
+    hx = (rng.normal(size=hx.shape) * 0.2 * (x1[..., :1] != 0)).astype(np.float32)
+    gnn = charge_gn.GNN_layer(charge_gn.MLP_layer, charge_gn.MLP_layer(layers, out_dim=48), T)
+    for t in range(T):
+        gnn.message_fns[t].set_weights(w["msg"][t])
+    gnn.update_fn.set_weights(w["upd"])
+    h_gpu = gnn.call(hx, e, x1, qx, m4)
+    h_ref = orc.gnn_layer(hx, e, x1, qx, m4, w["msg"], w["upd"], dtype=np.float64)
+    h_r32 = orc.gnn_layer(hx, e, x1, qx, m4, w["msg"], w["upd"], dtype=np.float32)
+    assert np.abs(h_gpu - h_ref).max() <= max(TOL, 3 * np.abs(h_r32 - h_ref).max())
+    # (5) the training step is built for [32, 32] only and says so
+    with pytest.raises(EpnnError, match="32, 32"):
+        charge_gn.Adam().bind(model)
