@@ -125,3 +125,24 @@ def test_corruption_is_detected(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.index").write_bytes(b"\x00" * 64)
         ck.read_index(str(tmp_path / "bad"))
+
+
+@pytest.mark.parametrize("widths", [[16], [64, 32], [8, 24, 40]])
+def test_round_trip_with_other_update_layers(tmp_path, widths):
+    """make_model(layers, ...) sizes the update MLP (charge_gn.py:371): the writer's object graph and keys follow the number of
+    Dense layers under update_fn/layer_set, the reader finds them all again; the reference's own [32, 32] graph is unchanged."""
+    from conftest import random_weights
+    from epnn_amd import checkpoint
+    w = random_weights(9, 2, seed=4)
+    rng = np.random.default_rng(0)
+    dims = [80] + widths + [48]
+    w["upd"] = [(rng.normal(size=(i, o)).astype(np.float32), rng.normal(size=(o,)).astype(np.float32)) for i, o in zip(dims[:-1], dims[1:])]
+    checkpoint.save_epnn_weights(str(tmp_path / "g"), w)
+    back = checkpoint.load_epnn_weights(str(tmp_path / "g"))
+    assert len(back["upd"]) == len(widths) + 1
+    for (k0, b0), (k1, b1) in zip(w["upd"], back["upd"]):
+        assert np.array_equal(k0, k1) and np.array_equal(b0, b1)
+    for t in range(2):
+        for l in range(3):
+            assert np.array_equal(w["msg"][t][l][0], back["msg"][t][l][0]) and np.array_equal(w["pas"][t][l][1], back["pas"][t][l][1])
+    assert checkpoint.keras_object_graph(2) == checkpoint.keras_object_graph(2, n_upd=3)
