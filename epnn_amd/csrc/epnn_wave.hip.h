@@ -152,6 +152,8 @@ typedef __attribute__((address_space(3))) const unsigned short w16_lds_cu16;
 __device__ __forceinline__ unsigned w16_lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p; }
 __device__ __forceinline__ f32x4 w16_lds_ld4(unsigned a) { return *(w16_lds_cf4 *)(size_t)a; }
 __device__ __forceinline__ unsigned w16_lds_ldu16(unsigned a) { return *(w16_lds_cu16 *)(size_t)a; }
+typedef __attribute__((address_space(3))) const unsigned w16_lds_cu32;
+__device__ __forceinline__ unsigned w16_lds_ldu32(unsigned a) { return *(w16_lds_cu32 *)(size_t)a; }
 __device__ __forceinline__ f32x2 w16_lo(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f32x2 w16_hi(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
 __device__ __forceinline__ f32x4 w16_cat(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
@@ -624,9 +626,11 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                         Sc[0] += w * zz[0];
                         Sc[1] += w * zz[1];
                     };
-#pragma unroll 1
-                    for (int blk = two ? 1 : 0; blk >= 0; --blk) {           // block 1 first, then block 0
-                        const bool b1 = blk == 1;
+                    // one column block.  B1 (compile time): block 1's copies take every C1-th partner (entries and R rows a stride
+                    // apart, read one by one); block 0 takes the partners in turn, so the entries of two consecutive tiles are ONE
+                    // aligned 32-bit word of the column's pair-map row: one LDS read per two tiles instead of two.
+                    auto pass = [&](auto b1_tag) {
+                        constexpr bool b1 = decltype(b1_tag)::value;
                         f32x2 Pc[4];
                         f32x4 Sc[2] = {w16_splat(0.f), w16_splat(0.f)};
 #pragma unroll
@@ -646,25 +650,42 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                         const unsigned ral = rl ? rbase + 4u * EPNN_PST * (unsigned)jl : lbase + zent;
                         const unsigned entl = w16_lds_ldu16(pbase + 2u * (unsigned)(col * NPM + min(jl, n)));
                         Ops oa, ob;
-                        unsigned en = w16_lds_ldu16(pa);          // entry of tile 0
-                        pa += ps;
+                        unsigned en, en2 = 0;
+                        if (b1) {
+                            en = w16_lds_ldu16(pa);               // entry of tile 0
+                            pa += ps;
+                        } else {
+                            en2 = w16_lds_ldu32(pa);              // entries of tiles 0 and 1
+                            pa += 4u;
+                            en = en2 & 0xffffu;
+                        }
                         load_rg(oa, ra, en);
                         ra += rs;
-                        en = w16_lds_ldu16(pa);                   // entry of tile 1
-                        pa += ps;
+                        if (b1) {
+                            en = w16_lds_ldu16(pa);               // entry of tile 1
+                            pa += ps;
+                        } else en = en2 >> 16;
                         int k = 0;
 #pragma unroll 1
                         for (; k + 3 <= ntr; k += 2) {            // tiles k, k + 1; tile k + 2 is a real one too
                             load_rg(ob, ra, en);
                             ra += rs;
-                            en = w16_lds_ldu16(pa);
-                            pa += ps;
+                            if (b1) {
+                                en = w16_lds_ldu16(pa);
+                                pa += ps;
+                            } else {
+                                en2 = w16_lds_ldu32(pa);          // entries of tiles k + 2 and k + 3
+                                pa += 4u;
+                                en = en2 & 0xffffu;
+                            }
                             WAVE_FENCE();
                             tile(Pc, Sc, oa);
                             load_rg(oa, ra, en);
                             ra += rs;
-                            en = w16_lds_ldu16(pa);
-                            pa += ps;
+                            if (b1) {
+                                en = w16_lds_ldu16(pa);
+                                pa += ps;
+                            } else en = en2 >> 16;
                             WAVE_FENCE();
                             tile(Pc, Sc, ob);
                         }
@@ -688,7 +709,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                             if (b1) S1[rb] = Sc[rb];
                             else S0[rb] = Sc[rb];
                         }
-                    }
+                    };
+                    if (two) pass(std::true_type{});              // block 1 first, then block 0
+                    pass(std::false_type{});
                 };
                 if (gover) sweep(std::true_type{});
                 else sweep(std::false_type{});
