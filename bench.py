@@ -40,6 +40,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
 """
 import argparse
 import hashlib
+import gc
 import json
 import os
 import subprocess
@@ -390,11 +391,14 @@ def main():
             step(k)
         pipe.sync()
         barrier()
+        gc.disable()                                        # (no collector pause inside a region that lasts two milliseconds)
         t_start = time.perf_counter()
         for k in range(args.steps):
             step(k)
         barrier()
-        return time.perf_counter() - t_start
+        dt_ = time.perf_counter() - t_start
+        gc.enable()
+        return dt_
 
     cold_dt = None
     if not args.no_extras:
@@ -472,12 +476,14 @@ def main():
         while time.perf_counter() < t_end:
             pass
     barrier()
+    gc.disable()                                            # (see timed_steps; a collection HERE would idle the GPU for milliseconds: clocks)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     t_enq = time.perf_counter() - t0                        # (host time of the K calls; the rest of dt is the wait for the GPU)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     # Kernel durations for the roofline: the same steps again (up to 600), right after the timed region, this time with
     # hipEvents recorded around every stage on the stream the kernels run on (four event records per forward cost
     # ~20 us of host time per step, which would otherwise be charged to `value`).
