@@ -106,17 +106,26 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
         xs[3 * lane + 1] = (double)A.xyz[3 * (size_t)(a0 + lane) + 1];
         xs[3 * lane + 2] = (double)A.xyz[3 * (size_t)(a0 + lane) + 2];
     }
-    // ---- per-column registers
-    const float nm = cat ? (A.nm_in ? A.nm_in[a0 + col] : 1.f) : 0.f;
+    // ---- per-column registers: every lane loads from a clamped row and selects afterwards (a load under a condition is a branch
+    //      with its own wait: see k_wave_forward)
+    const int ia = a0 + min(col, n - 1);
+    float nmv = 1.f, qa;
+    if (A.nm_in) nmv = A.nm_in[ia];
+    if (A.q_in) qa = A.q_in[ia];
+    else qa = A.Q[b] / (float)n;                                                          // charge_gn.py:337-338
+    float xv[EPNN_XS];
+#pragma unroll
+    for (int s = 0; s < EPNN_XS; ++s) xv[s] = A.xin[(size_t)ia * nx + min(max(4 * s + q - 1, 0), nx - 1)];
+    const float nm = cat ? nmv : 0.f;
     float xq[EPNN_XS];
     {
-        const float qv = cat ? (A.q_in ? A.q_in[a0 + col] : A.Q[b] / (float)n) : 0.f;     // charge_gn.py:337-338
+        const float qv = cat ? qa : 0.f;
 #pragma unroll
         for (int s = 0; s < EPNN_XS; ++s) {
             const int phi = 4 * s + q;
             float v = 0.f;
             if (phi == 0) v = nm;
-            else if (phi <= nx) { if (cat) v = A.xin[(size_t)(a0 + col) * nx + phi - 1]; }
+            else if (phi <= nx) v = cat ? xv[s] : 0.f;
             else if (phi == nx + 1) v = qv;
             else if (phi == nx + 2) v = cat ? 1.f : 0.f;
             xq[s] = v;
