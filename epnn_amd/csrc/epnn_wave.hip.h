@@ -938,8 +938,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     const float d = 0.5f * w16_sumq(fd);               // charge_gn.py:116; all lanes take part
                     // entries with weight 0 are never written (they stay 0): a one-sided entry (j,i) of the dense
                     // front-end must not clear what the entry (i,j) wrote
-                    if (q == 0 && valid && r_.wi != 0.f) Dm[li * EPNN_DST + lj] = r_.wi * d;
-                    if (q == 1 && valid && r_.wj != 0.f) Dm[lj * EPNN_DST + li] = -(r_.wj * d);
+                    // (ONE store instruction: lane group q = 0 writes what i receives, q = 1 what j receives)
+                    const float wq = q == 0 ? r_.wi : r_.wj;
+                    if (q < 2 && valid && wq != 0.f) Dm[q == 0 ? li * EPNN_DST + lj : lj * EPNN_DST + li] = q == 0 ? wq * d : -(wq * d);
                 };
                 if (nblk > 0) {
                     Rec r0, r1;
