@@ -204,6 +204,7 @@ struct epnn_handle {
     int l_natiles = 0, l_nstasks = 0, l_maxchunk = 0;
     // options / stats
     int opt_profile = 0, opt_force_path = 0;
+    int opt_sync_spin_us = 2000;      // finish_forward / epnn_sync: poll the stream this long before sleeping on its completion (0: sleep at once)
     float timing[4] = {0, 0, 0, 0};
     int64_t stats[4] = {0, 0, 0, 0};
     // page-locked staging: the plan's index arrays with, behind them, the inputs of the host entry (one upload per forward;

@@ -196,7 +196,7 @@ int epnn_last_timing(epnn_handle *h, float *out4);
 int epnn_timing_at(epnn_handle *h, int idx, float *out4);
 /* options: "profile" (0 = off, k > 0 = keep stage events of the last k forwards), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
  * "pair_cap_per_atom" (initial capacity of the near-pair list of the tiled / dense paths), "wave_front" (1: batches of small
- * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront), "wave3" (1, default: molecules of 33..48 / 49..64 atoms of the compact and the make_model entries run on three / four wavefronts of the block-per-wavefront fused kernel; 0: on the tiled kernels), "wave2" (block-per-wavefront kernel of the compact entry: molecules with at least this many atoms, 17..32, are split over two wavefronts and those of at most 16 run two to a workgroup; 0: one wavefront per molecule throughout; -1, default: 17 for batches of at most 1024 molecules, which halves the latency of a lone batch, else 0 -- set 0 on handles whose launches overlap), "large_fused" (0: the tiled path launches one kernel per stage),
+ * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront), "wave3" (1, default: molecules of 33..48 / 49..64 atoms of the compact and the make_model entries run on three / four wavefronts of the block-per-wavefront fused kernel; 0: on the tiled kernels), "wave2" (block-per-wavefront kernel of the compact entry: molecules with at least this many atoms, 17..32, are split over two wavefronts and those of at most 16 run two to a workgroup; 0: one wavefront per molecule throughout; -1, default: 17 for batches of at most 1024 molecules, which halves the latency of a lone batch, else 0 -- set 0 on handles whose launches overlap), "large_fused" (0: the tiled path launches one kernel per stage), "sync_spin_us" (2000, default: epnn_sync and every call that waits for a forward poll the stream this many microseconds before they sleep on its completion; 0: sleep at once),
  * "large_dedupe" (1, default: the tiled path's first GNN step of the compact entry groups the atoms by feature row -- h = 0 and one
  * q per molecule there, so the all-pairs sum of charge_gn.py:70 takes (distinct rows)^2 pair evaluations instead of n^2; 0: the
  * all-pairs sweep; a molecule with more than 64 distinct rows switches the handle back to the sweep by itself),
