@@ -274,7 +274,7 @@ class EPNNModel(_Stack):
         self.electron_net = EPN_layer(MLP_layer, T=T)
         if not 1 <= len(list(layers)) <= 7 or any(not 1 <= int(w) <= 256 for w in layers):
             raise EpnnError("make_model: layers must be 1..7 hidden widths of 1..256 units (charge_gn.py:371; [32, 32] is the "
-                            "reference's own choice and the shape the tuned kernels and the training step are built for)")
+                            "reference's own choice and the shape the tuned kernels are built for)")
         F = n_elems + h_dim + 1
         self.update_fn.build(h_dim + 32)
         for m in self.graph_net.message_fns + self.electron_net.pass_fns:

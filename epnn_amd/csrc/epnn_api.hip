@@ -368,7 +368,7 @@ extern "C" int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_
         if (widths[l] < 1 || widths[l] > EPNN_GMLP_WMAX) EPNN_FAIL("epnn_set_update_layers: width %d of layer %d (1 .. %d are built)", widths[l], l, EPNN_GMLP_WMAX);
     HIPCHK(hipSetDevice(h->device));
     if (h->pending.active && finish_forward(h)) return 1;
-    if (h->train) EPNN_FAIL("epnn_set_update_layers: the handle holds training state (the training step is built for layers == [32, 32] only)");
+    if (h->train) EPNN_FAIL("epnn_set_update_layers: the handle already holds training state (set the layers before epnn_train_init)");
     const int H = h->cfg.hidden;
     h->upd_generic = !(n_hidden == 2 && widths[0] == H && widths[1] == H);
     h->updg.clear();
@@ -1924,7 +1924,7 @@ extern "C" int epnn_train_apply(epnn_handle *h) {
 // shared tail of the two train-step entry points: slot arrays are on the device
 // forward + backward of one batch: row-fused kernels when the padded size fits their LDS budget ("train_fused", default 1),
 // else (or with the option at 0) the layer-by-layer kernels
-static bool train_is_fused(const epnn_handle *h, int N) { return h->opt_train_fused && N <= EPNN_TF_NMAX; }
+static bool train_is_fused(const epnn_handle *h, int N) { return h->opt_train_fused && N <= EPNN_TF_NMAX && !h->upd_generic; }   // (other update layers than [32, 32]: one launch per Dense layer)
 // d_loss: [B][N] loss terms (the layer-by-layer path fills one per molecule and leaves the rest zero); adam_now: the fused
 // path's last launch also takes the optimizer step
 static int train_fb(epnn_handle *h, int B, int N, const float *d_e, const float *d_mask, const float *d_x, const float *d_h0,

@@ -330,6 +330,7 @@ struct TrainState {
     bool ready = false;
     int P = 0;                                   // number of parameters
     TDense upd[3], msg[EPNN_MAXT][3], pas[EPNN_MAXT][3];
+    std::vector<TDense> updv;                    // the update MLP's layers when make_model was given other `layers` than [32, 32] (h->updg)
     DevBuf theta, grad, m, v, part, arena, loss;
     long step = 0;
     float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
@@ -359,6 +360,12 @@ static TrainState *train_state(epnn_handle *h) {
     return reinterpret_cast<TrainState *>(h->train);
 }
 
+// the update MLP of a state: its three standard layers, or (TrainState only) the layers of epnn_set_update_layers
+template <typename STATE> static std::vector<TDense> *updv_of(STATE *) { return nullptr; }
+static std::vector<TDense> *updv_of(TrainState *ts) { return &ts->updv; }
+template <typename STATE>
+static bool upd_is_generic(epnn_handle *h, STATE *ts) { return h->upd_generic && updv_of(ts) != nullptr; }
+
 template <typename STATE>
 static void train_layout(epnn_handle *h, STATE *ts) {
     int off = 0;
@@ -370,7 +377,12 @@ static void train_layout(epnn_handle *h, STATE *ts) {
         d.offB = off;
         off += hd.n_out;
     };
-    for (int l = 0; l < 3; ++l) put(ts->upd[l], h->upd[l]);
+    if (upd_is_generic(h, ts)) {
+        std::vector<TDense> &v = *updv_of(ts);
+        v.resize(h->updg.size());
+        for (size_t l = 0; l < v.size(); ++l) put(v[l], h->updg[l]);
+    } else
+        for (int l = 0; l < 3; ++l) put(ts->upd[l], h->upd[l]);
     for (int t = 0; t < h->cfg.T; ++t)
         for (int l = 0; l < 3; ++l) put(ts->msg[t][l], h->msg[t][l]);
     for (int t = 0; t < h->cfg.T; ++t)
@@ -386,7 +398,10 @@ static void train_gather_host(epnn_handle *h, STATE *ts, std::vector<float> &fla
         memcpy(flat.data() + d.offW, hd.W.data(), hd.W.size() * 4);
         memcpy(flat.data() + d.offB, hd.b.data(), hd.b.size() * 4);
     };
-    for (int l = 0; l < 3; ++l) cp(ts->upd[l], h->upd[l]);
+    if (upd_is_generic(h, ts))
+        for (size_t l = 0; l < h->updg.size(); ++l) cp((*updv_of(ts))[l], h->updg[l]);
+    else
+        for (int l = 0; l < 3; ++l) cp(ts->upd[l], h->upd[l]);
     for (int t = 0; t < h->cfg.T; ++t)
         for (int l = 0; l < 3; ++l) { cp(ts->msg[t][l], h->msg[t][l]); cp(ts->pas[t][l], h->pas[t][l]); }
 }
@@ -395,7 +410,10 @@ static void train_scatter_host(epnn_handle *h, TrainState *ts, const std::vector
         memcpy(hd.W.data(), flat.data() + d.offW, hd.W.size() * 4);
         memcpy(hd.b.data(), flat.data() + d.offB, hd.b.size() * 4);
     };
-    for (int l = 0; l < 3; ++l) cp(ts->upd[l], h->upd[l]);
+    if (upd_is_generic(h, ts))
+        for (size_t l = 0; l < h->updg.size(); ++l) cp(ts->updv[l], h->updg[l]);
+    else
+        for (int l = 0; l < 3; ++l) cp(ts->upd[l], h->upd[l]);
     for (int t = 0; t < h->cfg.T; ++t)
         for (int l = 0; l < 3; ++l) { cp(ts->msg[t][l], h->msg[t][l]); cp(ts->pas[t][l], h->pas[t][l]); }
 }
@@ -415,7 +433,6 @@ static int train_sync_to_host(epnn_handle *h) {
 }
 
 static int train_init(epnn_handle *h, float lr, float b1, float b2, float eps) {
-    if (h->upd_generic) EPNN_FAIL("train: the training step is built for an update MLP of layers == [32, 32] only (epnn_set_update_layers gave others)");
     TrainState *ts = train_state(h);
     if (train_sync_to_host(h)) return 1;
     train_layout(h, ts);
@@ -452,22 +469,32 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
     const float *theta = ts->theta.as<float>();
     float *grad = ts->grad.as<float>();
     const int NSL = 256;          // most row slices of one dW reduction (fixed by the row count: reproducible)
-    if (ts->part.ensure((size_t)NSL * (D + 1) * 48 * 4)) return 1;
+    // the update MLP: three layers of the reference's own [32, 32], or what make_model(layers, ...) asked for (charge_gn.py:371)
+    const bool genu = h->upd_generic;
+    const int NU = genu ? (int)ts->updv.size() : 3;
+    const TDense *UL = genu ? ts->updv.data() : ts->upd;
+    size_t part_elems = (size_t)(D + 1) * 48;
+    for (int l = 0; l < NU; ++l) part_elems = std::max(part_elems, (size_t)(UL[l].n_in + 1) * UL[l].n_out);
+    if (ts->part.ensure((size_t)NSL * part_elems * 4)) return 1;
     // ---- arena
     size_t need = 0;
     auto sz = [&](size_t n) { size_t o = need; need += (n + 63) & ~size_t(63); return o; };
-    struct GStep { size_t a, X, H1, H2, Mij, M, U0, U1, U2, hraw, hn; } gs[EPNN_MAXT];
+    struct GStep { size_t a, X, H1, H2, Mij, M, U[EPNN_GMLP_LMAX], hraw, hn; } gs[EPNN_MAXT];      // U[l]: input rows of update layer l
     struct EStep { size_t a, XN, H1N, H2N, fN, XT, H1T, H2T, fT, qn; } es[EPNN_MAXT];
     const size_t o_nm = sz(BN), o_wgt = sz(R);
     for (int t = 0; t < T; ++t) {
-        gs[t] = {sz((size_t)BN * F), sz(R * D), sz(R * 32), sz(R * 32), sz(R * 32), sz((size_t)BN * 32), sz((size_t)BN * 80),
-                 sz((size_t)BN * 32), sz((size_t)BN * 32), sz((size_t)BN * H), sz((size_t)BN * H)};
+        GStep &g = gs[t];
+        g.a = sz((size_t)BN * F); g.X = sz(R * D); g.H1 = sz(R * 32); g.H2 = sz(R * 32); g.Mij = sz(R * 32); g.M = sz((size_t)BN * 32);
+        for (int l = 0; l < NU; ++l) g.U[l] = sz((size_t)BN * UL[l].n_in);
+        g.hraw = sz((size_t)BN * H); g.hn = sz((size_t)BN * H);
     }
     for (int t = 0; t < T; ++t) {
         es[t] = {sz((size_t)BN * F), sz(R * D), sz(R * 32), sz(R * 32), sz(R), sz(R * D), sz(R * 32), sz(R * 32), sz(R), sz(BN)};
     }
-    const size_t o_dX = sz(R * D), o_dA = sz(R * 32), o_dB = sz(R * 32), o_dC = sz(R * 32), o_da = sz((size_t)BN * F),
-                 o_dU0 = sz((size_t)BN * 80), o_dU1 = sz((size_t)BN * 32), o_dU2 = sz((size_t)BN * 32), o_dh = sz((size_t)BN * H),
+    const size_t o_dX = sz(R * D), o_dA = sz(R * 32), o_dB = sz(R * 32), o_dC = sz(R * 32), o_da = sz((size_t)BN * F);
+    size_t o_dU[EPNN_GMLP_LMAX];                       // gradient with respect to the input rows of update layer l
+    for (int l = 0; l < NU; ++l) o_dU[l] = sz((size_t)BN * UL[l].n_in);
+    const size_t o_dU0 = o_dU[0], o_dh = sz((size_t)BN * H),
                  o_gh = sz((size_t)BN * H), o_gfeat = sz((size_t)BN * H), o_gq = sz(BN), o_dfN = sz(R), o_dfT = sz(R);
     if (ts->arena.ensure(need * 4)) return 1;
     if (size_only) return 0;            // scratch is allocated: nothing below calls the allocator (graph capture)
@@ -519,10 +546,8 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
         dense(P(g.H1), ts->msg[t][1], P(g.H2), R, 1);
         dense(P(g.H2), ts->msg[t][2], P(g.Mij), R, 0);
         hipLaunchKernelGGL(k_t_sumj, dim3(t_grid((size_t)BN * 32)), dim3(256), 0, st, P(g.Mij), P(g.M), B, N, 32);
-        hipLaunchKernelGGL(k_t_u0, dim3(t_grid((size_t)BN * 80)), dim3(256), 0, st, hcur, P(g.M), nm, P(g.U0), BN, H, 32);
-        dense(P(g.U0), ts->upd[0], P(g.U1), BN, 1);
-        dense(P(g.U1), ts->upd[1], P(g.U2), BN, 1);
-        dense(P(g.U2), ts->upd[2], P(g.hraw), BN, 0);
+        hipLaunchKernelGGL(k_t_u0, dim3(t_grid((size_t)BN * 80)), dim3(256), 0, st, hcur, P(g.M), nm, P(g.U[0]), BN, H, 32);
+        for (int l = 0; l < NU; ++l) dense(P(g.U[l]), UL[l], l + 1 < NU ? P(g.U[l + 1]) : P(g.hraw), BN, l + 1 < NU ? 1 : 0);
         hipLaunchKernelGGL(k_t_scale_rows, dim3(t_grid((size_t)BN * H)), dim3(256), 0, st, P(g.hraw), nm, P(g.hn), BN, H);
         hcur = P(g.hn);
     }
@@ -569,9 +594,8 @@ static int train_fwd_bwd(epnn_handle *h, int B, int N, const float *d_e, const f
         const GStep &g = gs[t];
         // h_{t+1} = hraw * nm
         hipLaunchKernelGGL(k_t_scale_rows, dim3(t_grid((size_t)BN * H)), dim3(256), 0, st, gh, nm, P(o_dh), BN, H);
-        dense_bwd(P(g.U2), P(o_dh), nullptr, ts->upd[2], P(o_dU2), BN);
-        dense_bwd(P(g.U1), P(o_dU2), P(g.U2), ts->upd[1], P(o_dU1), BN);
-        dense_bwd(P(g.U0), P(o_dU1), P(g.U1), ts->upd[0], P(o_dU0), BN);
+        for (int l = NU - 1; l >= 0; --l)              // (a hidden layer's gradient is masked by its own output > 0: the next layer's input)
+            dense_bwd(P(g.U[l]), l + 1 < NU ? P(o_dU[l + 1]) : P(o_dh), l + 1 < NU ? P(g.U[l + 1]) : nullptr, UL[l], P(o_dU[l]), BN);
         // U0 = [h | M] * nm ; M_i = sum_j m_ij
         hipLaunchKernelGGL(k_t_bcast_gm, dim3(t_grid(R * 32)), dim3(256), 0, st, P(o_dU0), nm, P(o_dC), BN, N, H, 32);
         dense_bwd(P(g.H2), P(o_dC), nullptr, ts->msg[t][2], P(o_dA), R);

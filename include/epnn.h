@@ -58,13 +58,12 @@ int epnn_device_count(void);
  * its scripts use layers = [32, 32], h_dim = e_dim = 48 (:413-417, infer.py:47-50).
  *   free :  nx in 1..10 (atom feature columns; 9 and 10 are the reference's two tables), T in 1..8, cutoff, eta, near_tol,
  *           the padded size N and the batch size of every call, every weight value; `layers` of the update MLP (1..7 hidden
- *           layers of 1..256 units each: epnn_set_update_layers) for every INFERENCE entry;
- *   fixed:  hidden == 32 (the reference's own constant for the message / pass MLPs), h_dim == e_dim == 48; the training step
- *           (epnn_train_*) additionally needs layers == [32, 32].
+ *           layers of 1..256 units each: epnn_set_update_layers) for every inference entry and the training step;
+ *   fixed:  hidden == 32 (the reference's own constant for the message / pass MLPs), h_dim == e_dim == 48.
  * epnn_create FAILS (returns non-zero, epnn_last_error says which field) for any other value.  `layers` == [32, 32] runs the
  * kernels DESIGN.md describes; any other `layers` runs every molecule through the tiled kernels with one launch per stage and a
- * generic (f32 FMA) Dense stack as the update stage -- the same results to float32 rounding, several times slower per small
- * molecule: a correctness path, not a tuned one. */
+ * generic (f32 FMA) Dense stack as the update stage, and the training step with one launch per Dense layer ("train_fused" = 0's
+ * kernels) -- the same results to float32 rounding, several times slower per small molecule: a correctness path, not a tuned one. */
 int epnn_create(const epnn_config *cfg, int device, epnn_handle **out);
 int epnn_destroy(epnn_handle *h);
 /* Leaves out `n` of the process's hardware queues: the HIP runtime deals a process's streams onto its hardware queues in the order
@@ -83,7 +82,7 @@ int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, int32_t *n_in
 /* make_model(layers, ...) / GNN_layer(message_fn, update_fn = MLP_layer(layers, out_dim = h_dim), T) (charge_gn.py:369-371): the
  * hidden widths of the update MLP, widths[n_hidden].  The default is {32, 32}.  Afterwards EPNN_W_UPD has n_hidden + 1 layers
  * (layer 0: h_dim + 32 -> widths[0]; the last: widths[n_hidden - 1] -> h_dim), all zero until epnn_set_weights fills them.
- * Fails on a handle that holds training state (see the CONTRACT above). */
+ * Fails on a handle that already holds training state (call it before epnn_train_init). */
 int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_t *widths);
 
 /* get_init_edges (charge_gn.py:122-163): xyz[n][3] float32 -> e[n][n][e_dim] float32, host pointers. */

@@ -549,7 +549,7 @@ def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp
     """make_model(layers, ...) sizes the update MLP from `layers` (charge_gn.py:369-371; the message / pass MLPs are [32, 32] by
     the reference's own constants).  Other widths than [32, 32] run the tiled kernels with the generic update stage: the literal
     dense call, the compact entry on molecules of 3..38 atoms and a 150-atom box, and GNN_layer.call, each vs the float64
-    oracle; the checkpoint writer / reader round trip keeps the layer count; the training step refuses such a model."""
+    oracle; the checkpoint writer / reader round trip keeps the layer count; the training step's gradients vs the float64 oracle."""
     from epnn_amd import charge_gn, synth
     from epnn_amd._lib import EpnnError
     from epnn_amd.engine import Engine
@@ -616,6 +616,30 @@ def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp
     h_ref = orc.gnn_layer(hx, e, x1, qx, m4, w["msg"], w["upd"], dtype=np.float64)
     h_r32 = orc.gnn_layer(hx, e, x1, qx, m4, w["msg"], w["upd"], dtype=np.float32)
     assert np.abs(h_gpu - h_ref).max() <= max(TOL, 3 * np.abs(h_r32 - h_ref).max())
-    # (5) the training step is built for [32, 32] only and says so
-    with pytest.raises(EpnnError, match="32, 32"):
-        charge_gn.Adam().bind(model)
+    # (5) the training step: gradient of sum (y - p)^2 (charge_gn.py:397-398) per parameter tensor vs the float64 oracle, then an
+    #     optimizer step through the reference-style API (the weights move, the layer count stays)
+    from oracle import epnn_oracle_train as ot
+    yb = (0.05 * rng.normal(size=(x.shape[0], x.shape[1]))).astype(np.float32)
+    loss_ref, pred_ref, g_ref = ot.loss_and_grads(h, e, x, q, mask, yb, w)
+    engt = Engine(nx=nx, T=T)
+    engt.set_weights(w)
+    engt.train_init()
+    predt, losst = engt.train_step_dense(h, e, x, q, mask, yb, apply=False)
+    assert np.abs(predt.reshape(pred_ref.shape) - pred_ref).max() < 2e-5 and abs(losst - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    g, gr = engt.get_gradients().astype(np.float64), ot.flatten(g_ref)
+    assert g.shape == gr.shape == (engt.param_count(),)
+    pos, worst = 0, 0.0
+    for m in [w["upd"]] + w["msg"] + w["pas"]:
+        for W_, b_ in m:
+            for arr in (W_, b_):
+                sl = slice(pos, pos + arr.size)
+                scale = np.abs(gr[sl]).max()
+                if scale > 0:
+                    worst = max(worst, np.abs(g[sl] - gr[sl]).max() / scale)
+                pos += arr.size
+    print(f"layers {layers}: worst per-tensor relative gradient error {worst:.2e}")
+    assert worst <= 2e-4
+    engt.train_apply()
+    w_after = engt.get_weights()
+    assert len(w_after["upd"]) == len(layers) + 1 and not np.array_equal(w_after["upd"][0][0], w["upd"][0][0])
+    engt.close()
