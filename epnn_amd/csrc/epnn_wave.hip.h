@@ -610,6 +610,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                         const f32x4 za = w16_relu((w16_cat(Pc[0], Pc[1]) + o_.r0) + o_.g0), zb = w16_relu((w16_cat(Pc[2], Pc[3]) + o_.r1) + o_.g1);
                         const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
                         f32x4 d[2] = {b2v[0], b2v[1]};
+                        // (all of the first layer's element-wise work in front of the tile's MFMAs: interleaved with them the compiler
+                        //  un-packs its v_pk_add_f32 "in the shadow" of the matrix instructions, 4 VALU instructions more per tile)
+                        WAVE_FENCE();
                         w16_mm<2, 8>(pb, z, d);
                         zz[0] = w16_relu(d[0]);
                         zz[1] = w16_relu(d[1]);
@@ -926,6 +929,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     const float zu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
                     const float zv[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
                     f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
+                    WAVE_FENCE();                                          // (the element-wise work first: see the sweep's tile)
                     w16_mm<2, 8>(pb, zu, au);
                     w16_mm<2, 8>(pb, zv, av);
                     float fd = 0.f;                                    // w3 . (relu(u) - relu(v)) over this lane's 8 features
