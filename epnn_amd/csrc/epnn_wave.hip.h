@@ -605,29 +605,24 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                             }
                         }
                     };
-                    // z1 = relu((P + R) + G), acc = W2^T z1 + b2, relu(acc)  (charge_gn.py:66-68)
-                    auto mlp = [&](const f32x2 (&Pc)[4], const Ops &o_, f32x4 (&zz)[2]) {
+                    // z1 = relu((P + R) + G), acc = W2^T z1 + b2, S += relu(acc)  (charge_gn.py:66-68).  The relu + sum of a tile runs one
+                    // tile LATER, in the next tile's block of element-wise work in front of its MFMAs (`dp` = the pending accumulators):
+                    // behind its own MFMAs it would wait for them and the compiler would un-pack its packed adds in their shadow.
+                    auto tile = [&](const f32x2 (&Pc)[4], f32x4 (&Sc)[2], const Ops &o_, f32x4 (&dp)[2]) {
+                        Sc[0] += w16_relu(dp[0]);
+                        Sc[1] += w16_relu(dp[1]);
                         const f32x4 za = w16_relu((w16_cat(Pc[0], Pc[1]) + o_.r0) + o_.g0), zb = w16_relu((w16_cat(Pc[2], Pc[3]) + o_.r1) + o_.g1);
                         const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
-                        f32x4 d[2] = {b2v[0], b2v[1]};
-                        // (all of the first layer's element-wise work in front of the tile's MFMAs: interleaved with them the compiler
-                        //  un-packs its v_pk_add_f32 "in the shadow" of the matrix instructions, 4 VALU instructions more per tile)
+                        dp[0] = b2v[0];
+                        dp[1] = b2v[1];
                         WAVE_FENCE();
-                        w16_mm<2, 8>(pb, z, d);
-                        zz[0] = w16_relu(d[0]);
-                        zz[1] = w16_relu(d[1]);
+                        w16_mm<2, 8>(pb, z, dp);
                     };
-                    auto tile = [&](const f32x2 (&Pc)[4], f32x4 (&Sc)[2], const Ops &o_) {
-                        f32x4 zz[2];
-                        mlp(Pc, o_, zz);
-                        Sc[0] += zz[0];
-                        Sc[1] += zz[1];
-                    };
-                    auto tile_w = [&](const f32x2 (&Pc)[4], f32x4 (&Sc)[2], const Ops &o_, float w) {
-                        f32x4 zz[2];
-                        mlp(Pc, o_, zz);
-                        Sc[0] += w * zz[0];
-                        Sc[1] += w * zz[1];
+                    // the block's last tile (weight w): the pending tile first, then its own contribution at once
+                    auto tile_w = [&](const f32x2 (&Pc)[4], f32x4 (&Sc)[2], const Ops &o_, float w, f32x4 (&dp)[2]) {
+                        tile(Pc, Sc, o_, dp);
+                        Sc[0] += w * w16_relu(dp[0]);
+                        Sc[1] += w * w16_relu(dp[1]);
                     };
                     // one column block.  B1 (compile time): block 1's copies take every C1-th partner (entries and R rows a stride
                     // apart, read one by one); block 0 takes the partners in turn, so the entries of two consecutive tiles are ONE
@@ -636,6 +631,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                         constexpr bool b1 = decltype(b1_tag)::value;
                         f32x2 Pc[4];
                         f32x4 Sc[2] = {w16_splat(0.f), w16_splat(0.f)};
+                        f32x4 dp[2] = {w16_splat(0.f), w16_splat(0.f)};      // no tile pending yet: relu(0) adds nothing
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb) {
                             Pc[2 * rb] = b1 ? w16_lo(P1[rb]) : w16_lo(P0[rb]);
@@ -682,7 +678,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                                 en = en2 & 0xffffu;
                             }
                             WAVE_FENCE();
-                            tile(Pc, Sc, oa);
+                            tile(Pc, Sc, oa, dp);
                             load_rg(oa, ra, en);
                             ra += rs;
                             if (b1) {
@@ -690,22 +686,22 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                                 pa += ps;
                             } else en = en2 >> 16;
                             WAVE_FENCE();
-                            tile(Pc, Sc, ob);
+                            tile(Pc, Sc, ob, dp);
                         }
                         if (!b1) { W16_LD(u1s, M.u1s, 2, 8); }   // first operand of the update MLP
                         if (ntr - k == 2) {                       // real tiles k, k + 1, then the last tile
                             load_rg(ob, ra, en);
                             WAVE_FENCE();
-                            tile(Pc, Sc, oa);
+                            tile(Pc, Sc, oa, dp);
                             load_rg(oa, ral, entl);
                             WAVE_FENCE();
-                            tile(Pc, Sc, ob);
-                            tile_w(Pc, Sc, oa, wl);
+                            tile(Pc, Sc, ob, dp);
+                            tile_w(Pc, Sc, oa, wl, dp);
                         } else {                                  // real tile k, then the last tile
                             load_rg(ob, ral, entl);
                             WAVE_FENCE();
-                            tile(Pc, Sc, oa);
-                            tile_w(Pc, Sc, ob, wl);
+                            tile(Pc, Sc, oa, dp);
+                            tile_w(Pc, Sc, ob, wl, dp);
                         }
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb) {
