@@ -928,6 +928,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     WAVE_FENCE();                                          // (the element-wise work first: see the sweep's tile)
                     w16_mm<2, 8>(pb, zu, au);
                     w16_mm<2, 8>(pb, zv, av);
+                    WAVE_FENCE();                                          // (... and the block's element-wise tail behind ALL of them)
                     float fd = 0.f;                                    // w3 . (relu(u) - relu(v)) over this lane's 8 features
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {

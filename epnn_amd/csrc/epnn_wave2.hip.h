@@ -555,6 +555,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                     WAVE_FENCE();
                     w16_mm<2, 8>(pb, zu, au);
                     w16_mm<2, 8>(pb, zv, av);
+                    WAVE_FENCE();
                     float fd = 0.f;
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb) {
