@@ -291,7 +291,10 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     unsigned short *pm = reinterpret_cast<unsigned short *>(sm + o_x);
     const int NPM = ((n + 9) & ~3) + 2;
     float *Pl = sm + o_x;                                  // [n][PST]   P_i rows
-    float *Dm = sm + o_x + n * EPNN_PST;                   // [n][DST]   weighted transfers: Dm[i][j] = what i receives from j
+    // [n][DMS] weighted transfers: what atom i receives from atom j sits at Dm[i * DMS + 8 (j & 3) + (j >> 2)] -- the columns a lane
+    // group q adds up (j = q, q + 4, ...: the charge update) are 8 consecutive floats, one or two 16-byte reads instead of up to eight
+    constexpr int DMS = 36;
+    float *Dm = sm + o_x + n * EPNN_PST;
     const int o_gg = o_x + ((((n * NPM + 1) >> 1) + 3) & ~3);
     const int grows_g = (A.lds_words - o_gg) / EPNN_PST - 1;
     float *Gl = sm + o_gg;                                 // GNN: row 0 all zeros, row 1 + s = G row of pair slot s < glds
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         gover = np > glds;
         ngt = (np + 31) >> 5;
         // above the G rows AND above the EPN stack's tables, so that the rows survive the change of layout
-        ptl = min(np, max(0, A.lds_words - max(o_gg + (glds + 1) * EPNN_PST, o_x + n * (EPNN_PST + EPNN_DST))) / EPNN_ER);
+        ptl = min(np, max(0, A.lds_words - max(o_gg + (glds + 1) * EPNN_PST, o_x + n * (EPNN_PST + DMS))) / EPNN_ER);
         wave_sync_lds();
         WAVE_STAMP_I();   // pair slots
         // ---- edge coefficients of every pair, one lane per pair: pt[pair] = B^T e(D), the 16 coordinates of the pair's Gaussian
@@ -834,10 +837,10 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     // ================================================================== EPN steps (charge_gn.py:98-118)
     if (EPN) {
         wave_sync_lds();                                    // the GNN's tables are dead: switch to the EPN layout
-        for (int i = lane; i < n * EPNN_DST; i += 64) Dm[i] = 0.f;
+        for (int i = lane; i < n * DMS; i += 64) Dm[i] = 0.f;
         if (FRONT && ptl < np) {
             // edge coordinates that went through HBM (no room beside the G rows): the EPN stack's layout has room for more of them
-            const int pte = min(np, (A.lds_words - (o_x + n * (EPNN_PST + EPNN_DST))) / EPNN_ER);
+            const int pte = min(np, (A.lds_words - (o_x + n * (EPNN_PST + DMS))) / EPNN_ER);
             for (int i = lane; i < (pte - ptl) * (EPNN_ER / 4); i += 64) {
                 const int r = ptl + (i >> 2), k = i & 3;
                 w16_st(sm + A.lds_words - (size_t)(r + 1) * EPNN_ER + 4 * k, w16_ld(A.pt + (size_t)(p0 + r) * EPNN_ER + 4 * k));
@@ -941,7 +944,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     // front-end must not clear what the entry (i,j) wrote
                     // (ONE store instruction: lane group q = 0 writes what i receives, q = 1 what j receives)
                     const float wq = q == 0 ? r_.wi : r_.wj;
-                    if (q < 2 && valid && wq != 0.f) Dm[q == 0 ? li * EPNN_DST + lj : lj * EPNN_DST + li] = q == 0 ? wq * d : -(wq * d);
+                    const int to = q == 0 ? li : lj, from = q == 0 ? lj : li;
+                    if (q < 2 && valid && wq != 0.f) Dm[to * DMS + ((from & 3) << 3) + (from >> 2)] = q == 0 ? wq * d : -(wq * d);
                 };
                 if (nblk > 0) {
                     Rec r0, r1;
@@ -974,10 +978,15 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of the rows of its two atoms
             {
                 float dq0 = 0.f, dq1 = 0.f;
-                const float *row0 = Dm + (cat0 ? n16 : 0) * EPNN_DST, *row1 = Dm + (cat1 ? col1 : 0) * EPNN_DST;
-                for (int j = q; j < n; j += 4) {
-                    dq0 += row0[j];
-                    dq1 += row1[j];
+                // (entries of columns >= n are never written: they add exact zeros, the order of the real ones is j = q, q + 4, ...)
+                const unsigned r0a = w16_lds_addr(Dm + (cat0 ? n16 : 0) * DMS) + 32u * (unsigned)q, r1a = w16_lds_addr(Dm + (cat1 ? col1 : 0) * DMS) + 32u * (unsigned)q;
+                const f32x4 u0 = w16_lds_ld4(r0a), u1 = w16_lds_ld4(r1a);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { dq0 += u0[k]; dq1 += u1[k]; }
+                if (two) {
+                    const f32x4 v0 = w16_lds_ld4(r0a + 16u), v1 = w16_lds_ld4(r1a + 16u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { dq0 += v0[k]; dq1 += v1[k]; }
                 }
                 dq0 = w16_sumq(dq0);
                 dq1 = w16_sumq(dq1);
