@@ -650,7 +650,12 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                         const bool rl = jl < n;
                         const float wl = rl ? 1.f : (jl == n ? padw : 0.f);
                         const unsigned ral = rl ? rbase + 4u * EPNN_PST * (unsigned)jl : lbase + zent;
-                        const unsigned entl = w16_lds_ldu16(pbase + 2u * (unsigned)(col * NPM + min(jl, n)));
+                        // (block 0: its last tile is the zero-padded partner alone -- R = 0, G = 0, nothing to read)
+                        const unsigned entl = b1 ? w16_lds_ldu16(pbase + 2u * (unsigned)(col * NPM + min(jl, n))) : zent;
+                        auto load_last = [&](Ops &o_) {
+                            if (b1) load_rg(o_, ral, entl);
+                            else { o_.r0 = w16_splat(0.f); o_.r1 = w16_splat(0.f); o_.g0 = w16_splat(0.f); o_.g1 = w16_splat(0.f); }
+                        };
                         Ops oa, ob;
                         unsigned en, en2 = 0;
                         if (b1) {
@@ -696,12 +701,12 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                             load_rg(ob, ra, en);
                             WAVE_FENCE();
                             tile(Pc, Sc, oa, dp);
-                            load_rg(oa, ral, entl);
+                            load_last(oa);
                             WAVE_FENCE();
                             tile(Pc, Sc, ob, dp);
                             tile_w(Pc, Sc, oa, wl, dp);
                         } else {                                  // real tile k, then the last tile
-                            load_rg(ob, ral, entl);
+                            load_last(ob);
                             WAVE_FENCE();
                             tile(Pc, Sc, oa, dp);
                             tile_w(Pc, Sc, ob, wl, dp);
