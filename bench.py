@@ -584,11 +584,19 @@ def main():
                 d.free()
         pipe.close()
         pipe = None
-        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--real-only", "--real-depth", str(args.real_depth)],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        # (rank 0 only: `real` is set by the parity block above.)  A child that hangs or cannot be started must not cost the line its
+        # already-measured `value`, nor leave the other ranks in the closing barrier: real_data is then null with the reason.
         try:
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--real-only", "--real-depth", str(args.real_depth)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
             extras["real_data"] = json.loads([l for l in child.stdout.splitlines() if l.startswith("{")][-1])
+        except (subprocess.TimeoutExpired, OSError) as exc:
+            extras["real_data"] = None
+            extras["real_data_error"] = f"{type(exc).__name__}: {exc}"[:300]
+            print(f"[bench] real-data child did not finish: {exc}", file=sys.stderr)
         except (IndexError, ValueError):
+            extras["real_data"] = None
+            extras["real_data_error"] = "no JSON line from the child: " + child.stderr[-200:]
             print(f"[bench] real-data child failed: {child.stderr[-400:]}", file=sys.stderr)
 
     if rank == 0:

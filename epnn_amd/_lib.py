@@ -53,7 +53,7 @@ SIGNATURES = {
     "epnn_gnn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_epn_forward": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "epnn_mlp_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
-    "epnn_mlp_forward_layers": (C.c_int, [_vp, C.c_int, C.c_int, _ip, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp]),
+    "epnn_mlp_forward_layers": (C.c_int, [_vp, C.c_int, C.c_int, _ip, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp, C.c_int]),
     "epnn_train_init": (C.c_int, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     "epnn_param_count": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "epnn_train_step_dense": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int]),

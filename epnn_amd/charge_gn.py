@@ -63,9 +63,14 @@ class _Dense:
 class MLP_layer:
     """charge_gn.py:30-45: Dense(n, activation) for n in nodes, then Dense(out_dim, None)."""
 
+    ACTIVATIONS = ('relu', None, 'linear', 'tanh', 'sigmoid')
+
     def __init__(self, nodes, out_dim=1, activation='relu'):
-        if activation != 'relu':
-            raise ValueError("only activation='relu' is built (the reference never uses another)")
+        # charge_gn.py:31,38 hands `activation` to keras.layers.Dense.  As a stand-alone operator (`.call`) the Keras names above are
+        # built; inside GNN_layer / EPN_layer / make_model only 'relu' is -- the reference's own stacks never pass anything else
+        # (charge_gn.py:52,84,371) and the fused kernels are built around the ReLU (_push refuses the rest).
+        if activation not in self.ACTIVATIONS:
+            raise ValueError(f"activation {activation!r} is not built: one of {self.ACTIVATIONS}")
         self.nodes = list(nodes)
         self.out_dim = out_dim
         self.activation = activation
@@ -90,10 +95,10 @@ class MLP_layer:
         lead = x.shape[:-1]
         self.build(x.shape[-1])
         eng = _scratch_engine()
-        if self.nodes == [32, 32]:
+        if self.nodes == [32, 32] and self.activation == 'relu':
             out = eng.mlp_forward(x.reshape(-1, x.shape[-1]), self.get_weights())           # the matrix-pipe kernel
-        else:
-            out = eng.mlp_forward_layers(x.reshape(-1, x.shape[-1]), self.get_weights())    # any widths (generic Dense stack)
+        else:                                                                               # any widths / activation (generic Dense stack)
+            out = eng.mlp_forward_layers(x.reshape(-1, x.shape[-1]), self.get_weights(), self.activation)
         return out.reshape(lead + (self.out_dim,))
 
     __call__ = call
@@ -129,6 +134,10 @@ class _Stack:
 
 def _push(eng, msg, upd, pas, nx):
     F = nx + 49
+    for m in list(msg or []) + ([upd] if upd is not None else []) + list(pas or []):
+        if getattr(m, "activation", "relu") != "relu":
+            raise EpnnError(f"an MLP_layer with activation={m.activation!r} inside GNN_layer / EPN_layer / make_model: the stacks are "
+                            "built for 'relu' (the reference's own, charge_gn.py:52,84,371); other activations run in MLP_layer.call only")
     for t, m in enumerate(msg or []):
         m.build(2 * F + 48)
         for l, (k, b) in enumerate(m.get_weights()):

@@ -102,8 +102,10 @@ struct WaveIndex {
 #define EPNN_GMLP_ROWS 16     // rows per workgroup
 #define EPNN_GMLP_WMAX 256    // widest layer
 #define EPNN_GMLP_LMAX 8      // Dense layers
+enum { EPNN_ACT_RELU = 0, EPNN_ACT_LINEAR = 1, EPNN_ACT_TANH = 2, EPNN_ACT_SIGMOID = 3 };     // (include/epnn.h: epnn_mlp_forward_layers)
 struct GenMlp {
     int n;
+    int act;                                             // activation of every layer but the last (EPNN_ACT_*; 0 = ReLU)
     int dims[EPNN_GMLP_LMAX + 1];
     int offW[EPNN_GMLP_LMAX], offB[EPNN_GMLP_LMAX];     // floats from `w`
     const float *w;

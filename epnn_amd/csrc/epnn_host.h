@@ -158,9 +158,8 @@ struct epnn_handle {
     int opt_train_skip_padded = 1;    // training, coordinate entry, matrix-pipe kernels: padded atom slots leave their workgroups at once (the same bits)
     const int *tr_moff = nullptr, *tr_real = nullptr;      // ... set around the step by epnn_train_step_xyz
     int opt_train_split = 0;          // training, matrix-pipe backward: workgroups per atom (0 = as many as fit the atom's XCD, at most 6)
-    int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels, Dense layers and weight gradients on the matrix pipe; 3 = the same
-                                      // decomposition as scalar FMA loops (also what 1 runs when nx + 49 > 60 features or the e rows are not
-                                      // 16-byte aligned); 0 = the layer-by-layer kernels
+    int opt_train_fused = 1;          // training: 1 = row-fused pair-MLP kernels, Dense layers and weight gradients on the matrix pipe;
+                                      // 0 = the layer-by-layer kernels
     int opt_train_graph = 1;          // training: 1 replays the step's launch sequence (optimizer step included) as a hipGraph: 0.22 vs 0.245 ms
                                       // per one-molecule step once the kernels were short enough for the launch boundaries to show
                                       // (round 2: 0.47 vs 0.45); a new (B, N, buffer set) means a new capture
@@ -197,7 +196,11 @@ struct epnn_handle {
     epnn_exchange_fn part_exchange = nullptr;
     void *part_ctx = nullptr;
     std::vector<int> part_lo, part_hi;       // every process's row range (the plan is the same everywhere)
-    int opt_part_collective = 0;             // developer switch: run the partition's RCCL exchange even at world size 1
+    int opt_part_collective = 0;             // developer switch: run the communicator's collectives (row exchange, gradient all-reduce, status guard) even at world size 1
+    int opt_comm_guard = 1;                  // a status word is all-reduced (max) in front of every payload collective: see comm_guard below
+    int opt_comm_inject_fail = 0;            // developer switch (tests): this rank reports a failure at its next status guard
+    bool guard_pending = false;              // an entry point that will reach a collective has been entered and its status guard has not run yet
+    DevBuf d_guard;
     // RCCL communicator (epnn_comm_init): gradient all-reduce of the train step, row exchange of a partitioned system
     ncclComm_t comm = nullptr;
     int comm_world = 1, comm_rank = 0;
@@ -236,3 +239,35 @@ struct epnn_handle {
     std::vector<int> dn_neff_host;
     void *train = nullptr;            // TrainState (epnn_train.hip.h)
 };
+
+// ---- fail-closed collectives.  RCCL has no timeout: a rank that leaves an entry point with an error BEFORE a collective its peers
+// have already enqueued leaves them blocked for good.  Every payload collective of this library (the gradient all-reduce of a train
+// step, the row exchange of a partitioned system) is therefore preceded by a 4-byte ncclAllReduce(max) of a status word on the same
+// stream, read back before the payload is enqueued: if ANY rank reports a failure, every rank returns non-zero ("... aborted on every
+// rank") and nobody enqueues the payload.  A rank that fails earlier -- argument checks, allocations, a launch error -- still joins
+// that status collective from its entry point's exit path (epnn_handle::guard_pending says it owes one), so its peers are released.
+// What this cannot cover is a rank whose GPU is gone (the guard itself then fails): rendezvous.launch_ranks stops the survivors.
+static inline bool comm_collectives(const epnn_handle *h) { return h->comm && (h->comm_world > 1 || h->opt_part_collective); }
+static inline int comm_guard(epnn_handle *h, int local_fail, const char *what) {
+    h->guard_pending = false;
+    if (!comm_collectives(h) || !h->opt_comm_guard) return local_fail ? 1 : 0;
+    if (h->opt_comm_inject_fail) { local_fail = 1; h->opt_comm_inject_fail = 0; g_epnn_err = std::string(what) + ": injected failure (developer switch comm_inject_fail)"; }
+    const std::string why = local_fail ? g_epnn_err : std::string();
+    int *word = h->h_status_base + 8;                      // page-locked (epnn_create allocates 12 ints)
+    *word = local_fail ? 1 : 0;
+    bool ok = h->d_guard.ensure(sizeof(int)) == 0;
+    ok = ok && hipMemcpyAsync(h->d_guard.p, word, sizeof(int), hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    ok = ok && ncclAllReduce(h->d_guard.p, h->d_guard.p, 1, ncclInt32, ncclMax, h->comm, h->stream) == ncclSuccess;
+    ok = ok && hipMemcpyAsync(word, h->d_guard.p, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+    if (!ok) EPNN_FAIL("%s: the status collective itself failed on this rank%s%s", what, local_fail ? " after: " : "", why.c_str());
+    if (local_fail) EPNN_FAIL("%s aborted on every rank; this rank failed: %s", what, why.c_str());
+    if (*word != 0) EPNN_FAIL("%s aborted on every rank: another rank reported a failure before the collective", what);
+    return 0;
+}
+// exit path of an entry point that owes its peers a status collective (it failed before reaching the payload collective)
+static inline int comm_guard_exit(epnn_handle *h, int rc, const char *what) {
+    if (rc && h->guard_pending) (void)comm_guard(h, 1, what);
+    h->guard_pending = false;
+    return rc;
+}

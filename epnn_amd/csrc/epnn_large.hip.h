@@ -1413,7 +1413,21 @@ struct PairSource;
 // `have_inc`: the pair list came with its incidence rows (compact entry: epnn_frontend.hip.h); otherwise (dense front-end) they
 // are built here.  `front`: when not null the pair list has NOT been built yet and this function drives the front-end's
 // launches itself, merged with what needs only the atoms (k_lg_first / k_lg_second above).
+// does a forward of this plan run the partition's row exchange over the handle's RCCL communicator?  (Every process has the same
+// inputs and options, so every process answers alike.)
+static bool large_exchanges_over_rccl(const epnn_handle *h, int run_gnn) {
+    return (h->part_world > 1 || h->opt_part_collective) && !h->part_exchange && h->comm && !h->plan.large_list.empty() && run_gnn && h->cfg.T > 0;
+}
+static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
+                             const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn, bool have_inc, const FrontArgs *front);
 static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
+                             const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn, bool have_inc, const FrontArgs *front) {
+    // a process that fails on its way to a row exchange still joins the exchange's status collective (comm_guard, epnn_host.h)
+    if (large_exchanges_over_rccl(h, run_gnn)) h->guard_pending = true;
+    return comm_guard_exit(h, launch_large_body(h, d_x, d_Q, d_hin, d_qin, d_nm, d_q, d_hout, run_gnn, run_epn, have_inc, front),
+                           "partitioned forward (row exchange)");
+}
+static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q, const float *d_hin, const float *d_qin,
                              const float *d_nm, float *d_q, float *d_hout, int run_gnn, int run_epn, bool have_inc, const FrontArgs *front) {
     const Plan &P = h->plan;
     hipStream_t st = h->stream;
@@ -1582,8 +1596,12 @@ static int launch_large_impl(epnn_handle *h, const float *d_x, const float *d_Q,
             } else {
                 // all-gather of unequal row ranges on the handle's stream: every process broadcasts its own rows in
                 // place, grouped into one RCCL operation (xGMI is point to point: `world` concurrent broadcasts use every
-                // link at once); no host synchronisation, the update kernel simply follows on the stream
+                // link at once); the update kernel simply follows on the stream
                 if (!h->comm || h->comm_world != h->part_world) EPNN_FAIL("forward: a partition is set but neither an exchange function nor a communicator");
+                // every process says "my rows are on their way" before anyone enqueues the broadcasts (comm_guard: one 4-byte
+                // all-reduce and a look at its result -- the one host synchronisation of a partitioned GNN step)
+                if (comm_guard(h, 0, "partitioned forward (row exchange)")) return 1;
+                if (t + 1 < Tg) h->guard_pending = true;          // the next step's exchange is owed from here on
                 ncclResult_t rc = ncclGroupStart();
                 for (int r = 0; r < h->part_world && rc == ncclSuccess; ++r) {
                     const size_t cnt = (size_t)(h->part_hi[r] - h->part_lo[r]) * 32;

@@ -70,7 +70,13 @@ __device__ __forceinline__ float *gmlp_rows(const GenMlp &G, float *a0, float *a
             const float *in = src + r * EPNN_GMLP_ST;
             float acc = b[o];
             for (int i = 0; i < ni; ++i) acc = fmaf(in[i], W[(size_t)i * no + o], acc);
-            dst[r * EPNN_GMLP_ST + o] = act ? fmaxf(acc, 0.f) : acc;
+            float v = acc;
+            if (act) {                                   // Dense(n, activation) of MLP_layer (charge_gn.py:38); Keras' definitions
+                if (G.act == EPNN_ACT_RELU) v = fmaxf(acc, 0.f);
+                else if (G.act == EPNN_ACT_TANH) v = tanhf(acc);
+                else if (G.act == EPNN_ACT_SIGMOID) v = 1.f / (1.f + expf(-acc));
+            }
+            dst[r * EPNN_GMLP_ST + o] = v;
         }
         __syncthreads();
         float *t = src; src = dst; dst = t;

@@ -649,15 +649,10 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     const size_t o_pu = sz((size_t)T * BN * EPNN_TF_PU);
     if (ts->arena.ensure(need * 4)) return 1;
     const size_t lds_fwd = ((size_t)N * FS + (size_t)N * 49 + (size_t)D * 32 + 4 * (size_t)N * 33 + EPNN_TF_NG * 32 + 32 + 3 * (size_t)N) * 4;
-    const size_t lds_bwd = ((size_t)N * FS + (size_t)N * 49 + 8 * (size_t)N * 33 + 32 * 33 + 192 + N + 336 + 128) * 4;
     if (!ts->fused_attr) {
         const int cap = 160 * 1024;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd_mm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tb_pair_bwd_mm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         ts->fused_attr = true;
@@ -667,8 +662,8 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     auto P = [&](size_t off) { return ar + off; };
     float *nm = P(o_nm), *wgt = P(o_wgt);
     float *gq = P(o_gq), *gfeat = P(o_gfeat), *gh = P(o_gh);
-    // hidden layers of the row-fused kernels on the matrix pipe ("train_fused" = 1, the default); 3 = the scalar FMA version
-    const bool mm = h->opt_train_fused != 3 && nx + 49 <= EPNN_TF_FMAX && ((uintptr_t)d_e & 15) == 0;
+    // (the row-fused kernels stage float4 rows of e: every buffer this library hands them is 256-byte aligned; nx + 49 <= EPNN_TF_FMAX by epnn_create)
+    if (((uintptr_t)d_e & 15) != 0 || nx + 49 > EPNN_TF_FMAX) EPNN_FAIL("training: internal error (row-fused kernels: e not 16-byte aligned or %d atom features > %d)", nx + 49, EPNN_TF_FMAX);
 #ifdef EPNN_TF_CLOCKS
     int nclk = 0;
     if (ts->clk.ensure(64 * 16 * 8)) return 1;
@@ -681,7 +676,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.N = N; A.nx = nx; A.wgt = wgt; A.nm = nm;
         A.nm_w = nm; A.wgt_w = wgt; A.tol = h->cfg.near_tol; A.pmode = -1;
         A.gfeat = gfeat; A.gh = gh; A.gqv = gq; A.gq = gq; A.dU0 = P(o_dU0);
-        if (mm) { A.moff = h->tr_moff; A.real = h->tr_real; }
+        A.moff = h->tr_moff; A.real = h->tr_real;
 #ifdef EPNN_TF_CLOCKS
         A.clk = ts->clk.as<unsigned long long>() + 16 * (nclk++);
 #endif
@@ -708,8 +703,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.M = P(gs[t].M);
         if (t == 0) A.mask = d_mask;                                    // ... and the node masks
         if (t == 0 && adam_now && step_on_device) A.step_p = ts->d_step.as<long long>();
-        if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<0, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));
-        else hipLaunchKernelGGL((k_tf_pair_fwd<0, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
+        hipLaunchKernelGGL((k_tf_pair_fwd<0>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, upd_args(t, hcur));    // + update MLP
         hcur = P(gs[t].hn);
     }
     const float *feats = hcur;
@@ -723,8 +717,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
             A.y = d_y; A.pred = d_pred; A.lterm = d_loss;
             A.out_h = out_host;
         }
-        if (mm) hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
-        else hipLaunchKernelGGL((k_tf_pair_fwd<1, false>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
+        hipLaunchKernelGGL((k_tf_pair_fwd<1>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         qcur = P(es[t].qn);
     }
     if (ts->host_out && ts->ev_fwd) HIPCHK(hipEventRecord(ts->ev_fwd, st));        // (an event-record node when the step is being captured)
@@ -737,14 +730,12 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.dz1 = P((nb & 1) ? o_dz1b : o_dz1a);
         A.pdz1 = P((nb & 1) ? o_dz1a : o_dz1b);
         A.pmode = pmode; A.poW1 = poW1; A.pfirst = pfirst;
-        if (mm) {
-            const bool odd = nb & 1;
-            A.nsplit = nsplit; A.natoms = BN;
-            A.gfeat = P(odd ? o_gfeatb : o_gfeat); A.gfeat_r = P(odd ? o_gfeat : o_gfeatb);
-            A.gqv = P(odd ? o_gqb : o_gq); A.gq_r = P(odd ? o_gq : o_gqb);
-            A.dU0_r = P(odd ? o_dU0 : o_dU0b);
-            A.rs_w = P(odd ? o_rsb : o_rsa); A.rs_r = P(odd ? o_rsa : o_rsb);
-        }
+        const bool odd = nb & 1;
+        A.nsplit = nsplit; A.natoms = BN;
+        A.gfeat = P(odd ? o_gfeatb : o_gfeat); A.gfeat_r = P(odd ? o_gfeat : o_gfeatb);
+        A.gqv = P(odd ? o_gqb : o_gq); A.gq_r = P(odd ? o_gq : o_gqb);
+        A.dU0_r = P(odd ? o_dU0 : o_dU0b);
+        A.rs_w = P(odd ? o_rsb : o_rsa); A.rs_r = P(odd ? o_rsa : o_rsb);
         nb += 1;
     };
     for (int t = T - 1; t >= 0; --t) {
@@ -752,8 +743,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         A.H1 = P(es[t].H1); A.H2 = P(es[t].H2); A.part = P(o_pp[t]);
         A.first = t == T - 1; A.y = d_y; A.pred = d_pred;
         chain(A);
-        if (mm) hipLaunchKernelGGL(k_tb_pair_bwd_mm<1>, dim3(bwd_grid), dim3(EPNN_TF_NT), lds_bwd_mm(2), st, A, TfUpd{});
-        else hipLaunchKernelGGL(k_tb_pair_bwd<1>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, TfUpd{});
+        hipLaunchKernelGGL(k_tb_pair_bwd_mm<1>, dim3(bwd_grid), dim3(EPNN_TF_NT), lds_bwd_mm(2), st, A, TfUpd{});
         pmode = 1; poW1 = ts->pas[t][0].offW; pfirst = t == T - 1;
     }
     for (int t = T - 1; t >= 0; --t) {
@@ -761,12 +751,9 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
         TfPair A = pair_args(ts->msg[t], hin, d_q0);
         A.H1 = P(gs[t].H1); A.H2 = P(gs[t].H2); A.part = P(o_pm[t]);
         chain(A);
-        if (mm) {
-            TfUpd Ub = upd_args(t, hin);
-            Ub.dU0 = P(((nb - 1) & 1) ? o_dU0b : o_dU0);               // chain() has counted this launch
-            hipLaunchKernelGGL(k_tb_pair_bwd_mm<0>, dim3(bwd_grid), dim3(EPNN_TF_NT), lds_bwd_mm(1), st, A, Ub);
-        }
-        else hipLaunchKernelGGL(k_tb_pair_bwd<0>, dim3(BN), dim3(EPNN_TF_NT), lds_bwd, st, A, upd_args(t, hin));     // update backward first
+        TfUpd Ub = upd_args(t, hin);                                   // (the update MLP's backward first)
+        Ub.dU0 = P(((nb - 1) & 1) ? o_dU0b : o_dU0);                   // chain() has counted this launch
+        hipLaunchKernelGGL(k_tb_pair_bwd_mm<0>, dim3(bwd_grid), dim3(EPNN_TF_NT), lds_bwd_mm(1), st, A, Ub);
         pmode = 0; poW1 = ts->msg[t][0].offW; pfirst = 0;
     }
     // ================================================================ gradient = sum of the workgroups' partials (+ Adam)
@@ -780,7 +767,7 @@ static int train_fwd_bwd_fused(epnn_handle *h, int B, int N, const float *d_e, c
     entry(ts->upd[0].offW, EPNN_TF_PU, T * BN, o_pu);
     for (int t = 0; t < T; ++t) entry(ts->msg[t][0].offW, Pm0, BN, o_pm[t]);
     for (int t = 0; t < T; ++t) entry(ts->pas[t][0].offW, Pm1, BN, o_pp[t]);
-    if (mm && h->tr_real) { Rd.real = h->tr_real; Rd.natoms = BN; }
+    if (h->tr_real) { Rd.real = h->tr_real; Rd.natoms = BN; }
     if (adam_now) {
         Rd.adam = 1;
         if (step_on_device) {                       // captured into a hipGraph: the caller keeps ts->step and the device counter in step
@@ -838,8 +825,8 @@ static int infer_rowfused_forward(epnn_handle *h, int B, int N, const float *d_e
     const size_t lds_fwd = ((size_t)N * FS + (size_t)N * 49 + (size_t)D * 32 + 4 * (size_t)N * 33 + EPNN_TF_NG * 32 + 32 + 3 * (size_t)N) * 4;
     if (!is->attr) {
         const int cap = 160 * 1024;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tf_pair_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         is->attr = true;
     }
     const float *theta = is->theta.as<float>();
@@ -860,7 +847,7 @@ static int infer_rowfused_forward(epnn_handle *h, int B, int N, const float *d_e
         U.oW0 = is->upd[0].offW; U.ob0 = is->upd[0].offB; U.oW1 = is->upd[1].offW; U.ob1 = is->upd[1].offB;
         U.oW2 = is->upd[2].offW; U.ob2 = is->upd[2].offB;
         U.hn = ar + ((t & 1) ? o_hb : o_ha);
-        hipLaunchKernelGGL((k_tf_pair_fwd<0, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, U);
+        hipLaunchKernelGGL((k_tf_pair_fwd<0>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, U);
         hcur = U.hn;
     }
     const float *qcur = d_q0;
@@ -868,7 +855,7 @@ static int infer_rowfused_forward(epnn_handle *h, int B, int N, const float *d_e
         TfPair A = pair_args(is->pas[t], hcur, qcur);
         if (t == 0) A.mask = d_mask;
         A.qn = t == T - 1 ? d_out : ar + ((t & 1) ? o_qb : o_qa);
-        hipLaunchKernelGGL((k_tf_pair_fwd<1, true>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
+        hipLaunchKernelGGL((k_tf_pair_fwd<1>), dim3(BN), dim3(EPNN_TF_NT), lds_fwd, st, A, TfUpd{});
         qcur = A.qn;
     }
     HIPCHK(hipGetLastError());
@@ -877,7 +864,9 @@ static int infer_rowfused_forward(epnn_handle *h, int B, int N, const float *d_e
 
 static int train_apply(epnn_handle *h) {
     TrainState *ts = train_state(h);
-    if (h->comm && h->comm_world > 1) {
+    if (comm_collectives(h)) {
+        // every rank says "my gradient is ready" before anyone enqueues the all-reduce (comm_guard, epnn_host.h)
+        if (comm_guard(h, 0, "train step (gradient all-reduce)")) return 1;
         ncclResult_t rc = ncclAllReduce(ts->grad.p, ts->grad.p, (size_t)ts->P, ncclFloat, ncclSum, h->comm, h->stream);
         if (rc != ncclSuccess) EPNN_FAIL("ncclAllReduce failed: %s", ncclGetErrorString(rc));
     }

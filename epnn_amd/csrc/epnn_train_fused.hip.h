@@ -6,9 +6,9 @@
 // partner rows -- both orders of the pair for the pass network -- with the rows [a_i | a_j | e_ij] (charge_gn.py:62-66,
 // 101-108) assembled in LDS instead of HBM; the backward kernel does the same and leaves one block of weight-gradient
 // partials per workgroup, summed in a fixed order by one launch at the end of the step.  2T + 2T + 1 launches instead of ~340.
-// Round 2 wrote the kernels as plain FMA loops over LDS-resident rows (k_tf_pair_fwd<MODE, false>, k_tb_pair_bwd: "train_fused" = 3);
-// round 3 put the Dense layers and every weight gradient on the matrix pipe and laid each launch out for latency (MM = true,
-// k_tb_pair_bwd_mm: DESIGN.md section 6b has the measurements that asked for each change).
+// The Dense layers and every weight gradient run on the matrix pipe and each launch is laid out for latency (k_tf_pair_fwd,
+// k_tb_pair_bwd_mm: HISTORY.md section 6b has the measurements that asked for each change; the scalar-FMA twins of rounds 2-4 were
+// removed in round 5 -- the layer-by-layer kernels of epnn_train.hip.h are the second implementation the tests compare).
 // All sums have a fixed order: gradients are bit-reproducible.
 #pragma once
 #include "epnn_host.h"
@@ -16,9 +16,7 @@
 #define EPNN_TF_NMAX 96          // LDS of the backward kernel: 372 N + 2 k floats
 #define EPNN_TF_NT 512           // threads of a pair workgroup: 16 row groups x 32 outputs
 #define EPNN_TF_NG (EPNN_TF_NT / 32)
-#define EPNN_TF_JM 3             // partner rows per thread and pass of the layer-1 loop (16 row groups x 3 = 48 rows)
 #define EPNN_TF_FMAX 60         // matrix-pipe layers: F = nx + 49 <= 60 (15 K steps of 4 per atom block)
-#define EPNN_TF_KT 4             // weight rows per thread and pass of the dW1 loops
 
 struct TfPair {                  // one sweep of a pair MLP (message network of GNN step t / pass network of EPN step t)
     const float *x, *h, *q;      // the step's per-atom inputs: x [BN][nx], h [BN][48], q [BN]   (a = [x | h | q])
@@ -110,27 +108,10 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ f32x2 tm_ld2u(const float *p) { return *reinterpret_cast<const f32x2u *>(p); }
 __device__ __forceinline__ f32x4 tm_ld4u(const float *p) { return *reinterpret_cast<const f32x4u *>(p); }
 
-// Staging loops: `total` elements, element idx loaded by ld(idx) and placed by st(idx, value).  Four loads of a thread are
-// in flight before the first store (a plain loop would wait for every load in front of its LDS write: the loop trip
-// counts are run-time values, the compiler does not overlap the iterations).  The loads are unconditional, of a clamped index.  (Twelve in flight measured no faster for one
-// molecule per step and 8 % slower for eight: 0.43 / 0.67 ms against 0.415 / 0.616.)
+// Staging loops (tf_stage_w below): a few loads of a thread are in flight before its first LDS store (a plain loop would wait for every
+// load in front of its LDS write: the trip counts are run-time values, the compiler does not overlap the iterations); the loads are
+// unconditional, of a clamped index.
 #define EPNN_TF_SD 4
-template <typename LD, typename ST>
-__device__ __forceinline__ void tf_stage(int total, int tid, LD &&ld, ST &&st) {
-    for (int base = 0; base < total; base += EPNN_TF_SD * EPNN_TF_NT) {
-        float v[EPNN_TF_SD];
-#pragma unroll
-        for (int u = 0; u < EPNN_TF_SD; ++u) {        // unconditional loads of a clamped index: a load under `if` becomes a branch
-            const int idx = base + u * EPNN_TF_NT + tid;    // with s_waitcnt vmcnt(0) in front of the next one -- one round trip EACH
-            v[u] = ld(idx < total ? idx : total - 1);
-        }
-#pragma unroll
-        for (int u = 0; u < EPNN_TF_SD; ++u) {
-            const int idx = base + u * EPNN_TF_NT + tid;
-            if (idx < total) st(idx, v[u]);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- forward, pair MLP
 // MODE 0: message network (out_dim 32, summed over ALL N partners); MODE 1: pass network (out_dim 1, both orders).
@@ -141,10 +122,11 @@ __device__ __forceinline__ void tf_stage(int total, int tid, LD &&ld, ST &&st) {
 // N = 41 is 3 or 6 jobs on the workgroup's 8 wavefronts) and runs [a_i | a_j | e_ij] W1 as 2 F / 4 + 12 K steps of
 // v_mfma_f32_16x16x4_f32 with its W1 / W2 fragments read from L2 straight into registers -- issued before the rows are staged, so
 // the two latencies overlap and W1 (21 KB, the largest staging) never goes through LDS -- then layer 2 from the accumulators as
-// they stand.  The scalar version (MM = false) is the same arithmetic as 164 + 32 dependent FMAs per thread behind LDS reads.
-template <int MODE, bool MM>
+// they stand.
+template <int MODE>
 __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     extern __shared__ __attribute__((aligned(16))) float tf_sm[];
+    constexpr bool MM = true;                 // (the scalar-FMA twin of rounds 2-4 is gone: the layer-by-layer kernels are the second implementation)
     const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
     const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
     const int tid = threadIdx.x, o = tid & 31, g = tid >> 5;
@@ -292,18 +274,7 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 if (iw < nW) tm_st4(W1s + w0 * 32 + 4 * iw, vw[u]);
             }
         }
-    } else {
-        tf_stage(N * F, tid,
-                 [&](int idx) {
-                     const int j = idx / F, k = idx - j * F;
-                     const size_t at = a0 + j;
-                     return *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));      // one load of a selected address
-                 },
-                 [&](int idx, float v) { const int j = idx / F; As[j * FS + (idx - j * F)] = v; });
-        tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
-                 [&](int idx, float v) { const int j = idx / 48; Es[j * 49 + (idx - j * 48)] = v; });
     }
-    if (!MM) tf_stage(D * 32, tid, [&](int idx) { return A.theta[A.oW1 + idx]; }, [&](int idx, float v) { W1s[idx] = v; });
     float *wl = red + EPNN_TF_NG * 32 + 32 + 2 * N;            // [N] pair weights of this atom's rows (pass network)
     if (MODE == 0 && A.mask && tid < 64) {
         // node mask of this atom (charge_gn.py:59): clip(sum_j mask[j][i], 0, 1); what k_t_nodemask did in a launch of its own
@@ -328,19 +299,6 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 for (int k = 0; k < 48; ++k) mx = fmaxf(mx, Es[j * 49 + k]);
                 w = mx > A.tol ? wpre : 0.f;
                 A.wgt_w[rowbase + j] = w;
-            }
-            wl[j] = w;
-        }
-    } else if (MODE == 1) {
-        for (int j = tid; j < N; j += EPNN_TF_NT) {
-            float w;
-            if (A.mask) {
-                float mx = 0.f;
-                for (int k = 0; k < 48; ++k) mx = fmaxf(mx, Es[j * 49 + k]);
-                w = mx > A.tol ? A.mask[rowbase + j] : 0.f;
-                A.wgt_w[rowbase + j] = w;
-            } else {
-                w = A.wgt[rowbase + j];
             }
             wl[j] = w;
         }
@@ -438,70 +396,6 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
                 }
             }
         }
-    } else {
-    // ---- layer 1: z1 = b1 + a_i W1[0:F] + a_j W1[F:2F] + e_ij W1[2F:]   (the a_i term once per thread, not per row)
-    const float b1 = A.theta[A.ob1 + o];
-    const float *ai = As + i * FS;
-    float pa = b1, ra = 0.f;
-    for (int k = 0; k < F; ++k) {
-        pa = fmaf(ai[k], W1s[k * 32 + o], pa);
-        if (MODE) ra = fmaf(ai[k], W1s[(F + k) * 32 + o], ra);
-    }
-    for (int jb = 0; jb < N; jb += EPNN_TF_NG * EPNN_TF_JM) {
-        float accR[EPNN_TF_JM], accG[EPNN_TF_JM], accP[EPNN_TF_JM];
-        int jr[EPNN_TF_JM];
-#pragma unroll
-        for (int m = 0; m < EPNN_TF_JM; ++m) {
-            jr[m] = min(jb + g + EPNN_TF_NG * m, N - 1);
-            accR[m] = accG[m] = accP[m] = 0.f;
-        }
-        for (int k = 0; k < F; ++k) {
-            const float wR = W1s[(F + k) * 32 + o], wP = MODE ? W1s[k * 32 + o] : 0.f;
-#pragma unroll
-            for (int m = 0; m < EPNN_TF_JM; ++m) {
-                const float a = As[jr[m] * FS + k];
-                accR[m] = fmaf(a, wR, accR[m]);
-                if (MODE) accP[m] = fmaf(a, wP, accP[m]);
-            }
-        }
-        for (int k = 0; k < 48; ++k) {
-            const float wG = W1s[(2 * F + k) * 32 + o];
-#pragma unroll
-            for (int m = 0; m < EPNN_TF_JM; ++m) accG[m] = fmaf(Es[jr[m] * 49 + k], wG, accG[m]);
-        }
-#pragma unroll
-        for (int m = 0; m < EPNN_TF_JM; ++m) {
-            const int j = jb + g + EPNN_TF_NG * m;
-            if (j < N) {
-                const float h1 = fmaxf((pa + accR[m]) + accG[m], 0.f);
-                H1s[j * 33 + o] = h1;
-                A.H1[(rowbase + j) * 32 + o] = h1;
-                if (MODE) {
-                    const float h1t = fmaxf(((b1 + accP[m]) + ra) + accG[m], 0.f);
-                    H1s[(N + j) * 33 + o] = h1t;
-                    A.H1[dstride + (rowbase + j) * 32 + o] = h1t;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- layer 2
-    {
-        float w2[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) w2[k] = A.theta[A.oW2 + k * 32 + o];
-        const float b2 = A.theta[A.ob2 + o];
-        for (int d = 0; d < ND; ++d)
-            for (int j = g; j < N; j += EPNN_TF_NG) {
-                const float *hr = H1s + (d * N + j) * 33;
-                float z = b2;
-#pragma unroll
-                for (int k = 0; k < 32; ++k) z = fmaf(hr[k], w2[k], z);
-                const float h2 = fmaxf(z, 0.f);
-                H2s[(d * N + j) * 33 + o] = h2;
-                A.H2[d * dstride + (rowbase + j) * 32 + o] = h2;
-            }
-    }
     }
     __syncthreads();
     TF_CLK(2);
@@ -567,64 +461,8 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
         TF_CLK_T(5, EPNN_TF_NT - 64);
         return;
     }
-    // ---- layer 3 (linear) and the reduction over partners
-    if (MODE == 0) {
-        // sum_j (H2_j W3 + b3) = (sum_j H2_j) W3 + N b3: column sums in a fixed order (row groups, then the groups in order), then one 32x32 product
-        float cs = 0.f;
-        for (int j = g; j < N; j += EPNN_TF_NG) cs += H2s[j * 33 + o];
-        red[g * 32 + o] = cs;
-        __syncthreads();
-        if (tid < 32) {
-            float s = 0.f;
-            for (int gg = 0; gg < EPNN_TF_NG; ++gg) s += red[gg * 32 + tid];
-            red[EPNN_TF_NG * 32 + tid] = s;
-        }
-        __syncthreads();
-        TF_CLK(3);
-        float *u0 = red, *u1 = red + 80, *u2 = red + 112;       // the group sums red[0 .. NG*32) are dead by now
-        const bool upd = U.theta != nullptr;
-        const float nm = upd ? (A.mask ? wl[0] : U.nm[bi]) : 0.f;
-        if (tid < 32) {
-            float mo = (float)N * A.theta[A.ob3 + tid];
-            for (int k = 0; k < 32; ++k) mo = fmaf(red[EPNN_TF_NG * 32 + k], A.theta[A.oW3 + k * 32 + tid], mo);
-            A.M[(size_t)bi * 32 + tid] = mo;
-            if (upd) {
-                const float v = mo * nm;
-                u0[48 + tid] = v;
-                U.U0[(size_t)bi * 80 + 48 + tid] = v;
-            }
-        } else if (upd && tid >= 64 && tid < 112) {
-            const int k = tid - 64;
-            const float v = U.h[(size_t)bi * 48 + k] * nm;
-            u0[k] = v;
-            U.U0[(size_t)bi * 80 + k] = v;
-        }
-        if (!upd) return;
-        __syncthreads();
-        TF_CLK(4);
-        if (tid < 32) {
-            float z = U.theta[U.ob0 + tid];
-            for (int k = 0; k < 80; ++k) z = fmaf(u0[k], U.theta[U.oW0 + k * 32 + tid], z);
-            z = fmaxf(z, 0.f);
-            u1[tid] = z;
-            U.U1[(size_t)bi * 32 + tid] = z;
-        }
-        __syncthreads();
-        if (tid < 32) {
-            float z = U.theta[U.ob1 + tid];
-            for (int k = 0; k < 32; ++k) z = fmaf(u1[k], U.theta[U.oW1 + k * 32 + tid], z);
-            z = fmaxf(z, 0.f);
-            u2[tid] = z;
-            U.U2[(size_t)bi * 32 + tid] = z;
-        }
-        __syncthreads();
-        if (tid < 48) {
-            float z = U.theta[U.ob2 + tid];
-            for (int k = 0; k < 32; ++k) z = fmaf(u2[k], U.theta[U.oW2 + k * 48 + tid], z);
-            U.hn[(size_t)bi * 48 + tid] = z * nm;
-        }
-        TF_CLK(5);
-    } else {
+    // ---- pass network: layer 3 (linear, out_dim 1) and the antisymmetric sum over partners (charge_gn.py:110-118)
+    {
         float *fs = red;                      // [2][N]
         for (int idx = tid; idx < 2 * N; idx += EPNN_TF_NT) {
             const float *hr = H2s + idx * 33;
@@ -642,8 +480,6 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
             for (int dd = 32; dd >= 1; dd >>= 1) s += __shfl_xor(s, dd, 64);
         }
         if (tid == 0) {
-            if (!MM)
-                for (int j = 0; j < N; ++j) s += 0.5f * (fs[j] - fs[N + j]) * wl[j];
             const float qn = A.q[bi] + s;
             A.qn[bi] = qn;
             if (A.pred && !A.y) A.pred[bi] = qn;      // inference: the charges, nothing else
@@ -661,281 +497,9 @@ __global__ __launch_bounds__(EPNN_TF_NT) void k_tf_pair_fwd(TfPair A, TfUpd U) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- backward, pair MLP
-// MODE 0 with U.theta set first runs the update MLP's backward for its atom (it needs only the atom's own rows: gh, U0..U2)
-// and takes dM_i straight from LDS.
-template <int MODE>
-__global__ __launch_bounds__(EPNN_TF_NT) void k_tb_pair_bwd(TfPair A, TfUpd U) {
-    extern __shared__ __attribute__((aligned(16))) float tf_sm[];
-    const int N = A.N, nx = A.nx, F = nx + 49, D = 2 * F + 48, FS = F | 1;
-    const int bi = blockIdx.x, b = bi / N, i = bi - b * N;
-    const int tid = threadIdx.x, o = tid & 31, g = tid >> 5;
-    constexpr int ND = MODE ? 2 : 1;
-    constexpr int O = MODE ? 1 : 32;
-    float *As = tf_sm;                        // [N][FS]
-    float *Es = As + N * FS;                  // [N][49]
-    float *H1s = Es + N * 49;                 // [ND][N][33]
-    float *H2s = H1s + ND * N * 33;
-    float *D1s = H2s + ND * N * 33;           // gradient at z1
-    float *D2s = D1s + ND * N * 33;           // gradient at z2
-    float *W2s = D2s + ND * N * 33;           // [32][33]
-    float *vec = W2s + 32 * 33;               // dms [32] | vs [32] | s1 [2][32] | sb2 [32] | c2 / dw3 [32] | df [N]
-    float *dms = vec, *vs = vec + 32, *s1 = vec + 64, *sb2 = vec + 128, *c2 = vec + 160, *dfs = vec + 192;
-    float *ub = dfs + N;                      // MODE 0, fused update backward: u0 [80] | u1 [32] | u2 [32] | dh [48] | du2 [32] | du1 [32] | dU0 [80]
-    float *psh = ub + 336;                    // [4][32] prologue: row / column sums of the previous sweep's dz1
-    const size_t a0 = (size_t)b * N, rowbase = (size_t)bi * N;
-    const size_t dstride = (size_t)gridDim.x * N * 32;
-    // ---- prologue: what the previous backward launch leaves for this atom -- the gradient that reaches a_i through the first
-    // Dense of that sweep (k_tb_atoms' arithmetic, a launch of its own before): gq / gfeat after a pass sweep, gh after a
-    // message sweep; and on the first pass sweep gq = -2 (y - pred)   (charge_gn.py:397-398)
-    TF_CLK(0);
-    if (MODE == 1 && A.first && tid == 0) A.gqv[bi] = -2.f * (A.y[bi] - A.pred[bi]);
-    if (A.pmode >= 0) {
-        if (tid < 128) {
-            const int which = tid >> 5;
-            float sacc = 0.f;
-            // which 0: listed rows (a, j), a is the first block;  1: listed rows (i, a), a is the second block;
-            //       2: swapped rows (i, a) = [a_a | a_i | e], first block;  3: swapped rows (a, j) = [a_j | a_a | e], second block
-            if (which < 2 || A.pmode == 1) {
-                const bool byrow = which == 0 || which == 3;
-                const float *p = A.pdz1 + (which >= 2 ? dstride : 0) + (byrow ? rowbase * 32 : (a0 * N + i) * 32) + o;
-                const size_t step = byrow ? 32 : (size_t)N * 32;
-                int t = 0;
-                for (; t + 8 <= N; t += 8) {          // eight loads in flight, summed in row order
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(t + u) * step];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sacc += v[u];
-                }
-                for (; t < N; ++t) sacc += p[(size_t)t * step];
-            }
-            psh[which * 32 + o] = sacc;
-        }
-        __syncthreads();
-        const int k = nx + tid;                   // h part: k in [nx, nx+48), q part: k = nx + 48
-        if (tid < 128 && k < F) {
-            float da = 0.f;
-            for (int oo = 0; oo < 32; ++oo) {
-                const float sP = psh[oo] + psh[64 + oo], sR = psh[32 + oo] + psh[96 + oo];
-                da = fmaf(sP, A.theta[A.poW1 + k * 32 + oo], da);
-                da = fmaf(sR, A.theta[A.poW1 + (F + k) * 32 + oo], da);
-            }
-            if (A.pmode == 1) {
-                if (tid < 48) {
-                    const float gf = (A.pfirst ? 0.f : A.gfeat[(size_t)bi * 48 + tid]) + da;
-                    A.gfeat[(size_t)bi * 48 + tid] = gf;
-                    if (MODE == 0) A.gh[(size_t)bi * 48 + tid] = gf;      // the pass stack is done: the feature gradient enters the GNN
-                } else {
-                    A.gqv[bi] += da;
-                }
-            } else if (tid < 48) {
-                A.gh[(size_t)bi * 48 + tid] = A.dU0[(size_t)bi * 80 + tid] * A.nm[bi] + da;
-            }
-        }
-        __threadfence_block();
-    }
-    __syncthreads();
-    TF_CLK(1);
-    tf_stage(N * F, tid,
-             [&](int idx) {
-                 const int j = idx / F, k = idx - j * F;
-                 const size_t at = a0 + j;
-                 return *(k < nx ? A.x + at * nx + k : (k < nx + 48 ? A.h + at * 48 + (k - nx) : A.q + at));      // one load of a selected address
-             },
-             [&](int idx, float v) { const int j = idx / F; As[j * FS + (idx - j * F)] = v; });
-    tf_stage(N * 48, tid, [&](int idx) { return A.e[rowbase * 48 + idx]; },
-             [&](int idx, float v) { const int j = idx / 48; Es[j * 49 + (idx - j * 48)] = v; });
-    for (int d = 0; d < ND; ++d) {
-        tf_stage(N * 32, tid, [&](int idx) { return A.H1[d * dstride + rowbase * 32 + idx]; },
-                 [&](int idx, float v) { H1s[(d * N + (idx >> 5)) * 33 + (idx & 31)] = v; });
-        tf_stage(N * 32, tid, [&](int idx) { return A.H2[d * dstride + rowbase * 32 + idx]; },
-                 [&](int idx, float v) { H2s[(d * N + (idx >> 5)) * 33 + (idx & 31)] = v; });
-    }
-    tf_stage(1024, tid, [&](int idx) { return A.theta[A.oW2 + idx]; }, [&](int idx, float v) { W2s[(idx >> 5) * 33 + (idx & 31)] = v; });
-    TF_CLK(2);
-    if (MODE == 0) {
-        if (U.theta != nullptr) {
-            float *u0 = ub, *u1 = ub + 80, *u2 = ub + 112, *dh = ub + 144, *du2 = ub + 192, *du1 = ub + 224, *dU = ub + 256;
-            const float nm = U.nm[bi];
-            if (tid < 80) u0[tid] = U.U0[(size_t)bi * 80 + tid];
-            else if (tid < 112) u1[tid - 80] = U.U1[(size_t)bi * 32 + tid - 80];
-            else if (tid < 144) u2[tid - 112] = U.U2[(size_t)bi * 32 + tid - 112];
-            else if (tid < 192) dh[tid - 144] = U.gh[(size_t)bi * 48 + tid - 144] * nm;
-            __syncthreads();
-            if (tid < 32) {
-                float sacc = 0.f;
-                for (int oo = 0; oo < 48; ++oo) sacc = fmaf(dh[oo], U.theta[U.oW2 + tid * 48 + oo], sacc);
-                du2[tid] = u2[tid] > 0.f ? sacc : 0.f;
-            }
-            __syncthreads();
-            if (tid < 32) {
-                float sacc = 0.f;
-                for (int oo = 0; oo < 32; ++oo) sacc = fmaf(du2[oo], U.theta[U.oW1 + tid * 32 + oo], sacc);
-                du1[tid] = u1[tid] > 0.f ? sacc : 0.f;
-            }
-            __syncthreads();
-            if (tid < 80) {
-                float sacc = 0.f;
-                for (int oo = 0; oo < 32; ++oo) sacc = fmaf(du1[oo], U.theta[U.oW0 + tid * 32 + oo], sacc);
-                dU[tid] = sacc;
-                U.dU0[(size_t)bi * 80 + tid] = sacc;
-            }
-            // weight-gradient partials of this atom (rank one per layer), parameter order
-            float *Pu = U.part + (size_t)bi * EPNN_TF_PU;
-            for (int idx = tid; idx < 80 * 32; idx += EPNN_TF_NT) Pu[idx] = u0[idx >> 5] * du1[idx & 31];
-            Pu += 80 * 32;
-            if (tid < 32) Pu[tid] = du1[tid];
-            Pu += 32;
-            for (int idx = tid; idx < 32 * 32; idx += EPNN_TF_NT) Pu[idx] = u1[idx >> 5] * du2[idx & 31];
-            Pu += 32 * 32;
-            if (tid < 32) Pu[tid] = du2[tid];
-            Pu += 32;
-            for (int idx = tid; idx < 32 * 48; idx += EPNN_TF_NT) Pu[idx] = u2[idx / 48] * dh[idx % 48];
-            Pu += 32 * 48;
-            if (tid < 48) Pu[tid] = dh[tid];
-            __syncthreads();
-            if (tid < 32) dms[tid] = dU[48 + tid] * nm;                            // dM_i: the same for every partner row
-        } else if (tid < 32) {
-            dms[tid] = A.dU0[(size_t)bi * 80 + 48 + tid] * A.nm[bi];
-        }
-    } else {
-        const float gqi = 0.5f * A.gq[bi];
-        for (int j = tid; j < N; j += EPNN_TF_NT) dfs[j] = gqi * A.wgt[rowbase + j];      // df_ij; the swapped row gets -df_ij
-    }
-    __syncthreads();
-    TF_CLK(3);
-    // ---- gradient at z2 = [H2 > 0] * (dOut W3^T)
-    if (MODE == 0) {
-        if (tid < 32) {
-            float v = 0.f;
-            for (int oo = 0; oo < 32; ++oo) v = fmaf(dms[oo], A.theta[A.oW3 + tid * 32 + oo], v);
-            vs[tid] = v;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < N * 32; idx += EPNN_TF_NT) {
-            const int j = idx >> 5, k = idx & 31;
-            D2s[j * 33 + k] = H2s[j * 33 + k] > 0.f ? vs[k] : 0.f;
-        }
-    } else {
-        const float w3 = A.theta[A.oW3 + o];
-        for (int d = 0; d < 2; ++d)
-            for (int j = g; j < N; j += EPNN_TF_NG) {
-                const float df = d ? -dfs[j] : dfs[j];
-                D2s[(d * N + j) * 33 + o] = H2s[(d * N + j) * 33 + o] > 0.f ? df * w3 : 0.f;
-            }
-    }
-    __syncthreads();
-    TF_CLK(4);
-    // ---- gradient at z1 = [H1 > 0] * (dz2 W2^T); thread = (k = o, row group g)
-    {
-        float w2row[32];
-#pragma unroll
-        for (int oo = 0; oo < 32; ++oo) w2row[oo] = W2s[o * 33 + oo];
-        for (int d = 0; d < ND; ++d)
-            for (int j = g; j < N; j += EPNN_TF_NG) {
-                const float *dr = D2s + (d * N + j) * 33;
-                float s = 0.f;
-#pragma unroll
-                for (int oo = 0; oo < 32; ++oo) s = fmaf(dr[oo], w2row[oo], s);
-                const float v = H1s[(d * N + j) * 33 + o] > 0.f ? s : 0.f;
-                D1s[(d * N + j) * 33 + o] = v;
-                A.dz1[d * dstride + (rowbase + j) * 32 + o] = v;
-            }
-    }
-    __syncthreads();
-    TF_CLK(5);
-    // ---- column sums (fixed order over j)
-    if (tid < 32 * ND) {                      // s1[d][o] = sum_j dz1
-        const int d = tid >> 5;
-        float s = 0.f;
-        for (int j = 0; j < N; ++j) s += D1s[(d * N + j) * 33 + o];
-        s1[d * 32 + o] = s;
-    } else if (tid >= 64 && tid < 96) {       // sb2[o] = sum_d sum_j dz2
-        float s = 0.f;
-        for (int d = 0; d < ND; ++d)
-            for (int j = 0; j < N; ++j) s += D2s[(d * N + j) * 33 + o];
-        sb2[o] = s;
-    } else if (tid >= 96 && tid < 128) {      // message: c2[k] = sum_j H2; pass: dw3[k] = sum_d sum_j H2 * df
-        float s = 0.f;
-        if (MODE == 0) {
-            for (int j = 0; j < N; ++j) s += H2s[j * 33 + o];
-        } else {
-            for (int j = 0; j < N; ++j) s = fmaf(H2s[j * 33 + o], dfs[j], s);
-            for (int j = 0; j < N; ++j) s = fmaf(H2s[(N + j) * 33 + o], -dfs[j], s);
-        }
-        c2[o] = s;
-    }
-    __syncthreads();
-    TF_CLK(6);
-    // ---- weight-gradient partials of this workgroup, in parameter order: W1 [D][32] | b1 | W2 [32][32] | b2 | W3 [32][O] | b3
-    const int Pm = D * 32 + 32 + 1024 + 32 + 32 * O + O;
-    float *P = A.part + (size_t)bi * Pm;
-    const float *ai = As + i * FS;
-    // dW1[k][o] = sum over the rows of X[row][k] dz1[row][o].  The a_i block of a row is the same for every row of the
-    // workgroup (a_i x column sum); the partner block a_j feeds both orders of the pair from ONE read; KT weight rows per
-    // thread share the reads of dz1.
-    for (int k0 = g * EPNN_TF_KT; k0 < F; k0 += EPNN_TF_NG * EPNN_TF_KT) {
-        float accA[EPNN_TF_KT], accB[EPNN_TF_KT];
-#pragma unroll
-        for (int kk = 0; kk < EPNN_TF_KT; ++kk) accA[kk] = accB[kk] = 0.f;
-#pragma unroll 2
-        for (int j = 0; j < N; ++j) {
-            const float dN = D1s[j * 33 + o], dT = MODE ? D1s[(N + j) * 33 + o] : 0.f;
-#pragma unroll
-            for (int kk = 0; kk < EPNN_TF_KT; ++kk) {
-                const float a = As[j * FS + min(k0 + kk, F - 1)];
-                accB[kk] = fmaf(a, dN, accB[kk]);              // second block of the listed rows
-                if (MODE) accA[kk] = fmaf(a, dT, accA[kk]);    // first block of the swapped rows
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < EPNN_TF_KT; ++kk) {
-            const int k = k0 + kk;
-            if (k < F) {
-                P[k * 32 + o] = ai[k] * s1[o] + accA[kk];
-                P[(F + k) * 32 + o] = accB[kk] + (MODE ? ai[k] * s1[32 + o] : 0.f);
-            }
-        }
-    }
-    for (int k0 = g * EPNN_TF_KT; k0 < 48; k0 += EPNN_TF_NG * EPNN_TF_KT) {      // edge block: the same e_ij in both orders
-        float acc[EPNN_TF_KT];
-#pragma unroll
-        for (int kk = 0; kk < EPNN_TF_KT; ++kk) acc[kk] = 0.f;
-#pragma unroll 2
-        for (int j = 0; j < N; ++j) {
-            const float dS = D1s[j * 33 + o] + (MODE ? D1s[(N + j) * 33 + o] : 0.f);
-#pragma unroll
-            for (int kk = 0; kk < EPNN_TF_KT; ++kk) acc[kk] = fmaf(Es[j * 49 + k0 + kk], dS, acc[kk]);
-        }
-#pragma unroll
-        for (int kk = 0; kk < EPNN_TF_KT; ++kk) P[(2 * F + k0 + kk) * 32 + o] = acc[kk];
-    }
-    TF_CLK(7);
-    float *Pb1 = P + D * 32, *PW2 = Pb1 + 32, *Pb2 = PW2 + 1024, *PW3 = Pb2 + 32, *Pb3 = PW3 + 32 * O;
-    if (tid < 32) {
-        Pb1[tid] = s1[tid] + (MODE ? s1[32 + tid] : 0.f);
-        Pb2[tid] = sb2[tid];
-    }
-    for (int k = g; k < 32; k += EPNN_TF_NG) {         // dW2[k][o] = sum_d sum_j H1[j][k] dz2[j][o]
-        float s = 0.f;
-        for (int d = 0; d < ND; ++d)
-            for (int j = 0; j < N; ++j) s = fmaf(H1s[(d * N + j) * 33 + k], D2s[(d * N + j) * 33 + o], s);
-        PW2[k * 32 + o] = s;
-    }
-    if (MODE == 0) {
-        for (int k = g; k < 32; k += EPNN_TF_NG) PW3[k * 32 + o] = c2[k] * dms[o];
-        if (tid < 32) Pb3[tid] = (float)N * dms[tid];
-    } else {
-        if (tid < 32) PW3[tid] = c2[tid];
-        if (tid == 0) Pb3[0] = 0.f;           // sum over the rows of df and of -df, each in the same order: exactly 0
-    }
-    TF_CLK(8);
-}
-
 // ---------------------------------------------------------------------------------------------- backward, pair MLP, matrix pipe
-// The same arithmetic as k_tb_pair_bwd, laid out for latency (clock stamps of one workgroup, tools/train_clocks.py: the scalar
-// kernel spent 3.3 us in the prologue, 3.8 us staging, 2.6 us in the update MLP's backward, 2-3 us in dz2 / dz1 / column sums and
+// The backward of one pair MLP, laid out for latency (clock stamps of one workgroup, tools/train_clocks.py: a scalar
+// row-per-thread kernel spent 3.3 us in the prologue, 3.8 us staging, 2.6 us in the update MLP's backward, 2-3 us in dz2 / dz1 / column sums and
 // 5.5-6.5 us in the weight-gradient loops, one after the other):
 //   * wavefront 0 runs the whole serial chain -- prologue (the previous sweep's gradient at this atom), the update MLP's backward,
 //     dM W3^T / df -- with wavefront-level LDS hand-offs, WHILE wavefronts 1-7 stage the rows (float4 rows of 36 / 52 floats);

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -200,8 +201,13 @@ class Engine:
     def epn_forward(self, h, e, x, q, mask):
         return self._layer(self.lib.epnn_epn_forward, h, e, x, q, mask, 1)
 
-    def mlp_forward_layers(self, rows, layers):
-        """MLP_layer(nodes, out_dim).call for any `nodes`: rows (R, n_in) through [(W,b), ...], ReLU after all but the last."""
+    ACTIVATIONS = {"relu": 0, None: 1, "linear": 1, "tanh": 2, "sigmoid": 3}
+
+    def mlp_forward_layers(self, rows, layers, activation="relu"):
+        """MLP_layer(nodes, out_dim, activation).call for any `nodes`: rows (R, n_in) through [(W,b), ...], `activation` after all
+        but the last layer ('relu', None / 'linear', 'tanh', 'sigmoid': charge_gn.py:38-39)."""
+        if activation not in self.ACTIVATIONS:
+            raise EpnnError(f"mlp_forward_layers: activation {activation!r} is not built (relu, None / linear, tanh, sigmoid)")
         rows = _f32(rows)
         ws = [(_f32(k), _f32(b)) for k, b in layers]
         dims = [rows.shape[1]] + [k.shape[1] for k, _ in ws]
@@ -214,7 +220,7 @@ class Engine:
         bp = (FP * n)(*[fptr(b) for _, b in ws])
         darr = np.ascontiguousarray(dims, dtype=np.int32)
         out = np.empty((rows.shape[0], dims[-1]), dtype=np.float32)
-        check(self.lib.epnn_mlp_forward_layers(self.h, rows.shape[0], n, iptr(darr), Wp, bp, fptr(rows), fptr(out)), self.lib)
+        check(self.lib.epnn_mlp_forward_layers(self.h, rows.shape[0], n, iptr(darr), Wp, bp, fptr(rows), fptr(out), self.ACTIVATIONS[activation]), self.lib)
         return out
 
     def mlp_forward(self, rows, layers):
@@ -403,12 +409,23 @@ class Pipeline:
         more lanes than that need every queue (stride 1)."""
         depth = max(1, int(depth))
         if queue_stride is None:
-            queue_stride = 2 if depth <= 8 else 1
+            # every other queue only while the lanes still get a queue each: with a user-set GPU_MAX_HW_QUEUES of 4 or 8 a stride of
+            # 2 would fold eight lanes onto 2 or 4 queues (kernels of streams that share a queue serialise)
+            _lib.load()                                       # (sets GPU_MAX_HW_QUEUES to 16 unless the caller decided otherwise)
+            try:
+                queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+            except ValueError:
+                queues = 4
+            queue_stride = 2 if depth <= 8 and 2 * depth <= queues else 1
         self.engines = []
+        self._device = int(engine_kwargs.get("device", 0))
+        self._skipped = False
         for k in range(depth):
             self.engines.append(Engine(**engine_kwargs))
             if queue_stride > 1 and k + 1 < depth:
-                check(self.engines[0].lib.epnn_skip_hw_queues(int(engine_kwargs.get("device", 0)), int(queue_stride) - 1), self.engines[0].lib)
+                # (the placement is defined for the first pipeline of a process: later streams land where the runtime's round robin is)
+                check(self.engines[0].lib.epnn_skip_hw_queues(self._device, int(queue_stride) - 1), self.engines[0].lib)
+                self._skipped = True
         self._next = 0
         if len(self.engines) > 1:
             # batches side by side fill the GPU: every molecule on one wavefront (the split over two is for a lone batch)
@@ -452,5 +469,9 @@ class Pipeline:
             e.sync()
 
     def close(self):
+        lib = self.engines[0].lib if self.engines else None
         for e in self.engines:
             e.close()
+        if self._skipped and lib is not None:
+            lib.epnn_skip_hw_queues(self._device, 0)          # the placeholder streams between the lanes
+            self._skipped = False

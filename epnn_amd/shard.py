@@ -122,10 +122,19 @@ def dp_step_molecules(order, world, step, per_rank=1):
     return [[int(i) for i in order[(step * world + r) * per_rank:(step * world + r + 1) * per_rank]] for r in range(world)]
 
 
-def allreduce_sum_host(vec, dist):
+def allreduce_sum_host(vec, dist, failed=None):
     """Gradient all-reduce through the host (gloo) -- the portable counterpart of the RCCL all-reduce the library does
-    on the device (epnn_comm_init / epnn_train_apply); used by CPU tests and as a fallback without RCCL."""
+    on the device (epnn_comm_init / epnn_train_apply); used by CPU tests and as a fallback without RCCL.
+
+    Fails closed like the device path (comm_guard in csrc/epnn_host.h): every rank first all-reduces (max) a status word --
+    `failed` is this rank's exception, or a true value, if its step went wrong before the collective (then `vec` may be None)
+    -- and if ANY rank reports a failure ALL ranks raise together; nobody is left waiting in the payload collective."""
     import torch
+    status = torch.tensor([1 if failed else 0], dtype=torch.int32)
+    dist.all_reduce(status, op=dist.ReduceOp.MAX)
+    if int(status.item()) != 0:
+        raise RuntimeError("gradient all-reduce aborted on every rank" +
+                           (f"; this rank failed: {failed}" if failed else ": another rank reported a failure before the collective"))
     t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.numpy()

@@ -135,11 +135,13 @@ int epnn_gnn_forward(epnn_handle *h, int B, int N, const float *hin, const float
 int epnn_epn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,
                      const float *q, const float *mask, float *q_out);
 
-/* MLP_layer(nodes, out_dim).call (charge_gn.py:31-45) for ANY `nodes`: n_layers Dense layers, dims[n_layers + 1] = n_in, nodes...,
- * out_dim (each 1..256; ReLU after every layer but the last), W[l] in Keras layout [dims[l]][dims[l + 1]], b[l][dims[l + 1]].
+/* MLP_layer(nodes, out_dim, activation).call (charge_gn.py:31-45) for ANY `nodes`: n_layers Dense layers, dims[n_layers + 1] = n_in,
+ * nodes..., out_dim (each 1..256), W[l] in Keras layout [dims[l]][dims[l + 1]], b[l][dims[l + 1]].  `activation` follows every layer
+ * but the last (charge_gn.py:38-39: Dense(n, activation=activation) ..., Dense(out_dim, activation=None)): 0 = 'relu' (the
+ * reference's default and only use), 1 = None / 'linear', 2 = 'tanh', 3 = 'sigmoid' (Keras' definitions); anything else fails.
  * x[rows][dims[0]] -> out[rows][dims[n_layers]].  Host pointers. */
 int epnn_mlp_forward_layers(epnn_handle *h, int rows, int n_layers, const int32_t *dims, const float *const *W,
-                            const float *const *b, const float *x, float *out);
+                            const float *const *b, const float *x, float *out, int activation);
 /* MLP_layer.call (charge_gn.py:41-45) as a stand-alone operator: x[rows][n_in] -> relu 32 -> relu 32 -> out[rows][n_out];
  * kernels in Keras layout [in][out].  Host pointers. */
 int epnn_mlp_forward(epnn_handle *h, int rows, int n_in, int n_out, const float *W1, const float *b1,
@@ -193,44 +195,30 @@ int epnn_timer_end(epnn_handle *h, float *elapsed_ms);
 int epnn_last_timing(epnn_handle *h, float *out4);
 /* same for the idx-th forward issued since "profile" was set (pool of that many event sets; no sync in between). */
 int epnn_timing_at(epnn_handle *h, int idx, float *out4);
-/* options: "profile" (0 = off, k > 0 = keep stage events of the last k forwards), "force_path" (0 auto, 1 fused small-molecule kernel only, 2 tiled kernels only),
- * "pair_cap_per_atom" (initial capacity of the near-pair list of the tiled / dense paths), "wave_front" (1: batches of small
- * molecules build their pair lists inside the fused kernel, 0: separate front-end kernels), "wave_lds" (LDS bytes per wavefront), "wave3" (1, default: molecules of 33..48 / 49..64 atoms of the compact and the make_model entries run on three / four wavefronts of the block-per-wavefront fused kernel; 0: on the tiled kernels), "wave2" (block-per-wavefront kernel of the compact entry: molecules with at least this many atoms, 17..32, are split over two wavefronts and those of at most 16 run two to a workgroup; 0: one wavefront per molecule throughout; -1, default: 17 for batches of at most 1024 molecules, which halves the latency of a lone batch, else 0 -- set 0 on handles whose launches overlap), "large_fused" (0: the tiled path launches one kernel per stage), "sync_spin_us" (2000, default: epnn_sync and every call that waits for a forward poll the stream this many microseconds before they sleep on its completion; 0: sleep at once),
- * "large_dedupe" (1, default: the tiled path's first GNN step of the compact entry groups the atoms by feature row -- h = 0 and one
- * q per molecule there, so the all-pairs sum of charge_gn.py:70 takes (distinct rows)^2 pair evaluations instead of n^2; 0: the
- * all-pairs sweep; a molecule with more than 64 distinct rows switches the handle back to the sweep by itself),
- * "large_merge" (1, default: the compact entry launches the pair-list construction of tiled molecules merged with the work that
- * needs only the atoms -- feature rows, atom types, first projections, the first step's type sums and correction tiles -- in
- * two launches whose workgroups take their kind of work from the block index; 0: every kernel its own launch), "large_chunks" (developer
- * switch: number of pieces the partner range of a tiled molecule's all-pairs sweep is cut into; 0, default: by size), "wave_prio" (fused kernel: molecules with at least this many atoms run at raised wave priority, 0 = off), "wave_order" (developer switch, order of a launch's wavefronts: 0 largest molecule first, 1 largest / smallest interleaved, 2 smallest first), "part_collective" (developer switch: 1 runs the partition's RCCL row exchange even at world size 1, for tests),
- * "forward_ahead" (1, default: epnn_forward_xyz_dev called again with the batch and the device buffers of the call before enqueues the
- * new forward first and looks at the previous one's status after -- two status slots, a forward that overflowed a capacity is redone
- * with its successor behind it; 0: every call waits for the one before it before it enqueues anything; the same bits),
- * "dense_small" (1, default: a make_model call on one or a few molecules -- B N^2 <= 65536 -- builds its per-atom features, flags,
- * effective atom counts and pair list in four launches instead of two memsets, seven kernels and a download; 0: the general sequence;
- * the same bits),
- * "dense_rowfused" (1, default: such a small call with B N <= 256 runs the row-fused forward kernels of the training step -- a
- * workgroup per atom slot, the reference's literal arithmetic, nothing stored for a backward pass -- instead of one CU for the whole
- * molecule: always when N <= 48 (the call then has no host synchronisation inside), beyond that when its largest molecule fills more
- * than 55 % of N; epnn_last_stats then reports 0 molecules on the fused and 0 on the tiled path; 0: always the fused / tiled kernels),
- * "train_graph" (1, default: a train step that waits for its own end -- "train_async" = 0, or several ranks -- has its launch sequence,
- * optimizer step included, captured once per (B, N, buffer set) and replayed as a hipGraph; 0: kernel by kernel -- the same bits),
- * "train_fused" (1, default: one workgroup per atom runs a whole pair MLP over its rows, forward and backward, 2T + 2T + 1
- * launches per step, the Dense layers and every weight gradient as 16x16x4 f32 MFMA tiles; 3: the same decomposition with
- * scalar FMA loops -- what 1 itself runs for models with more than 60 atom features (nx > 11), and the second implementation
- * the tests compare; 0: one launch per Dense layer on materialised rows -- also taken when N exceeds the fused kernels' LDS
- * budget of 96 atoms),
- * "train_skip_padded" (1, default: epnn_train_step_xyz tells the "train_fused" = 1 kernels which atom slots of the padded size are
- * real -- the workgroups of the others, which would compute zeros for N rows each, return at once; 0: every slot is computed; the
- * same bits),
- * "train_async" (1, default: a training step returns as soon as its forward pass is done -- the loss and the predictions it returns are
- * on the host then; the backward pass and the optimizer step keep running, the next step queues up behind them and every call that
- * reads gradients or weights waits for them first; 0: a step returns when all of it is done; the same bits),
- * "train_inline" (1, default: the inputs of an epnn_train_step_xyz step of up to ~69 atoms travel in the argument block of the kernel
- * that pads them -- no upload, no copy kernel in front of the step; 0: always staged in page-locked memory and uploaded; the same bits),
- * "train_split" (workgroups that share one atom's weight-gradient jobs in the backward launches of "train_fused" = 1; 0,
- * default: as many as fit the XCD the atom's workgroups are placed on, at most 6 -- 5 for a one-molecule step of 41 atoms; results
- * are bit-identical for every value). */
+/* Options a caller may want to touch (every other name epnn_set_option accepts is a developer switch that selects between
+ * implementations with identical results: include/epnn_dev.h).  Unknown names and out-of-range values fail.
+ *   "profile"           0 = off (default); k > 0: keep the stage events of the last k forwards (epnn_timing_at)
+ *   "force_path"        0 = by molecule size (default); 1 = fused small-molecule kernels only (fails above 32 atoms); 2 = tiled kernels only
+ *   "pair_cap_per_atom" initial capacity of the near-pair list of the tiled / dense paths (it grows by itself; default 16)
+ *   "wave2"             how batches of small molecules use the block-per-wavefront kernel: -1 (default) = molecules of 17..32 atoms
+ *                       on two wavefronts and smaller ones two to a workgroup when the batch has at most 1024 molecules (halves the
+ *                       latency of a lone batch); 0 = one wavefront per molecule throughout (set on handles whose launches overlap:
+ *                       engine.Pipeline does); 17..32 = split from that many atoms
+ *   "wave3"             1 (default) = molecules of 33..48 / 49..64 atoms run on three / four wavefronts of the fused kernel; 0 = on the
+ *                       tiled kernels
+ *   "sync_spin_us"      epnn_sync and every call that waits for a forward poll the stream this many microseconds (yielding the core
+ *                       between polls) before they sleep on its completion; default 2000, 0 = sleep at once
+ *   "large_dedupe"      1 (default) = the tiled path's first GNN step of the compact entry groups the atoms by feature row (h = 0 and one
+ *                       q per molecule there: the all-pairs sum of charge_gn.py:70 takes (distinct rows)^2 pair evaluations instead of
+ *                       n^2; a molecule with more than 64 distinct rows switches the handle back by itself); 0 = always the all-pairs sweep
+ *   "train_fused"       1 (default) = train step with one workgroup per atom and pair MLP, Dense layers and weight gradients as f32
+ *                       MFMA tiles, 2T + 2T + 1 launches; 0 = one launch per Dense layer on materialised rows (also taken above 96
+ *                       atoms and for update layers other than [32, 32])
+ *   "train_async"       1 (default) = a training step returns as soon as its forward pass is done (loss and predictions are on the host
+ *                       then; backward and optimizer keep running, every call that reads weights or gradients waits for them); 0 = a
+ *                       step returns when all of it is done
+ *   "train_graph"       1 (default) = a train step that waits for its own end has its launch sequence captured once per (B, N, buffers)
+ *                       and replayed as a hipGraph; 0 = kernel by kernel */
 int epnn_set_option(epnn_handle *h, const char *name, int value);
 /* The fused kernel's own front-end runs its G products in a 16-dimensional basis of the Gaussian edge features
  * (charge_gn.py:148-161: 48 overlapping bumps of one variable).  Returns max |e - B B^T e| over D in [0, cutoff], relative

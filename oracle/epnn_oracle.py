@@ -147,10 +147,25 @@ def gen_padded_init_state(path, h_dim=48, e_dim=48, nx=9, names=None):
 
 
 # --------------------------------------------------------------------------- layers
-def mlp(rows, layers):
-    """reference charge_gn.py:30-45 (MLP_layer): relu Dense for every layer but the last."""
+def _activation(name):
+    """Keras activations by name, as keras.layers.Dense(activation=name) resolves them (reference charge_gn.py:38)."""
+    if name == "relu":
+        return lambda v: np.maximum(v, 0)
+    if name is None or name == "linear":
+        return lambda v: v
+    if name == "tanh":
+        return np.tanh
+    if name == "sigmoid":
+        return lambda v: 1.0 / (1.0 + np.exp(-v))
+    raise ValueError(f"activation {name!r}")
+
+
+def mlp(rows, layers, activation="relu"):
+    """reference charge_gn.py:30-45 (MLP_layer): Dense(n, activation) for every layer but the last (:38), Dense(out_dim, None) (:39);
+    `activation` defaults to 'relu' (:31), the only one the reference's own stacks use (:52,84,371)."""
+    act = _activation(activation)
     for W, b in layers[:-1]:
-        rows = np.maximum(rows @ W + b, 0)
+        rows = act(rows @ W + b)
     W, b = layers[-1]
     return rows @ W + b
 

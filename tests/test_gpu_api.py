@@ -330,7 +330,9 @@ def test_bench_line_of_the_drivers_command(tmp_path):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_cold", "prewarm_ms"):
         assert key in o, key
-    assert 0.5 * o["value"] < o["value_cold"] <= 1.25 * o["value"] and o["prewarm_ms"] > 10     # the cold figure stands beside `value`
+    # the cold figure stands beside `value`; the warmed-up timed region is not allowed to read more than 10 % under it (what a host
+    # thread that woke up late from the completion interrupt did once in round 4: 172 M against 189 M cold -- sync_spin_us fixed it)
+    assert 0.5 * o["value"] < o["value_cold"] and o["value"] >= 0.9 * o["value_cold"] and o["prewarm_ms"] > 10
     assert o["n_gpus"] == 1 and o["steps"] == 20 and o["warmup"] == 5 and o["higher_is_better"] is True
     assert o["unit"] == "atoms/s" and o["dtype"] == "f32" and o["data"] == "synthetic" and o["vs_baseline"] is None
     assert o["config"]["workload"] == "qm9_like_b1024_N29" and "model" not in o["config"]
@@ -542,6 +544,42 @@ def test_mlp_layer_call_with_any_nodes(nodes, out_dim):
     ref = orc.mlp(rows.reshape(-1, 23).astype(np.float64), orc._cast_layers(ws, np.float64)).reshape(3, 37, out_dim)
     assert got.shape == (3, 37, out_dim) and got.dtype == np.float32
     assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("activation", [None, "linear", "tanh", "sigmoid", "relu"])
+@pytest.mark.parametrize("nodes", [[32, 32], [20]])
+def test_mlp_layer_call_with_other_activations(nodes, activation):
+    """MLP_layer(nodes, out_dim, activation).call (charge_gn.py:31,38: `activation` goes to every Dense but the last): the Keras names
+    None / 'linear', 'tanh', 'sigmoid' next to the default 'relu' vs the float64 oracle; anything else, and any non-relu MLP inside a
+    GNN / EPN stack, is refused loudly."""
+    from epnn_amd import charge_gn
+    from epnn_amd._lib import EpnnError
+    from oracle import epnn_oracle as orc
+    rng = np.random.default_rng(7 + len(nodes))
+    rows = rng.normal(size=(5, 29, 17)).astype(np.float32)
+    m = charge_gn.MLP_layer(nodes, out_dim=3, activation=activation)
+    dims = [17] + list(nodes) + [3]
+    ws = [((rng.normal(size=(i, o)) / np.sqrt(i)).astype(np.float32), (0.1 * rng.normal(size=(o,))).astype(np.float32))
+          for i, o in zip(dims[:-1], dims[1:])]
+    m.build(17)
+    m.set_weights(ws)
+    got = m(rows)
+    ref = orc.mlp(rows.reshape(-1, 17).astype(np.float64), orc._cast_layers(ws, np.float64), activation).reshape(5, 29, 3)
+    assert got.shape == (5, 29, 3) and got.dtype == np.float32
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())         # float32 Dense stack + tanhf / expf vs float64
+    if activation not in (None, "linear", "relu"):                             # the activation really ran
+        lin = orc.mlp(rows.reshape(-1, 17).astype(np.float64), orc._cast_layers(ws, np.float64), None).reshape(5, 29, 3)
+        assert np.abs(got - lin).max() > 1e-2
+    with pytest.raises(ValueError, match="not built"):
+        charge_gn.MLP_layer(nodes, activation="selu")
+    if activation != "relu":
+        class Tanh(charge_gn.MLP_layer):
+            def __init__(self, nodes, out_dim=1):
+                super().__init__(nodes, out_dim, activation=activation)
+        gnn = charge_gn.GNN_layer(Tanh, charge_gn.MLP_layer([32, 32], out_dim=48), 1)
+        z = np.zeros((1, 4, 4, 48), np.float32)
+        with pytest.raises(EpnnError, match="built for 'relu'"):
+            gnn(np.zeros((1, 4, 48), np.float32), z, np.zeros((1, 4, 9), np.float32), np.zeros((1, 4, 1), np.float32), np.ones((1, 4, 4, 1), np.float32))
 
 
 @pytest.mark.parametrize("layers", [[16], [64, 32], [8, 24, 40]])

@@ -419,6 +419,64 @@ def test_rccl_single_rank_allreduce(gpu_engine_factory):
     assert not np.array_equal(eng.get_weights()["pas"][0][0][0], w["pas"][0][0][0])
 
 
+def test_collectives_fail_closed_world1(gpu_engine_factory):
+    """The status guard in front of the payload collectives (comm_guard, csrc/epnn_host.h): with a world-size-1 communicator and the
+    developer switch that runs the collectives anyway, (a) a train step with apply=1 goes guard -> gradient all-reduce -> Adam and
+    gives the bits of the plain step; (b) an injected failure on "a rank" makes the call return non-zero with the guard's message
+    BEFORE the payload collective is enqueued, leaves the weights untouched, and the handle works afterwards; (c) a step that fails
+    on its way to the collective (molecule larger than N) still runs its status collective from the exit path; (d) the same three for
+    the row exchange of a partitioned system."""
+    from epnn_amd import synth
+    from epnn_amd._lib import EpnnError
+    from epnn_amd.engine import Engine
+    nx, T, N = 9, 2, 12
+    w = random_weights(nx, T, seed=8, scale=0.5)
+    mols_n = [7, 11]
+    rng = np.random.default_rng(3)
+    off = np.array([0, 7, 18], np.int32)
+    xyz = rng.uniform(0, 4.0, (18, 3)).astype(np.float32)
+    x = synth.features(rng.choice(["H", "C", "N", "O"], size=18)).astype(np.float32)
+    Q = np.zeros(2, np.float32)
+    y = rng.normal(0, 0.2, 18).astype(np.float32)
+    plain = gpu_engine_factory(nx=nx, T=T)
+    plain.set_weights(w)
+    plain.train_init()
+    q0, l0 = plain.train_step_xyz(off, xyz, x, Q, y, N, apply=True)
+    w_plain = plain.get_weights()
+    eng = gpu_engine_factory(nx=nx, T=T)
+    eng.set_weights(w)
+    eng.train_init()
+    eng.comm_init(Engine.comm_unique_id(), 0, 1)
+    eng.set_option("part_collective", 1)
+    # (b) first: the failing step must leave everything as it was
+    eng.set_option("comm_inject_fail", 1)
+    with pytest.raises(EpnnError, match="aborted on every rank"):
+        eng.train_step_xyz(off, xyz, x, Q, y, N, apply=True)
+    assert np.array_equal(eng.get_weights()["pas"][0][0][0], w["pas"][0][0][0])
+    # (c) a failure in front of the collective: the exit path reports it through the status collective
+    with pytest.raises(EpnnError, match="aborted on every rank; this rank failed: .*does not fit N"):
+        eng.train_step_xyz(off, xyz, x, Q, y, 8, apply=True)
+    # (a)
+    q1, l1 = eng.train_step_xyz(off, xyz, x, Q, y, N, apply=True)
+    assert np.array_equal(q1, q0) and l1 == l0
+    w_coll = eng.get_weights()
+    for a, b in zip(w_coll["pas"][0] + w_coll["msg"][1] + w_coll["upd"], w_plain["pas"][0] + w_plain["msg"][1] + w_plain["upd"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # (d) partitioned forward, rows over the communicator
+    offs, bxyz, bx, bQ, bN = synth.box_system(n_atoms=300, seed=4)
+    fwd = gpu_engine_factory(nx=nx, T=T)
+    fwd.set_weights(w)
+    whole = fwd.forward_xyz(offs, bxyz, bx, bQ, bN)
+    fwd.comm_init(Engine.comm_unique_id(), 0, 1)
+    fwd.set_option("part_collective", 1)
+    fwd.set_option("comm_inject_fail", 1)
+    with pytest.raises(EpnnError, match="row exchange.*aborted on every rank"):
+        fwd.forward_xyz(offs, bxyz, bx, bQ, bN)
+    assert np.array_equal(fwd.forward_xyz(offs, bxyz, bx, bQ, bN), whole)
+    fwd.set_option("comm_guard", 0)
+    assert np.array_equal(fwd.forward_xyz(offs, bxyz, bx, bQ, bN), whole)
+
+
 def test_train_script_and_mirror(tmp_path, golden_dir):
     """train.py end to end on the four-file fixture directory (two epochs), and the charge_gn.train_step mirror."""
     import subprocess, sys

@@ -45,11 +45,17 @@ def test_no_silent_cpu_fallback():
 
 
 def test_every_option_is_documented_in_the_header():
-    """epnn_set_option's names (epnn_api.hip) all appear in include/epnn.h."""
+    """epnn_set_option's names all appear in include/epnn.h (the options a caller may touch: about ten) or in include/epnn_dev.h (the
+    developer switches), and in exactly one of the two."""
+    import glob
     import re
-    src = open(os.path.join(ROOT, "epnn_amd", "csrc", "epnn_api.hip")).read()
+    src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "epnn_amd", "csrc", "*.hip"))))
     hdr = open(os.path.join(ROOT, "include", "epnn.h")).read()
+    dev = open(os.path.join(ROOT, "include", "epnn_dev.h")).read()
     names = re.findall(r'!strcmp\(name, "([a-z0-9_]+)"\)', src)
     assert len(names) >= 10
-    missing = [n for n in names if f'"{n}"' not in hdr]
+    missing = [n for n in names if (f'"{n}"' in hdr) == (f'"{n}"' in dev)]
     assert not missing, missing
+    public = [n for n in names if f'"{n}"' in hdr]
+    assert len(public) <= 12, public
+    assert not re.findall(r"\bepnn_[a-z0-9_]+\s*\(", re.sub(r"/\*.*?\*/", "", dev, flags=re.S)), "epnn_dev.h declares no symbols"

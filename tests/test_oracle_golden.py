@@ -84,3 +84,20 @@ def test_blocked_large_system_form_equals_the_dense_form(weights_decay, golden_d
     a32 = orc.forward_xyz(xyz, x, np.float32(1.0), weights_decay, dtype=np.float32)
     b32 = orc.forward_xyz_large(xyz, x, np.float32(1.0), weights_decay, dtype=np.float32, row_block=24)
     assert np.abs(a32 - b32).max() < 2e-6
+
+
+def test_cached_oracle_fixtures_are_current():
+    """tests/golden/oracle_box1500.npz / oracle_subbox4096.npz cache OUR oracle's float64 output for two synthetic systems of the GPU
+    suite (made by tests/golden/make_oracle_fixtures.py; not reference data).  The 1500-atom one is recomputed here -- same bits --
+    and both files carry the hash of the inputs the GPU tests will rebuild (a stale cache is ignored there, never trusted)."""
+    from golden import make_oracle_fixtures as fx
+    from oracle import epnn_oracle as orc
+    xyz, x, Q, N, w = fx.box1500_case()
+    z = fx.load("oracle_box1500.npz", xyz, x, Q, N, w)
+    assert z is not None, "oracle_box1500.npz is missing or was made from other inputs: run tests/golden/make_oracle_fixtures.py"
+    assert "not reference data" in str(z["made_by"])
+    ref = orc.forward_xyz(xyz, x, Q[0], w, N=N, dtype=np.float64, row_block=128)
+    assert np.array_equal(ref, z["q_float64"])
+    assert abs(float(ref.sum())) < 1e-9 and np.abs(z["q_float32"] - ref).max() < 1e-4
+    z4 = np.load(os.path.join(os.path.dirname(fx.__file__), "oracle_subbox4096.npz"))
+    assert z4["q_float64"].shape == (4096,) and abs(float(z4["q_float64"].sum()) - 1.0) < 1e-9 and len(str(z4["inputs_sha256"])) == 64

@@ -209,3 +209,58 @@ def test_row_exchange_all_gathers_and_fails_together_world2_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "EXCHANGE_OK" in out.stdout
+
+
+_GUARD_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch.distributed as dist
+from epnn_amd import shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+class FakeEngine:                                  # the gradient of a train step, or the step's failure (EPNN_FAIL before the collective)
+    def __init__(self, fail):
+        self.fail = fail
+    def get_gradients(self):
+        if self.fail:
+            raise OSError("hipMalloc failed: out of memory")
+        return np.full(5, 1.0 + rank, np.float32)
+
+def step(eng):
+    g, err = None, None
+    try:
+        g = eng.get_gradients()
+    except Exception as exc:                       # the step failed on THIS rank: its peers must not wait for it
+        err = exc
+    return shard.allreduce_sum_host(g, dist, failed=err)
+
+assert np.array_equal(step(FakeEngine(False)), np.full(5, 3.0))
+t0 = time.time()
+try:
+    step(FakeEngine(rank == 1))
+    raise SystemExit("the all-reduce did not fail")
+except RuntimeError as exc:
+    assert "aborted on every rank" in str(exc), str(exc)
+    assert ("this rank failed" in str(exc)) == (rank == 1), str(exc)
+assert time.time() - t0 < 30
+assert np.array_equal(step(FakeEngine(False)), np.full(5, 3.0))      # the group is still usable afterwards
+dist.barrier()
+if rank == 0:
+    print("GUARD_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_gradient_allreduce_fails_together_world2_gloo(tmp_path):
+    """The status guard in front of the gradient all-reduce (the host-staged counterpart of comm_guard in csrc/epnn_host.h): a rank
+    whose step failed before the collective makes EVERY rank raise instead of leaving its peer blocked in the all-reduce."""
+    script = tmp_path / "guard_worker.py"
+    script.write_text(_GUARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "GUARD_OK" in out.stdout
