@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libepnn_hip.so")
+LIB_PATH = os.environ.get("EPNN_LIB") or os.path.join(_HERE, "libepnn_hip.so")      # (EPNN_LIB: a development build, tools/)
 
 W_MSG, W_UPD, W_PAS = 0, 1, 2
 

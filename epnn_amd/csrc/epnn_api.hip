@@ -223,7 +223,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
                       &h->d_deg, &h->d_incoff, &h->d_nbr, &h->d_desti, &h->d_destj, &h->d_prec, &h->l_Nn, &h->l_Yb, &h->l_qbuf,
                       &h->l_Pst, &h->l_Rst, &h->l_lmol, &h->l_typrow, &h->l_typtab, &h->l_stype, &h->l_typhash,
-                      &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->l_sfrac, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
+                      &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->l_sfrac, &h->l_stasks2, &h->l_sfrac2, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->tr_realbuf, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
                       &h->sd_e, &h->sd_x, &h->sd_q, &h->sd_mask, &h->sd_out};
     for (DevBuf *b : bufs) b->release();
@@ -362,6 +362,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "large_merge")) { h->opt_large_merge = value; }
     else if (!strcmp(name, "large_chunks")) { h->opt_large_chunks = value; h->plan.valid = false; }
+    else if (!strcmp(name, "large_sweep_old")) { h->opt_large_sweep_old = value != 0; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "comm_guard")) { h->opt_comm_guard = value != 0; }
     else if (!strcmp(name, "comm_inject_fail")) { h->opt_comm_inject_fail = value != 0; }

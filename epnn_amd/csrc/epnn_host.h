@@ -182,6 +182,9 @@ struct epnn_handle {
     // large path workspace (epnn_large.hip.h)
     DevBuf l_a, l_P, l_R, l_zp, l_S0, l_corr, l_dl, l_tiles, l_csr_off, l_csr_ent, l_cnt, l_nm;
     DevBuf l_stasks, l_schunk, l_sfin, l_sfrac;
+    DevBuf l_stasks2, l_sfrac2;                     // tile-workgroup sweep (k_lg_sweep2): tasks, correction-tile shares
+    int l_nstasks2 = 0;
+    int opt_large_sweep_old = 0;      // developer switch: every tiled molecule on the four-tile sweep kernel of rounds 1-4
     DevBuf l_Nn, l_Yb, l_qbuf, l_Pst, l_Rst;        // sweep operands (-R, b2 + W2^T R); EPN stack: charges, projections with q = 0
     DevBuf l_lmol, l_typrow, l_typtab, l_stype, l_typhash;     // first GNN step by atom types
     bool sweep_attr = false;                        // k_lg_sweep's dynamic LDS limit has been raised

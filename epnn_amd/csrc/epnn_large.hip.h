@@ -83,6 +83,10 @@ struct LargeArgs {
     const int *stask_chunk;                 // chunk index of each sweep task
     const float2 *stask_frac;               // share [lo, hi) of the step's correction tiles each sweep task's wavefronts run
     int nstasks;
+    // tile-workgroup sweep (k_lg_sweep2: molecules of at most EPNN_LG_TW_TILES tiles)
+    const int4 *stasks2;                    // (atile or -1: correction tiles only, index of its partial sum, j_lo, j_hi)
+    const float2 *stask2_frac;              // share [lo, hi) of the step's correction tiles of each of these workgroups
+    int nstasks2;
     int pcap;
     // first GNN step by atom types (k_lg_types)
     const int *lmol;                        // [nlarge] molecules on this path
@@ -493,6 +497,32 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
         S0[0] += w16_relu(d0[0]);
         S0[1] += w16_relu(d0[1]);
     };
+#ifdef EPNN_EXP_FETCH2
+    // experiment: the rows of TWO partners requested back to back (eight LDS reads in one batch), two partners ahead
+    f32x4 na[2], ya[2], nb[2], yb[2], nc[2], yc[2], nd[2], yd[2];
+    fetch(0, na, ya);
+    fetch(min(1, nj - 1), nb, yb);
+    int j = 0;
+    for (; j + 4 <= nj; j += 4) {
+        if ((j & 7) == 0) {
+            if ((((jg + j) >> 3) & 1) ^ flip) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        fetch(j + 2, nc, yc);
+        fetch(j + 3, nd, yd);
+        partner(na, ya);
+        partner(nb, yb);
+        fetch(min(j + 4, nj - 1), na, ya);
+        fetch(min(j + 5, nj - 1), nb, yb);
+        partner(nc, yc);
+        partner(nd, yd);
+    }
+    for (; j < nj; ++j) {
+        fetch(j, na, ya);
+        partner(na, ya);
+    }
+    return;
+#else
     f32x4 na[2], ya[2], nb[2], yb[2];
     fetch(0, na, ya);
     int j = 0;
@@ -510,6 +540,7 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
         partner(nb, yb);
     }
     if (j < nj) partner(na, ya);
+#endif
 }
 __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, float *Ns, float *Ys) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
@@ -662,6 +693,100 @@ __global__ __launch_bounds__(256) void k_lg_sweep(LargeArgs L, int w2off, PairMl
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ tile-workgroup sweep
+// The sweep of molecules of up to EPNN_LG_TW_TILES tiles (4096 atoms): workgroup = ONE 32-atom tile x four consecutive pieces of
+// the partner range, one piece per wavefront.  Against k_lg_sweep (four tiles x one piece, the staged partner rows shared):
+//   * a wavefront stages its own partners (Nn_j, Yb_j rows: 256 bytes each, up to EPNN_LG_JP per trip) in its own quarter of the
+//     workgroup's LDS -- no workgroup barrier anywhere in the partner loop (the shared staging had two per 64 partners);
+//   * the four wavefronts' sums are added in LDS, ((w0 + w1) + w2) + w3, and ONE partial sum per workgroup goes to memory: the
+//     reduction behind the sweep reads 7 partial sums per atom of the 2220-atom protein instead of 28;
+// (Round 5 also ran a tile's tail -- reduction, update MLP, next projections -- inside this launch, by the last of the tile's
+// workgroups to store its partial sum: SLOWER than the launch it replaces.  All workgroups of a 2220-atom system are resident at once
+// and end together, so every tile's tail starts at the launch's end and is a 17.7 us chain on one workgroup against 13.8 us for the
+// launch; and the release / acquire fences that order the partial sums across the XCDs' L2s, ~500 per launch, cost 41 us by
+// themselves.  HISTORY.md part B has the four timings.)
+// It reads 4 x the partner rows of the shared staging from L2 (protein: 40 MB per sweep, L2-resident arrays), which is why systems
+// of more than EPNN_LG_TW_TILES tiles keep k_lg_sweep.
+#define EPNN_LG_JP 80                       // partners a wavefront stages per trip: 4 x 80 x 256 B = 80 KB per workgroup, two per CU
+#define EPNN_LG_TW_TILES 128
+__device__ __forceinline__ void lg_wave_sync() {         // LDS written by this wavefront is read by this wavefront: order only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(256) void k_lg_sweep2(LargeArgs L, int w2off, PairMlpPack Mpair, int do_pairs) {
+    extern __shared__ __attribute__((aligned(16))) float lg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
+    const int4 tk = L.stasks2[blockIdx.x];           // atile (or -1), partial index, j_lo, j_hi (global atom indices)
+    if (do_pairs) {
+        const int np = L.row_off[L.A];
+        const float2 fr = L.stask2_frac[blockIdx.x];
+        if (np <= L.pcap && fr.y > fr.x) {
+            const int npt = (np + 31) >> 5;
+            const int lo = min(npt, (int)(fr.x * (float)npt)), hi = fr.y >= 1.f ? npt : min(npt, (int)(fr.y * (float)npt));
+            for (int pt = lo + wave; pt < hi; pt += 4) lg_pair_tile<false>(L, Mpair, pt, np, nullptr);
+        }
+    }
+    if (tk.x < 0) return;
+    const int4 tl = L.atiles[tk.x];
+    const float *wp = L.wpack;
+    const bool two = __builtin_amdgcn_readfirstlane(tl.y) > 16;      // the tile's second column block holds atoms
+    const int po = 16 * (q & 1) + 4 * (q >> 1);                       // (operand order of P / Nn rows: see lg_sweep_body)
+    const int c0 = n16 < tl.y ? n16 : 0, c1 = 16 + n16 < tl.y ? 16 + n16 : 0;
+    f32x4 P0[2], P1[2], S0[2], S1[2];
+    float pb[2][8];
+    W16_LD(pb, w2off, 2, 8);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        P0[rb] = w16_ld(L.P + (size_t)(tl.x + c0) * 32 + po + 8 * rb);
+        P1[rb] = w16_ld(L.P + (size_t)(tl.x + c1) * 32 + po + 8 * rb);
+        S0[rb] = w16_splat(0.f);
+        S1[rb] = w16_splat(0.f);
+    }
+    // this wavefront's piece of the workgroup's partner range
+    const int sub = (tk.w - tk.z + 3) >> 2;
+    const int jlo = min(tk.w, tk.z + wave * sub), jhi = min(tk.w, jlo + sub);
+    float *Ns = lg_smem + wave * (EPNN_LG_JP * 64), *Ys = Ns + EPNN_LG_JP * 32;
+    const int flip = 2 * blockIdx.x >= gridDim.x ? 1 : 0;
+    for (int j0 = jlo; j0 < jhi; j0 += EPNN_LG_JP) {
+        const int nj = min(EPNN_LG_JP, jhi - j0);
+        if (j0 > jlo) lg_wave_sync();                     // the rows of the trip before have been read
+        {
+            const f32x4 *gn = reinterpret_cast<const f32x4 *>(L.Nn + (size_t)j0 * 32), *gy = reinterpret_cast<const f32x4 *>(L.Yb + (size_t)j0 * 32);
+            constexpr int PER = EPNN_LG_JP * 8 / 64;      // 16-byte pieces per lane and array
+            f32x4 v[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) v[u] = gn[min(u * 64 + lane, nj * 8 - 1)];       // unconditional loads of a clamped index
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (u * 64 + lane < nj * 8) reinterpret_cast<f32x4 *>(Ns)[u * 64 + lane] = v[u];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) v[u] = gy[min(u * 64 + lane, nj * 8 - 1)];
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (u * 64 + lane < nj * 8) reinterpret_cast<f32x4 *>(Ys)[u * 64 + lane] = v[u];
+        }
+        lg_wave_sync();
+        if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - jlo, flip);
+        else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - jlo, flip);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // the four wavefronts' sums, added in wavefront order; one partial sum per workgroup
+    lg_wave_sync();
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        w16_st(Ns + n16 * 32 + 16 * rb + fo, S0[rb]);
+        w16_st(Ns + (16 + n16) * 32 + 16 * rb + fo, S1[rb]);
+    }
+    __syncthreads();
+    {
+        float *dst = L.S0 + ((size_t)tk.y * L.A) * 32 + (size_t)tl.x * 32;
+        const f32x4 a = reinterpret_cast<const f32x4 *>(lg_smem)[tid], b = reinterpret_cast<const f32x4 *>(lg_smem + EPNN_LG_JP * 64)[tid],
+                    c = reinterpret_cast<const f32x4 *>(lg_smem + 2 * EPNN_LG_JP * 64)[tid], d = reinterpret_cast<const f32x4 *>(lg_smem + 3 * EPNN_LG_JP * 64)[tid];
+        if ((tid >> 3) < tl.y) reinterpret_cast<f32x4 *>(dst)[tid] = ((a + b) + c) + d;      // element 4 tid .. 4 tid + 3 = atom tid >> 3
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ merged launches of the compact entry
 // What a forward of the compact entry can do at once goes into ONE launch, the kinds of work told apart by the block index
 // (a second stream would do the same on paper; its fork / join events cost more than these short kernels last):
@@ -803,9 +928,15 @@ __device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, con
     bool ok[NA];
     float s[NA], zpv[NA];
     // The loads are issued in as few dependent rounds as the data allows (every round is ~1 us on data the previous launch
-    // wrote): (1) row bounds, the padded partners' term, the first partial sums (or the atom's type); (2) the LAST batch of
-    // partial sums (or the type's row) together with the first eight slots of the atom's row; (3) the rest of the row.  The order
-    // in which an element's terms are ADDED is what it always was: partial sums in piece order, slots in slot order, padding.
+    // wrote): (1) row bounds, the padded partners' term, the atom's type, and the first batch of partial sums -- ALL of them for a
+    // system on the tile-workgroup sweep, which leaves one partial sum per workgroup (7 for the protein); (2) the type's row and the
+    // first sixteen slots of the atom's row (a protein atom has at most 19 partners); (3) the rest.  The order in which an element's
+    // terms are ADDED is what it always was: partial sums in piece order, slots in slot order, padding.
+    constexpr int CB = 32 / NA;                                // partial sums of a thread in flight (64 spill in the fused tail)
+    constexpr int S1 = 32 / NA < 16 ? 32 / NA : 16;
+    const size_t step = (size_t)L.A * 32;
+    int trow[NA];
+    float v0[NA][CB];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         ok[k] = a[k] < tl.y;
@@ -813,45 +944,40 @@ __device__ __forceinline__ void lg_reduce(const LargeArgs &L, const int4 tl, con
         lo[k] = L.inc_off[at[k]];
         hi[k] = L.inc_off[at[k] + 1];
         zpv[k] = L.zp[(size_t)at[k] * 32 + o];
+        trow[k] = types ? L.typ_row[at[k]] : 0;
         s[k] = 0.f;
-    }
-    constexpr int CB = 32 / NA;                                // 32 partial sums of a thread in flight (64 spill in the fused tail)
-    constexpr int S1 = 8;
-    const size_t step = (size_t)L.A * 32;
-    int trow[NA];
-    if (types) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) trow[k] = L.typ_row[at[k]];
+        // (unconditional loads of a clamped index: `cond ? p[i] : 0` is a branch per load, each waiting for the one before)
+        for (int u = 0; u < CB; ++u) v0[k][u] = L.S0[(size_t)at[k] * 32 + o + (size_t)max(min(u, nchunk - 1), 0) * step];
     }
-    int ch = 0;
-    for (; ch + CB < nchunk; ch += CB) {                       // every batch but the last
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+#pragma unroll
+        for (int u = 0; u < CB; ++u)
+            if (u < nchunk) s[k] += v0[k][u];
+    for (int ch = CB; ch < nchunk; ch += CB) {                 // (systems on the four-tile sweep: more pieces than one batch)
         float v[NA][CB];
 #pragma unroll
         for (int k = 0; k < NA; ++k)
 #pragma unroll
-            for (int u = 0; u < CB; ++u) v[k][u] = L.S0[(size_t)at[k] * 32 + o + (size_t)(ch + u) * step];
+            for (int u = 0; u < CB; ++u) v[k][u] = L.S0[(size_t)at[k] * 32 + o + (size_t)min(ch + u, nchunk - 1) * step];
 #pragma unroll
         for (int k = 0; k < NA; ++k)
 #pragma unroll
-            for (int u = 0; u < CB; ++u) s[k] += v[k][u];
+            for (int u = 0; u < CB; ++u)
+                if (ch + u < nchunk) s[k] += v[k][u];
     }
     {
-        float v[NA][CB], c1[NA][S1], tv[NA];
+        float c1[NA][S1], tv[NA];
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             tv[k] = types ? L.S_type[(size_t)trow[k] * 32 + o] : 0.f;
-#pragma unroll
-            // (unconditional loads of a clamped index: `cond ? p[i] : 0` is a branch per load, each waiting for the one before)
-            for (int u = 0; u < CB; ++u) v[k][u] = L.S0[(size_t)at[k] * 32 + o + (size_t)max(min(ch + u, nchunk - 1), 0) * step];
 #pragma unroll
             for (int u = 0; u < S1; ++u) c1[k][u] = L.corrA[(size_t)max(min(lo[k] + u, hi[k] - 1), 0) * 32 + o];
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             if (types) s[k] = tv[k];
-#pragma unroll
-            for (int u = 0; u < CB; ++u)
-                if (ch + u < nchunk) s[k] += v[k][u];
 #pragma unroll
             for (int u = 0; u < S1; ++u)
                 if (lo[k] + u < hi[k]) s[k] += c1[k][u];
@@ -898,36 +1024,35 @@ __global__ __launch_bounds__(256) void k_lg_reduce(LargeArgs L, float *Sfin, int
 // forty MFMAs (the fused tail keeps its registers for the reduction that runs before this).
 // `bs` (optional): the five bias vectors staged by the caller as [cb3p 32 | bu1p 32 | bu2p 32 | bu3p 64] (LDS): read from the
 // weight pack they are three round trips in the middle of a chain of dependent MFMAs.
-template <bool LATE>
-__device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack &U, const float (&w1)[40], float (&w2)[16],
-                                               float (&w3)[32], const int4 tl, const float *arow, const float *srow,
-                                               float *dst, float *dst2, int lane, const float *bs = nullptr) {
-    const int c = lane & 31, hh = lane >> 5;
-    if (LATE) {
-        const float *wq = L.wpack;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) w2[s] = wq[U.u2F + s * 64 + lane];
-#pragma unroll
-        for (int s = 0; s < 32; ++s) w3[s] = wq[U.u3F + s * 64 + lane];
-    }
-    const bool live = c < tl.y;
-    const int at = tl.x + (live ? c : 0);
-    const int nx = L.nx;
+// (in two halves: the h part of the first layer does not depend on the step's message sum, so the tail launch runs it on wavefront 0
+// WHILE the other wavefronts reduce S -- the same chain in the same order, 24 of its 40 matrix instructions off the critical path)
+__device__ __forceinline__ f32x16 lg_update_h(const LargeArgs &L, const UpdPack &U, const float (&w1)[40], const float *arow, int lane, const float *bs) {
+    const int hh = lane >> 5;
     const float *wp = L.wpack;
-    float hv[24], sv[16];
+    float hv[24], cb[16];
 #pragma unroll
     for (int s = 0; s < 24; ++s) hv[s] = arow[s];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) sv[s] = srow[2 * s + hh];
-    float cb[16], b1[16];
     epnn_ld16(bs ? bs + hh * 16 : wp + U.cb3p + hh * 16, cb);
-    epnn_ld16(bs ? bs + 32 + hh * 16 : wp + U.bu1p + hh * 16, b1);
     const float Nf = (float)L.N;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = Nf * cb[r];
 #pragma unroll
     for (int s = 0; s < 24; ++s) acc = epnn_mfma(w1[s], hv[s], acc);
+    return acc;
+}
+__device__ __forceinline__ void lg_update_rest(const LargeArgs &L, const UpdPack &U, f32x16 acc, const float (&w1)[40], const float (&w2)[16],
+                                               const float (&w3)[32], const int4 tl, const float *srow, float *dst, float *dst2, int lane,
+                                               const float *bs) {
+    const int c = lane & 31, hh = lane >> 5;
+    const bool live = c < tl.y;
+    const int at = tl.x + (live ? c : 0);
+    const int nx = L.nx;
+    const float *wp = L.wpack;
+    float sv[16], b1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sv[s] = srow[2 * s + hh];
+    epnn_ld16(bs ? bs + 32 + hh * 16 : wp + U.bu1p + hh * 16, b1);
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = epnn_mfma(w1[24 + s], sv[s], acc);
     float u1[16], b2v[16];
@@ -965,6 +1090,20 @@ __device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack
             }
         }
     }
+}
+template <bool LATE>
+__device__ __forceinline__ void lg_update_wave(const LargeArgs &L, const UpdPack &U, const float (&w1)[40], float (&w2)[16],
+                                               float (&w3)[32], const int4 tl, const float *arow, const float *srow,
+                                               float *dst, float *dst2, int lane, const float *bs = nullptr) {
+    if (LATE) {
+        const float *wq = L.wpack;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) w2[s] = wq[U.u2F + s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) w3[s] = wq[U.u3F + s * 64 + lane];
+    }
+    const f32x16 acc = lg_update_h(L, U, w1, arow, lane, bs);
+    lg_update_rest(L, U, acc, w1, w2, w3, tl, srow, dst, dst2, lane, bs);
 }
 #define LG_LOAD_UPD_WEIGHTS(w1, w2, w3, U)                                            \
     _Pragma("unroll") for (int s = 0; s < 40; ++s) w1[s] = wp[U.u1F + s * 64 + lane]; \
@@ -1068,10 +1207,16 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     const int np = L.row_off[L.A];                               // (looked at below: the loads in between do not depend on the pair list)
     const int4 tl = L.atiles[blockIdx.x];
     const float *wp = L.wpack;
+    const int row = c < tl.y ? c : 0;
     float w1[40], w2[16], w3[32], wA[EPNN_KA];
+    f32x16 acc_h = epnn_splat16(0.f);
     if (wave == 0) {
-#pragma unroll
-        for (int s = 0; s < 40; ++s) w1[s] = wp[U.u1F + s * 64 + lane];
+        // Wavefront 0 takes no part in the reduction: it has the update MLP's weights in registers from the start and runs the h
+        // part of the first layer (24 of its 40 matrix instructions, straight from the tile's rows in memory) while the others
+        // reduce S -- the chain and its order are those of lg_update_wave, so the bits are the same.
+        LG_LOAD_UPD_WEIGHTS(w1, w2, w3, U)
+        const int u0 = (L.nx - hh + 1) >> 1;
+        acc_h = lg_update_h(L, U, w1, L.a_eo + (size_t)(tl.x + row) * EPNN_AST + hh * 32 + u0, lane, nullptr);
     }
     if (tid >= 352) {                                            // (waves 5..7: nothing else to request)
         const int k = tid - 352;
@@ -1096,24 +1241,21 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     for (int i = tid; i < tl.y * (EPNN_AST / 4); i += 512)
         reinterpret_cast<f32x4 *>(Ai)[i] = reinterpret_cast<const f32x4 *>(L.a_eo + (size_t)tl.x * EPNN_AST)[i];
     if (np > L.pcap) return;
-    {
-        const int o = tid & 31, a16 = tid >> 5, n = L.moff[tl.z + 1] - L.moff[tl.z];
-        const int a[2] = {a16, a16 + 16};
-        float sv[2];
+    if (wave > 0) {                                              // 448 threads: output o of atoms g, g + 14, g + 28
+        const int t7 = tid - 64, o = t7 & 31, g = t7 >> 5, n = L.moff[tl.z + 1] - L.moff[tl.z];
+        const int a[3] = {g, g + 14, g + 28};
+        float sv[3];
         LG_CLK(16 * X.run, 1);
-        lg_reduce<2>(L, tl, a, o, n, types, sv);
+        lg_reduce<3>(L, tl, a, o, n, types, sv);
         LG_CLK(16 * X.run, 2);
-        Ss[a16 * EPNN_SST + o] = sv[0];
-        Ss[(a16 + 16) * EPNN_SST + o] = sv[1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (a[k] < 32) Ss[a[k] * EPNN_SST + o] = sv[k];
     }
     __syncthreads();
     LG_CLK(16 * X.run, 3);
-    const int row = c < tl.y ? c : 0;
-    if (wave == 0) {
-        const int u0 = (L.nx - hh + 1) >> 1;
-        lg_update_wave<true>(L, U, w1, w2, w3, tl, Ai + row * EPNN_AST + hh * 32 + u0, Ss + c * EPNN_SST,
-                             L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane, Bs);
-    }
+    if (wave == 0)
+        lg_update_rest(L, U, acc_h, w1, w2, w3, tl, Ss + c * EPNN_SST, L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane, Bs);
     LG_CLK(16 * X.run, 4);
     if (!X.run) return;
     __syncthreads();                                            // the image now holds the new h
@@ -1292,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_lg_export_q(LargeArgs L) {
 
 // ================================================================================================ host side
 struct LargePlanHost {
-    std::vector<int4> atiles, stasks;
+    std::vector<int4> atiles, stasks, stasks2;
     std::vector<int> stask_chunk;
     std::vector<float> slack;               // per sweep task: partners its range is shorter than its molecule's longest
     int maxchunk = 0;
@@ -1317,6 +1459,31 @@ static int large_plan(epnn_handle *h) {
         const int a0 = P.offsets[b], n = P.offsets[b + 1] - a0;
         const int first_tile = (int)lp.atiles.size();
         const int ntile = (n + 31) / 32, ngroup = (ntile + 3) / 4;
+        if (ntile <= EPNN_LG_TW_TILES && !h->opt_large_sweep_old) {
+            // tile-workgroup sweep (k_lg_sweep2): workgroup = one tile x four pieces of 1 / nwg of the partner range.  nwg depends on
+            // the molecule alone (its results do not depend on what else is in the batch): as many as keep one molecule's
+            // workgroups resident at once (two per CU), pieces of at least ~16 partners
+            int nwg = std::max(1, std::min(512 / ntile, (n + 63) / 64));
+            if (h->opt_large_chunks > 0) nwg = std::min(h->opt_large_chunks, n);
+            const int wlen = (n + nwg - 1) / nwg;
+            nwg = (n + wlen - 1) / wlen;
+            for (int i0 = 0; i0 < n; i0 += 32) lp.atiles.push_back(make_int4(a0 + i0, std::min(32, n - i0), b, nwg));
+            lp.maxchunk = std::max(lp.maxchunk, nwg);
+            for (int tg = 0; tg < ntile; tg += 4, ++gidx) {
+                {   // owner of this tile group (same formula on every process)
+                    int r = 0;
+                    while (r + 1 < h->part_world && gidx >= (int)((long long)total_groups * (r + 1) / h->part_world)) ++r;
+                    h->part_lo[r] = std::min(h->part_lo[r], a0 + tg * 32);
+                    h->part_hi[r] = std::max(h->part_hi[r], a0 + std::min(n, (tg + 4) * 32));
+                }
+                if (gidx < g_own0 || gidx >= g_own1) continue;
+                h->part_row_lo = std::min(h->part_row_lo, a0 + tg * 32);
+                h->part_row_hi = std::max(h->part_row_hi, a0 + std::min(n, (tg + 4) * 32));
+                for (int t = tg; t < std::min(ntile, tg + 4); ++t)
+                    for (int w = 0; w < nwg; ++w) lp.stasks2.push_back(make_int4(first_tile + t, w, a0 + w * wlen, a0 + std::min(n, (w + 1) * wlen)));
+            }
+            continue;
+        }
         // split the j range so that the sweep has a few thousand workgroups, in pieces of EPNN_LG_JC atoms
         // workgroups of the sweep = ngroup * nchunk.  Measured on the 2220-atom protein: a whole number of rounds of 512
         // workgroups (two per CU) beats 1024 smaller ones (per-workgroup prologue and more partial sums to reduce);
@@ -1363,10 +1530,37 @@ static int large_plan(epnn_handle *h) {
     h->l_natiles = (int)lp.atiles.size();
     h->l_nstasks = (int)lp.stasks.size();
     h->l_maxchunk = lp.maxchunk;
+    // the tile-workgroup launch: its sweep workgroups, then workgroups that run correction tiles only.  While all of them are
+    // resident at once (two per CU) the spare slots take the step's correction tiles -- a wavefront with a full sweep task that
+    // also ran a tile would end ~5 us after the others --; without (enough) spare slots the tiles are dealt evenly.
+    std::vector<float2> frac2;
+    {
+        const int ns2 = (int)lp.stasks2.size();
+        double tiles = 0;
+        for (int b : P.large_list) tiles += 1.2 * (double)(P.offsets[b + 1] - P.offsets[b]) * 6.0 / 32.0;
+        const int spare = ns2 > 0 && lp.stasks.empty() ? std::max(0, 512 - ns2) : 0;
+        int ncorr = std::min(spare, (int)std::ceil(tiles / 12.0));           // ~3 tiles per wavefront
+        if (ncorr > 0 && tiles / (4.0 * ncorr) > 10.0) ncorr = 0;               // too few: dealt evenly instead
+        for (int k = 0; k < ncorr; ++k) lp.stasks2.push_back(make_int4(-1, 0, 0, 0));
+        frac2.resize(lp.stasks2.size());
+        if (!lp.stasks.empty()) {
+            for (auto &f : frac2) f = make_float2(0.f, 0.f);                    // (the four-tile launch of the same step runs them)
+        } else {
+            const size_t first = ncorr > 0 ? (size_t)ns2 : 0, cnt = frac2.size() - first;
+            for (size_t k = 0; k < frac2.size(); ++k) {
+                if (k < first) { frac2[k] = make_float2(0.f, 0.f); continue; }
+                frac2[k].x = (float)((double)(k - first) / (double)cnt);
+                frac2[k].y = k + 1 == frac2.size() ? 1.f : (float)((double)(k - first + 1) / (double)cnt);
+            }
+        }
+    }
+    h->l_nstasks2 = (int)lp.stasks2.size();
     if (P.large_list.empty()) return 0;          // (the molecule flags travel with the plan's other index arrays)
     const size_t A = (size_t)P.A, nl = P.large_list.size(), T = (size_t)std::max(1, h->cfg.T);
     if (h->l_tiles.ensure(lp.atiles.size() * sizeof(int4)) || h->l_stasks.ensure(lp.stasks.size() * sizeof(int4)) ||
-        h->l_schunk.ensure(lp.stask_chunk.size() * sizeof(int)) || h->l_a.ensure(A * EPNN_AST * 4) ||
+        h->l_schunk.ensure(lp.stask_chunk.size() * sizeof(int)) || h->l_stasks2.ensure(lp.stasks2.size() * sizeof(int4)) ||
+        h->l_sfrac2.ensure(std::max<size_t>(1, frac2.size()) * sizeof(float2)) ||
+        h->l_a.ensure(A * EPNN_AST * 4) ||
         h->l_P.ensure(A * 32 * 4) || h->l_R.ensure(A * 32 * 4) || h->l_zp.ensure(A * 32 * 4) ||
         h->l_Nn.ensure(A * 32 * 4) || h->l_Yb.ensure(A * 32 * 4) || h->l_qbuf.ensure(2 * A * 4) ||
         h->l_Pst.ensure(T * A * 32 * 4) || h->l_Rst.ensure(T * A * 32 * 4) ||
@@ -1395,6 +1589,10 @@ static int large_plan(epnn_handle *h) {
     if (!frac.empty()) HIPCHK(hipMemcpyAsync(h->l_sfrac.p, frac.data(), frac.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->l_tiles.p, lp.atiles.data(), lp.atiles.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->l_lmol.p, P.large_list.data(), nl * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!lp.stasks2.empty()) {
+        HIPCHK(hipMemcpyAsync(h->l_stasks2.p, lp.stasks2.data(), lp.stasks2.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->l_sfrac2.p, frac2.data(), frac2.size() * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+    }
     if (!lp.stasks.empty()) {
         HIPCHK(hipMemcpyAsync(h->l_stasks.p, lp.stasks.data(), lp.stasks.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->l_schunk.p, lp.stask_chunk.data(), lp.stask_chunk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1501,6 +1699,9 @@ static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q,
     L.stask_chunk = h->l_schunk.as<int>();
     L.stask_frac = h->l_sfrac.as<float2>();
     L.nstasks = h->l_nstasks;
+    L.stasks2 = h->l_stasks2.as<int4>();
+    L.stask2_frac = h->l_sfrac2.as<float2>();
+    L.nstasks2 = h->l_nstasks2;
     L.pcap = h->pcap;
     L.lmol = h->l_lmol.as<int>();
     L.nlarge = (int)P.large_list.size();
@@ -1571,14 +1772,20 @@ static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q,
     // the sweep's workgroups per CU: as many as its task count fills evenly, enforced through the launch's LDS size
     const int wpc = L.nstasks <= 256 ? 1 : L.nstasks <= 512 ? 2 : L.nstasks <= 768 ? 3 : 4;
     const size_t sweep_lds = std::max<size_t>((size_t)2 * EPNN_LG_JC * 32 * 4, ((size_t)163840 / wpc) & ~size_t(255));
-    if (L.nstasks > 0 && !h->sweep_attr) {
+    if (L.nstasks + L.nstasks2 > 0 && !h->sweep_attr) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lg_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lg_sweep2), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
         h->sweep_attr = true;
     }
+    // tile-workgroup launch: 80 KB of LDS per workgroup = two per CU
+    const size_t sweep2_lds = (size_t)4 * EPNN_LG_JP * 64 * sizeof(float);
     for (int t = 0; t < Tg; ++t) {
         const bool ty = types && t == 0;
-        const bool sweep = !ty && L.nstasks > 0;
-        if (sweep) hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), sweep_lds, st, L, h->wvidx.g[t].w2, h->widx.msg[t], 1);
+        const bool sweep = !ty && L.nstasks + L.nstasks2 > 0;
+        if (sweep) {
+            if (L.nstasks > 0) hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), sweep_lds, st, L, h->wvidx.g[t].w2, h->widx.msg[t], 1);
+            if (L.nstasks2 > 0) hipLaunchKernelGGL(k_lg_sweep2, dim3((unsigned)L.nstasks2), dim3(256), sweep2_lds, st, L, h->wvidx.g[t].w2, h->widx.msg[t], L.nstasks > 0 ? 0 : 1);
+        }
         else if (!(ty && step0_pairs_done)) hipLaunchKernelGGL(k_lg_pairs, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
         if (!split) {
             hipLaunchKernelGGL(k_lg_gnn_tail, dim3(gTile), dim3(512), 0, st, L, h->widx.upd[t], next_after_gnn(t), ty ? 1 : 0);

@@ -14,6 +14,8 @@
  *   "large_merge"       1 (default): the compact entry launches the pair-list construction of tiled molecules merged with the work that
  *                       needs only the atoms (feature rows, atom types, first projections, the first step's type sums and correction
  *                       tiles); 0: every kernel its own launch
+ *   "large_sweep_old"   1: every tiled molecule runs the four-tile sweep kernel (k_lg_sweep) that systems above 4096 atoms use
+ *                       (results differ from the tile-workgroup kernel's by the order of the partner sum)
  *   "large_chunks"      number of pieces the partner range of a tiled molecule's all-pairs sweep is cut into (0, default: by size)
  *   "part_collective"   1: the communicator's collectives (row exchange of a partition, gradient all-reduce, their status guards) run
  *                       even at world size 1 (tests on one GPU)

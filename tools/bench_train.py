@@ -24,10 +24,10 @@ N, T, F = 41, 5, 58
 # the reference's literal work per step (charge_gn.py:62-68, 101-111): every one of the N^2 pair rows through a 164 -> 32 -> 32 -> 32
 # message MLP and, in both orders, a 164 -> 32 -> 32 -> 1 pass MLP, T times; the backward taken as twice the forward
 fwd_flop = B * T * N * N * (2 * (164 * 32 + 32 * 32 + 32 * 32) + 2 * 2 * (164 * 32 + 32 * 32 + 32))
-names_of = {3: "row-fused, scalar FMA layers", 1: "row-fused, matrix-pipe layers", 0: "layer by layer"}
+names_of = {1: "row-fused, matrix-pipe layers", 0: "layer by layer"}
 # --mode=F[:G[:A]]: "train_fused" = F, "train_graph" = G, "train_async" = A (defaults 1, 1: the library's defaults; a step that returns
 # behind its forward pass is launched kernel by kernel whatever G says)
-modes = [tuple(int(v) for v in (a.split("=")[1] + ":1:1").split(":")[:3]) for a in sys.argv[2:] if a.startswith("--mode=")] or [(1, 1, 1), (1, 1, 0), (1, 0, 0), (3, 0, 0), (0, 0, 0)]
+modes = [tuple(int(v) for v in (a.split("=")[1] + ":1:1").split(":")[:3]) for a in sys.argv[2:] if a.startswith("--mode=")] or [(1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 0)]
 best = None
 for fused, graph, asyn in modes:
     eng.set_option("train_fused", fused)
@@ -40,7 +40,7 @@ for fused, graph, asyn in modes:
         q, loss = eng.train_step_xyz(*batch(k % nb), 41); tot += loss
     eng.sync()                                                # (the last step's backward pass and optimizer step may still be running)
     dt = (time.perf_counter() - t0) / nst
-    how = "returns behind its forward pass" if asyn and fused in (1, 3) else ("hipGraph replay" if graph else "kernel by kernel")
+    how = "returns behind its forward pass" if asyn and fused == 1 else ("hipGraph replay" if graph else "kernel by kernel")
     print(f"train step ({names_of[fused]}, {how}): B={B} molecule(s) per step, N=41: {dt*1e3:.3f} ms/step "
           f"({1/dt:.1f} steps/s, {B/dt:.1f} molecules/s); mean loss {tot/nst:.4f}", flush=True)
     if best is None: best = (fused, dt, how)
