@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_lg_epn_static(LargeArgs L) {
 // interleaved.
 template <bool TWO>
 __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const float (&pb)[2][8],
-                                              const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2], int jg, int flip) {
+                                              const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
     auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
     auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
         nn[0] = w16_ld(Ns + j * 32 + po);
@@ -471,76 +471,54 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
         yy[0] = w16_ld(Ys + j * 32 + fo);
         yy[1] = w16_ld(Ys + j * 32 + 16 + fo);
     };
-    auto partner = [&](const f32x4 (&nn)[2], const f32x4 (&yy)[2]) {
+    // The element-wise work of a partner is ONE block in front of its matrix instructions -- the ReLU + sum of the partner BEFORE
+    // it (its accumulators are `dp`), then this partner's first layer --, a scheduling barrier, then its 32 MFMAs (the fused
+    // kernel's recipe of round 4).  Left to itself the compiler weaves the v_max / v_add instructions between the MFMAs, one
+    // `s_nop` behind each, and un-packs packed adds in their shadow: the same arithmetic in the same order, but 4.5 % more of the
+    // SIMD's issue time (protein 0.570 -> 0.545 ms, 10 000-atom box 8.12 -> 7.60 ms).
+    f32x4 dp0[2] = {w16_splat(0.f), w16_splat(0.f)}, dp1[2] = {w16_splat(0.f), w16_splat(0.f)};      // nothing pending: relu(0) adds nothing
+    auto partner_b = [&](const f32x4 (&nn)[2], const f32x4 (&yy)[2]) {
+        S0[0] += w16_relu(dp0[0]);
+        S0[1] += w16_relu(dp0[1]);
+        if (TWO) {
+            S1[0] += w16_relu(dp1[0]);
+            S1[1] += w16_relu(dp1[1]);
+        }
         const f32x4 za = vmax(P0[0], nn[0]), zb = vmax(P0[1], nn[1]);
         const float z0[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
-        f32x4 d0[2] = {yy[0], yy[1]}, d1[2] = {yy[0], yy[1]};
-        if (TWO) {
-            const f32x4 zc = vmax(P1[0], nn[0]), zd = vmax(P1[1], nn[1]);
-            const float z1[8] = {zc[0], zc[1], zc[2], zc[3], zd[0], zd[1], zd[2], zd[3]};
+        const f32x4 zc = vmax(P1[0], nn[0]), zd = vmax(P1[1], nn[1]);
+        const float z1[8] = {zc[0], zc[1], zc[2], zc[3], zd[0], zd[1], zd[2], zd[3]};
+        dp0[0] = yy[0]; dp0[1] = yy[1];
+        dp1[0] = yy[0]; dp1[1] = yy[1];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                d0[0] = w16_mfma(pb[0][k], z0[k], d0[0]);
-                d0[1] = w16_mfma(pb[1][k], z0[k], d0[1]);
-                d1[0] = w16_mfma(pb[0][k], z1[k], d1[0]);
-                d1[1] = w16_mfma(pb[1][k], z1[k], d1[1]);
-            }
-            S1[0] += w16_relu(d1[0]);
-            S1[1] += w16_relu(d1[1]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                d0[0] = w16_mfma(pb[0][k], z0[k], d0[0]);
-                d0[1] = w16_mfma(pb[1][k], z0[k], d0[1]);
+        for (int k = 0; k < 8; ++k) {
+            dp0[0] = w16_mfma(pb[0][k], z0[k], dp0[0]);
+            dp0[1] = w16_mfma(pb[1][k], z0[k], dp0[1]);
+            if (TWO) {
+                dp1[0] = w16_mfma(pb[0][k], z1[k], dp1[0]);
+                dp1[1] = w16_mfma(pb[1][k], z1[k], dp1[1]);
             }
         }
-        S0[0] += w16_relu(d0[0]);
-        S0[1] += w16_relu(d0[1]);
     };
-#ifdef EPNN_EXP_FETCH2
-    // experiment: the rows of TWO partners requested back to back (eight LDS reads in one batch), two partners ahead
-    f32x4 na[2], ya[2], nb[2], yb[2], nc[2], yc[2], nd[2], yd[2];
-    fetch(0, na, ya);
-    fetch(min(1, nj - 1), nb, yb);
-    int j = 0;
-    for (; j + 4 <= nj; j += 4) {
-        if ((j & 7) == 0) {
-            if ((((jg + j) >> 3) & 1) ^ flip) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        fetch(j + 2, nc, yc);
-        fetch(j + 3, nd, yd);
-        partner(na, ya);
-        partner(nb, yb);
-        fetch(min(j + 4, nj - 1), na, ya);
-        fetch(min(j + 5, nj - 1), nb, yb);
-        partner(nc, yc);
-        partner(nd, yd);
-    }
-    for (; j < nj; ++j) {
-        fetch(j, na, ya);
-        partner(na, ya);
-    }
-    return;
-#else
     f32x4 na[2], ya[2], nb[2], yb[2];
     fetch(0, na, ya);
     int j = 0;
     for (; j + 2 <= nj; j += 2) {
-        // the two wavefronts of a SIMD (one of each of the CU's two workgroups) take turns at the higher issue priority, eight
-        // partners at a time: with equal priorities the older one is always served first and finishes 17 us before the other
-        // (protein: tasks end at 84 / 91 us instead of 76 / 92, the launch 1.3 us earlier; r04_protein_sweep_clocks.txt)
-        if ((j & 7) == 0) {
-            if ((((jg + j) >> 3) & 1) ^ flip) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
         fetch(j + 1, nb, yb);
-        partner(na, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        partner_b(na, ya);
         fetch(min(j + 2, nj - 1), na, ya);
-        partner(nb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        partner_b(nb, yb);
     }
-    if (j < nj) partner(na, ya);
-#endif
+    if (j < nj) partner_b(na, ya);
+    S0[0] += w16_relu(dp0[0]);
+    S0[1] += w16_relu(dp0[1]);
+    if (TWO) {
+        S1[0] += w16_relu(dp1[0]);
+        S1[1] += w16_relu(dp1[1]);
+    }
 }
 __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, float *Ns, float *Ys) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
@@ -573,9 +551,8 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
         }
         __syncthreads();
         if (active) {
-            const int flip = 2 * blockIdx.x >= gridDim.x ? 1 : 0;
-            if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - tk.z, flip);
-            else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - tk.z, flip);
+            if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
+            else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
         }
     }
     if (!active) return;
@@ -747,7 +724,6 @@ __global__ __launch_bounds__(256) void k_lg_sweep2(LargeArgs L, int w2off, PairM
     const int sub = (tk.w - tk.z + 3) >> 2;
     const int jlo = min(tk.w, tk.z + wave * sub), jhi = min(tk.w, jlo + sub);
     float *Ns = lg_smem + wave * (EPNN_LG_JP * 64), *Ys = Ns + EPNN_LG_JP * 32;
-    const int flip = 2 * blockIdx.x >= gridDim.x ? 1 : 0;
     for (int j0 = jlo; j0 < jhi; j0 += EPNN_LG_JP) {
         const int nj = min(EPNN_LG_JP, jhi - j0);
         if (j0 > jlo) lg_wave_sync();                     // the rows of the trip before have been read
@@ -767,10 +743,9 @@ __global__ __launch_bounds__(256) void k_lg_sweep2(LargeArgs L, int w2off, PairM
                 if (u * 64 + lane < nj * 8) reinterpret_cast<f32x4 *>(Ys)[u * 64 + lane] = v[u];
         }
         lg_wave_sync();
-        if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - jlo, flip);
-        else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1, j0 - jlo, flip);
+        if (two) lg_sweep_rows<true>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
+        else lg_sweep_rows<false>(Ns, Ys, nj, po, fo, pb, P0, P1, S0, S1);
     }
-    __builtin_amdgcn_s_setprio(0);
     // the four wavefronts' sums, added in wavefront order; one partial sum per workgroup
     lg_wave_sync();
 #pragma unroll
