@@ -221,7 +221,7 @@ extern "C" int epnn_destroy(epnn_handle *h) {
                       &h->d_status, &h->d_guard, &h->d_bsum, &h->d_pi, &h->d_pj, &h->d_psym, &h->d_pe, &h->d_pwi, &h->d_pwj, &h->s_xyz,
                       &h->s_train, &h->s_misc, &h->s_gx, &h->s_pt, &h->f_pw, &h->d_etab, &h->l_a, &h->l_P, &h->l_R, &h->l_zp, &h->l_S0,
                       &h->l_corr, &h->l_dl, &h->l_tiles, &h->l_csr_off, &h->l_csr_ent, &h->l_cnt, &h->l_nm,
-                      &h->d_deg, &h->d_incoff, &h->d_nbr, &h->d_desti, &h->d_destj, &h->d_prec, &h->l_Nn, &h->l_Yb, &h->l_qbuf,
+                      &h->d_deg, &h->d_incoff, &h->d_nbr, &h->d_nearbits, &h->d_desti, &h->d_destj, &h->d_prec, &h->l_Nn, &h->l_Yb, &h->l_qbuf,
                       &h->l_Pst, &h->l_Rst, &h->l_lmol, &h->l_typrow, &h->l_typtab, &h->l_stype, &h->l_typhash,
                       &h->l_stasks, &h->l_schunk, &h->l_sfin, &h->l_sfrac, &h->l_stasks2, &h->l_sfrac2, &h->dn_xs, &h->dn_hs, &h->dn_qs, &h->dn_nms,
                       &h->dn_flag, &h->dn_neff, &h->dn_den, &h->tr_realbuf, &h->dn_xf, &h->dn_hf, &h->dn_qf, &h->dn_nmf, &h->dn_out, &h->sd_h,
@@ -317,7 +317,14 @@ extern "C" int epnn_timing_at(epnn_handle *h, int idx, float *out4) {
     HIPCHK(hipSetDevice(h->device));
     if (finish_forward(h)) return 1;
     hipEvent_t *ev = h->evpool.data() + 4 * (idx % h->opt_profile);
-    for (int k = 0; k < 3; ++k) HIPCHK(hipEventElapsedTime(&out4[k], ev[k], ev[k + 1]));
+    // boundaries that were not recorded (a stage without kernels of its own) coincide with the one before: that stage reads 0
+    const unsigned char has = (idx % h->opt_profile) < (int)h->ev_recorded.size() ? h->ev_recorded[idx % h->opt_profile] : 0;
+    hipEvent_t b[4] = {ev[0], (has & 1) ? ev[1] : ev[0], ev[2], ev[3]};
+    b[2] = (has & 2) ? ev[2] : (has & 4) ? ev[3] : b[1];     // (a forward of fused molecules only: the fused stage is all of it)
+    for (int k = 0; k < 3; ++k) {
+        out4[k] = 0.f;
+        if (b[k] != b[k + 1]) HIPCHK(hipEventElapsedTime(&out4[k], b[k], b[k + 1]));
+    }
     HIPCHK(hipEventElapsedTime(&out4[3], ev[0], ev[3]));
     return 0;
 }
@@ -362,6 +369,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "large_merge")) { h->opt_large_merge = value; }
     else if (!strcmp(name, "large_chunks")) { h->opt_large_chunks = value; h->plan.valid = false; }
+    else if (!strcmp(name, "front_bits")) { h->opt_front_bits = value != 0; }
     else if (!strcmp(name, "large_sweep_old")) { h->opt_large_sweep_old = value != 0; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }
     else if (!strcmp(name, "comm_guard")) { h->opt_comm_guard = value != 0; }

@@ -350,6 +350,16 @@ static int make_front_args(epnn_handle *h, const float *d_xyz, FrontArgs &F) {
     F.pwi = h->d_pwi.as<float>();
     F.pwj = h->d_pwj.as<float>();
     F.status = h->d_status.as<int>();
+    // the count pass's decisions as a bit per candidate (epnn_frontend.hip.h): while a row's molecule has at most 4096 atoms and
+    // the rows' words fit 64 MB
+    int nmax = 0;
+    for (int b = 0; b < P.B; ++b) nmax = std::max(nmax, P.offsets[b + 1] - P.offsets[b]);
+    const int bw = (nmax + 63) / 64;
+    if (h->opt_front_bits && bw <= 64 && (size_t)P.A * bw * 8 <= ((size_t)64 << 20)) {
+        if (h->d_nearbits.ensure((size_t)P.A * bw * 8)) return 1;
+        F.bits = h->d_nearbits.as<unsigned long long>();
+        F.bits_w = bw;
+    }
     return 0;
 }
 static int run_frontend_xyz(epnn_handle *h, const FrontArgs &F) {
@@ -387,9 +397,17 @@ static int enqueue_forward_planned(epnn_handle *h, const float *d_xyz, const flo
     if (!h->ctl_clean) HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
     h->ctl_clean = false;
     h->last_front = pure;
+    // stage events ("profile"): a boundary is recorded only where a stage with kernels of its own ends -- a timed event record
+    // between two launches is ~5 us of stream time, and a forward of tiled molecules only has neither a separate front-end
+    // nor fused kernels (its events used to read 11 us for those two empty stages)
     hipEvent_t *ev = nullptr;
+    unsigned char *ev_has = nullptr;
     if (h->opt_profile > 0) {
-        ev = h->evpool.data() + 4 * (h->ev_next % h->opt_profile);
+        const int slot = h->ev_next % h->opt_profile;
+        ev = h->evpool.data() + 4 * slot;
+        if ((int)h->ev_recorded.size() < h->opt_profile) h->ev_recorded.resize(h->opt_profile, 0);
+        ev_has = &h->ev_recorded[slot];
+        *ev_has = 0;
         h->ev_next += 1;
     }
     if (ev) HIPCHK(hipEventRecord(ev[0], h->stream));
@@ -402,9 +420,11 @@ static int enqueue_forward_planned(epnn_handle *h, const float *d_xyz, const flo
     if (!pure) {
         if (make_front_args(h, d_xyz, F)) return 1;
         if (h->opt_large_merge && !P.large_list.empty() && (front_small || P.fused_count() == 0)) front_later = &F;
-        else if (run_frontend_xyz(h, F)) return 1;
+        else {
+            if (run_frontend_xyz(h, F)) return 1;
+            if (ev) { HIPCHK(hipEventRecord(ev[1], h->stream)); *ev_has |= 1; }
+        }
     }
-    if (ev) HIPCHK(hipEventRecord(ev[1], h->stream));
     PairSource S;
     S.d_x = d_x;
     S.d_Q = d_Q;
@@ -412,7 +432,8 @@ static int enqueue_forward_planned(epnn_handle *h, const float *d_xyz, const flo
     S.d_xyz = front_small ? d_xyz : nullptr;
     S.handoff = pure;
     if (launch_small(h, S)) return 1;
-    if (ev) HIPCHK(hipEventRecord(ev[2], h->stream));
+    if (ev && P.fused_count() > 0 && !P.large_list.empty()) { HIPCHK(hipEventRecord(ev[2], h->stream)); *ev_has |= 2; }
+    if (ev && P.large_list.empty()) *ev_has |= 4;           // (no tiled stage: the fused stage runs to the forward's end)
     h->want_large_handoff = !pure;
     h->did_large_handoff = false;
     const int rc_large = launch_large(h, S, true, front_later);

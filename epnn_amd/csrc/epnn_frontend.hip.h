@@ -32,6 +32,9 @@ struct FrontArgs {
     int *dest_i, *dest_j;  // [pcap]  incidence slots of a pair's first / second atom
     int4 *prec;            // [2 pcap] per pair: (i, j, inc_lo_i, inc_hi_i), (inc_lo_j, inc_hi_j, dest_i, dest_j)
     double cut2;           // smallest double whose correctly rounded sqrt reaches the cutoff: D < cutoff <=> D^2 < cut2
+    unsigned long long *bits;   // [A][bits_w] or null: the count pass leaves every row's D < cutoff decisions as a bit per candidate of the
+    int bits_w;                 // row's molecule (word t = candidates 64 t .. 64 t + 63): the fill pass walks the set bits instead of
+                                // measuring all n distances a second time (systems of up to 4096 atoms)
     int pcap;
     int *pi, *pj, *psym;
     float *pe, *pwi, *pwj;
@@ -65,7 +68,8 @@ __device__ __forceinline__ double epnn_dist2p(double xi, double yi, double zi, c
 // candidates per trip straight from memory paid one L2 round trip per trip: 35 of them for a 2220-atom system).  Rows of a
 // workgroup that belong to another molecule than its first row (molecule boundaries) read memory directly.
 #define EPNN_FRONT_JB 2048
-// calls body(j, near, d2) for every candidate j of the row's molecule, 64 per trip, lane = candidate; wave-uniform trips
+// calls body(j, near, d2, trip) for every candidate j of the row's molecule, 64 per trip (trip t = candidates 64 t .. of the
+// molecule), lane = candidate; wave-uniform trips
 template <typename Body>
 __device__ __forceinline__ void front_scan_row(const FrontArgs &F, float *sx, int row, bool live, Body &&body) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +103,7 @@ __device__ __forceinline__ void front_scan_row(const FrontArgs &F, float *sx, in
                         near = d2 < F.cut2;
                     }
                 }
-                body(jb + j, near, d2);
+                body(jb + j, near, d2, (jb - beg0 + j0) >> 6);
             }
     }
     if (live && !shared) {
@@ -112,7 +116,7 @@ __device__ __forceinline__ void front_scan_row(const FrontArgs &F, float *sx, in
                 d2 = epnn_dist2p(xi, yi, zi, F.xyz + 3 * j);
                 near = d2 < F.cut2;
             }
-            body(j, near, d2);
+            body(j, near, d2, (j0 - beg) >> 6);
         }
     }
 }
@@ -123,14 +127,18 @@ __device__ __forceinline__ void front_count_body(const FrontArgs &F, float *sx, 
     const int row = blk * 4 + wave;
     const bool live = row < F.A;
     int up = 0, all = 0;
-    front_scan_row(F, sx, row, live, [&](int j, bool near, double) {
-        all += __popcll(__ballot(near));
+    unsigned long long mine = 0ull;                           // lane t keeps the decisions of trip t
+    front_scan_row(F, sx, row, live, [&](int j, bool near, double, int trip) {
+        const unsigned long long bal = __ballot(near);
+        all += __popcll(bal);
         up += __popcll(__ballot(near && j > row));
+        if (trip == lane) mine = bal;
     });
     if (live && lane == 0) {
         F.row_cnt[row] = up;
         F.deg[row] = all;
     }
+    if (live && F.bits && lane < F.bits_w) F.bits[(size_t)row * F.bits_w + lane] = mine;
 }
 __global__ __launch_bounds__(256) void k_front_count(FrontArgs F) {
     __shared__ float sx[EPNN_FRONT_JB * 3];
@@ -267,7 +275,7 @@ __device__ __forceinline__ void front_fill_body(const FrontArgs &F, FrontFillSha
     int slot0 = live ? F.row_off[row] : 0;
     int inc0 = live ? F.inc_off[row] : 0;
     const double pi_d = 3.141592653589793;
-    front_scan_row(F, sx, row, live, [&](int j, bool near, double d2) {
+    auto body = [&](int j, bool near, double d2, int) {
         const unsigned long long bal = __ballot(near);
         if (bal == 0ull) return;
         const int pos = inc0 + __popcll(bal & ((1ull << lane) - 1ull));      // this partner's slot in the atom's incidence row
@@ -311,7 +319,26 @@ __device__ __forceinline__ void front_fill_body(const FrontArgs &F, FrontFillSha
         }
         __builtin_amdgcn_wave_barrier();
         slot0 += m;
-    });
+    };
+    if (F.bits) {
+        // the count pass left this row's decisions: only the trips with a set bit are looked at, only their near candidates measured
+        const int b = live ? F.mol_of[row] : 0, beg = live ? F.moff[b] : 0;
+        const unsigned long long word = live && lane < F.bits_w ? F.bits[(size_t)row * F.bits_w + lane] : 0ull;
+        unsigned long long trips = __ballot(word != 0ull);
+        double xi = 0.0, yi = 0.0, zi = 0.0;
+        if (live) { xi = (double)F.xyz[3 * row]; yi = (double)F.xyz[3 * row + 1]; zi = (double)F.xyz[3 * row + 2]; }
+        while (trips) {
+            const int t = __ffsll((long long)trips) - 1;
+            trips &= trips - 1ull;
+            const unsigned long long bal = __shfl(word, t, 64);
+            const int j = beg + 64 * t + lane;
+            const bool near = (bal >> lane) & 1ull;
+            const double d2 = near ? epnn_dist2p(xi, yi, zi, F.xyz + 3 * j) : 0.0;
+            body(j, near, d2, t);
+        }
+        return;
+    }
+    front_scan_row(F, sx, row, live, body);
 }
 __global__ __launch_bounds__(256) void k_front_fill(FrontArgs F) {
     __shared__ FrontFillShared Sh;

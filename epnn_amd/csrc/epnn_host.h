@@ -105,6 +105,7 @@ struct epnn_handle {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> evpool;   // 4 stage events per profiled forward ("profile" option = pool size)
     int ev_next = 0;                  // forwards recorded since the option was set
+    std::vector<unsigned char> ev_recorded;   // per pool slot: bit 0 / 1 = the boundary behind the front-end / the fused kernels was recorded
     // weights
     HostDense msg[EPNN_MAXT][3], pas[EPNN_MAXT][3], upd[3];
     // make_model(layers != [32, 32]) / MLP_layer(nodes) as update_fn (charge_gn.py:369-371): the update MLP with any hidden widths
@@ -135,6 +136,8 @@ struct epnn_handle {
     DevBuf d_rowcnt, d_rowoff, d_status, d_bsum;
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     DevBuf d_deg, d_incoff, d_nbr, d_desti, d_destj, d_prec;   // incidence rows of the pair list (epnn_frontend.hip.h)
+    DevBuf d_nearbits;                // the count pass's D < cutoff decisions, a bit per candidate (FrontArgs::bits)
+    int opt_front_bits = 1;           // developer switch: 0 = the fill pass measures every distance again
     int pcap = 0;
     int pair_cap_per_atom = 16;
     int *h_status = nullptr;      // pinned: [0] status bits, [1] total near pairs -- of the forward being enqueued: one of two slots of

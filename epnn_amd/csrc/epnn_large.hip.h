@@ -51,8 +51,11 @@ __device__ __forceinline__ f32x16 lg_gtile(const float *__restrict__ weF, const 
 #ifdef EPNN_LG_CLOCKS
 // development build (tools/large_clocks.py): 100 MHz wall clock of workgroup 0 at phase boundaries of the tail and EPN-step launches
 #define LG_CLK(base, k) do { if (L.clk && blockIdx.x == 0 && threadIdx.x == 0) L.clk[(base) + (k)] = wall_clock64(); } while (0)
+// ... of the workgroup for which `cond` holds (the merged launches of the compact entry: one workgroup of every kind of work)
+#define LG_CLKB(cond, slot) do { if (L.clk && (cond) && threadIdx.x == 0) L.clk[slot] = wall_clock64(); } while (0)
 #else
 #define LG_CLK(base, k) do { } while (0)
+#define LG_CLKB(cond, slot) do { } while (0)
 #endif
 struct LargeArgs {
 #ifdef EPNN_LG_CLOCKS
@@ -695,6 +698,11 @@ __global__ __launch_bounds__(256) void k_lg_sweep2(LargeArgs L, int w2off, PairM
     extern __shared__ __attribute__((aligned(16))) float lg_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
     const int4 tk = L.stasks2[blockIdx.x];           // atile (or -1), partial index, j_lo, j_hi (global atom indices)
+#ifdef EPNN_LG_CLOCKS
+    // development build: shader clock (s_memtime) and 100 MHz clock (s_memrealtime) at the start and the end of this workgroup
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (threadIdx.x == 0) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (do_pairs) {
         const int np = L.row_off[L.A];
         const float2 fr = L.stask2_frac[blockIdx.x];
@@ -760,6 +768,12 @@ __global__ __launch_bounds__(256) void k_lg_sweep2(LargeArgs L, int w2off, PairM
                     c = reinterpret_cast<const f32x4 *>(lg_smem + 2 * EPNN_LG_JP * 64)[tid], d = reinterpret_cast<const f32x4 *>(lg_smem + 3 * EPNN_LG_JP * 64)[tid];
         if ((tid >> 3) < tl.y) reinterpret_cast<f32x4 *>(dst)[tid] = ((a + b) + c) + d;      // element 4 tid .. 4 tid + 3 = atom tid >> 3
     }
+#ifdef EPNN_LG_CLOCKS
+    if (threadIdx.x == 0 && L.clk && blockIdx.x < 1024) {
+        unsigned long long *o = L.clk + 128 + 4 * (size_t)blockIdx.x;
+        o[0] = clk_c0; o[1] = clk_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ merged launches of the compact entry
@@ -777,14 +791,20 @@ __global__ __launch_bounds__(1024) void k_lg_scan_types(LargeArgs L, FrontArgs F
     __shared__ LgTypeShared T;
     __shared__ int wsA[16], wsB[16];
     __shared__ int carryA, carryB;
+    LG_CLKB(blockIdx.x == 0, 114);
+    LG_CLKB(blockIdx.x == 1, 122);
     if (blockIdx.x == 0) front_scan_both_body(F, wsA, wsB, carryA, carryB);
     else lg_types_table<1024, true>(L, T, (int)blockIdx.x - 1);
+    LG_CLKB(blockIdx.x == 0, 115);
+    LG_CLKB(blockIdx.x == 1, 123);
 }
 // the fill of the pair list | every tiled atom's type
 __global__ __launch_bounds__(256) void k_lg_fill_assign(LargeArgs L, FrontArgs F, int fill_wgs) {
     __shared__ FrontFillShared Sh;
+    LG_CLKB(blockIdx.x == 0, 112);
     if ((int)blockIdx.x < fill_wgs) {
         front_fill_body(F, Sh, (int)blockIdx.x);
+        LG_CLKB(blockIdx.x == 0, 113);
         return;
     }
     const int at = ((int)blockIdx.x - fill_wgs) * 256 + (int)threadIdx.x;
@@ -796,6 +816,8 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
     __shared__ __attribute__((aligned(16))) float sm[4 * 32 * EPNN_AST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hh = lane >> 5;
     int blk = (int)blockIdx.x;
+    LG_CLKB(blk == 0, 104);
+    LG_CLKB(blk == W.tile_wgs, 109);
     if (blk < W.tile_wgs) {
         // feature rows of the workgroup's (up to) four tiles: built in LDS by all threads (one slot each per trip), stored to
         // a_eo from there, projected from there (k_lg_init + k_lg_proj without the round trip through memory)
@@ -847,11 +869,14 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 4 * 32 * EPNN_AST; idx += 256) {
-            const int w = idx / (32 * EPNN_AST), rem = idx - w * (32 * EPNN_AST);
-            const int a = rem / EPNN_AST;
-            const int4 tl = w == 0 ? tls[0] : w == 1 ? tls[1] : w == 2 ? tls[2] : tls[3];
-            if (a < tl.y) L.a_eo[(size_t)tl.x * EPNN_AST + rem] = sm[idx];
+        LG_CLKB(blk == 0, 105);
+        // (16-byte stores, each wavefront its own tile's rows: 34 four-byte stores per thread, and a reload of the tile record
+        //  behind them -- a load waits for every store before it --, held the projections back 8.8 us of this launch's 19.5)
+        {
+            const int4 tlw = wave == 0 ? tls[0] : wave == 1 ? tls[1] : wave == 2 ? tls[2] : tls[3];
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(sm + wave * 32 * EPNN_AST);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(L.a_eo + (size_t)tlw.x * EPNN_AST);
+            for (int i = lane; i < tlw.y * (EPNN_AST / 4); i += 64) dst[i] = src[i];
         }
         if (W.hash && tid < 128) {                             // hash of every atom's feature row (the atom types of the first step)
             const int w = tid >> 5, a = tid & 31;
@@ -863,26 +888,34 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
             }
         }
         if (t0 + wave >= L.natiles) return;
-        const int4 tl = L.atiles[t0 + wave];
+        const int4 tl = wave == 0 ? tls[0] : wave == 1 ? tls[1] : wave == 2 ? tls[2] : tls[3];
         const int row = c < tl.y ? c : 0;
+        LG_CLKB(blk == 0, 106);
         lg_proj_wave<3, true, false, true, true>(L, M, 1, tl, sm + (wave * 32 + row) * EPNN_AST + hh * 32, lane, wI, L.P, L.R, wJ, w2n);
+        LG_CLKB(blk == 0, 107);
         return;
     }
     blk -= W.tile_wgs;
     if (blk < W.count_wgs) front_count_body(F, sm, blk);
+    LG_CLKB(blk == 0, 110);
 }
 struct LgSecond {
     int link_wgs, tsweep_wgs, all_tiled;
 };
 __global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, LgSecond W, FrontArgs F) {
     int blk = (int)blockIdx.x;
+    LG_CLKB(blk == 0, 116);
+    LG_CLKB(blk == W.link_wgs, 118);
+    LG_CLKB(blk == W.link_wgs + W.tsweep_wgs, 120);
     if (blk < W.link_wgs) {
         front_link_body(F, blk, W.link_wgs);
+        LG_CLKB(blk == 0, 117);
         return;
     }
     blk -= W.link_wgs;
     if (blk < W.tsweep_wgs) {
         if (threadIdx.x < 64) lg_tsweep_wave(L, M, blk);
+        LG_CLKB(blk == 0, 119);
         return;
     }
     blk -= W.tsweep_wgs;
@@ -890,6 +923,7 @@ __global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, L
     if (np > L.pcap) return;
     const int pt = blk * 4 + (int)(threadIdx.x >> 6);
     if (pt * 32 < np) lg_pair_tile<true>(L, M, pt, np, F.nbr, W.all_tiled != 0);
+    LG_CLKB(blk == 0, 121);
 }
 
 // ------------------------------------------------------------------------------------------------ reduction of S
@@ -1229,12 +1263,17 @@ __global__ __launch_bounds__(512) void k_lg_gnn_tail(LargeArgs L, UpdPack U, LgN
     }
     __syncthreads();
     LG_CLK(16 * X.run, 3);
-    if (wave == 0)
-        lg_update_rest(L, U, acc_h, w1, w2, w3, tl, Ss + c * EPNN_SST, L.a_eo + (size_t)(tl.x + row) * EPNN_AST, Ai + row * EPNN_AST, lane, Bs);
+    // (the new h goes into the LDS image only; wavefront 0 copies the tile's rows to memory as 16-byte stores AFTER the barrier,
+    //  beside the other wavefronts' projections: 24 four-byte stores per lane in front of the barrier were waited for by all)
+    if (wave == 0) lg_update_rest(L, U, acc_h, w1, w2, w3, tl, Ss + c * EPNN_SST, Ai + row * EPNN_AST, nullptr, lane, Bs);
     LG_CLK(16 * X.run, 4);
-    if (!X.run) return;
     __syncthreads();                                            // the image now holds the new h
     LG_CLK(16 * X.run, 5);
+    if (wave == 0) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(L.a_eo + (size_t)tl.x * EPNN_AST);
+        for (int i = lane; i < tl.y * (EPNN_AST / 4); i += 64) dst[i] = reinterpret_cast<const f32x4 *>(Ai)[i];
+    }
+    if (!X.run) return;
     const float *arow = Ai + row * EPNN_AST + hh * 32;
     if (X.run == 1) {
         if (wave == 1) lg_proj_wave<1, true, false, false, true>(L, X.M, 1, tl, arow, lane, wA, L.P, L.R, nullptr, w2n);

@@ -14,6 +14,8 @@
  *   "large_merge"       1 (default): the compact entry launches the pair-list construction of tiled molecules merged with the work that
  *                       needs only the atoms (feature rows, atom types, first projections, the first step's type sums and correction
  *                       tiles); 0: every kernel its own launch
+ *   "front_bits"        1 (default): the separate front-end's count pass leaves its D < cutoff decisions as a bit per candidate and the
+ *                       fill pass walks the set bits (systems of up to 4096 atoms); 0: the fill pass measures every distance again
  *   "large_sweep_old"   1: every tiled molecule runs the four-tile sweep kernel (k_lg_sweep) that systems above 4096 atoms use
  *                       (results differ from the tile-workgroup kernel's by the order of the partner sum)
  *   "large_chunks"      number of pieces the partner range of a tiled molecule's all-pairs sweep is cut into (0, default: by size)

@@ -67,6 +67,13 @@ def main():
     dq = eng.alloc(A * 4)
     eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, N)
     eng.sync()
+    # first without the stage events (four timed event records per forward sit between one forward's last kernel and the next one's
+    # first: ~20 us of an otherwise back-to-back stream), then with them
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward_xyz_dev(offsets, d[0], d[1], d[2], dq, N)
+    eng.sync()
+    dt_plain = (time.perf_counter() - t0) / steps
     eng.set_option("profile", steps)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -78,7 +85,7 @@ def main():
     q = dq.download((A,))
     flops = synth.algorithmic_flops([A], int(stats[0]))
     if rank == 0:
-      print((f"[{world} processes, rows of atoms partitioned, exchange {how}] " if world > 1 else "") + f"{what}: {A} atoms, {stats[0]} near pairs; {dt*1e3:.3f} ms/forward wall, device stages front/fused/tiled/total ms = {np.round(st,3)}; "
+      print((f"[{world} processes, rows of atoms partitioned, exchange {how}] " if world > 1 else "") + f"{what}: {A} atoms, {stats[0]} near pairs; {dt_plain*1e3:.3f} ms/forward wall without stage events, {dt*1e3:.3f} with; device stages front/fused/tiled/total ms = {np.round(st,3)}; "
           f"{A/dt:.3e} atoms/s; algorithmic {flops/1e9:.1f} Gflop -> {flops/(st[3]*1e-3)/1e12:.1f} TFLOP/s; sum q = {q.sum(dtype=np.float64):.6f}", flush=True)
       import json
       # the same facts as ONE JSON line in bench.py's vocabulary (last line of the output)

@@ -43,7 +43,16 @@ for t in range(5):
     r = c[64 + 8 * t:64 + 8 * t + 8]
     if r[0]: print(f"  step {t}", " ".join(f"{(r[k] - r[0]):6d}" if r[k] else "     -" for k in range(1, 5)))
 
-# k_lg_sweep (the LAST sweep launch of the forward): per workgroup s_memtime / s_memrealtime at the start and the end of its task
+# the merged launches of the compact entry's front (100 MHz stamps of one workgroup of every kind of work; absolute differences)
+def span(a, b):
+    return f"{(c[b] - c[a]) * 0.01:6.2f}" if c[a] and c[b] else "     -"
+print("front-end launches, us (start -> end of ONE workgroup of each kind; kernel start = its first stamp):")
+print(f"  k_lg_first   tile workgroup 0: rows built {span(104, 105)}  a_eo stored / hashes {span(105, 106)}  projections {span(106, 107)}   total {span(104, 107)} | first count workgroup {span(109, 110)} (starts {span(104, 109)} after the tile workgroup)")
+print(f"  k_lg_scan_types   scan {span(114, 115)} | type table {span(122, 123)}      (first -> scan start {span(104, 114)})")
+print(f"  k_lg_fill_assign  fill workgroup 0 {span(112, 113)}                        (scan start -> fill start {span(114, 112)})")
+print(f"  k_lg_second  link workgroup 0 {span(116, 117)} | type sums {span(118, 119)} | correction tiles {span(120, 121)}   (fill start -> second start {span(112, 116)})")
+
+# k_lg_sweep2 (the LAST sweep launch of the forward): per workgroup s_memtime / s_memrealtime at the start and the end of its task
 sw = c[128:].reshape(1024, 4)
 sw = sw[sw[:, 0] > 0]
 if len(sw):
@@ -51,14 +60,14 @@ if len(sw):
     ghz = dt / np.maximum(dr, 1) * 0.1
     t0 = sw[:, 1].min()
     st, en = (sw[:, 1] - t0) * 0.01, (sw[:, 3] - t0) * 0.01
-    print(f"k_lg_sweep, last launch of the forward ({nfw} forwards in a row): {len(sw)} workgroups; shader clock seen by them "
+    print(f"k_lg_sweep2, last launch of the forward ({nfw} forwards in a row): {len(sw)} workgroups; shader clock seen by them "
           f"(s_memtime / s_memrealtime) mean {ghz.mean():.3f} GHz, 5 % .. 95 %: {np.percentile(ghz, 5):.3f} .. {np.percentile(ghz, 95):.3f}")
     print(f"  task length {dr.mean() * 0.01:.1f} us (min {dr.min() * 0.01:.1f}, max {dr.max() * 0.01:.1f}); starts after the first workgroup's: "
           f"median {np.median(st):.1f} us, 95 % {np.percentile(st, 95):.1f}, last {st.max():.1f}; ends: first {en.min():.1f} us, median {np.median(en):.1f}, last {en.max():.1f}")
     # which tasks are the slow ones: 18 tile groups x 28 j-chunks on the protein (block = group * nchunk + chunk)
     if "--detail" in sys.argv:
         dur = dr * 0.01
-        nchunk = 28 if len(sw) == 504 else 1
+        nchunk = 7 if len(sw) in (490, 512) else 1
         g = dur[:len(dur) // nchunk * nchunk].reshape(-1, nchunk)
         print("  mean task length by tile group:", " ".join(f"{v:.0f}" for v in g.mean(axis=1)))
         print("  mean task length by j-chunk:   ", " ".join(f"{v:.0f}" for v in g.mean(axis=0)))
