@@ -15,7 +15,7 @@ static size_t plan_payload_offset(int B, int A) { return (plan_ctl_ints(B, A) * 
 static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
                       bool *ctl_fresh = nullptr) {
     Plan &P = h->plan;
-    allow_mid = allow_mid && h->opt_force_path == 0 && !h->upd_generic;
+    allow_mid = allow_mid && h->opt_force_path == 0 && !upd_tiled_only(h);
     if (ctl_fresh) *ctl_fresh = false;
     if (P.valid && P.B == B && P.N == N && P.allow_mid == allow_mid && (int)P.offsets.size() == B + 1 &&
         memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0 &&
@@ -62,8 +62,8 @@ static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool
         const int n = offsets[b + 1] - offsets[b];
         for (int a = offsets[b]; a < offsets[b + 1]; ++a) c_molof[a] = b;
         // (an update MLP of other widths than [32, 32]: the fused kernels are not built for it, everything is tiled)
-        const bool small = !h->upd_generic && ((h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok));
-        if (h->upd_generic && h->opt_force_path == 1) EPNN_FAIL("forward: force_path=1 with an update MLP other than [32, 32] (tiled path only)");
+        const bool small = !upd_tiled_only(h) && ((h->opt_force_path == 1) || (h->opt_force_path == 0 && n <= EPNN_SMALL_NMAX && wave_ok));
+        if (upd_tiled_only(h) && h->opt_force_path == 1) EPNN_FAIL("forward: force_path=1 with an update MLP that does not fit [32, 32] (tiled path only)");
         if (small && (n > EPNN_SMALL_NMAX || !wave_ok))
             EPNN_FAIL("forward: force_path=1 but molecule %d has %d atoms (fused kernel: n <= %d, nx <= %d)", b, n, EPNN_SMALL_NMAX, 4 * EPNN_XS - 3);
         const bool mid = !small && allow_mid && h->opt_wave3 && wave_ok && n > EPNN_SMALL_NMAX && n <= EPNN_W2_NMAX4;

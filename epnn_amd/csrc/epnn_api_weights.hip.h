@@ -140,6 +140,11 @@ extern "C" int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_
     if (h->train) EPNN_FAIL("epnn_set_update_layers: the handle already holds training state (set the layers before epnn_train_init)");
     const int H = h->cfg.hidden;
     h->upd_generic = !(n_hidden == 2 && widths[0] == H && widths[1] == H);
+    // One or two hidden layers of at most 32 units fit INSIDE the tuned kernels' 80 -> 32 -> 32 -> 48 update MLP exactly: missing units
+    // are units with zero weights and zero bias (relu(0) = 0 feeds nothing), a missing second layer is the identity on the first
+    // layer's outputs (they are >= 0 behind their ReLU, so relu(I u + 0) = u).  pack_weights builds that padded copy; such a model
+    // runs every inference kernel of the [32, 32] model, not the generic update stage.
+    h->upd_embed = h->upd_generic && n_hidden <= 2 && widths[0] <= H && (n_hidden == 1 || widths[1] <= H);
     h->updg.clear();
     if (h->upd_generic) {
         int n_in = h->cfg.h_dim + H;                       // [h | summed messages] (charge_gn.py:71)
@@ -194,6 +199,28 @@ static int pack_weights(epnn_handle *h) {
     if (train_sync_to_host(h)) return 1;          // weights trained on the device are the current ones
     if (!h->weights_dirty) return 0;
     const int nx = h->cfg.nx, F = nx + EPNN_EDIM + 1, T = h->cfg.T;
+    if (h->upd_embed) {
+        // the update MLP of `layers` = [w1] or [w1, w2] (w <= 32) as a [32, 32] one (epnn_set_update_layers): exact
+        const int H = h->cfg.hidden, nh = (int)h->updg.size() - 1, w1 = h->updg[0].n_out, wl = h->updg[nh - 1].n_out;
+        for (int l = 0; l < 3; ++l) {
+            std::fill(h->upd[l].W.begin(), h->upd[l].W.end(), 0.f);
+            std::fill(h->upd[l].b.begin(), h->upd[l].b.end(), 0.f);
+        }
+        for (int i = 0; i < h->upd[0].n_in; ++i)
+            for (int o = 0; o < w1; ++o) h->upd[0].W[(size_t)i * H + o] = h->updg[0].W[(size_t)i * w1 + o];
+        for (int o = 0; o < w1; ++o) h->upd[0].b[o] = h->updg[0].b[o];
+        if (nh == 2) {
+            for (int i = 0; i < w1; ++i)
+                for (int o = 0; o < wl; ++o) h->upd[1].W[(size_t)i * H + o] = h->updg[1].W[(size_t)i * wl + o];
+            for (int o = 0; o < wl; ++o) h->upd[1].b[o] = h->updg[1].b[o];
+        } else {
+            for (int i = 0; i < w1; ++i) h->upd[1].W[(size_t)i * H + i] = 1.f;
+        }
+        const HostDense &last = h->updg[nh];
+        for (int i = 0; i < wl; ++i)
+            for (int o = 0; o < last.n_out; ++o) h->upd[2].W[(size_t)i * last.n_out + o] = last.W[(size_t)i * last.n_out + o];
+        for (int o = 0; o < last.n_out; ++o) h->upd[2].b[o] = last.b[o];
+    }
     std::vector<float> buf;
     auto alloc = [&](size_t n) {
         size_t off = (buf.size() + 63) & ~size_t(63);      // 256-byte aligned sections

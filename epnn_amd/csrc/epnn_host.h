@@ -113,6 +113,7 @@ struct epnn_handle {
     // generic Dense stack of epnn_mlp.hip.h; `upd` above keeps its standard shapes (zeros) so that the fragment packers run unchanged.
     std::vector<HostDense> updg;
     bool upd_generic = false;
+    bool upd_embed = false;           // ... of one or two hidden layers of <= 32 units: `upd` holds it zero-padded to [32, 32] (exact) and every tuned inference kernel runs
     DevBuf d_updgen;                  // raw kernels / biases of updg + the message MLPs' last Dense (W3_t, b3_t), see pack_weights
     GenMlp gen_upd{};                 // offsets into d_updgen
     int gen_w3[EPNN_MAXT] = {0}, gen_b3[EPNN_MAXT] = {0};
@@ -253,6 +254,8 @@ struct epnn_handle {
 // rank") and nobody enqueues the payload.  A rank that fails earlier -- argument checks, allocations, a launch error -- still joins
 // that status collective from its entry point's exit path (epnn_handle::guard_pending says it owes one), so its peers are released.
 // What this cannot cover is a rank whose GPU is gone (the guard itself then fails): rendezvous.launch_ranks stops the survivors.
+// the model's update MLP needs the generic update stage (tiled kernels, one launch per stage)
+static inline bool upd_tiled_only(const epnn_handle *h) { return h->upd_generic && !h->upd_embed; }
 static inline bool comm_collectives(const epnn_handle *h) { return h->comm && (h->comm_world > 1 || h->opt_part_collective); }
 static inline int comm_guard(epnn_handle *h, int local_fail, const char *what) {
     h->guard_pending = false;

@@ -61,9 +61,12 @@ int epnn_device_count(void);
  *           layers of 1..256 units each: epnn_set_update_layers) for every inference entry and the training step;
  *   fixed:  hidden == 32 (the reference's own constant for the message / pass MLPs), h_dim == e_dim == 48.
  * epnn_create FAILS (returns non-zero, epnn_last_error says which field) for any other value.  `layers` == [32, 32] runs the
- * kernels DESIGN.md describes; any other `layers` runs every molecule through the tiled kernels with one launch per stage and a
- * generic (f32 FMA) Dense stack as the update stage, and the training step with one launch per Dense layer ("train_fused" = 0's
- * kernels) -- the same results to float32 rounding, several times slower per small molecule: a correctness path, not a tuned one. */
+ * kernels DESIGN.md describes, and so does every `layers` of one or two hidden layers of at most 32 units: the library runs it as a
+ * [32, 32] model on a zero-padded copy of its weights (units with zero weights and bias feed nothing; a missing second layer is the
+ * identity on the first layer's non-negative outputs) -- exact, not an approximation.  Any other `layers` (a width above 32, three
+ * or more hidden layers) runs every molecule through the tiled kernels with one launch per stage and a generic (f32 FMA) Dense stack
+ * as the update stage.  The training step of any `layers` but [32, 32] runs one launch per Dense layer ("train_fused" = 0's kernels)
+ * on the model's own shapes -- the same results to float32 rounding, several times slower per small molecule. */
 int epnn_create(const epnn_config *cfg, int device, epnn_handle **out);
 int epnn_destroy(epnn_handle *h);
 /* Leaves out `n` of the process's hardware queues: the HIP runtime deals a process's streams onto its hardware queues in the order

@@ -582,12 +582,14 @@ def test_mlp_layer_call_with_other_activations(nodes, activation):
             gnn(np.zeros((1, 4, 48), np.float32), z, np.zeros((1, 4, 9), np.float32), np.zeros((1, 4, 1), np.float32), np.ones((1, 4, 4, 1), np.float32))
 
 
-@pytest.mark.parametrize("layers", [[16], [64, 32], [8, 24, 40]])
+@pytest.mark.parametrize("layers", [[16], [64, 32], [8, 24, 40], [24, 8], [32]])
 def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp_path, layers):
     """make_model(layers, ...) sizes the update MLP from `layers` (charge_gn.py:369-371; the message / pass MLPs are [32, 32] by
-    the reference's own constants).  Other widths than [32, 32] run the tiled kernels with the generic update stage: the literal
-    dense call, the compact entry on molecules of 3..38 atoms and a 150-atom box, and GNN_layer.call, each vs the float64
-    oracle; the checkpoint writer / reader round trip keeps the layer count; the training step's gradients vs the float64 oracle."""
+    the reference's own constants).  One or two hidden layers of at most 32 units run the tuned kernels of the [32, 32] model on a
+    zero-padded copy of the update MLP (a missing second layer = the identity: exact, epnn_set_update_layers); anything else runs
+    the tiled kernels with the generic update stage.  The literal dense call, the compact entry on molecules of 3..38 atoms and a
+    150-atom box, and GNN_layer.call, each vs the float64 oracle; the checkpoint writer / reader round trip keeps the layer count;
+    the training step's gradients vs the float64 oracle."""
     from epnn_amd import charge_gn, synth
     from epnn_amd._lib import EpnnError
     from epnn_amd.engine import Engine
@@ -625,7 +627,9 @@ def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp
     eng = Engine(nx=nx, T=T)
     eng.set_weights(w)
     got = eng.forward_xyz(offsets, xyz, xx, QQ, N)
-    assert eng.last_stats()[1] == 0                              # nothing went through the fused kernels
+    embeds = len(layers) <= 2 and max(layers) <= 32
+    assert eng.last_stats()[1] == (30 if embeds else 0)          # the tuned kernels take such a model's small molecules, or none
+    assert eng.last_stats()[2] == (1 if embeds else 31)
     worst = 0.0
     for k in range(len(offsets) - 1):
         sl = slice(offsets[k], offsets[k + 1])
