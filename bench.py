@@ -31,7 +31,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
                       the timed region / f32 MFMA peak; `pipe_frac` the same with the flops the kernel really executes
                       (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); `single_launch` = a launch with the GPU to itself
                       (65536 molecules, depth 1: flops / hipEvent duration IS its fraction, reproducible from
-                      profiles/r04_big_launch_kernel_stats.csv)
+                      profiles/r05_big_launch_kernel_stats.csv)
   parity              max |dq| of the reference's 871 validation systems against the TensorFlow predictions it stored for them
   real_data           atoms/s on that batch (real molecules of 3..38 atoms, N = 41), device-resident, pipelined
   host_to_host        the same forward from host arrays to host arrays (Pipeline.map, a DIFFERENT batch every call)
@@ -57,7 +57,7 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
 KNAME = "k_wave_forward<true,true,true>"
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
 
 
 def kernel_source_sha():
@@ -153,7 +153,7 @@ def collect_pmc(args):
     gfx950 correction: FETCH_SIZE x 2, MI355X_MICROARCH.md), the SQ counters at depth 1 (a launch alone).  Writes PMC_JSON."""
     import glob
     import pandas as pd
-    base = os.path.join(ROOT, "gpurun_out", "pmc_r04")
+    base = os.path.join(ROOT, "gpurun_out", "pmc_r05")
     passes = [("fetch", "FETCH_SIZE", args.depth), ("write", "WRITE_SIZE", args.depth),
               ("mops", "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE", 1),
               ("lds", "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY", 1)]
@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--molecules", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-launch and host-to-host measurements")
-    ap.add_argument("--pmc", action="store_true", help="first run the rocprofv3 counter passes of this workload (writes profiles/r04_pmc_bench.json)")
+    ap.add_argument("--pmc", action="store_true", help="first run the rocprofv3 counter passes of this workload (writes profiles/r05_pmc_bench.json)")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight per GPU (handles/streams used round robin); 0 = by run "
                     "length: 8 for long runs (steady state: 7-10 deep measured 213-215 M atoms/s, 6 deep 207 M on the same box), for short ones the divisor of --steps among 5, 4, 6 -- the last "
                     "round of launches then fills every lane (a launch takes ~0.3 ms whatever shares the GPU with it, so a short run "
@@ -614,7 +614,7 @@ def main():
         roof = {"bound": "mfma", "kernel": KNAME, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "frac_basis": "algorithmic flops (SURVEY section 8d); the matrix pipe's own utilisation (executed MFMA flops, PMC) is pipe_frac",
                 "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
-                "traffic_source": (pmc["command"] + f"; kernel source {pmc['kernel_source_sha']}; profiles/r04_pmc_bench.json") if pmc else None,
+                "traffic_source": (pmc["command"] + f"; kernel source {pmc['kernel_source_sha']}; profiles/r05_pmc_bench.json") if pmc else None,
                 "algorithmic_gflop_per_launch": flops / 1e9,
                 "executed_gflop_per_launch": executed,
                 "pipe_frac": (executed * 1e9 / (k_ms / in_flight * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if executed else None,

@@ -369,6 +369,7 @@ extern "C" int epnn_set_option(epnn_handle *h, const char *name, int value) {
     else if (!strcmp(name, "large_fused")) { h->opt_large_fused = value; }
     else if (!strcmp(name, "large_merge")) { h->opt_large_merge = value; }
     else if (!strcmp(name, "large_chunks")) { h->opt_large_chunks = value; h->plan.valid = false; }
+    else if (!strcmp(name, "front_inline")) { h->opt_front_inline = value != 0; }
     else if (!strcmp(name, "front_bits")) { h->opt_front_bits = value != 0; }
     else if (!strcmp(name, "large_sweep_old")) { h->opt_large_sweep_old = value != 0; h->plan.valid = false; }
     else if (!strcmp(name, "part_collective")) { h->opt_part_collective = value; }

@@ -138,6 +138,7 @@ struct epnn_handle {
     DevBuf d_pi, d_pj, d_psym, d_pe, d_pwi, d_pwj;
     DevBuf d_deg, d_incoff, d_nbr, d_desti, d_destj, d_prec;   // incidence rows of the pair list (epnn_frontend.hip.h)
     DevBuf d_nearbits;                // the count pass's D < cutoff decisions, a bit per candidate (FrontArgs::bits)
+    int opt_front_inline = 1;         // developer switch: 0 = the prefix sums of the pair list always in a launch of their own
     int opt_front_bits = 1;           // developer switch: 0 = the fill pass measures every distance again
     int pcap = 0;
     int pair_cap_per_atom = 16;

@@ -257,26 +257,47 @@ __device__ __forceinline__ void lg_types_table(const LargeArgs &L, LgTypeShared 
     for (int s = tid; s < EPNN_TYPE_SLOTS; s += NT) { T.key[s] = 0ull; T.first[s] = 0x7fffffff; T.cnt[s] = 0; }
     if (tid == 0) { T.bad = 0; T.used = 0; }
     __syncthreads();
-    // a wavefront's atoms of equal hash are entered by ONE lane (a molecule has a handful of types: lane-by-lane atomics on
-    // five LDS words serialise the whole workgroup)
-    for (int k0 = 0; k0 < n; k0 += NT) {
-        const int k = k0 + tid;
-        const bool act = k < n;
-        const unsigned long long hsh = !act ? 0ull : HASHED ? L.typ_hash[a0 + k] : lg_hash_row(L, a0 + k);
-        unsigned long long todo = __ballot(act);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const unsigned long long lh = __shfl(hsh, leader, 64);
-            const unsigned long long same = __ballot(act && hsh == lh);
-            if (lane == leader) {                            // the lowest lane of its group: the group's first atom
-                const int s = lg_type_find(T, lh, true);
-                if (s < 0) atomicOr(&T.bad, 1);
+    // A thread holds eight atoms' hashes at a time (one round trip for all of them), and a wavefront's 512 atoms of EQUAL hash are
+    // entered by ONE lane in ONE round: a molecule has a handful of types, so a wavefront needs a handful of rounds per 512 atoms
+    // (lane-by-lane atomics on five LDS words serialise the workgroup; a round per 64 atoms and type was 14 us for the 2220-atom
+    // protein on a 256-thread workgroup)
+    for (int kb = 0; kb < n; kb += 8 * NT) {
+        unsigned long long hv[8];
+        bool act[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = kb + u * NT + tid;
+            act[u] = k < n;
+            hv[u] = HASHED ? L.typ_hash[a0 + min(k, n - 1)] : (act[u] ? lg_hash_row(L, a0 + k) : 0ull);
+        }
+        for (;;) {
+            // this lane's first hash still to be entered; the lowest lane that has one leads the round
+            unsigned long long cand = 0ull;
+            bool any = false;
+#pragma unroll
+            for (int u = 7; u >= 0; --u)
+                if (act[u]) { cand = hv[u]; any = true; }
+            const unsigned long long havers = __ballot(any);
+            if (havers == 0ull) break;
+            const int leader = __ffsll((long long)havers) - 1;
+            const unsigned long long lh = __shfl(cand, leader, 64);
+            int cnt = 0, first = 0x7fffffff;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool m = act[u] && hv[u] == lh;
+                const unsigned long long bal = __ballot(m);
+                cnt += __popcll(bal);
+                if (bal != 0ull && first == 0x7fffffff) first = a0 + kb + u * NT + (tid & ~63) + (__ffsll((long long)bal) - 1);
+                if (m) act[u] = false;
+            }
+            if (lane == leader) {
+                const int sl = lg_type_find(T, lh, true);
+                if (sl < 0) atomicOr(&T.bad, 1);
                 else {
-                    atomicMin(&T.first[s], a0 + k);
-                    atomicAdd(&T.cnt[s], __popcll(same));
+                    atomicMin(&T.first[sl], first);
+                    atomicAdd(&T.cnt[sl], cnt);
                 }
             }
-            todo &= ~same;
         }
     }
     __syncthreads();
@@ -803,7 +824,7 @@ __global__ __launch_bounds__(256) void k_lg_fill_assign(LargeArgs L, FrontArgs F
     __shared__ FrontFillShared Sh;
     LG_CLKB(blockIdx.x == 0, 112);
     if ((int)blockIdx.x < fill_wgs) {
-        front_fill_body(F, Sh, (int)blockIdx.x);
+        front_fill_body<false>(F, Sh, (int)blockIdx.x);
         LG_CLKB(blockIdx.x == 0, 113);
         return;
     }
@@ -899,14 +920,29 @@ __global__ __launch_bounds__(256) void k_lg_first(LargeArgs L, PairMlpPack M, Lg
     if (blk < W.count_wgs) front_count_body(F, sm, blk);
     LG_CLKB(blk == 0, 110);
 }
+// systems of up to EPNN_FRONT_INLINE_A atoms: the fill of the pair list with the prefix sums worked out by every workgroup itself
+// (front_fill_body<true>) | the type table of every tiled molecule -- no k_lg_scan_types launch; the atoms' types are assigned in
+// k_lg_second then
+__global__ __launch_bounds__(256) void k_lg_fill_types(LargeArgs L, FrontArgs F, int fill_wgs) {
+    __shared__ FrontFillShared Sh;
+    LG_CLKB(blockIdx.x == 0, 112);
+    LG_CLKB((int)blockIdx.x == fill_wgs, 122);
+    if ((int)blockIdx.x < fill_wgs) {
+        front_fill_body<true>(F, Sh, (int)blockIdx.x);
+        LG_CLKB(blockIdx.x == 0, 113);
+        return;
+    }
+    lg_types_table<256, true>(L, *reinterpret_cast<LgTypeShared *>(&Sh), (int)blockIdx.x - fill_wgs);
+    LG_CLKB((int)blockIdx.x == fill_wgs, 123);
+}
 struct LgSecond {
-    int link_wgs, tsweep_wgs, all_tiled;
+    int link_wgs, tsweep_wgs, all_tiled, assign_wgs;
 };
 __global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, LgSecond W, FrontArgs F) {
     int blk = (int)blockIdx.x;
     LG_CLKB(blk == 0, 116);
     LG_CLKB(blk == W.link_wgs, 118);
-    LG_CLKB(blk == W.link_wgs + W.tsweep_wgs, 120);
+    LG_CLKB(blk == W.link_wgs + W.tsweep_wgs + W.assign_wgs, 120);
     if (blk < W.link_wgs) {
         front_link_body(F, blk, W.link_wgs);
         LG_CLKB(blk == 0, 117);
@@ -919,6 +955,14 @@ __global__ __launch_bounds__(256) void k_lg_second(LargeArgs L, PairMlpPack M, L
         return;
     }
     blk -= W.tsweep_wgs;
+    if (blk < W.assign_wgs) {                                  // (the type table comes from k_lg_fill_types: every tiled atom's type)
+        const int at = blk * 256 + (int)threadIdx.x;
+        if (at >= L.A) return;
+        const int lm = L.mflag[L.mol_of[at]] - 1;
+        if (lm >= 0) lg_type_assign(L, at, lm, L.typ_hash[at]);
+        return;
+    }
+    blk -= W.assign_wgs;
     const int np = L.row_off[L.A];
     if (np > L.pcap) return;
     const int pt = blk * 4 + (int)(threadIdx.x >> 6);
@@ -1759,11 +1803,18 @@ static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q,
     if (merged) {
         LgFirst W1{(int)gT, (int)rows4, types ? 1 : 0};
         hipLaunchKernelGGL(k_lg_first, dim3((unsigned)(W1.tile_wgs + W1.count_wgs)), dim3(256), 0, st, L, h->widx.msg[0], W1, *front);
-        hipLaunchKernelGGL(k_lg_scan_types, dim3(1u + (types ? (unsigned)L.nlarge : 0u)), dim3(1024), 0, st, L, *front);
-        hipLaunchKernelGGL(k_lg_fill_assign, dim3(rows4 + (types ? (unsigned)((P.A + 255) / 256) : 0u)), dim3(256), 0, st, L, *front, (int)rows4);
+        // (up to EPNN_FRONT_INLINE_A atoms: no scan launch, see k_lg_fill_types)
+        const bool inl = P.A <= EPNN_FRONT_INLINE_A && h->opt_front_inline;
+        const unsigned gAssign = types ? (unsigned)((P.A + 255) / 256) : 0u;
+        if (inl) {
+            hipLaunchKernelGGL(k_lg_fill_types, dim3(rows4 + (types ? (unsigned)L.nlarge : 0u)), dim3(256), 0, st, L, *front, (int)rows4);
+        } else {
+            hipLaunchKernelGGL(k_lg_scan_types, dim3(1u + (types ? (unsigned)L.nlarge : 0u)), dim3(1024), 0, st, L, *front);
+            hipLaunchKernelGGL(k_lg_fill_assign, dim3(rows4 + gAssign), dim3(256), 0, st, L, *front, (int)rows4);
+        }
         if (types) {
-            LgSecond W2{(int)gLink, L.nlarge * 2, P.fused_count() == 0 ? 1 : 0};
-            hipLaunchKernelGGL(k_lg_second, dim3((unsigned)(W2.link_wgs + W2.tsweep_wgs) + gPT), dim3(256), 0, st, L, h->widx.msg[0], W2, *front);
+            LgSecond W2{(int)gLink, L.nlarge * 2, P.fused_count() == 0 ? 1 : 0, inl ? (int)gAssign : 0};
+            hipLaunchKernelGGL(k_lg_second, dim3((unsigned)(W2.link_wgs + W2.tsweep_wgs + W2.assign_wgs) + gPT), dim3(256), 0, st, L, h->widx.msg[0], W2, *front);
             step0_pairs_done = true;
         } else {
             hipLaunchKernelGGL(k_front_link, dim3(gLink), dim3(256), 0, st, *front);

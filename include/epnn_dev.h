@@ -14,6 +14,8 @@
  *   "large_merge"       1 (default): the compact entry launches the pair-list construction of tiled molecules merged with the work that
  *                       needs only the atoms (feature rows, atom types, first projections, the first step's type sums and correction
  *                       tiles); 0: every kernel its own launch
+ *   "front_inline"      1 (default): compact entry, tiled systems of up to 8192 atoms: every workgroup of the pair list's fill pass works
+ *                       out its rows' prefix sums itself (no single-workgroup scan launch between count and fill); 0: the scan launch
  *   "front_bits"        1 (default): the separate front-end's count pass leaves its D < cutoff decisions as a bit per candidate and the
  *                       fill pass walks the set bits (systems of up to 4096 atoms); 0: the fill pass measures every distance again
  *   "large_sweep_old"   1: every tiled molecule runs the four-tile sweep kernel (k_lg_sweep) that systems above 4096 atoms use
