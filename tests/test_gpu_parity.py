@@ -140,6 +140,47 @@ def test_tiled_random_weights_vs_oracle(gpu_engine_factory, val_dir, val_names, 
     assert np.abs(qa - qb).max() <= 2e-6
 
 
+def test_tile_workgroup_sweep_sizes_vs_oracle(gpu_engine_factory):
+    """The tile-workgroup sweep kernel (k_lg_sweep2, systems of up to 4096 atoms) around its boundaries: one tile with a single
+    column block (n <= 16 on the tiled path), 32 / 33 atoms (a second tile of one atom), pieces of one partner, a partial last piece,
+    several systems in one batch, a piece longer than one staging trip (large_chunks = 1: 321 partners per wavefront) -- each against
+    the float64 oracle with non-degenerate weights, and the four-tile kernel (large_sweep_old) within float32 rounding of it."""
+    from epnn_amd import synth
+    from oracle import epnn_oracle as orc
+    nx, T = 9, 2
+    w = random_weights(nx, T, seed=41, scale=0.35)
+    for t in range(T):                                       # (all-pairs sums over hundreds of partners: keep |h| of order one)
+        w["msg"][t][2] = (w["msg"][t][2][0] / 8.0, w["msg"][t][2][1] / 8.0)
+    sizes = [5, 16, 17, 32, 33, 64, 65, 97, 129, 161, 257, 321]
+    mols = []
+    for k, n in enumerate(sizes):
+        _, xyz, x, Q, _ = synth.box_system(n_atoms=n, seed=100 + k)
+        mols.append((xyz, x, np.float32(Q[0])))
+    off, xyz, x, Q = _batch(mols)
+    N = 330
+    ref = _oracle_batch(mols, w, N)
+    ref32 = _oracle_batch(mols, w, N, np.float32)
+    noise = max(np.abs(ref32[k] - ref[k]).max() for k in range(len(mols)))
+    got = {}
+    for name, opts in (("tile workgroups", {}), ("one piece per tile", {"large_chunks": 1}), ("four-tile kernel", {"large_sweep_old": 1})):
+        eng = gpu_engine_factory(nx=nx, T=T)
+        eng.set_weights(w)
+        eng.set_option("force_path", 2)
+        for k_, v_ in opts.items():
+            eng.set_option(k_, v_)
+        q = eng.forward_xyz(off, xyz, x, Q, N=N)
+        assert eng.last_stats()[2] == len(mols)
+        worst = max(np.abs(q[off[k]:off[k + 1]] - ref[k][:len(m[0])]).max() for k, m in enumerate(mols))
+        print(f"{name}: worst |dq| {worst:.3e} over sizes {sizes}; float32 oracle noise {noise:.3e}")
+        assert worst <= max(TOL, 3 * noise), (name, worst, noise)
+        got[name] = q
+        # every system alone gives the bits it has in the batch (its plan depends on its own size only)
+        k = sizes.index(97)
+        alone = eng.forward_xyz(np.array([0, 97], np.int32), mols[k][0], mols[k][1], np.array([mols[k][2]], np.float32), N=N)
+        assert np.array_equal(alone, q[off[k]:off[k + 1]]), name
+    assert np.abs(got["tile workgroups"] - got["four-tile kernel"]).max() <= max(TOL, 3 * noise)
+
+
 def test_sharded_equals_whole_bit_for_bit(gpu_engine_factory, weights_full, val_dir, val_names):
     """molecules are independent, so any partition of the batch (here: the 2-, 3- and
     8-way partitions bench.py / shard.py would use) gives bit-identical charges; also run-to-run determinism.
@@ -1106,6 +1147,18 @@ def test_tiled_path_variants_agree(gpu_engine_factory, weights_full, golden_dir)
     print(f"protein, model_weights: first step by types vs by sweep: max |dq| {np.abs(sweep - ref).max():.2e} (|q| up to {scale:.2f})")
     assert np.abs(sweep - ref).max() <= 2e-4 * scale          # model_weights: |h| ~ 150, float32 noise of the algorithm itself ~1e-4
     assert np.array_equal(run(large_dedupe=0, large_merge=0), sweep)
+    # round 5's front-end forms are the same arithmetic: the fill pass walking the count pass's bits or measuring every distance
+    # again, the prefix sums worked out by the fill workgroups or by a launch of their own -- bit-identical
+    assert np.array_equal(run(front_bits=0), ref)
+    assert np.array_equal(run(front_inline=0), ref)
+    assert np.array_equal(run(front_inline=0, front_bits=0, large_merge=0), ref)
+    # the four-tile sweep kernel (what systems above 4096 atoms run) sums the partners in other pieces: float32 rounding apart
+    old = run(large_sweep_old=1)
+    print(f"protein, model_weights: tile-workgroup vs four-tile sweep kernel: max |dq| {np.abs(old - ref).max():.2e}")
+    # (model_weights on the protein is the numerically wild case -- |q| ~ 2e4, |h| ~ 150 --: another order of a 2220-term float32 sum
+    #  moves the charges by 2e-3 of their size; test_tile_workgroup_sweep_sizes_vs_oracle compares the two kernels where |q| ~ 1)
+    assert np.abs(old - ref).max() <= 5e-3 * scale
+    assert np.array_equal(run(large_sweep_old=1, large_fused=0), old)
 
 
 def test_more_atom_types_than_the_table_holds_falls_back_to_the_sweep(gpu_engine_factory):

@@ -108,3 +108,12 @@ by = {}
 for n_ in sorted(set(wn)):
     by[n_] = tot[wn == n_].mean()
 print("lifetime by atoms:", {int(a): int(b) for a, b in by.items()})
+if "--by-size" in args:
+    # the phases of the wavefronts of some sizes side by side: where the step from 16 to 17 atoms (a second column block) goes
+    sizes = [n_ for n_ in (12, 14, 15, 16, 17, 18, 20, 22, 24) if (wn == n_).sum() >= 8]
+    print("phase (mean shader clocks) by atoms:   " + " ".join(f"{n_:>7d}" for n_ in sizes))
+    for i in range(d.shape[1]):
+        nm = names[i] if i < len(names) else f"phase {i}"
+        print(f"  {nm:36s}" + " ".join(f"{d[wn == n_, i].mean():7.0f}" for n_ in sizes))
+    print(f"  {'total':36s}" + " ".join(f"{tot[wn == n_].mean():7.0f}" for n_ in sizes))
+    print(f"  {'near pairs (unordered)':36s}" + " ".join(f"{npair[wn == n_].mean():7.0f}" for n_ in sizes))
