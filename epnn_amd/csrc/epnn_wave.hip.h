@@ -122,6 +122,26 @@ __device__ __forceinline__ bool wave_near(const double *flip, int nflip, double 
     return !(cnt & 1);
 }
 
+// The last wavefront of a forward to finish hands status + pair count to the host and re-zeroes the control words (no other kernel
+// runs behind the fused ones of a batch of small molecules).  ONE 64-bit atomic carries the pair count (low word) and the number of
+// finished reports (high word): its return value tells the last reporter so and gives it the total, so nothing has to be ordered
+// between two atomics.  (Rounds 1-4 used two 32-bit atomics with a __threadfence() between them in EVERY wavefront: an
+// agent-scope fence writes the XCD's L2 back and invalidates it -- 1024 of them per launch of the bench batch.)  The status bits
+// (word 0) are not written by the fused kernels themselves.
+__device__ __forceinline__ void wave_handoff(const WaveArgs &A, int np) {
+    unsigned long long *ctr = reinterpret_cast<unsigned long long *>(A.status + 2);       // 8-byte aligned: words 2 | 3 of the control block
+    const unsigned long long old = atomicAdd(ctr, (unsigned long long)(unsigned)np | (1ull << 32));
+    if ((int)(old >> 32) == A.total_waves - 1) {
+        const int cnt = (int)(unsigned)(old & 0xffffffffull) + np;
+        const int st = atomicExch(A.status + 0, 0);
+        atomicExch(ctr, 0ull);
+        volatile int *hs = A.host_status;
+        hs[0] = st;
+        hs[1] = cnt;
+        __threadfence_system();
+    }
+}
+
 #ifndef EPNN_WAVES_PER_SIMD
 #define EPNN_WAVES_PER_SIMD 2     // register budget of the fused kernel: 2 -> 256 VGPRs (3 -> 168: measured slower)
 #endif
@@ -1009,20 +1029,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 if (own1) A.q_out[a0 + col1] = xq1[s];
             }
     }
-    if (FRONT && A.handoff && lane == 0) {
-        // the last wave to finish hands status + pair count to the host and re-zeroes the control words
-        atomicAdd(A.status + 1, np);
-        __threadfence();
-        if (atomicAdd(A.status + 2, 1) == A.total_waves - 1) {
-            __threadfence();
-            const int st = atomicExch(A.status + 0, 0), cnt = atomicExch(A.status + 1, 0);
-            atomicExch(A.status + 2, 0);
-            volatile int *hs = A.host_status;
-            hs[0] = st;
-            hs[1] = cnt;
-            __threadfence_system();
-        }
-    }
+    if (FRONT && A.handoff && lane == 0) wave_handoff(A, np);
     WAVE_STAMP();
 #ifdef EPNN_STAMPS
     if (lane == 0 && A.stamps) {

@@ -614,17 +614,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
         sync();
         if (split ? threadIdx.x == 0 : lane == 0) {
             // one report per molecule; the last one to finish hands status + pair count to the host and re-zeroes the control words
-            atomicAdd(A.status + 1, np);
-            __threadfence();
-            if (atomicAdd(A.status + 2, 1) == A.total_waves - 1) {
-                __threadfence();
-                const int st = atomicExch(A.status + 0, 0), cnt = atomicExch(A.status + 1, 0);
-                atomicExch(A.status + 2, 0);
-                volatile int *hs = A.host_status;
-                hs[0] = st;
-                hs[1] = cnt;
-                __threadfence_system();
-            }
+            wave_handoff(A, np);
         }
     }
 }
