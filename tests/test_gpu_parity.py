@@ -1106,7 +1106,7 @@ def test_cutoff_and_is_near_edges_on_every_path(gpu_engine_factory):
     print("cutoff / is_near edges, worst |dq| per path:", {k: f"{v:.1e}" for k, v in results.items()})
 
 
-@pytest.mark.parametrize("script,seed", [("fuzz_forward.py", 301), ("fuzz_dense.py", 302), ("fuzz_model.py", 303), ("fuzz_train.py", 304)])
+@pytest.mark.parametrize("script,seed", [("fuzz_forward.py", 301), ("fuzz_dense.py", 302), ("fuzz_model.py", 303), ("fuzz_train.py", 304), ("fuzz_tiled.py", 305)])
 def test_randomised_sweeps_with_a_fixed_seed(script, seed):
     """The four randomised sweeps against the float64 oracle (tests/fuzz_*.py; they found round 1's only real defect) with a
     fixed seed and a 25 s budget each, as part of the suite instead of by hand."""
