@@ -1216,8 +1216,8 @@ __global__ __launch_bounds__(256) void k_lg_update_generic(LargeArgs L, GenMlp G
         a1[r * EPNN_GMLP_ST + k] = r0 + r < tl.y ? Sfin[(size_t)(tl.x + r0 + r) * 32 + k] : 0.f;
     }
     __syncthreads();
-    for (int idx = tid; idx < EPNN_GMLP_ROWS * (EPNN_EDIM + 32); idx += 256) {
-        const int r = idx % EPNN_GMLP_ROWS, f = idx / EPNN_GMLP_ROWS;
+    for (int idx = tid; idx < EPNN_GMLP_ROWS * (EPNN_EDIM + 32); idx += 256) {      // (feature fastest: coalesced rows of W3)
+        const int r = idx / (EPNN_EDIM + 32), f = idx - r * (EPNN_EDIM + 32);
         const bool live = r0 + r < tl.y;
         const int at = tl.x + (live ? r0 + r : 0);
         const float nmc = L.nm_in ? L.nm_in[at] : 1.f;
@@ -1226,6 +1226,7 @@ __global__ __launch_bounds__(256) void k_lg_update_generic(LargeArgs L, GenMlp G
         else {
             const int o = f - EPNN_EDIM;
             float acc = Nf * b3[o];
+#pragma unroll 8
             for (int k = 0; k < 32; ++k) acc = fmaf(a1[r * EPNN_GMLP_ST + k], W3[k * 32 + o], acc);
             v = acc;
         }
@@ -1234,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_lg_update_generic(LargeArgs L, GenMlp G
     __syncthreads();
     const float *res = gmlp_rows(G, a0, a1);
     for (int idx = tid; idx < EPNN_GMLP_ROWS * EPNN_EDIM; idx += 256) {
-        const int r = idx % EPNN_GMLP_ROWS, f = idx / EPNN_GMLP_ROWS;
+        const int r = idx / EPNN_EDIM, f = idx - r * EPNN_EDIM;
         if (r0 + r >= tl.y) continue;
         const int at = tl.x + r0 + r;
         const float nmc = L.nm_in ? L.nm_in[at] : 1.f;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_mlp_forward(MlpArgs M) {
 }
 
 // ---- any widths (GenMlp, epnn_common.h).  EPNN_GMLP_ROWS rows of activations live in LDS (row stride WMAX + 1: the rows of one output
-// column sit in different banks); thread (row r, output o) runs the dot product over the layer's inputs.
+// column sit in different banks); thread (output o, four rows) runs the dot products over the layer's inputs.
 #define EPNN_GMLP_ST (EPNN_GMLP_WMAX + 1)
 // the stack on the rows held in `a0`; the result is in the returned buffer (a0 or a1).  All threads of the workgroup call it.
 __device__ __forceinline__ float *gmlp_rows(const GenMlp &G, float *a0, float *a1) {
@@ -65,18 +65,28 @@ __device__ __forceinline__ float *gmlp_rows(const GenMlp &G, float *a0, float *a
         const int ni = G.dims[l], no = G.dims[l + 1];
         const float *W = G.w + G.offW[l], *b = G.w + G.offB[l];
         const bool act = l + 1 < G.n;
-        for (int idx = threadIdx.x; idx < EPNN_GMLP_ROWS * no; idx += blockDim.x) {
-            const int r = idx % EPNN_GMLP_ROWS, o = idx / EPNN_GMLP_ROWS;
-            const float *in = src + r * EPNN_GMLP_ST;
-            float acc = b[o];
-            for (int i = 0; i < ni; ++i) acc = fmaf(in[i], W[(size_t)i * no + o], acc);
-            float v = acc;
-            if (act) {                                   // Dense(n, activation) of MLP_layer (charge_gn.py:38); Keras' definitions
-                if (G.act == EPNN_ACT_RELU) v = fmaxf(acc, 0.f);
-                else if (G.act == EPNN_ACT_TANH) v = tanhf(acc);
-                else if (G.act == EPNN_ACT_SIGMOID) v = 1.f / (1.f + expf(-acc));
+        // thread = (output o, four rows): neighbouring threads read neighbouring kernel columns (one coalesced row of W per input,
+        // used for four rows), the activations are LDS broadcasts; every dot product runs over its inputs in ascending order
+        for (int idx = threadIdx.x; idx < (EPNN_GMLP_ROWS / 4) * no; idx += blockDim.x) {
+            const int o = idx % no, r4 = (idx / no) * 4;
+            const float *in = src + r4 * EPNN_GMLP_ST;
+            float acc[4] = {b[o], b[o], b[o], b[o]};
+#pragma unroll 4
+            for (int i = 0; i < ni; ++i) {
+                const float wv = W[(size_t)i * no + o];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(in[r * EPNN_GMLP_ST + i], wv, acc[r]);
             }
-            dst[r * EPNN_GMLP_ST + o] = v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[r];
+                if (act) {                                   // Dense(n, activation) of MLP_layer (charge_gn.py:38); Keras' definitions
+                    if (G.act == EPNN_ACT_RELU) v = fmaxf(acc[r], 0.f);
+                    else if (G.act == EPNN_ACT_TANH) v = tanhf(acc[r]);
+                    else if (G.act == EPNN_ACT_SIGMOID) v = 1.f / (1.f + expf(-acc[r]));
+                }
+                dst[(r4 + r) * EPNN_GMLP_ST + o] = v;
+            }
         }
         __syncthreads();
         float *t = src; src = dst; dst = t;
