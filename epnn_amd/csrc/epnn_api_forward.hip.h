@@ -15,7 +15,7 @@ static size_t plan_payload_offset(int B, int A) { return (plan_ctl_ints(B, A) * 
 static int build_plan(epnn_handle *h, int B, int N, const int32_t *offsets, bool allow_mid = false, size_t payload_bytes = 0,
                       bool *ctl_fresh = nullptr) {
     Plan &P = h->plan;
-    allow_mid = allow_mid && h->opt_force_path == 0 && !upd_tiled_only(h);
+    allow_mid = allow_mid && h->opt_force_path == 0 && !upd_generic_stage(h);
     if (ctl_fresh) *ctl_fresh = false;
     if (P.valid && P.B == B && P.N == N && P.allow_mid == allow_mid && (int)P.offsets.size() == B + 1 &&
         memcmp(P.offsets.data(), offsets, (B + 1) * sizeof(int)) == 0 &&
@@ -305,7 +305,11 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     }
     if (side_mid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     if (P.small_order.empty()) return 0;
-    if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+    if (h->upd_wide && S.run_gnn) {              // update MLP of up to [64, 64] (the EPN stack alone has no update MLP)
+        if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true, 4>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+        else if (S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false, 4>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+        else hipLaunchKernelGGL((k_wave_forward<true, false, false, 4>), grid, dim3(64), (size_t)lds, h->stream, A, X);
+    } else if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else if (S.run_gnn && S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else hipLaunchKernelGGL((k_wave_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);

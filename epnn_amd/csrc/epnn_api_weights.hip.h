@@ -145,6 +145,9 @@ extern "C" int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_
     // layer's outputs (they are >= 0 behind their ReLU, so relu(I u + 0) = u).  pack_weights builds that padded copy; such a model
     // runs every inference kernel of the [32, 32] model, not the generic update stage.
     h->upd_embed = h->upd_generic && n_hidden <= 2 && widths[0] <= H && (n_hidden == 1 || widths[1] <= H);
+    // One or two hidden layers of at most 64 units: the same embedding into [64, 64], which the one-wavefront-per-molecule kernel
+    // is also built for (k_wave_forward<.., NRU = 4>); molecules of more than 32 atoms take the tiled path's generic update stage.
+    h->upd_wide = h->upd_generic && !h->upd_embed && n_hidden <= 2 && widths[0] <= 2 * H && (n_hidden == 1 || widths[1] <= 2 * H) && H == 32;
     h->updg.clear();
     if (h->upd_generic) {
         int n_in = h->cfg.h_dim + H;                       // [h | summed messages] (charge_gn.py:71)
@@ -199,27 +202,32 @@ static int pack_weights(epnn_handle *h) {
     if (train_sync_to_host(h)) return 1;          // weights trained on the device are the current ones
     if (!h->weights_dirty) return 0;
     const int nx = h->cfg.nx, F = nx + EPNN_EDIM + 1, T = h->cfg.T;
-    if (h->upd_embed) {
-        // the update MLP of `layers` = [w1] or [w1, w2] (w <= 32) as a [32, 32] one (epnn_set_update_layers): exact
-        const int H = h->cfg.hidden, nh = (int)h->updg.size() - 1, w1 = h->updg[0].n_out, wl = h->updg[nh - 1].n_out;
+    if (h->upd_embed || h->upd_wide) {
+        // the update MLP of `layers` = [w1] or [w1, w2] as a [HP, HP] one (epnn_set_update_layers): exact.  HP = 32: `upd`, every tuned
+        // kernel; HP = 64: `updw`, the 64-unit variant of the one-wavefront-per-molecule kernel
+        const int HP = h->upd_embed ? h->cfg.hidden : 2 * h->cfg.hidden, nh = (int)h->updg.size() - 1, w1 = h->updg[0].n_out, wl = h->updg[nh - 1].n_out;
+        HostDense *dst = h->upd_embed ? h->upd : h->updw;
+        const int dims[4] = {h->updg[0].n_in, HP, HP, h->cfg.h_dim};
         for (int l = 0; l < 3; ++l) {
-            std::fill(h->upd[l].W.begin(), h->upd[l].W.end(), 0.f);
-            std::fill(h->upd[l].b.begin(), h->upd[l].b.end(), 0.f);
+            dst[l].n_in = dims[l];
+            dst[l].n_out = dims[l + 1];
+            dst[l].W.assign((size_t)dims[l] * dims[l + 1], 0.f);
+            dst[l].b.assign(dims[l + 1], 0.f);
         }
-        for (int i = 0; i < h->upd[0].n_in; ++i)
-            for (int o = 0; o < w1; ++o) h->upd[0].W[(size_t)i * H + o] = h->updg[0].W[(size_t)i * w1 + o];
-        for (int o = 0; o < w1; ++o) h->upd[0].b[o] = h->updg[0].b[o];
+        for (int i = 0; i < dst[0].n_in; ++i)
+            for (int o = 0; o < w1; ++o) dst[0].W[(size_t)i * HP + o] = h->updg[0].W[(size_t)i * w1 + o];
+        for (int o = 0; o < w1; ++o) dst[0].b[o] = h->updg[0].b[o];
         if (nh == 2) {
             for (int i = 0; i < w1; ++i)
-                for (int o = 0; o < wl; ++o) h->upd[1].W[(size_t)i * H + o] = h->updg[1].W[(size_t)i * wl + o];
-            for (int o = 0; o < wl; ++o) h->upd[1].b[o] = h->updg[1].b[o];
+                for (int o = 0; o < wl; ++o) dst[1].W[(size_t)i * HP + o] = h->updg[1].W[(size_t)i * wl + o];
+            for (int o = 0; o < wl; ++o) dst[1].b[o] = h->updg[1].b[o];
         } else {
-            for (int i = 0; i < w1; ++i) h->upd[1].W[(size_t)i * H + i] = 1.f;
+            for (int i = 0; i < w1; ++i) dst[1].W[(size_t)i * HP + i] = 1.f;
         }
         const HostDense &last = h->updg[nh];
         for (int i = 0; i < wl; ++i)
-            for (int o = 0; o < last.n_out; ++o) h->upd[2].W[(size_t)i * last.n_out + o] = last.W[(size_t)i * last.n_out + o];
-        for (int o = 0; o < last.n_out; ++o) h->upd[2].b[o] = last.b[o];
+            for (int o = 0; o < last.n_out; ++o) dst[2].W[(size_t)i * last.n_out + o] = last.W[(size_t)i * last.n_out + o];
+        for (int o = 0; o < last.n_out; ++o) dst[2].b[o] = last.b[o];
     }
     std::vector<float> buf;
     auto alloc = [&](size_t n) {
@@ -325,8 +333,13 @@ static int pack_weights(epnn_handle *h) {
     }
     // ------------------------------------------------------------ fragments of the fused kernel (epnn_wave.hip.h)
     {
+        // (HU units in the update MLP's hidden layers: 32, or 64 for the k_wave_forward<.., NRU = 4> variant -- NRU = HU / 16 row
+        //  blocks per layer, KU = HU / 4 K steps of nm * u2; the block-per-wavefront kernels only ever see HU = 32)
         WaveIndex &X = h->wvidx;
-        const float *bu1 = h->upd[0].b.data(), *bu2 = h->upd[1].b.data(), *bu3 = h->upd[2].b.data();
+        const HostDense *ud = h->upd_wide ? h->updw : h->upd;
+        const int HU = h->upd_wide ? 64 : 32, NRU = HU / 16, KU = HU / 4;
+        const float *Wu1 = ud[0].W.data(), *Wu2 = ud[1].W.data(), *Wu3 = ud[2].W.data();
+        const float *bu1 = ud[0].b.data(), *bu2 = ud[1].b.data(), *bu3 = ud[2].b.data();
         auto vec = [&](int len, auto &&fn) {
             const int off = alloc(len);
             for (int k = 0; k < len; ++k) buf[off + k] = (float)fn(k);
@@ -356,9 +369,9 @@ static int pack_weights(epnn_handle *h) {
                 return W1[(size_t)(r0 + nx + accf(s - EPNN_XS, q)) * 32 + m];
             });
         };
-        auto folded = [&](const float *W1, const float *b1, int r0) {        // 8 acc steps (Wu3 M_h), then the xq steps
-            std::vector<double> prod(32 * 32), cb(32);
-            for (int k = 0; k < 32; ++k)
+        auto folded = [&](const float *W1, const float *b1, int r0) {        // KU acc steps (Wu3 M_h), then the xq steps
+            std::vector<double> prod((size_t)HU * 32), cb(32);
+            for (int k = 0; k < HU; ++k)
                 for (int m = 0; m < 32; ++m) {
                     double a = 0;
                     for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
@@ -369,9 +382,9 @@ static int pack_weights(epnn_handle *h) {
                 for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
                 cb[m] = a;
             }
-            return frag(2, 8 + EPNN_XS, [&](int s, int q, int m) -> double {
-                if (s < 8) return prod[accf(s, q) * 32 + m];
-                return xq_row(W1, b1, r0, 4 * (s - 8) + q, m, cb[m]);
+            return frag(2, KU + EPNN_XS, [&](int s, int q, int m) -> double {
+                if (s < KU) return prod[accf(s, q) * 32 + m];
+                return xq_row(W1, b1, r0, 4 * (s - KU) + q, m, cb[m]);
             });
         };
         const bool have_basis = (int)h->edge_B.size() == EPNN_EDIM * EPNN_ER;
@@ -387,41 +400,41 @@ static int pack_weights(epnn_handle *h) {
             w2 = frag(2, 8, [&](int s, int q, int m) { return (double)W2[(size_t)accf(s, q) * 32 + m]; });
             b2 = vec(32, [&](int k) { return (double)bb2[k]; });
         };
-        std::vector<double> pu1(32 * 32), cu3(32);
-        for (int k = 0; k < 32; ++k)
-            for (int m = 0; m < 32; ++m) {
+        std::vector<double> pu1((size_t)HU * HU), cu3(HU);
+        for (int k = 0; k < HU; ++k)
+            for (int m = 0; m < HU; ++m) {
                 double a = 0;
-                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)Wu1[(size_t)f * 32 + m];
-                pu1[k * 32 + m] = a;
+                for (int f = 0; f < EPNN_EDIM; ++f) a += (double)Wu3[(size_t)k * EPNN_EDIM + f] * (double)Wu1[(size_t)f * HU + m];
+                pu1[(size_t)k * HU + m] = a;
             }
-        for (int m = 0; m < 32; ++m) {
+        for (int m = 0; m < HU; ++m) {
             double a = 0;
-            for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)Wu1[(size_t)f * 32 + m];
+            for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)Wu1[(size_t)f * HU + m];
             cu3[m] = a;
         }
-        const int off_pu1 = frag(2, 8, [&](int s, int q, int m) { return pu1[accf(s, q) * 32 + m]; });
-        const int off_cu3 = vec(32, [&](int k) { return cu3[k]; });
-        const int off_u2 = frag(2, 8, [&](int s, int q, int m) { return (double)Wu2[(size_t)accf(s, q) * 32 + m]; });
-        const int off_bu1 = vec(32, [&](int k) { return (double)bu1[k]; });
-        const int off_bu2 = vec(32, [&](int k) { return (double)bu2[k]; });
+        const int off_pu1 = frag(NRU, KU, [&](int s, int q, int m) { return pu1[(size_t)accf(s, q) * HU + m]; });
+        const int off_cu3 = vec(HU, [&](int k) { return cu3[k]; });
+        const int off_u2 = frag(NRU, KU, [&](int s, int q, int m) { return (double)Wu2[(size_t)accf(s, q) * HU + m]; });
+        const int off_bu1 = vec(HU, [&](int k) { return (double)bu1[k]; });
+        const int off_bu2 = vec(HU, [&](int k) { return (double)bu2[k]; });
         for (int t = 0; t < T; ++t) {
             WaveGnnPack &G = X.g[t];
             pair_common(h->msg[t], G.we, G.we16, G.w2, G.b2);
             const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
-            std::vector<double> fold(32 * 32), cb3(32);
+            std::vector<double> fold((size_t)32 * HU), cb3(HU);
             for (int k = 0; k < 32; ++k)
-                for (int m = 0; m < 32; ++m) {
+                for (int m = 0; m < HU; ++m) {
                     double a = 0;
-                    for (int j = 0; j < 32; ++j) a += (double)W3[k * 32 + j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
-                    fold[k * 32 + m] = a;
+                    for (int j = 0; j < 32; ++j) a += (double)W3[k * 32 + j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * HU + m];
+                    fold[(size_t)k * HU + m] = a;
                 }
-            for (int m = 0; m < 32; ++m) {
+            for (int m = 0; m < HU; ++m) {
                 double a = 0;
-                for (int j = 0; j < 32; ++j) a += (double)b3[j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * 32 + m];
+                for (int j = 0; j < 32; ++j) a += (double)b3[j] * (double)Wu1[(size_t)(EPNN_EDIM + j) * HU + m];
                 cb3[m] = a;
             }
-            G.u1s = frag(2, 8, [&](int s, int q, int m) { return fold[accf(s, q) * 32 + m]; });
-            G.cb3 = vec(32, [&](int k) { return cb3[k]; });
+            G.u1s = frag(NRU, 8, [&](int s, int q, int m) { return fold[(size_t)accf(s, q) * HU + m]; });
+            G.cb3 = vec(HU, [&](int k) { return cb3[k]; });
             G.bu1 = off_bu1;
             G.u2 = off_u2;
             G.bu2 = off_bu2;
@@ -437,8 +450,8 @@ static int pack_weights(epnn_handle *h) {
         }
         X.wi0 = unfolded(h->msg[0][0].W.data(), h->msg[0][0].b.data(), 0);
         X.wj0 = unfolded(h->msg[0][0].W.data(), nullptr, F);
-        X.u1h0 = frag(2, 12, [&](int s, int q, int m) { return (double)Wu1[(size_t)accf(s, q) * 32 + m]; });
-        X.u3 = frag(3, 8, [&](int s, int q, int m) { return (double)Wu3[(size_t)accf(s, q) * EPNN_EDIM + m]; });
+        X.u1h0 = frag(NRU, 12, [&](int s, int q, int m) { return (double)Wu1[(size_t)accf(s, q) * HU + m]; });
+        X.u3 = frag(3, KU, [&](int s, int q, int m) { return (double)Wu3[(size_t)accf(s, q) * EPNN_EDIM + m]; });
         X.bu3 = vec(48, [&](int k) { return (double)bu3[k]; });
         for (int t = 0; t < T; ++t) {
             WaveEpnPack &E = X.e[t];

@@ -113,6 +113,8 @@ struct epnn_handle {
     // generic Dense stack of epnn_mlp.hip.h; `upd` above keeps its standard shapes (zeros) so that the fragment packers run unchanged.
     std::vector<HostDense> updg;
     bool upd_generic = false;
+    bool upd_wide = false;            // ... of one or two hidden layers of <= 64 units (not embedded): k_wave_forward<.., NRU = 4> takes molecules of <= 32 atoms, `updw` holds the layers zero-padded to [64, 64]
+    HostDense updw[3];
     bool upd_embed = false;           // ... of one or two hidden layers of <= 32 units: `upd` holds it zero-padded to [32, 32] (exact) and every tuned inference kernel runs
     DevBuf d_updgen;                  // raw kernels / biases of updg + the message MLPs' last Dense (W3_t, b3_t), see pack_weights
     GenMlp gen_upd{};                 // offsets into d_updgen
@@ -256,7 +258,10 @@ struct epnn_handle {
 // that status collective from its entry point's exit path (epnn_handle::guard_pending says it owes one), so its peers are released.
 // What this cannot cover is a rank whose GPU is gone (the guard itself then fails): rendezvous.launch_ranks stops the survivors.
 // the model's update MLP needs the generic update stage (tiled kernels, one launch per stage)
-static inline bool upd_tiled_only(const epnn_handle *h) { return h->upd_generic && !h->upd_embed; }
+// an update MLP that is neither [32, 32] nor embedded in it: the tiled path runs its generic update stage, the block-per-wavefront
+// kernels are not built for it; the one-wavefront-per-molecule kernel has a 64-unit variant (upd_wide), without it everything is tiled
+static inline bool upd_generic_stage(const epnn_handle *h) { return h->upd_generic && !h->upd_embed; }
+static inline bool upd_tiled_only(const epnn_handle *h) { return h->upd_generic && !h->upd_embed && !h->upd_wide; }
 static inline bool comm_collectives(const epnn_handle *h) { return h->comm && (h->comm_world > 1 || h->opt_part_collective); }
 static inline int comm_guard(epnn_handle *h, int local_fail, const char *what) {
     h->guard_pending = false;

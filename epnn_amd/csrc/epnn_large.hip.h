@@ -1791,7 +1791,7 @@ static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q,
     // transfers.  With a partition the other processes' rows of S arrive between the reduction and the update, so those stay
     // separate launches.
     const bool collective = h->part_world > 1 || h->opt_part_collective;
-    const bool split = collective || !h->opt_large_fused || upd_tiled_only(h);
+    const bool split = collective || !h->opt_large_fused || upd_generic_stage(h);
     const bool merged = front && Tg > 0 && !split;           // k_lg_first / k_lg_second
     const unsigned gTile = (unsigned)L.natiles;
     auto next_after_gnn = [&](int t) {
@@ -1887,7 +1887,7 @@ static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q,
                     EPNN_FAIL("forward: RCCL row exchange failed: %s", ncclGetErrorString(rc != ncclSuccess ? rc : rc2));
             }
         }
-        if (upd_tiled_only(h)) {
+        if (upd_generic_stage(h)) {
             GenMlp G = h->gen_upd;
             G.w = h->d_updgen.as<float>();
             hipLaunchKernelGGL(k_lg_update_generic, dim3(2u * (unsigned)L.natiles), dim3(256), 0, st, L, G, h->gen_w3[t], h->gen_b3[t], h->l_sfin.as<float>());

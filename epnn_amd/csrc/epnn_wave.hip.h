@@ -218,13 +218,17 @@ __device__ __forceinline__ void w16_mm_skip(const float (&w)[NRB][S], const floa
             }
         }
 }
-// an accumulator set [2 row blocks] of one column block as the next product's 8 input steps
-__device__ __forceinline__ void w16_feed(const f32x4 (&a)[2], float (&in)[8]) {
+// an accumulator set [NRB row blocks] of one column block as the next product's 4 NRB input steps
+template <int NRB>
+__device__ __forceinline__ void w16_feed(const f32x4 (&a)[NRB], float (&in)[4 * NRB]) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) in[s] = a[s >> 2][s & 3];
+    for (int s = 0; s < 4 * NRB; ++s) in[s] = a[s >> 2][s & 3];
 }
 
-template <bool GNN, bool EPN, bool FRONT>
+// NRU: row blocks (16 units each) of the update MLP's two hidden layers -- 2 for the reference's [32, 32] (and anything embedded
+// in it), 4 for make_model(layers) of up to [64, 64] (charge_gn.py:369-371; epnn_set_update_layers pads to 64 units).  The state
+// between steps is nm * u2 (4 NRU K steps), the pair sweep and the EPN stack are the same for every NRU.
+template <bool GNN, bool EPN, bool FRONT, int NRU = 2>
 __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveArgs A, WaveIndex X) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, q = lane >> 4, n16 = lane & 15;
@@ -541,14 +545,21 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         v[0] = w16_ld(wp + off + fo);
         v[1] = w16_ld(wp + off + 16 + fo);
     };
+    auto vecu = [&](int off, f32x4 (&v)[NRU]) {            // one value per unit of an update layer
+#pragma unroll
+        for (int rb = 0; rb < NRU; ++rb) v[rb] = w16_ld(wp + off + 16 * rb + fo);
+    };
+    constexpr int KU = 4 * NRU;                            // K steps of nm * u2 / of u1
 
     // With both stacks in one launch the EPN takes h the way the GNN steps do, through nm*u2 of the last step and the
     // folded matrices (K = 32 + xq instead of 48 + xq, h itself is then needed only when the caller asks for it).
     constexpr bool FOLD = GNN && EPN;
-    f32x4 B0[2] = {w16_splat(0.f), w16_splat(0.f)}, B1[2] = {w16_splat(0.f), w16_splat(0.f)};     // nm*u2 of the two columns
+    f32x4 B0[NRU], B1[NRU];                                 // nm*u2 of the two columns
+#pragma unroll
+    for (int rb = 0; rb < NRU; ++rb) { B0[rb] = w16_splat(0.f); B1[rb] = w16_splat(0.f); }
     // ================================================================== GNN steps (charge_gn.py:60-74)
     if (GNN) {
-        f32x4 P0[2], P1[2], U0[2], U1[2];                   // P, u1pre of the two columns
+        f32x4 P0[2], P1[2], U0[NRU], U1[NRU];               // P, u1pre of the two columns
         float pb[2][8];
         f32x4 b2v[2];
         // ---- step 0: G rows, then P / R / u1pre from (xq | h)
@@ -563,7 +574,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             WAVE_FENCE();
             f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); U0[rb] = w16_splat(0.f); U1[rb] = w16_splat(0.f); }
+            for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); }
+#pragma unroll
+            for (int rb = 0; rb < NRU; ++rb) { U0[rb] = w16_splat(0.f); U1[rb] = w16_splat(0.f); }
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq0, P0, xs3);
             w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq0, r0, xs3);
             if (two) { w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wa, xq1, P1, xs3); w16_mm_skip<2, EPNN_XS, EPNN_XS - 1>(wc, xq1, r1, xs3); }
@@ -579,9 +592,10 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 if (two) w16_mm<2, 12>(wh, hin1, r1);
                 // the h block of the update MLP's first layer; masked_input = [h, m] * node_mask (charge_gn.py:72): the mask
                 // multiplies the whole pre-activation where the summed messages join it (once: it may be fractional)
-                W16_LD(wh, X.u1h0, 2, 12);
-                w16_mm<2, 12>(wh, hin0, U0);
-                if (two) w16_mm<2, 12>(wh, hin1, U1);
+                float wu[NRU][12];
+                W16_LD(wu, X.u1h0, NRU, 12);
+                w16_mm<NRU, 12>(wu, hin0, U0);
+                if (two) w16_mm<NRU, 12>(wu, hin1, U1);
             }
             if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
             if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
@@ -597,7 +611,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             const WaveGnnPack &M = X.g[t];
             const bool lastg = t + 1 == Tg;
             f32x4 S0[2] = {w16_splat(0.f), w16_splat(0.f)}, S1[2] = {w16_splat(0.f), w16_splat(0.f)};
-            float u1s[2][8];
+            float u1s[NRU][8];
             {
                 // ---- partner tiles.  Tile k of a block gives column i the partner jp = j0 + k * step: block 0 takes the
                 //      partners one by one (j0 = 0, step 1), copy c of block 1 every C1-th from c on -- block 1 is finished
@@ -716,7 +730,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                             WAVE_FENCE();
                             tile(Pc, Sc, ob, dp);
                         }
-                        if (!b1) { W16_LD(u1s, M.u1s, 2, 8); }   // first operand of the update MLP
+                        if (!b1) { W16_LD(u1s, M.u1s, NRU, 8); }   // first operand of the update MLP
                         if (ntr - k == 2) {                       // real tiles k, k + 1, then the last tile
                             load_rg(ob, ra, en);
                             WAVE_FENCE();
@@ -765,89 +779,93 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             if (t < 2) WAVE_STAMP();   // pair tiles
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
             {
-                float w2[2][8], in0[8], in1[8];
-                f32x4 cv[2], bv[2];
-                W16_LD(w2, M.u2, 2, 8);
-                vec2(M.cb3, cv);
-                vec2(M.bu1, bv);
+                float w2[NRU][KU], in0[8], in1[8];
+                f32x4 cv[NRU], bv[NRU];
+                W16_LD(w2, M.u2, NRU, KU);
+                vecu(M.cb3, cv);
+                vecu(M.bu1, bv);
                 WAVE_FENCE();
-                f32x4 d0[2] = {U0[0], U0[1]}, d1[2] = {U1[0], U1[1]};
-                w16_feed(S0, in0);
-                w16_mm<2, 8>(u1s, in0, d0);
-                if (two) { w16_feed(S1, in1); w16_mm<2, 8>(u1s, in1, d1); }
-                f32x4 a0_[2], a1_[2];
+                f32x4 d0[NRU], d1[NRU];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
+                for (int rb = 0; rb < NRU; ++rb) { d0[rb] = U0[rb]; d1[rb] = U1[rb]; }
+                w16_feed<2>(S0, in0);
+                w16_mm<NRU, 8>(u1s, in0, d0);
+                if (two) { w16_feed<2>(S1, in1); w16_mm<NRU, 8>(u1s, in1, d1); }
+                f32x4 a0_[NRU], a1_[NRU];
+#pragma unroll
+                for (int rb = 0; rb < NRU; ++rb) {
                     a0_[rb] = w16_relu(nm0 * (d0[rb] + Nf * cv[rb]) + bv[rb]);
                     a1_[rb] = w16_relu(nm1 * (d1[rb] + Nf * cv[rb]) + bv[rb]);
                 }
-                vec2(M.bu2, bv);
+                vecu(M.bu2, bv);
                 if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
                 else if (Te > 0) { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
                 WAVE_FENCE();
-                d0[0] = bv[0]; d0[1] = bv[1]; d1[0] = bv[0]; d1[1] = bv[1];
-                w16_feed(a0_, in0);
-                w16_mm<2, 8>(w2, in0, d0);
-                if (two) { w16_feed(a1_, in1); w16_mm<2, 8>(w2, in1, d1); }
+                float ain0[KU], ain1[KU];
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) { B0[rb] = nm0 * w16_relu(d0[rb]); B1[rb] = nm1 * w16_relu(d1[rb]); }
+                for (int rb = 0; rb < NRU; ++rb) { d0[rb] = bv[rb]; d1[rb] = bv[rb]; }
+                w16_feed<NRU>(a0_, ain0);
+                w16_mm<NRU, KU>(w2, ain0, d0);
+                if (two) { w16_feed<NRU>(a1_, ain1); w16_mm<NRU, KU>(w2, ain1, d1); }
+#pragma unroll
+                for (int rb = 0; rb < NRU; ++rb) { B0[rb] = nm0 * w16_relu(d0[rb]); B1[rb] = nm1 * w16_relu(d1[rb]); }
             }
             if (t < 2) WAVE_STAMP();   // U1, U2
             if (!lastg) {
                 // next step: G rows, then P / R / u1pre from (nm*u2 | xq) through the folded matrices
-                float wa[2][8 + EPNN_XS], wb[2][8 + EPNN_XS], in0[8 + EPNN_XS], in1[8 + EPNN_XS];
-                W16_LD(wa, M.pwi, 2, 8 + EPNN_XS);
+                float wa[2][KU + EPNN_XS], wb[2][KU + EPNN_XS], in0[KU + EPNN_XS], in1[KU + EPNN_XS];
+                W16_LD(wa, M.pwi, 2, KU + EPNN_XS);
                 WAVE_FENCE();
                 gtiles();
                 if (t < 2) WAVE_STAMP();   // G tiles
 #pragma unroll
-                for (int s = 0; s < 8; ++s) { in0[s] = B0[s >> 2][s & 3]; in1[s] = B1[s >> 2][s & 3]; }
+                for (int s = 0; s < KU; ++s) { in0[s] = B0[s >> 2][s & 3]; in1[s] = B1[s >> 2][s & 3]; }
 #pragma unroll
-                for (int s = 0; s < EPNN_XS; ++s) { in0[8 + s] = xq0[s]; in1[8 + s] = xq1[s]; }
-                W16_LD(wb, M.pwj, 2, 8 + EPNN_XS);
-                float wu[2][8];
-                f32x4 cu[2];
-                W16_LD(wu, M.pu1, 2, 8);
-                vec2(M.cu3, cu);
+                for (int s = 0; s < EPNN_XS; ++s) { in0[KU + s] = xq0[s]; in1[KU + s] = xq1[s]; }
+                W16_LD(wb, M.pwj, 2, KU + EPNN_XS);
+                float wu[NRU][KU];
+                f32x4 cu[NRU];
+                W16_LD(wu, M.pu1, NRU, KU);
+                vecu(M.cu3, cu);
                 WAVE_FENCE();
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); }
-                w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wa, in0, P0, xs3);
-                if (two) w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wa, in1, P1, xs3);
+                w16_mm_skip<2, KU + EPNN_XS, KU - 1 + EPNN_XS>(wa, in0, P0, xs3);
+                if (two) w16_mm_skip<2, KU + EPNN_XS, KU - 1 + EPNN_XS>(wa, in1, P1, xs3);
                 f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
-                w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wb, in0, r0, xs3);
-                if (two) w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wb, in1, r1, xs3);
+                w16_mm_skip<2, KU + EPNN_XS, KU - 1 + EPNN_XS>(wb, in0, r0, xs3);
+                if (two) w16_mm_skip<2, KU + EPNN_XS, KU - 1 + EPNN_XS>(wb, in1, r1, xs3);
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
                 vec2(X.g[t + 1].b2, b2v);
                 WAVE_FENCE();
-                float bin0[8], bin1[8];
-                w16_feed(B0, bin0);
-                w16_feed(B1, bin1);
+                float bin0[KU], bin1[KU];
+                w16_feed<NRU>(B0, bin0);
+                w16_feed<NRU>(B1, bin1);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) { U0[rb] = nm0 * cu[rb]; U1[rb] = nm1 * cu[rb]; }
-                w16_mm<2, 8>(wu, bin0, U0);
-                if (two) w16_mm<2, 8>(wu, bin1, U1);
+                for (int rb = 0; rb < NRU; ++rb) { U0[rb] = nm0 * cu[rb]; U1[rb] = nm1 * cu[rb]; }
+                w16_mm<NRU, KU>(wu, bin0, U0);
+                if (two) w16_mm<NRU, KU>(wu, bin1, U1);
                 wave_sync_all();
                 if (t < 2) WAVE_STAMP();   // projections
             }
         }
         if (!FOLD || A.h_out) {
             // h = node_mask * (Wu3^T u2 + bu3)  (charge_gn.py:73-74) after the last step, straight into the h registers
-            float w[3][8], bin0[8], bin1[8];
-            W16_LD(w, X.u3, 3, 8);
+            float w[3][KU], bin0[KU], bin1[KU];
+            W16_LD(w, X.u3, 3, KU);
             f32x4 bv[3];
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) bv[rb] = w16_ld(wp + X.bu3 + 16 * rb + fo);
             WAVE_FENCE();
-            w16_feed(B0, bin0);
-            w16_feed(B1, bin1);
+            w16_feed<NRU>(B0, bin0);
+            w16_feed<NRU>(B1, bin1);
             // B = nm * u2 already: h = nm * (Wu3^T u2) + nm * bu3
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) { hk0[rb] = nm0 * bv[rb]; hk1[rb] = nm1 * bv[rb]; }
-            w16_mm<3, 8>(w, bin0, hk0);
-            if (two) w16_mm<3, 8>(w, bin1, hk1);
+            w16_mm<3, KU>(w, bin0, hk0);
+            if (two) w16_mm<3, KU>(w, bin1, hk1);
         }
         if (A.h_out) {
 #pragma unroll
@@ -879,14 +897,14 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         for (int t = 0; t < Te; ++t) {
             const WaveEpnPack &M = X.e[t];
             {
-                constexpr int KS = FOLD ? 8 + EPNN_XS : EPNN_XS + 12;
-                constexpr int SK = FOLD ? 7 + EPNN_XS : EPNN_XS - 1;         // the last xq step
+                constexpr int KS = FOLD ? KU + EPNN_XS : EPNN_XS + 12;
+                constexpr int SK = FOLD ? KU - 1 + EPNN_XS : EPNN_XS - 1;    // the last xq step
                 float wa[2][KS], wb[2][KS], in0[KS], in1[KS];
                 if (FOLD) {
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) { in0[s] = B0[s >> 2][s & 3]; in1[s] = B1[s >> 2][s & 3]; }
+                    for (int s = 0; s < KU; ++s) { in0[s] = B0[s >> 2][s & 3]; in1[s] = B1[s >> 2][s & 3]; }
 #pragma unroll
-                    for (int s = 0; s < EPNN_XS; ++s) { in0[8 + s] = xq0[s]; in1[8 + s] = xq1[s]; }
+                    for (int s = 0; s < EPNN_XS; ++s) { in0[KU + s] = xq0[s]; in1[KU + s] = xq1[s]; }
                 } else {
 #pragma unroll
                     for (int s = 0; s < EPNN_XS; ++s) { in0[s] = xq0[s]; in1[s] = xq1[s]; }

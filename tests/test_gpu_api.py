@@ -582,12 +582,13 @@ def test_mlp_layer_call_with_other_activations(nodes, activation):
             gnn(np.zeros((1, 4, 48), np.float32), z, np.zeros((1, 4, 9), np.float32), np.zeros((1, 4, 1), np.float32), np.ones((1, 4, 4, 1), np.float32))
 
 
-@pytest.mark.parametrize("layers", [[16], [64, 32], [8, 24, 40], [24, 8], [32]])
+@pytest.mark.parametrize("layers", [[16], [64, 32], [8, 24, 40], [24, 8], [48, 48], [64]])
 def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp_path, layers):
     """make_model(layers, ...) sizes the update MLP from `layers` (charge_gn.py:369-371; the message / pass MLPs are [32, 32] by
     the reference's own constants).  One or two hidden layers of at most 32 units run the tuned kernels of the [32, 32] model on a
-    zero-padded copy of the update MLP (a missing second layer = the identity: exact, epnn_set_update_layers); anything else runs
-    the tiled kernels with the generic update stage.  The literal dense call, the compact entry on molecules of 3..38 atoms and a
+    zero-padded copy of the update MLP (a missing second layer = the identity: exact, epnn_set_update_layers); of at most 64 units
+    the 64-unit variant of the one-wavefront-per-molecule kernel for molecules of up to 32 atoms (the same embedding into [64, 64])
+    and the tiled kernels with the generic update stage for larger ones; anything else the tiled kernels alone.  The literal dense call, the compact entry on molecules of 3..38 atoms and a
     150-atom box, and GNN_layer.call, each vs the float64 oracle; the checkpoint writer / reader round trip keeps the layer count;
     the training step's gradients vs the float64 oracle."""
     from epnn_amd import charge_gn, synth
@@ -620,16 +621,20 @@ def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp
     # (3) the compact entry: QM9-like molecules of every path's sizes + a 150-atom box in one batch
     mnames = [nm for nm in val_names][:30]
     mols, offsets, xyz, xx, QQ = load_molecules(val_dir, mnames, nx)
-    _, bxyz, bx, bQ, _ = synth.box_system(n_atoms=150, seed=9)
-    offsets = np.concatenate([offsets, [offsets[-1] + 150]]).astype(np.int32)
-    xyz, xx, QQ = np.concatenate([xyz, bxyz]), np.concatenate([xx, bx]), np.concatenate([QQ, bQ]).astype(np.float32)
+    for nb, seed in ((40, 10), (150, 9)):      # a 40-atom system (block-per-wavefront kernels) and a 150-atom one (tiled kernels)
+        _, bxyz, bx, bQ, _ = synth.box_system(n_atoms=nb, seed=seed)
+        offsets = np.concatenate([offsets, [offsets[-1] + nb]]).astype(np.int32)
+        xyz, xx, QQ = np.concatenate([xyz, bxyz]), np.concatenate([xx, bx]), np.concatenate([QQ, bQ]).astype(np.float32)
     N = 150
     eng = Engine(nx=nx, T=T)
     eng.set_weights(w)
     got = eng.forward_xyz(offsets, xyz, xx, QQ, N)
     embeds = len(layers) <= 2 and max(layers) <= 32
-    assert eng.last_stats()[1] == (30 if embeds else 0)          # the tuned kernels take such a model's small molecules, or none
-    assert eng.last_stats()[2] == (1 if embeds else 31)
+    wide = len(layers) <= 2 and 32 < max(layers) <= 64
+    n_le32 = int((np.diff(offsets) <= 32).sum())
+    assert n_le32 == 30
+    fused = 31 if embeds else (30 if wide else 0)                # the tuned kernels take such a model's small molecules, or none
+    assert eng.last_stats()[1] == fused and eng.last_stats()[2] == 32 - fused
     worst = 0.0
     for k in range(len(offsets) - 1):
         sl = slice(offsets[k], offsets[k + 1])
@@ -640,10 +645,10 @@ def test_make_model_with_other_update_layers(golden_dir, val_dir, val_names, tmp
     # the same handle back on the reference's layers: the tuned kernels again
     w32 = random_weights(nx, T, seed=31, scale=0.35)
     eng.set_weights(w32)
-    got32 = eng.forward_xyz(offsets[:-1], xyz[:offsets[-2]], xx[:offsets[-2]], QQ[:-1], 41)
+    got32 = eng.forward_xyz(offsets[:-2], xyz[:offsets[-3]], xx[:offsets[-3]], QQ[:-2], 41)
     eng_ref = Engine(nx=nx, T=T)
     eng_ref.set_weights(w32)
-    assert np.array_equal(got32, eng_ref.forward_xyz(offsets[:-1], xyz[:offsets[-2]], xx[:offsets[-2]], QQ[:-1], 41))
+    assert np.array_equal(got32, eng_ref.forward_xyz(offsets[:-2], xyz[:offsets[-3]], xx[:offsets[-3]], QQ[:-2], 41))
     assert eng.last_stats()[1] > 0
     eng.close(); eng_ref.close()
     # (4) GNN_layer with such an update_fn
