@@ -68,6 +68,9 @@ struct WeightIndex {
 #define EPNN_ETAB_N 2049     // grid points of the table of B^T e(D) over [0, cutoff]
 #define EPNN_NFLIP_MAX 128   // changes of the near flag as a function of the distance beyond dsafe that the fused front-end can hold
 #define EPNN_DST 33          // LDS row stride (floats) of the per-molecule charge-transfer matrix
+// (HU = units of the update MLP's hidden layers as the fused kernel sees them: 32, or 64 for k_wave_forward<.., NRU = 4>; the
+//  shapes below are written for 32 -- with 64, "[2][8]" of u2 / pu1 reads [4][16], of u1s [4][8], of pwi / pwj [2][16+XS], of u3
+//  [3][16], the [32] vectors of the update MLP [64]: pack_weights, epnn_api_weights.hip.h)
 struct WaveGnnPack {           // GNN step t
     int we;               // [2][12][64]  e order       We_t
     int we16;             // [2][4][64]   k = 4q + s    B^T We_t   (edge features in the 16-dimensional basis)

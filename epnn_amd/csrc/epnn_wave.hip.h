@@ -781,7 +781,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             {
                 float w2[NRU][KU], in0[8], in1[8];
                 f32x4 cv[NRU], bv[NRU];
-                W16_LD(w2, M.u2, NRU, KU);
+                // (NRU = 2: every operand of the block requested up front, it all fits the registers; 4: the second layer's kernel
+                //  is requested once the first layer's operands are dead -- up front it spilled some 130 registers)
+                if constexpr (NRU == 2) { W16_LD(w2, M.u2, NRU, KU); }
                 vecu(M.cb3, cv);
                 vecu(M.bu1, bv);
                 WAVE_FENCE();
@@ -797,6 +799,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     a0_[rb] = w16_relu(nm0 * (d0[rb] + Nf * cv[rb]) + bv[rb]);
                     a1_[rb] = w16_relu(nm1 * (d1[rb] + Nf * cv[rb]) + bv[rb]);
                 }
+                if constexpr (NRU != 2) { W16_LD(w2, M.u2, NRU, KU); }
                 vecu(M.bu2, bv);
                 if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
                 else if (Te > 0) { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 W16_LD(wb, M.pwj, 2, KU + EPNN_XS);
                 float wu[NRU][KU];
                 f32x4 cu[NRU];
-                W16_LD(wu, M.pu1, NRU, KU);
+                if constexpr (NRU == 2) { W16_LD(wu, M.pu1, NRU, KU); }
                 vecu(M.cu3, cu);
                 WAVE_FENCE();
 #pragma unroll
@@ -837,6 +840,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 if (two) w16_mm_skip<2, KU + EPNN_XS, KU - 1 + EPNN_XS>(wb, in1, r1, xs3);
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
+                if constexpr (NRU != 2) { W16_LD(wu, M.pu1, NRU, KU); }
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
                 vec2(X.g[t + 1].b2, b2v);
                 WAVE_FENCE();
