@@ -123,32 +123,37 @@ class _Stack:
     def _mlps(self):
         raise NotImplementedError
 
-    def _engine_for(self, nx, T):
-        if self._engine is None or self._engine.nx != nx or self._engine.T != T:
+    def _engine_for(self, nx, T, h_dim=48):
+        """h_dim: the channels of h and e (make_model gives e_inp h_dim channels, charge_gn.py:376-377); 1..48 are built -- below
+        48 the library runs the model zero-padded to 48 channels (exact; include/epnn.h)."""
+        if not 1 <= int(h_dim) <= 48:
+            raise EpnnError(f"h_dim = {h_dim}: the HIP kernels hold 48 channels of h and e (h_dim = e_dim in 1..48 are built)")
+        if self._engine is None or self._engine.nx != nx or self._engine.T != T or self._engine.h_dim != h_dim:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = Engine(nx=nx, T=T, device=_DEVICE)
+            self._engine = Engine(nx=nx, T=T, h_dim=int(h_dim), e_dim=int(h_dim), device=_DEVICE)
             self._pushed = None
         return self._engine
 
 
 def _push(eng, msg, upd, pas, nx):
-    F = nx + 49
+    hd = eng.h_dim
+    F = nx + hd + 1
     for m in list(msg or []) + ([upd] if upd is not None else []) + list(pas or []):
         if getattr(m, "activation", "relu") != "relu":
             raise EpnnError(f"an MLP_layer with activation={m.activation!r} inside GNN_layer / EPN_layer / make_model: the stacks are "
                             "built for 'relu' (the reference's own, charge_gn.py:52,84,371); other activations run in MLP_layer.call only")
     for t, m in enumerate(msg or []):
-        m.build(2 * F + 48)
+        m.build(2 * F + hd)
         for l, (k, b) in enumerate(m.get_weights()):
             eng.set_layer("msg", t, l, k, b)
     if upd is not None:
-        upd.build(80)
+        upd.build(hd + 32)
         eng.set_update_layers(upd.nodes)          # make_model(layers, ...): any hidden widths ([32, 32]: the tuned kernels)
         for l, (k, b) in enumerate(upd.get_weights()):
             eng.set_layer("upd", 0, l, k, b)
     for t, m in enumerate(pas or []):
-        m.build(2 * F + 48)
+        m.build(2 * F + hd)
         for l, (k, b) in enumerate(m.get_weights()):
             eng.set_layer("pas", t, l, k, b)
 
@@ -165,9 +170,10 @@ class GNN_layer(_Stack):
 
     def call(self, h, e, x, q, mask):
         x = np.asarray(x)
-        if self.update_fn.out_dim != 48:
-            raise EpnnError(f"GNN_layer: update_fn.out_dim must be 48 (h_dim), got {self.update_fn.out_dim}")
-        eng = self._engine_for(x.shape[-1], self.T)
+        hd = int(np.shape(h)[-1])
+        if self.update_fn.out_dim != hd:
+            raise EpnnError(f"GNN_layer: update_fn.out_dim must equal h's channels ({hd}: h is fed back every step, charge_gn.py:71-73), got {self.update_fn.out_dim}")
+        eng = self._engine_for(x.shape[-1], self.T, hd)
         _push(eng, self.message_fns, self.update_fn, None, x.shape[-1])
         return eng.gnn_forward(h, e, x, q, mask)
 
@@ -184,7 +190,7 @@ class EPN_layer(_Stack):
 
     def call(self, h, e, x, q, mask):
         x = np.asarray(x)
-        eng = self._engine_for(x.shape[-1], self.T)
+        eng = self._engine_for(x.shape[-1], self.T, int(np.shape(h)[-1]))
         _push(eng, None, None, self.pass_fns, x.shape[-1])
         return eng.epn_forward(h, e, x, q, mask)
 
@@ -275,8 +281,9 @@ class EPNNModel(_Stack):
 
     def __init__(self, layers, h_dim, T, n_elems, natom):
         super().__init__()
-        if h_dim != 48:
-            raise EpnnError("make_model: h_dim must be 48 (the HIP kernels are built for h_dim == e_dim == 48)")
+        if not 1 <= int(h_dim) <= 48:
+            raise EpnnError("make_model: h_dim must be in 1..48 (the HIP kernels hold 48 channels of h and e; a smaller model runs "
+                            "zero-padded, exactly; the reference's own scripts use 48, charge_gn.py:413, infer.py:47)")
         self.h_dim, self.T, self.n_elems, self.natom = h_dim, T, n_elems, natom
         self.update_fn = MLP_layer(layers, out_dim=h_dim)
         self.graph_net = GNN_layer(MLP_layer, self.update_fn, T)
@@ -294,7 +301,7 @@ class EPNNModel(_Stack):
 
     # ---- weights
     def _eng(self):
-        eng = self._engine_for(self.n_elems, self.T)
+        eng = self._engine_for(self.n_elems, self.T, self.h_dim)
         if self._dirty or self._pushed is None:
             _push(eng, self.graph_net.message_fns, self.update_fn, self.electron_net.pass_fns, self.n_elems)
             self._pushed = True
@@ -313,7 +320,7 @@ class EPNNModel(_Stack):
         first = w["msg"][0][0][0].shape[0]
         want = 2 * (self.n_elems + self.h_dim + 1) + self.h_dim
         if first != want:
-            raise EpnnError(f"weights were trained with {(first - 48) // 2 - 49} atom-feature columns, "
+            raise EpnnError(f"weights were trained with {(first - self.h_dim) // 2 - self.h_dim - 1} atom-feature columns (at h_dim = {self.h_dim}), "
                             f"model was built with n_elems={self.n_elems} (first kernel {first} rows, expected {want})")
         for t in range(self.T):
             self.graph_net.message_fns[t].set_weights(w["msg"][t])
@@ -364,7 +371,7 @@ class EPNNModel(_Stack):
         """Charges of every (offsets, xyz, x, Q) batch of `batches`, in order, with `depth` batches in flight on the GPU
         (engine.Pipeline.map: the loop of infer.py:62-76 at the throughput of the compact entry)."""
         from .engine import Pipeline
-        pipe = Pipeline(depth=depth, nx=self.n_elems, T=self.T, device=_DEVICE)
+        pipe = Pipeline(depth=depth, nx=self.n_elems, T=self.T, h_dim=self.h_dim, e_dim=self.h_dim, device=_DEVICE)
         try:
             pipe.set_weights(self.weights_dict())
             yield from pipe.map(batches, self.natom if N is None else N)

@@ -82,8 +82,9 @@ extern "C" int epnn_skip_hw_queues(int device, int n) {
 
 extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out) {
     if (!cfg || !out) EPNN_FAIL("epnn_create: null argument");
-    if (cfg->h_dim != EPNN_EDIM || cfg->e_dim != EPNN_EDIM)
-        EPNN_FAIL("epnn_create: h_dim and e_dim must both be %d (charge_gn.py:377 requires e_dim == h_dim)", EPNN_EDIM);
+    if (cfg->h_dim != cfg->e_dim) EPNN_FAIL("epnn_create: e_dim (%d) must equal h_dim (%d): make_model gives e_inp h_dim channels (charge_gn.py:377)", cfg->e_dim, cfg->h_dim);
+    if (cfg->h_dim < 1 || cfg->h_dim > EPNN_EDIM)
+        EPNN_FAIL("epnn_create: h_dim = e_dim must be in 1..%d (the kernels hold %d channels; a smaller model runs zero-padded, a larger one is not built)", EPNN_EDIM, EPNN_EDIM);
     if (cfg->hidden != EPNN_HID) EPNN_FAIL("epnn_create: hidden must be %d", EPNN_HID);
     if (cfg->T < 1 || cfg->T > EPNN_MAXT) EPNN_FAIL("epnn_create: T must be in 1..%d", EPNN_MAXT);
     if (cfg->nx < 1 || cfg->nx + EPNN_EDIM + 1 > EPNN_F1) EPNN_FAIL("epnn_create: nx must be in 1..%d", EPNN_F1 - EPNN_EDIM - 1);
@@ -98,6 +99,8 @@ extern "C" int epnn_create(const epnn_config *cfg, int device, epnn_handle **out
         EPNN_FAIL("epnn_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     epnn_handle *h = new epnn_handle();
     h->cfg = *cfg;
+    h->model_dim = cfg->h_dim;
+    h->cfg.h_dim = h->cfg.e_dim = EPNN_EDIM;     // what the kernels see (epnn_host.h: model_dim)
     h->device = device;
     if (create_resources(h)) {                   // the message is set; nothing of a half-built handle stays behind
         const std::string why = g_epnn_err;
@@ -122,12 +125,14 @@ static int create_resources(epnn_handle *h) {
     for (auto &e : h->ev_done) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (h->d_status.ensure(4 * sizeof(int))) return 1;
     HIPCHK(hipMemsetAsync(h->d_status.p, 0, 4 * sizeof(int), h->stream));
-    // mu = np.linspace(0.1, cutoff, e_dim): arange(num)*step + start, last element forced to stop
-    std::vector<double> mu(cfg->e_dim);
+    // mu = np.linspace(0.1, cutoff, e_dim): arange(num)*step + start, last element forced to stop (num == 1: [start]).  The
+    // channels beyond the model's e_dim get a centre so far away that exp(-eta (D - mu)^2) is 0 for every distance: zero channels
+    const int ME = h->model_dim;
+    std::vector<double> mu(cfg->e_dim, 1.0e4);
     const double start = 0.1, stop = (double)cfg->cutoff;
-    const double step = (stop - start) / (double)(cfg->e_dim - 1);
-    for (int k = 0; k < cfg->e_dim; ++k) mu[k] = (double)k * step + start;
-    mu[cfg->e_dim - 1] = stop;
+    const double step = ME > 1 ? (stop - start) / (double)(ME - 1) : 0.0;
+    for (int k = 0; k < ME; ++k) mu[k] = (double)k * step + start;
+    if (ME > 1) mu[ME - 1] = stop;
     if (h->d_mu.ensure(mu.size() * sizeof(double))) return 1;
     HIPCHK(hipMemcpy(h->d_mu.p, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice));
     shape_layers(h);
@@ -142,8 +147,8 @@ static int create_resources(epnn_handle *h) {
     {   // dsafe: largest D up to which a lower bound of max_k e_k stays above 2 tol (every pair closer than that is a near
         // pair, charge_gn.py:90-94).  Bound: C(D), decreasing in D, times the Gaussian at the largest possible distance
         // `gap` from D to its nearest mu_k (half the widest spacing; mu_0 itself for D below it).
-        double gap = std::max(mu[0], stop - mu[cfg->e_dim - 1]);
-        for (int k = 0; k + 1 < cfg->e_dim; ++k) gap = std::max(gap, 0.5 * (mu[k + 1] - mu[k]));
+        double gap = std::max(mu[0], stop - mu[ME - 1]);
+        for (int k = 0; k + 1 < ME; ++k) gap = std::max(gap, 0.5 * (mu[k + 1] - mu[k]));
         const double floor_g = exp(-(double)cfg->eta * gap * gap);
         double lo = 0.0, hi = stop;
         for (int it = 0; it < 60; ++it) {
@@ -159,7 +164,7 @@ static int create_resources(epnn_handle *h) {
         // With the reference's parameters there is exactly one, 6.0e-3 below the cutoff.
         const double eta = (double)cfg->eta;
         const float tol = cfg->near_tol;
-        const int E = cfg->e_dim;
+        const int E = ME;
         auto nearf = [&](double D) -> bool {
             if (D >= stop) return false;
             const double C = (cos(3.141592653589793 * (D - 0.0) / stop) + 1.0) / 2.0;

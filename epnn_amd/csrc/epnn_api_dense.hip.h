@@ -202,9 +202,32 @@ static int dense_dev(epnn_handle *h, int B, int N, int mode, const float *d_h, c
     return 0;
 }
 
+// rows of d channels -> rows of EPNN_EDIM channels, the rest zero (a model with h_dim = e_dim = d < 48: epnn_host.h, model_dim)
+static void pad_channels(const float *src, size_t rows, int d, std::vector<float> &dst) {
+    dst.assign(rows * EPNN_EDIM, 0.f);
+    for (size_t r = 0; r < rows; ++r) memcpy(dst.data() + r * EPNN_EDIM, src + r * (size_t)d, (size_t)d * sizeof(float));
+}
+static int dense_host_48(epnn_handle *h, int B, int N, int mode, const float *hh, const float *e, const float *x,
+                         const float *q, const float *mask, float *out);
 static int dense_host(epnn_handle *h, int B, int N, int mode, const float *hh, const float *e, const float *x,
                       const float *q, const float *mask, float *out) {
     if (!h || !hh || !e || !x || !q || !mask || !out) EPNN_FAIL("dense forward: null argument");
+    if (h->model_dim == EPNN_EDIM) return dense_host_48(h, B, N, mode, hh, e, x, q, mask, out);
+    if (B < 1 || N < 1) EPNN_FAIL("dense forward: B and N must be positive");
+    // h_dim = e_dim below 48: the tensors' channels are padded with zeros on the way in, h_out is cut on the way out
+    const int d = h->model_dim;
+    const size_t pairs = (size_t)B * N * N, atoms = (size_t)B * N;
+    std::vector<float> ph, pe, po;
+    pad_channels(hh, mode == 0 ? pairs : atoms, d, ph);
+    pad_channels(e, pairs, d, pe);
+    if (mode != 1) return dense_host_48(h, B, N, mode, ph.data(), pe.data(), x, q, mask, out);
+    po.resize(atoms * EPNN_EDIM);
+    if (dense_host_48(h, B, N, mode, ph.data(), pe.data(), x, q, mask, po.data())) return 1;
+    for (size_t r = 0; r < atoms; ++r) memcpy(out + r * (size_t)d, po.data() + r * EPNN_EDIM, (size_t)d * sizeof(float));
+    return 0;
+}
+static int dense_host_48(epnn_handle *h, int B, int N, int mode, const float *hh, const float *e, const float *x,
+                         const float *q, const float *mask, float *out) {
     HIPCHK(hipSetDevice(h->device));
     const int nx = h->cfg.nx;
     const size_t pairs = (size_t)B * N * N, atoms = (size_t)B * N;
@@ -263,6 +286,8 @@ extern "C" int epnn_model_forward_dense(epnn_handle *h, int B, int N, const floa
 extern "C" int epnn_model_forward_dense_dev(epnn_handle *h, int B, int N, const float *d_h_inp, const float *d_e_inp,
                                             const float *d_x_inp, const float *d_q_inp, const float *d_mask_inp,
                                             float *d_q_out) {
+    if (h && h->model_dim != EPNN_EDIM)
+        EPNN_FAIL("epnn_model_forward_dense_dev: device tensors are read as they are, with %d channels; a model with h_dim = %d goes through epnn_model_forward_dense", EPNN_EDIM, h->model_dim);
     return dense_dev(h, B, N, 0, d_h_inp, d_e_inp, d_x_inp, d_q_inp, d_mask_inp, d_q_out);
 }
 extern "C" int epnn_gnn_forward(epnn_handle *h, int B, int N, const float *hin, const float *e, const float *x,

@@ -671,7 +671,7 @@ extern "C" int epnn_edges(epnn_handle *h, int n, const float *xyz, float *e_out)
     if (!h || !xyz || !e_out || n < 1) EPNN_FAIL("epnn_edges: bad argument");
     HIPCHK(hipSetDevice(h->device));
     if (h->pending.active && finish_forward(h)) return 1;
-    return edges_impl(h, n, xyz, h->cfg.e_dim, (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), e_out, nullptr);
+    return edges_impl(h, n, xyz, h->model_dim, (double)h->cfg.cutoff, (double)h->cfg.eta, h->d_mu.as<double>(), e_out, nullptr);
 }
 
 // get_init_edges with the reference's own parameters (charge_gn.py:122: num, and the constants 3.0 / 2.0 of :148-161 as

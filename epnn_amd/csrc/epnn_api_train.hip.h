@@ -81,8 +81,36 @@ extern "C" int epnn_train_init(epnn_handle *h, float lr, float beta1, float beta
     if (train_quiesce(h)) return 1;
     return train_init(h, lr, beta1, beta2, eps);
 }
+// A model with h_dim below 48 (epnn_host.h: model_dim): where the MODEL's parameters -- Keras order, the model's own shapes -- sit
+// in the flat vector of the padded layers the handle trains (the padding's gradients are zero and are not part of the interface).
+static void model_flat_index(epnn_handle *h, std::vector<int> &idx) {
+    TrainState ts;
+    train_layout(h, &ts);
+    idx.clear();
+    auto add = [&](const TDense &d, const HostDense &hd, int which, int layer) {
+        ModelMaps M;
+        model_maps(h, which, layer, hd, M);
+        for (int r : M.rows)
+            for (int c : M.cols) idx.push_back(d.offW + r * d.n_out + c);
+        for (int c : M.cols) idx.push_back(d.offB + c);
+    };
+    if (upd_is_generic(h, &ts))
+        for (size_t l = 0; l < h->updg.size(); ++l) add(ts.updv[l], h->updg[l], EPNN_W_UPD, (int)l);
+    else
+        for (int l = 0; l < 3; ++l) add(ts.upd[l], h->upd[l], EPNN_W_UPD, l);
+    for (int t = 0; t < h->cfg.T; ++t)
+        for (int l = 0; l < 3; ++l) add(ts.msg[t][l], h->msg[t][l], EPNN_W_MSG, l);
+    for (int t = 0; t < h->cfg.T; ++t)
+        for (int l = 0; l < 3; ++l) add(ts.pas[t][l], h->pas[t][l], EPNN_W_PAS, l);
+}
 extern "C" int epnn_param_count(epnn_handle *h, int64_t *out) {
     if (!h || !out) EPNN_FAIL("epnn_param_count: null argument");
+    if (h->model_dim != EPNN_EDIM) {
+        std::vector<int> idx;
+        model_flat_index(h, idx);
+        *out = (int64_t)idx.size();
+        return 0;
+    }
     TrainState ts;
     train_layout(h, &ts);
     *out = ts.P;
@@ -91,8 +119,18 @@ extern "C" int epnn_param_count(epnn_handle *h, int64_t *out) {
 extern "C" int epnn_get_gradients(epnn_handle *h, float *out, int64_t count) {
     if (!h || !out) EPNN_FAIL("epnn_get_gradients: null argument");
     TrainState *ts = train_state(h);
-    if (!ts->ready || count != ts->P) EPNN_FAIL("epnn_get_gradients: training not initialised or wrong count (%d parameters)", ts->P);
     HIPCHK(hipSetDevice(h->device));
+    if (h->model_dim != EPNN_EDIM) {
+        std::vector<int> idx;
+        model_flat_index(h, idx);
+        if (!ts->ready || count != (int64_t)idx.size()) EPNN_FAIL("epnn_get_gradients: training not initialised or wrong count (%zu parameters)", idx.size());
+        std::vector<float> flat(ts->P);
+        HIPCHK(hipMemcpyAsync(flat.data(), ts->grad.p, (size_t)ts->P * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (size_t k = 0; k < idx.size(); ++k) out[k] = flat[idx[k]];
+        return 0;
+    }
+    if (!ts->ready || count != ts->P) EPNN_FAIL("epnn_get_gradients: training not initialised or wrong count (%d parameters)", ts->P);
     HIPCHK(hipMemcpyAsync(out, ts->grad.p, (size_t)ts->P * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -100,8 +138,18 @@ extern "C" int epnn_get_gradients(epnn_handle *h, float *out, int64_t count) {
 extern "C" int epnn_set_gradients(epnn_handle *h, const float *in, int64_t count) {
     if (!h || !in) EPNN_FAIL("epnn_set_gradients: null argument");
     TrainState *ts = train_state(h);
-    if (!ts->ready || count != ts->P) EPNN_FAIL("epnn_set_gradients: training not initialised or wrong count (%d parameters)", ts->P);
     HIPCHK(hipSetDevice(h->device));
+    if (h->model_dim != EPNN_EDIM) {
+        std::vector<int> idx;
+        model_flat_index(h, idx);
+        if (!ts->ready || count != (int64_t)idx.size()) EPNN_FAIL("epnn_set_gradients: training not initialised or wrong count (%zu parameters)", idx.size());
+        std::vector<float> flat(ts->P, 0.f);
+        for (size_t k = 0; k < idx.size(); ++k) flat[idx[k]] = in[k];
+        HIPCHK(hipMemcpyAsync(ts->grad.p, flat.data(), (size_t)ts->P * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    if (!ts->ready || count != ts->P) EPNN_FAIL("epnn_set_gradients: training not initialised or wrong count (%d parameters)", ts->P);
     HIPCHK(hipMemcpyAsync(ts->grad.p, in, (size_t)ts->P * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -253,6 +301,13 @@ static int train_step_dense_impl(epnn_handle *h, int B, int N, const float *h_in
 extern "C" int epnn_train_step_dense(epnn_handle *h, int B, int N, const float *h_inp, const float *e_inp, const float *x_inp,
                                      const float *q_inp, const float *mask_inp, const float *y, float *pred_out,
                                      float *loss_out, int apply) {
+    std::vector<float> ph, pe;
+    if (h && h->model_dim != EPNN_EDIM && h_inp && e_inp && B > 0 && N > 0) {      // h_dim = e_dim below 48: zero channels added (epnn_host.h)
+        pad_channels(h_inp, (size_t)B * N * N, h->model_dim, ph);
+        pad_channels(e_inp, (size_t)B * N * N, h->model_dim, pe);
+        h_inp = ph.data();
+        e_inp = pe.data();
+    }
     if (!train_step_guarded(h, apply)) return train_step_dense_impl(h, B, N, h_inp, e_inp, x_inp, q_inp, mask_inp, y, pred_out, loss_out, apply);
     h->guard_pending = true;
     return comm_guard_exit(h, train_step_dense_impl(h, B, N, h_inp, e_inp, x_inp, q_inp, mask_inp, y, pred_out, loss_out, apply), "train step (gradient all-reduce)");

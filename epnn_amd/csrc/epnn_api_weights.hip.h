@@ -129,6 +129,33 @@ static HostDense *find_layer(epnn_handle *h, int which, int t, int layer) {
     return nullptr;
 }
 
+// A model whose h_dim = e_dim = d is below the kernels' 48 (epnn_host.h: model_dim): where the rows / columns of the MODEL's Dense
+// layer (which, layer) sit in the padded layer the handle holds.  Inputs of a pair MLP are [x_i, h_i, q_i, x_j, h_j, q_j, e]
+// (charge_gn.py:61-64, 103-107), of the update MLP [h, messages] (:71), its output is h (:73).
+struct ModelMaps { std::vector<int> rows, cols; };
+static void model_maps(const epnn_handle *h, int which, int layer, const HostDense &D, ModelMaps &M) {
+    const int d = h->model_dim, nx = h->cfg.nx, F = nx + EPNN_EDIM + 1;
+    M.rows.clear();
+    M.cols.clear();
+    const bool first = layer == 0;
+    const bool last_upd = which == EPNN_W_UPD && layer == (h->upd_generic ? (int)h->updg.size() - 1 : 2);
+    if (d != EPNN_EDIM && first && which != EPNN_W_UPD) {
+        for (int side = 0; side < 2; ++side) {
+            for (int k = 0; k < nx; ++k) M.rows.push_back(side * F + k);
+            for (int k = 0; k < d; ++k) M.rows.push_back(side * F + nx + k);
+            M.rows.push_back(side * F + nx + EPNN_EDIM);
+        }
+        for (int k = 0; k < d; ++k) M.rows.push_back(2 * F + k);
+    } else if (d != EPNN_EDIM && first) {
+        for (int k = 0; k < d; ++k) M.rows.push_back(k);
+        for (int k = 0; k < D.n_in - EPNN_EDIM; ++k) M.rows.push_back(EPNN_EDIM + k);
+    } else {
+        for (int k = 0; k < D.n_in; ++k) M.rows.push_back(k);
+    }
+    const int nc = d != EPNN_EDIM && last_upd ? d : D.n_out;
+    for (int k = 0; k < nc; ++k) M.cols.push_back(k);
+}
+
 static int finish_forward(epnn_handle *h);
 extern "C" int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_t *widths) {
     if (!h || !widths) EPNN_FAIL("epnn_set_update_layers: null argument");
@@ -169,8 +196,10 @@ extern "C" int epnn_set_update_layers(epnn_handle *h, int n_hidden, const int32_
 extern "C" int epnn_weight_shape(epnn_handle *h, int which, int t, int layer, int32_t *n_in, int32_t *n_out) {
     HostDense *d = find_layer(h, which, t, layer);
     if (!d) EPNN_FAIL("epnn_weight_shape: bad (which=%d, t=%d, layer=%d)", which, t, layer);
-    if (n_in) *n_in = d->n_in;
-    if (n_out) *n_out = d->n_out;
+    ModelMaps M;
+    model_maps(h, which, layer, *d, M);
+    if (n_in) *n_in = (int)M.rows.size();
+    if (n_out) *n_out = (int)M.cols.size();
     return 0;
 }
 
@@ -178,8 +207,19 @@ extern "C" int epnn_set_weights(epnn_handle *h, int which, int t, int layer, con
     HostDense *d = find_layer(h, which, t, layer);
     if (!d || !kernel || !bias) EPNN_FAIL("epnn_set_weights: bad (which=%d, t=%d, layer=%d) or null pointer", which, t, layer);
     if (h->train) { if (train_sync_to_host(h)) return 1; train_state(h)->ready = false; }   // masters are stale now
-    memcpy(d->W.data(), kernel, d->W.size() * sizeof(float));
-    memcpy(d->b.data(), bias, d->b.size() * sizeof(float));
+    if (h->model_dim == EPNN_EDIM) {
+        memcpy(d->W.data(), kernel, d->W.size() * sizeof(float));
+        memcpy(d->b.data(), bias, d->b.size() * sizeof(float));
+    } else {                                      // the model's rows / columns into the zero-padded layer
+        ModelMaps M;
+        model_maps(h, which, layer, *d, M);
+        std::fill(d->W.begin(), d->W.end(), 0.f);
+        std::fill(d->b.begin(), d->b.end(), 0.f);
+        const size_t nc = M.cols.size();
+        for (size_t r = 0; r < M.rows.size(); ++r)
+            for (size_t c = 0; c < nc; ++c) d->W[(size_t)M.rows[r] * d->n_out + M.cols[c]] = kernel[r * nc + c];
+        for (size_t c = 0; c < nc; ++c) d->b[M.cols[c]] = bias[c];
+    }
     h->weights_dirty = true;
     return 0;
 }
@@ -188,8 +228,19 @@ extern "C" int epnn_get_weights(epnn_handle *h, int which, int t, int layer, flo
     HostDense *d = find_layer(h, which, t, layer);
     if (!d) EPNN_FAIL("epnn_get_weights: bad (which=%d, t=%d, layer=%d)", which, t, layer);
     if (train_sync_to_host(h)) return 1;
-    if (kernel) memcpy(kernel, d->W.data(), d->W.size() * sizeof(float));
-    if (bias) memcpy(bias, d->b.data(), d->b.size() * sizeof(float));
+    if (h->model_dim == EPNN_EDIM) {
+        if (kernel) memcpy(kernel, d->W.data(), d->W.size() * sizeof(float));
+        if (bias) memcpy(bias, d->b.data(), d->b.size() * sizeof(float));
+        return 0;
+    }
+    ModelMaps M;
+    model_maps(h, which, layer, *d, M);
+    const size_t nc = M.cols.size();
+    if (kernel)
+        for (size_t r = 0; r < M.rows.size(); ++r)
+            for (size_t c = 0; c < nc; ++c) kernel[r * nc + c] = d->W[(size_t)M.rows[r] * d->n_out + M.cols[c]];
+    if (bias)
+        for (size_t c = 0; c < nc; ++c) bias[c] = d->b[M.cols[c]];
     return 0;
 }
 

@@ -112,6 +112,11 @@ struct epnn_handle {
     // (epnn_set_update_layers).  Every molecule then takes the tiled path with one kernel per stage, whose update stage is the
     // generic Dense stack of epnn_mlp.hip.h; `upd` above keeps its standard shapes (zeros) so that the fragment packers run unchanged.
     std::vector<HostDense> updg;
+    // make_model(layers, h_dim, ...) with h_dim (= the channels of e, charge_gn.py:376-377) below the 48 the kernels are built for:
+    // the model runs as a 48-channel one whose extra channels of h and e are zero and whose extra kernel rows / columns are zero
+    // (exact: they feed nothing and stay zero through every step, and their gradients are zero).  `cfg` holds the kernels' 48;
+    // model_dim the caller's h_dim: the weight entries and the dense entries translate at the boundary (model_maps, pad_channels).
+    int model_dim = EPNN_EDIM;
     bool upd_generic = false;
     bool upd_wide = false;            // ... of one or two hidden layers of <= 64 units (not embedded): k_wave_forward<.., NRU = 4> takes molecules of <= 32 atoms, `updw` holds the layers zero-padded to [64, 64]
     HostDense updw[3];

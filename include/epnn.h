@@ -34,8 +34,8 @@ typedef struct epnn_handle epnn_handle;
  * 1e-5 of EPN_layer.call (charge_gn.py:90). */
 typedef struct epnn_config {
     int32_t nx;       /* atom feature columns: 9 (infer.py table) or 10 (charge_gn.py table)          */
-    int32_t h_dim;    /* 48 (must equal e_dim, charge_gn.py:377)                                       */
-    int32_t e_dim;    /* 48                                                                            */
+    int32_t h_dim;    /* channels of h, 1..48 (48 in the reference's scripts; must equal e_dim, charge_gn.py:377) */
+    int32_t e_dim;    /* channels of e = Gaussians of get_init_edges, == h_dim                         */
     int32_t T;        /* message / electron passing steps, 1..8                                        */
     int32_t hidden;   /* 32: hidden width of every MLP and the message width (charge_gn.py:52,84,415)  */
     float cutoff;     /* 3.0                                                                           */
@@ -57,9 +57,13 @@ int epnn_device_count(void);
  * ([32, 32], 1) by its own constants (:52, :84), and every width follows h_dim (:369-374).  Every checkpoint it ships and both of
  * its scripts use layers = [32, 32], h_dim = e_dim = 48 (:413-417, infer.py:47-50).
  *   free :  nx in 1..10 (atom feature columns; 9 and 10 are the reference's two tables), T in 1..8, cutoff, eta, near_tol,
+ *           h_dim = e_dim in 1..48 (below 48 the model runs as a 48-channel one: zero channels of h and e, zero rows / columns of
+ *           the kernels that touch them -- exact, the padding feeds nothing, stays zero through every step and has zero gradient;
+ *           every weight, tensor and epnn_edges row at this interface has the MODEL's h_dim channels),
  *           the padded size N and the batch size of every call, every weight value; `layers` of the update MLP (1..7 hidden
  *           layers of 1..256 units each: epnn_set_update_layers) for every inference entry and the training step;
- *   fixed:  hidden == 32 (the reference's own constant for the message / pass MLPs), h_dim == e_dim == 48.
+ *   fixed:  hidden == 32 (the reference's own constant for the message / pass MLPs), h_dim == e_dim (make_model gives e_inp h_dim
+ *           channels, charge_gn.py:377) and at most 48 (the kernels' register / LDS layouts hold 48 channels).
  * epnn_create FAILS (returns non-zero, epnn_last_error says which field) for any other value.  `layers` == [32, 32] runs the
  * kernels DESIGN.md describes, and so does every `layers` of one or two hidden layers of at most 32 units: the library runs it as a
  * [32, 32] model on a zero-padded copy of its weights (units with zero weights and bias feed nothing; a missing second layer is the

@@ -255,11 +255,12 @@ def model_forward(h_inp, e_inp, x_inp, q_inp, mask_inp, weights, dtype=np.float3
     return epn_layer(feats, e_inp, x, q, mask, weights["pas"], dtype, row_block)                 # :387
 
 
-def forward_xyz(xyz, x, Q, weights, N=None, dtype=np.float32, row_block=64, cutoff=3.0, eta=2.0):
-    """Featurise one molecule like gen_padded_init_state and run the model; returns (N,) charges."""
+def forward_xyz(xyz, x, Q, weights, N=None, dtype=np.float32, row_block=64, cutoff=3.0, eta=2.0, h_dim=48):
+    """Featurise one molecule like gen_padded_init_state and run the model; returns (N,) charges.  (h_dim: the channels of h and of
+    e -- make_model gives both h_dim, charge_gn.py:376-377; infer.py:42-43 uses 48.)"""
     n = x.shape[0]
     N = n if N is None else N
-    h_p, e_p, x_p, q_p, mask = dense_inputs(xyz, x, Q, N, cutoff=cutoff, eta=eta)
+    h_p, e_p, x_p, q_p, mask = dense_inputs(xyz, x, Q, N, h_dim=h_dim, e_dim=h_dim, cutoff=cutoff, eta=eta)
     out = model_forward(h_p[None], e_p[None], x_p[None], q_p[None], mask[None], weights, dtype, row_block)
     return out[0, :, 0]
 

@@ -65,19 +65,19 @@ def weights_full():
     return checkpoint.load_epnn_weights(os.path.join(ROOT, "models", "model_weights"))
 
 
-def random_weights(nx, T, seed=0, scale=1.0):
+def random_weights(nx, T, seed=0, scale=1.0, h_dim=48):
     """Glorot-uniform kernels like Keras Dense defaults (charge_gn.py:38-39) but with non-zero biases, so that
     every term of the path is exercised (the shipped decay_model_weights has a collapsed GNN)."""
     rng = np.random.default_rng(seed)
-    F = nx + 49
+    F = nx + h_dim + 1
 
     def dense(i, o, bias=0.1):
         lim = scale * np.sqrt(6.0 / (i + o))
         return (rng.uniform(-lim, lim, (i, o)).astype(np.float32), rng.uniform(-bias, bias, (o,)).astype(np.float32))
 
-    return {"msg": [[dense(2 * F + 48, 32), dense(32, 32), dense(32, 32)] for _ in range(T)],
-            "upd": [dense(80, 32), dense(32, 32), dense(32, 48)],
-            "pas": [[dense(2 * F + 48, 32), dense(32, 32), dense(32, 1, 0.0)] for _ in range(T)]}
+    return {"msg": [[dense(2 * F + h_dim, 32), dense(32, 32), dense(32, 32)] for _ in range(T)],
+            "upd": [dense(h_dim + 32, 32), dense(32, 32), dense(32, h_dim)],
+            "pas": [[dense(2 * F + h_dim, 32), dense(32, 32), dense(32, 1, 0.0)] for _ in range(T)]}
 
 
 def load_molecules(val_dir, names, nx=9):

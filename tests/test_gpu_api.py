@@ -391,8 +391,10 @@ def test_error_behaviour_at_the_boundary(weights_decay):
         eng.train_step_xyz(offsets, xyz, x, Q, np.zeros(int(offsets[-1]), np.float32), N)    # train_init not called
     assert np.array_equal(eng.forward_xyz(offsets, xyz, x, Q, N), good)                     # still usable
     eng.close()
-    with pytest.raises(EpnnError):
-        Engine(nx=9, T=5, h_dim=32)                                 # the kernels are built for h_dim == e_dim == 48
+    with pytest.raises(EpnnError, match="e_dim"):
+        Engine(nx=9, T=5, h_dim=32)                                 # e_dim must equal h_dim (charge_gn.py:377)
+    with pytest.raises(EpnnError, match="1..48"):
+        Engine(nx=9, T=5, h_dim=64, e_dim=64)                       # the kernels hold 48 channels
 
 
 def test_layer_calls_on_a_system_for_the_tiled_kernels():
@@ -580,6 +582,128 @@ def test_mlp_layer_call_with_other_activations(nodes, activation):
         z = np.zeros((1, 4, 4, 48), np.float32)
         with pytest.raises(EpnnError, match="built for 'relu'"):
             gnn(np.zeros((1, 4, 48), np.float32), z, np.zeros((1, 4, 9), np.float32), np.zeros((1, 4, 1), np.float32), np.ones((1, 4, 4, 1), np.float32))
+
+
+@pytest.mark.parametrize("h_dim,layers", [(32, [32, 32]), (20, [64, 32]), (7, [12, 20, 9])])
+def test_make_model_with_other_h_dim(golden_dir, val_dir, val_names, tmp_path, h_dim, layers):
+    """make_model(layers, h_dim, ...) with h_dim below the 48 of the reference's scripts (charge_gn.py:369-377: h_inp and e_inp have
+    h_dim channels, the update MLP ends in h_dim units, gen_padded_init_state(path, h_dim, e_dim) builds e from e_dim Gaussians).
+    The library runs such a model as a 48-channel one with zero channels / zero kernel rows and columns (include/epnn.h): every
+    tensor and weight at the interface has the model's own shapes.  The literal dense call, the compact entry on the three kernel
+    families, GNN_layer.call / EPN_layer.call, get_init_edges, the checkpoint round trip, the training step's gradients (flat vector
+    in the model's shapes) and an optimizer step, each vs the float64 oracle on the model as the reference would build it."""
+    from epnn_amd import charge_gn, synth
+    from epnn_amd._lib import EpnnError
+    from epnn_amd.engine import Engine
+    from oracle import epnn_oracle as orc
+    from oracle import epnn_oracle_train as ot
+    from conftest import load_molecules
+    nx, T = 9, 3
+    w = random_weights(nx, T, seed=41, scale=0.35, h_dim=h_dim)
+    dims = [h_dim + 32] + list(layers) + [h_dim]
+    rng = np.random.default_rng(h_dim)
+    w["upd"] = [(rng.uniform(-1, 1, (i, o)).astype(np.float32) * np.float32(0.35 * np.sqrt(6.0 / (i + o))), rng.uniform(-0.1, 0.1, (o,)).astype(np.float32))
+                for i, o in zip(dims[:-1], dims[1:])]
+    # (1) the literal make_model call on gen_padded_init_state(path, h_dim, h_dim)
+    path = os.path.join(golden_dir, "qm9_small") + "/"
+    x, h, q, e, Q, y, mask, names = charge_gn.gen_padded_init_state(path, h_dim, h_dim, n_elems=nx)
+    assert h.shape[-1] == h_dim and e.shape[-1] == h_dim
+    model = charge_gn.make_model(layers, h_dim, T, nx, x.shape[1])
+    model.set_weights_dict(w)
+    pred = model([h, e, x, q, mask])
+    ref = orc.model_forward(h, e, x, q, mask, w, dtype=np.float64)
+    noise = np.abs(orc.model_forward(h, e, x, q, mask, w, dtype=np.float32) - ref).max()
+    err = np.abs(pred - ref).max()
+    print(f"h_dim {h_dim}, layers {layers}: dense call |dq| {err:.3e} (float32 oracle noise {noise:.3e})")
+    assert err <= max(TOL, 3 * noise)
+    # (2) weights come back in the model's shapes; checkpoint round trip
+    w_back = model.engine().get_weights()
+    for key in ("msg", "pas"):
+        for t in range(T):
+            for (k0, b0), (k1, b1) in zip(w[key][t], w_back[key][t]):
+                assert k0.shape == k1.shape and np.array_equal(k0, k1) and np.array_equal(b0, b1)
+    for (k0, b0), (k1, b1) in zip(w["upd"], w_back["upd"]):
+        assert k0.shape == k1.shape and np.array_equal(k0, k1) and np.array_equal(b0, b1)
+    model.save_weights(str(tmp_path / "m"))
+    again = charge_gn.make_model(layers, h_dim, T, nx, x.shape[1])
+    again.load_weights(str(tmp_path / "m"))
+    assert np.array_equal(again([h, e, x, q, mask]), pred)
+    # (3) get_init_edges of the handle: e_dim Gaussians
+    eng = Engine(nx=nx, T=T, h_dim=h_dim, e_dim=h_dim)
+    eng.set_weights(w)
+    xyz0 = (np.random.default_rng(3).normal(size=(11, 3)) * 1.5).astype(np.float32)
+    e_dev, e_ref = eng.edges(xyz0), orc.get_init_edges(xyz0, num=h_dim)[0]
+    assert e_dev.shape == (11, 11, h_dim) and np.abs(e_dev - e_ref).max() <= 1e-6
+    # (4) the compact entry: QM9-like molecules, a 40-atom and a 150-atom system in one batch
+    mols, offsets, xyz, xx, QQ = load_molecules(val_dir, [nm for nm in val_names][:20], nx)
+    for nb, seed in ((40, 10), (150, 9)):
+        _, bxyz, bx, bQ, _ = synth.box_system(n_atoms=nb, seed=seed)
+        offsets = np.concatenate([offsets, [offsets[-1] + nb]]).astype(np.int32)
+        xyz, xx, QQ = np.concatenate([xyz, bxyz]), np.concatenate([xx, bx]), np.concatenate([QQ, bQ]).astype(np.float32)
+    N = 150
+    got = eng.forward_xyz(offsets, xyz, xx, QQ, N)
+    worst = 0.0
+    for k in range(len(offsets) - 1):
+        sl = slice(offsets[k], offsets[k + 1])
+        r = orc.forward_xyz(xyz[sl], xx[sl], QQ[k], w, N=N, dtype=np.float64, h_dim=h_dim)
+        worst = max(worst, float(np.abs(got[sl] - r[:offsets[k + 1] - offsets[k]]).max()))
+    print(f"h_dim {h_dim}: compact entry worst |dq| {worst:.3e} over {len(offsets) - 1} systems (fused / tiled: {eng.last_stats()[1]} / {eng.last_stats()[2]})")
+    assert worst <= TOL
+    eng.close()
+    # (5) GNN_layer / EPN_layer calls with h of h_dim channels
+    hx, x1, qx, m4 = orc.model_reduce(h, x, q, mask)
+    hx = (rng.normal(size=hx.shape) * 0.2 * (x1[..., :1] != 0)).astype(np.float32)
+    gnn = charge_gn.GNN_layer(charge_gn.MLP_layer, charge_gn.MLP_layer(layers, out_dim=h_dim), T)
+    for t in range(T):
+        gnn.message_fns[t].set_weights(w["msg"][t])
+    gnn.update_fn.set_weights(w["upd"])
+    h_gpu = gnn.call(hx, e, x1, qx, m4)
+    h_ref = orc.gnn_layer(hx, e, x1, qx, m4, w["msg"], w["upd"], dtype=np.float64)
+    h_r32 = orc.gnn_layer(hx, e, x1, qx, m4, w["msg"], w["upd"], dtype=np.float32)
+    assert h_gpu.shape == h_ref.shape == hx.shape
+    assert np.abs(h_gpu - h_ref).max() <= max(TOL, 3 * np.abs(h_r32 - h_ref).max())
+    epn = charge_gn.EPN_layer(charge_gn.MLP_layer, T=T)
+    for t in range(T):
+        epn.pass_fns[t].set_weights(w["pas"][t])
+    q_gpu = epn.call(h_ref.astype(np.float32), e, x1, qx, m4)
+    q_ref = orc.epn_layer(h_ref.astype(np.float32), e, x1, qx, m4, w["pas"], dtype=np.float64)
+    assert np.abs(q_gpu - q_ref).max() <= TOL
+    with pytest.raises(EpnnError, match="out_dim"):
+        charge_gn.GNN_layer(charge_gn.MLP_layer, charge_gn.MLP_layer(layers, out_dim=48), T).call(hx, e, x1, qx, m4)
+    # (6) the training step: gradients in the model's shapes vs the float64 oracle, then an optimizer step
+    yb = (0.05 * rng.normal(size=(x.shape[0], x.shape[1])) * np.asarray(mask).reshape(x.shape[0], x.shape[1], x.shape[1]).max(axis=2)).astype(np.float32)   # (labels of real atoms)
+    loss_ref, pred_ref, g_ref = ot.loss_and_grads(h, e, x, q, mask, yb, w)
+    engt = Engine(nx=nx, T=T, h_dim=h_dim, e_dim=h_dim)
+    engt.set_weights(w)
+    engt.train_init()
+    predt, losst = engt.train_step_dense(h, e, x, q, mask, yb, apply=False)
+    assert np.abs(predt.reshape(pred_ref.shape) - pred_ref).max() < 2e-5 and abs(losst - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    g, gr = engt.get_gradients().astype(np.float64), ot.flatten(g_ref)
+    assert g.shape == gr.shape == (engt.param_count(),)
+    pos, worst = 0, 0.0
+    for m in [w["upd"]] + w["msg"] + w["pas"]:
+        for W_, b_ in m:
+            for arr in (W_, b_):
+                sl = slice(pos, pos + arr.size)
+                scale = np.abs(gr[sl]).max()
+                if scale > 0:
+                    worst = max(worst, np.abs(g[sl] - gr[sl]).max() / scale)
+                pos += arr.size
+    print(f"h_dim {h_dim}: worst per-tensor relative gradient error {worst:.2e}")
+    assert worst <= 2e-4
+    # the compact training entry (its own featurisation with e_dim Gaussians): the same gradient for the same molecules
+    cm, coff, cxyz, cx, cQ = load_molecules(os.path.join(golden_dir, "qm9_small"), [str(nm) for nm in names], nx)
+    cy = np.concatenate([yb[k, :coff[k + 1] - coff[k]] for k in range(len(coff) - 1)])
+    qc, lossc = engt.train_step_xyz(coff, cxyz, cx, cQ, cy, x.shape[1], apply=False)
+    assert abs(lossc - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    gc = engt.get_gradients().astype(np.float64)
+    assert np.abs(gc - gr).max() <= 2e-4 * np.abs(gr).max()
+    engt.set_gradients(g.astype(np.float32))
+    assert np.array_equal(engt.get_gradients(), g.astype(np.float32))
+    engt.train_apply()
+    w_after = engt.get_weights()
+    assert w_after["upd"][-1][0].shape == w["upd"][-1][0].shape and not np.array_equal(w_after["upd"][0][0], w["upd"][0][0])
+    engt.close()
 
 
 @pytest.mark.parametrize("layers", [[16], [64, 32], [8, 24, 40], [24, 8], [48, 48], [64]])
