@@ -256,6 +256,8 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wave_forward2<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             h->wave23_attr = true;
         }
+        // (Pipeline lanes with a side stream each, on the hardware queue next to the lane's own, were measured in round 5: the
+        //  validation batch at eight lanes 187 -> 175 M atoms/s -- the GPU is full either way and the fork / join cost stream time)
         side_mid = h->opt_wave2 != 0 && (P.pair_wgs > 0 || !P.small_order.empty());     // a lone handle (engine.Pipeline sets 0 on its
                                                                                         // lanes) with a launch to run beside
         // (the second stream is created when a handle first needs it: every stream takes one of the process's hardware queues,
@@ -303,8 +305,13 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
         else hipLaunchKernelGGL((k_wave_forward2<2, false>), dim3((unsigned)P.pair_wgs), dim3(128), (size_t)lds2, h->stream, A2, h->wvidx);
         HIPCHK(hipGetLastError());
     }
-    if (side_mid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    if (P.small_order.empty()) return 0;
+    // (the side stream joins BEHIND the launch of the small molecules: until round 5 it joined in front of it, so that only the
+    //  block-per-wavefront launch of a small batch ran beside the 33..64-atom molecules and the two launches of a batch of more
+    //  than 1024 molecules, or with "wave2" > 17, one after the other)
+    if (P.small_order.empty()) {
+        if (side_mid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        return 0;
+    }
     if (h->upd_wide && S.run_gnn) {              // update MLP of up to [64, 64] (the EPN stack alone has no update MLP)
         if (S.d_xyz) hipLaunchKernelGGL((k_wave_forward<true, true, true, 4>), grid, dim3(64), (size_t)lds, h->stream, A, X);
         else if (S.run_epn) hipLaunchKernelGGL((k_wave_forward<true, true, false, 4>), grid, dim3(64), (size_t)lds, h->stream, A, X);
@@ -314,6 +321,7 @@ static int launch_wave(epnn_handle *h, const PairSource &S) {
     else if (S.run_gnn) hipLaunchKernelGGL((k_wave_forward<true, false, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     else hipLaunchKernelGGL((k_wave_forward<false, true, false>), grid, dim3(64), (size_t)lds, h->stream, A, X);
     HIPCHK(hipGetLastError());
+    if (side_mid) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return 0;
 }
 

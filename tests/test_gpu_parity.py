@@ -77,10 +77,13 @@ def test_val_golden_all(gpu_engine_factory, weights_decay, val_dir, val_names, v
     mols, offsets, xyz, x, Q = load_molecules(val_dir, val_names)
     nmid = sum(1 for m in mols if m[1].shape[0] > 32)
     assert nmid == 22 and max(m[1].shape[0] for m in mols) == 38
-    for wave3 in (1, 0):
+    # (third pass, "wave2" = 28: molecules of 17..27 atoms on one wavefront each in a launch of their own, which the launch of the 22
+    #  larger systems runs beside on the handle's side stream)
+    for wave3, wave2 in ((1, -1), (0, -1), (1, 28)):
         eng = gpu_engine_factory(nx=9, T=5)
         eng.set_weights(weights_decay)
         eng.set_option("wave3", wave3)
+        eng.set_option("wave2", wave2)
         q = eng.forward_xyz(offsets, xyz, x, Q, N=41)
         st = eng.last_stats()
         assert (st[1], st[2]) == ((871, 0) if wave3 else (871 - nmid, nmid)), st
@@ -91,7 +94,7 @@ def test_val_golden_all(gpu_engine_factory, weights_decay, val_dir, val_names, v
             worst = max(worst, np.abs(qi - val_gold[i, :n]).max())
             assert abs(float(qi.sum(dtype=np.float64)) - float(m[2])) < 5e-6
             assert np.all(val_gold[i, n:] == 0)      # the reference's padded atoms stay exactly 0
-        print(f"871 systems (wave3 = {wave3}): worst |dq| vs TF golden {worst:.3e}; fused / tiled = {st[1]} / {st[2]}")
+        print(f"871 systems (wave3 = {wave3}, wave2 = {wave2}): worst |dq| vs TF golden {worst:.3e}; fused / tiled = {st[1]} / {st[2]}")
         assert worst <= TOL, worst
 
 
@@ -1109,11 +1112,11 @@ def test_cutoff_and_is_near_edges_on_every_path(gpu_engine_factory):
 @pytest.mark.parametrize("script,seed", [("fuzz_forward.py", 301), ("fuzz_dense.py", 302), ("fuzz_model.py", 303), ("fuzz_train.py", 304), ("fuzz_tiled.py", 305)])
 def test_randomised_sweeps_with_a_fixed_seed(script, seed):
     """The four randomised sweeps against the float64 oracle (tests/fuzz_*.py; they found round 1's only real defect) with a
-    fixed seed and a 20 s budget each, as part of the suite instead of by hand."""
+    fixed seed and a 12 s budget each, as part of the suite instead of by hand."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    out = subprocess.run([sys.executable, os.path.join(here, script), str(seed), "20"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(here, script), str(seed), "12"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "fuzz ok" in out.stdout or "0 not explained by a ReLU kink" in out.stdout, out.stdout[-500:]
 
