@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing of REAL data: the reference's 871-system validation batch of its `mixed` set (molecules of 3..38 atoms, N = 41):
 molecules up to 32 atoms on the two-block fused kernel, 33..48 on three wavefronts of the block-per-wavefront kernel (`--opt wave3=0`: on the tiled
-kernels, as before round 2).   python tools/bench_mixed.py [depth]"""
+kernels, as before round 2).   python tools/bench_mixed.py [depth] [--opt=name:value ...]"""
 import os, sys, tarfile, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +26,7 @@ def timeit(sel, label):
     for _ in range(20): eng.forward_xyz_dev(o, dv[0], dv[1], dv[2], dq, 41)
     eng.sync(); dt = (time.perf_counter() - t0) / 20
     print(f"{label}: {len(m)} systems, {int(o[-1])} atoms: {dt*1e3:.3f} ms per forward = {o[-1]/dt/1e6:.1f} M atoms/s; stats {eng.last_stats()}", flush=True)
-only_pipe = len(sys.argv) > 1
+only_pipe = len(sys.argv) > 1 and not sys.argv[1].startswith("--")
 if not only_pipe: timeit(range(len(mols)), "all")
 if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] <= 32], "n <= 32 (fused kernel)")
 if not only_pipe: timeit([i for i in range(len(mols)) if ns[i] > 32], "n > 32 (three wavefronts per molecule; tiled with wave3=0)")
@@ -36,6 +36,8 @@ from epnn_amd.engine import Pipeline
 gold = np.load(GOLDEN + "/test_pred_charges.npy")
 for depth in ((int(sys.argv[1]),) if only_pipe else (1, 4, 8, 14)):
     pipe = Pipeline(depth=depth, nx=9, T=5); pipe.set_weights(w)
+    for o in [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--opt=")]:      # --opt=name:value on every lane
+        pipe.set_option(o.split(":")[0], int(o.split(":")[1]))
     lanes = []
     for e in pipe.engines:
         dv = [e.to_device(a) for a in (xyz, x, Q)]; lanes.append((e, dv, e.alloc(int(off[-1]) * 4)))
