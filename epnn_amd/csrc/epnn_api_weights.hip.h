@@ -407,6 +407,33 @@ static int pack_weights(epnn_handle *h) {
             return off;
         };
         auto accf = [](int s, int q) { return 16 * (s >> 2) + 4 * q + (s & 3); };       // "acc" K order
+        // a K = 32 kernel as three bf16 pieces per weight (epnn_wave.hip.h, w16_split3: truncation, exact), [2][3][64 lanes][4 dwords]:
+        // lane (q, m) of row block rb: K slots s = 0..7 = input feature accf(s, q), output feature 16 rb + m; dword j = slots 2j | 2j+1 << 16
+        auto frag_bf3 = [&](auto &&fn) {
+            const int off = alloc((size_t)2 * 3 * 64 * 4);
+            for (int rb = 0; rb < 2; ++rb)
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t pc[3][8];
+                    for (int s = 0; s < 8; ++s) {
+                        float v = (float)fn(accf(s, l >> 4), 16 * rb + (l & 15));
+                        for (int k = 0; k < 3; ++k) {
+                            uint32_t bits;
+                            memcpy(&bits, &v, 4);
+                            bits &= 0xffff0000u;
+                            float top;
+                            memcpy(&top, &bits, 4);
+                            pc[k][s] = bits >> 16;
+                            v = v - top;
+                        }
+                    }
+                    for (int k = 0; k < 3; ++k)
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t word = pc[k][2 * j] | pc[k][2 * j + 1] << 16;
+                            memcpy(&buf[off + ((rb * 3 + k) * 64 + l) * 4 + j], &word, 4);
+                        }
+                }
+            return off;
+        };
         auto xq_row = [&](const float *W1, const float *b1, int r0, int phi, int m, double nmrow) -> double {
             if (phi == 0) return nmrow;
             if (phi <= nx) return W1[(size_t)(r0 + phi - 1) * 32 + m];
@@ -471,6 +498,10 @@ static int pack_weights(epnn_handle *h) {
         for (int t = 0; t < T; ++t) {
             WaveGnnPack &G = X.g[t];
             pair_common(h->msg[t], G.we, G.we16, G.w2, G.b2);
+            {
+                const float *W2m = h->msg[t][1].W.data();
+                G.w2b = frag_bf3([&](int in, int out) { return (double)W2m[(size_t)in * 32 + out]; });
+            }
             const float *W3 = h->msg[t][2].W.data(), *b3 = h->msg[t][2].b.data();
             std::vector<double> fold((size_t)32 * HU), cb3(HU);
             for (int k = 0; k < 32; ++k)
@@ -507,6 +538,10 @@ static int pack_weights(epnn_handle *h) {
         for (int t = 0; t < T; ++t) {
             WaveEpnPack &E = X.e[t];
             pair_common(h->pas[t], E.we, E.we16, E.w2, E.b2);
+            {
+                const float *W2p = h->pas[t][1].W.data();
+                E.w2b = frag_bf3([&](int in, int out) { return (double)W2p[(size_t)in * 32 + out]; });
+            }
             const float *W1 = h->pas[t][0].W.data(), *b1 = h->pas[t][0].b.data();
             E.w3 = vec(32, [&](int k) { return (double)h->pas[t][2].W[k]; });
             E.wi = unfolded(W1, b1, 0);

@@ -27,6 +27,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Offsets (in floats) into the packed weight buffer.
 struct PairMlpPack {      // one message_fns[t] / pass_fns[t]
@@ -75,6 +76,7 @@ struct WaveGnnPack {           // GNN step t
     int we;               // [2][12][64]  e order       We_t
     int we16;             // [2][4][64]   k = 4q + s    B^T We_t   (edge features in the 16-dimensional basis)
     int w2;               // [2][8][64]   acc order     W2_t
+    int w2b;              // [2][3][64][4] dwords       W2_t as three bf16 pieces per weight (w16_split3 / pack_bf16x3), K slot s of lane q = acc order
     int b2;               // [32]
     int u1s;              // [2][8][64]   acc order     W3_t Wu1_M
     int cb3, bu1;         // [32]         Wu1_M^T b3_t (times N at run time), bu1
@@ -86,6 +88,7 @@ struct WaveGnnPack {           // GNN step t
 };
 struct WaveEpnPack {           // EPN step t
     int we, w2, b2, w3;   // w3: [32]
+    int w2b;              // [2][3][64][4] dwords: W2_t as three bf16 pieces per weight (see WaveGnnPack)
     int we16;             // [2][4][64]   B^T We_t
     int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features): h given by the caller
     int wif, wjf;         // [2][8+XS][64]   acc rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]: h = nm (Wu3^T u2 + bu3) of the GNN stack

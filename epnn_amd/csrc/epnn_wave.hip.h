@@ -152,6 +152,47 @@ __device__ __forceinline__ f32x4 w16_mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 w16_splat(float v) { return f32x4{v, v, v, v}; }
+// ---- f32-grade products on the bf16 matrix pipe.  x = x1 + x2 + x3 EXACTLY, each piece the upper 16 bits of what is left (8 + 8 + 8
+// mantissa bits: truncation, so the remainders are exact and the third piece fits a bf16); of the nine partial products of two such
+// operands the six largest are summed in f32 -- what is left out is below 2^-24 of the product, the f32 MFMA's own rounding.  One
+// v_mfma_f32_16x16x32_bf16 takes a whole K = 32 in 16 cycles: six of them 96 cycles against 8 x 32 of v_mfma_f32_16x16x4_f32
+// (tools/micro/bf16x6.hip: layout, accuracy against float64 -- 1.3e-6 against the f32 MFMA's 2.4e-6 on |C| ~ 13 -- and timing).
+// Operand layout: lane 16 q + m holds row / column m and the K slots 8 q .. 8 q + 7 as four dwords of bf16 pairs (even slot low).
+typedef __bf16 w16_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 w16_mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w16_bf16x8, a), __builtin_bit_cast(w16_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void w16_split3(const float (&v)[8], u32x4 &p1, u32x4 &p2, u32x4 &p3) {
+    float r1[8], r2[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        r1[s] = v[s] - __uint_as_float(__float_as_uint(v[s]) & 0xffff0000u);
+        r2[s] = r1[s] - __uint_as_float(__float_as_uint(r1[s]) & 0xffff0000u);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {      // v_perm_b32: the upper halves of two floats side by side
+        p1[j] = __builtin_amdgcn_perm(__float_as_uint(v[2 * j + 1]), __float_as_uint(v[2 * j]), 0x07060302u);
+        p2[j] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * j + 1]), __float_as_uint(r1[2 * j]), 0x07060302u);
+        p3[j] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * j + 1]), __float_as_uint(r2[2 * j]), 0x07060302u);
+    }
+}
+// D[rb] += W[rb] z for one column block: w = the kernel's three pieces per row block, z1..z3 the activations' (smallest terms first)
+__device__ __forceinline__ void w16_mm_bf(const u32x4 (&w)[2][3], u32x4 z1, u32x4 z2, u32x4 z3, f32x4 (&d)[2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        d[rb] = w16_mfma_bf(w[rb][0], z3, d[rb]);
+        d[rb] = w16_mfma_bf(w[rb][1], z2, d[rb]);
+        d[rb] = w16_mfma_bf(w[rb][2], z1, d[rb]);
+        d[rb] = w16_mfma_bf(w[rb][0], z2, d[rb]);
+        d[rb] = w16_mfma_bf(w[rb][1], z1, d[rb]);
+        d[rb] = w16_mfma_bf(w[rb][0], z1, d[rb]);
+    }
+}
+// the three-piece kernel of a product: [2 row blocks][3 pieces][64 lanes][4 dwords], one 16-byte load each
+#define W16_LDB(dst, off)                                                                                       \
+    _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                         \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_)                                                     \
+            (dst)[rb_][pc_] = reinterpret_cast<const u32x4 *>(wp + (size_t)(unsigned)(off))[(rb_ * 3 + pc_) * 64 + lane];
 __device__ __forceinline__ f32x4 w16_relu(f32x4 v) {
     return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
 }
@@ -560,7 +601,11 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     // ================================================================== GNN steps (charge_gn.py:60-74)
     if (GNN) {
         f32x4 P0[2], P1[2], U0[NRU], U1[NRU];               // P, u1pre of the two columns
+#ifdef EPNN_SWEEP_F32
         float pb[2][8];
+#else
+        u32x4 pb[2][3];
+#endif
         f32x4 b2v[2];
         // ---- step 0: G rows, then P / R / u1pre from (xq | h)
         {
@@ -569,7 +614,11 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             W16_LDX(wc, X.wj0, 2, EPNN_XS, EPNN_XS + 12, 0);
             WAVE_FENCE();
             gtiles();
+#ifdef EPNN_SWEEP_F32
             W16_LD(pb, X.g[0].w2, 2, 8);
+#else
+            W16_LDB(pb, X.g[0].w2b);
+#endif
             vec2(X.g[0].b2, b2v);
             WAVE_FENCE();
             f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
@@ -650,10 +699,19 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                         Sc[1] += w16_relu(dp[1]);
                         const f32x4 za = w16_relu((w16_cat(Pc[0], Pc[1]) + o_.r0) + o_.g0), zb = w16_relu((w16_cat(Pc[2], Pc[3]) + o_.r1) + o_.g1);
                         const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+#ifdef EPNN_SWEEP_F32
                         dp[0] = b2v[0];
                         dp[1] = b2v[1];
                         WAVE_FENCE();
                         w16_mm<2, 8>(pb, z, dp);
+#else
+                        u32x4 z1, z2, z3;
+                        w16_split3(z, z1, z2, z3);
+                        dp[0] = b2v[0];
+                        dp[1] = b2v[1];
+                        WAVE_FENCE();
+                        w16_mm_bf(pb, z1, z2, z3, dp);
+#endif
                     };
                     // the block's last tile (weight w): the pending tile first, then its own contribution at once
                     auto tile_w = [&](const f32x2 (&Pc)[4], f32x4 (&Sc)[2], const Ops &o_, float w, f32x4 (&dp)[2]) {
@@ -841,7 +899,11 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
                 if constexpr (NRU != 2) { W16_LD(wu, M.pu1, NRU, KU); }
+#ifdef EPNN_SWEEP_F32
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
+#else
+                W16_LDB(pb, X.g[t + 1].w2b);
+#endif
                 vec2(X.g[t + 1].b2, b2v);
                 WAVE_FENCE();
                 float bin0[KU], bin1[KU];
@@ -929,9 +991,14 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
             }
+#ifdef EPNN_SWEEP_F32
             float pb[2][8];
-            f32x4 b2v[2], w3[2];
             W16_LD(pb, M.w2, 2, 8);
+#else
+            u32x4 pb[2][3];
+            W16_LDB(pb, M.w2b);
+#endif
+            f32x4 b2v[2], w3[2];
             vec2(M.b2, b2v);
             vec2(M.w3, w3);
             wave_sync_all();
@@ -975,9 +1042,18 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     const float zu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
                     const float zv[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
                     f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
+#ifdef EPNN_SWEEP_F32
                     WAVE_FENCE();                                          // (the element-wise work first: see the sweep's tile)
                     w16_mm<2, 8>(pb, zu, au);
                     w16_mm<2, 8>(pb, zv, av);
+#else
+                    u32x4 zu1, zu2, zu3, zv1, zv2, zv3;
+                    w16_split3(zu, zu1, zu2, zu3);
+                    w16_split3(zv, zv1, zv2, zv3);
+                    WAVE_FENCE();                                          // (the element-wise work first: see the sweep's tile)
+                    w16_mm_bf(pb, zu1, zu2, zu3, au);
+                    w16_mm_bf(pb, zv1, zv2, zv3, av);
+#endif
                     WAVE_FENCE();                                          // (... and the block's element-wise tail behind ALL of them)
                     float fd = 0.f;                                    // w3 . (relu(u) - relu(v)) over this lane's 8 features
 #pragma unroll

@@ -289,7 +289,11 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     // ================================================================== GNN steps (charge_gn.py:60-74)
     {
         f32x4 P[2], U[2];
+#ifdef EPNN_SWEEP_F32
         float pb[2][8];
+#else
+        u32x4 pb[2][3];                                     // W2 as three bf16 pieces (k_wave_forward: w16_split3)
+#endif
         f32x4 b2v[2];
         {
             float wa[2][EPNN_XS], wc[2][EPNN_XS];
@@ -297,7 +301,11 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
             W16_LDX(wc, X.wj0, 2, EPNN_XS, EPNN_XS + 12, 0);
             WAVE_FENCE();
             gtiles();
+#ifdef EPNN_SWEEP_F32
             W16_LD(pb, X.g[0].w2, 2, 8);
+#else
+            W16_LDB(pb, X.g[0].w2b);
+#endif
             vec2(X.g[0].b2, b2v);
             WAVE_FENCE();
             f32x4 r[2] = {w16_splat(0.f), w16_splat(0.f)};
@@ -359,8 +367,15 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                             const f32x4 za = w16_relu((Pc[0] + o_.r[0]) + o_.g[0]), zb = w16_relu((Pc[1] + o_.r[1]) + o_.g[1]);
                             const float z[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
                             f32x4 d[2] = {b2v[0], b2v[1]};
+#ifdef EPNN_SWEEP_F32
                             WAVE_FENCE();                              // (the element-wise work in front of the MFMAs: see k_wave_forward)
                             w16_mm<2, 8>(pb, z, d);
+#else
+                            u32x4 z1, z2, z3;
+                            w16_split3(z, z1, z2, z3);
+                            WAVE_FENCE();                              // (the element-wise work in front of the MFMAs: see k_wave_forward)
+                            w16_mm_bf(pb, z1, z2, z3, d);
+#endif
 #pragma unroll
                             for (int rb = 0; rb < 2; ++rb) Sc[rb] += o_.w * w16_relu(d[rb]);
                         };
@@ -473,7 +488,11 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                 w16_mm_skip<2, 8 + EPNN_XS, 7 + EPNN_XS>(wbm, in, r, xs3);
                 if (own) { w16_st(Rl + col * EPNN_PST + fo, r[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, r[1]); }
                 if (nxt > 0 && !blk1) { w16_st(P0t + col * EPNN_PST + fo, P[0]); w16_st(P0t + col * EPNN_PST + 16 + fo, P[1]); }
+#ifdef EPNN_SWEEP_F32
                 W16_LD(pb, X.g[t + 1].w2, 2, 8);
+#else
+                W16_LDB(pb, X.g[t + 1].w2b);
+#endif
                 vec2(X.g[t + 1].b2, b2v);
                 WAVE_FENCE();
                 float bin[8];
@@ -511,9 +530,14 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                 w16_mm_skip<2, KS, SK>(wbm, in, d, xs3);
                 if (own) { w16_st(Rl + col * EPNN_PST + fo, d[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, d[1]); }
             }
+#ifdef EPNN_SWEEP_F32
             float pb[2][8];
-            f32x4 b2v[2], w3[2];
             W16_LD(pb, M.w2, 2, 8);
+#else
+            u32x4 pb[2][3];
+            W16_LDB(pb, M.w2b);
+#endif
+            f32x4 b2v[2], w3[2];
             vec2(M.b2, b2v);
             vec2(M.w3, w3);
             sync();                                         // P / R rows (and, in step 0, the cleared transfer matrix) are in place
@@ -552,9 +576,18 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                     const float zu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
                     const float zv[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
                     f32x4 au[2] = {b2v[0], b2v[1]}, av[2] = {b2v[0], b2v[1]};
+#ifdef EPNN_SWEEP_F32
                     WAVE_FENCE();
                     w16_mm<2, 8>(pb, zu, au);
                     w16_mm<2, 8>(pb, zv, av);
+#else
+                    u32x4 zu1, zu2, zu3, zv1, zv2, zv3;
+                    w16_split3(zu, zu1, zu2, zu3);
+                    w16_split3(zv, zv1, zv2, zv3);
+                    WAVE_FENCE();
+                    w16_mm_bf(pb, zu1, zu2, zu3, au);
+                    w16_mm_bf(pb, zv1, zv2, zv3, av);
+#endif
                     WAVE_FENCE();
                     float fd = 0.f;
 #pragma unroll
