@@ -485,8 +485,17 @@ __global__ __launch_bounds__(256) void k_lg_epn_static(LargeArgs L) {
 // tile).  Two partners per trip: the rows of partner j + 1 are fetched while partner j is in the matrix pipe, into the
 // other register set (no copies); the four accumulator chains of a partner (two column blocks x two row blocks) are issued
 // interleaved.
+// the sweep's kernel W2: three bf16 pieces per weight (f32-grade products on the bf16 matrix pipe, epnn_wave.hip.h: w16_split3), or
+// with -DEPNN_SWEEP_F32 (development builds, for comparison) the f32 fragments of v_mfma_f32_16x16x4_f32
+#ifdef EPNN_SWEEP_F32
+typedef float LgW2[2][8];
+#define LG_LDW2(dst, off) W16_LD(dst, off, 2, 8)
+#else
+typedef u32x4 LgW2[2][3];
+#define LG_LDW2(dst, off) W16_LDB(dst, off)
+#endif
 template <bool TWO>
-__device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const float (&pb)[2][8],
+__device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const LgW2 (&pb),
                                               const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
     auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
     auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
@@ -514,6 +523,7 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
         const float z1[8] = {zc[0], zc[1], zc[2], zc[3], zd[0], zd[1], zd[2], zd[3]};
         dp0[0] = yy[0]; dp0[1] = yy[1];
         dp1[0] = yy[0]; dp1[1] = yy[1];
+#ifdef EPNN_SWEEP_F32
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -524,6 +534,14 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
                 dp1[1] = w16_mfma(pb[1][k], z1[k], dp1[1]);
             }
         }
+#else
+        u32x4 a1, a2, a3, b1, b2, b3;
+        w16_split3(z0, a1, a2, a3);
+        if (TWO) w16_split3(z1, b1, b2, b3);
+        __builtin_amdgcn_sched_barrier(0);
+        w16_mm_bf(pb, a1, a2, a3, dp0);
+        if (TWO) w16_mm_bf(pb, b1, b2, b3, dp1);
+#endif
     };
     f32x4 na[2], ya[2], nb[2], yb[2];
     fetch(0, na, ya);
@@ -544,6 +562,11 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
         S1[1] += w16_relu(dp1[1]);
     }
 }
+#ifdef EPNN_SWEEP_F32
+static inline int lg_w2_off(const epnn_handle *h, int t) { return h->wvidx.g[t].w2; }
+#else
+static inline int lg_w2_off(const epnn_handle *h, int t) { return h->wvidx.g[t].w2b; }
+#endif
 __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, float *Ns, float *Ys) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15, fo = 4 * q;
     const int4 tk = L.stasks[blockIdx.x];            // first atile, #atiles, j_lo, j_hi (global atom indices)
@@ -557,8 +580,8 @@ __device__ __forceinline__ void lg_sweep_body(const LargeArgs &L, int w2off, flo
     const int po = 16 * (q & 1) + 4 * (q >> 1);
     const int c0 = n16 < tl.y ? n16 : 0, c1 = 16 + n16 < tl.y ? 16 + n16 : 0;
     f32x4 P0[2], P1[2], S0[2], S1[2];
-    float pb[2][8];
-    W16_LD(pb, w2off, 2, 8);
+    LgW2 pb;
+    LG_LDW2(pb, w2off);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         P0[rb] = w16_ld(L.P + (size_t)(tl.x + c0) * 32 + po + 8 * rb);
@@ -740,8 +763,8 @@ __global__ __launch_bounds__(256) void k_lg_sweep2(LargeArgs L, int w2off, PairM
     const int po = 16 * (q & 1) + 4 * (q >> 1);                       // (operand order of P / Nn rows: see lg_sweep_body)
     const int c0 = n16 < tl.y ? n16 : 0, c1 = 16 + n16 < tl.y ? 16 + n16 : 0;
     f32x4 P0[2], P1[2], S0[2], S1[2];
-    float pb[2][8];
-    W16_LD(pb, w2off, 2, 8);
+    LgW2 pb;
+    LG_LDW2(pb, w2off);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         P0[rb] = w16_ld(L.P + (size_t)(tl.x + c0) * 32 + po + 8 * rb);
@@ -1849,8 +1872,8 @@ static int launch_large_body(epnn_handle *h, const float *d_x, const float *d_Q,
         const bool ty = types && t == 0;
         const bool sweep = !ty && L.nstasks + L.nstasks2 > 0;
         if (sweep) {
-            if (L.nstasks > 0) hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), sweep_lds, st, L, h->wvidx.g[t].w2, h->widx.msg[t], 1);
-            if (L.nstasks2 > 0) hipLaunchKernelGGL(k_lg_sweep2, dim3((unsigned)L.nstasks2), dim3(256), sweep2_lds, st, L, h->wvidx.g[t].w2, h->widx.msg[t], L.nstasks > 0 ? 0 : 1);
+            if (L.nstasks > 0) hipLaunchKernelGGL(k_lg_sweep, dim3((unsigned)L.nstasks), dim3(256), sweep_lds, st, L, lg_w2_off(h, t), h->widx.msg[t], 1);
+            if (L.nstasks2 > 0) hipLaunchKernelGGL(k_lg_sweep2, dim3((unsigned)L.nstasks2), dim3(256), sweep2_lds, st, L, lg_w2_off(h, t), h->widx.msg[t], L.nstasks > 0 ? 0 : 1);
         }
         else if (!(ty && step0_pairs_done)) hipLaunchKernelGGL(k_lg_pairs, dim3(gPT), dim3(256), 0, st, L, h->widx.msg[t]);
         if (!split) {
