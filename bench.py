@@ -28,8 +28,10 @@ warm-up steps (--no-extras) they read 182-185 M atoms/s instead of 194-197 M (`o
 
 Prints ONE JSON line on rank 0.  Besides the contract's fields:
   roofline.*          dominant kernel k_wave_forward; `frac` is ALGORITHMIC flops of the launches per second of
-                      the timed region / f32 MFMA peak; `pipe_frac` the same with the flops the kernel really executes
-                      (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512); `single_launch` = a launch with the GPU to itself
+                      the timed region / `peak`, the bound of the two matrix pipes the kernel uses (f32 MFMA 157.3 TFLOP/s; the pair
+                      MLPs' second Dense as six bf16 MFMAs per f32-grade product, 2500 / 6: `peak_basis`); `pipe_frac` = the pipes'
+                      time for the MFMA flops the kernel really executes (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 / _BF16 x 512) over the
+                      time taken; `frac_vs_f32_mfma_peak` = against 157.3 alone; `single_launch` = a launch with the GPU to itself
                       (65536 molecules, depth 1: flops / hipEvent duration IS its fraction, reproducible from
                       profiles/r05_big_launch_kernel_stats.csv)
   parity              max |dq| of the reference's 871 validation systems against the TensorFlow predictions it stored for them
@@ -55,7 +57,12 @@ if ROOT not in sys.path:
 # (GPU_MAX_HW_QUEUES is decided in main(), before anything initialises HIP in this process: one hardware queue per batch in
 # flight, fewer when ranks share a device)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
+# Matrix-pipe peaks (MI355X_MICROARCH.md, dense): f32 MFMA 157.3 TFLOP/s, bf16 MFMA 2500.  The kernels run the pair MLPs' second
+# Dense -- 41 % of the bench batch's algorithmic flops -- on the bf16 pipe as SIX bf16 products of exact three-piece splits
+# (f32-grade): an f32-grade flop there is priced at 2500 / 6 = 416.7 TFLOP/s, and `roofline.peak` is the bound
+# of the two pipes together, total flops / (f32 flops / 157.3 + second-Dense flops / 416.7) (synth.mixed_pipe_peak).
+FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0
 KNAME = "k_wave_forward<true,true,true>"
 PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_bench.json")
 
@@ -156,6 +163,7 @@ def collect_pmc(args):
     base = os.path.join(ROOT, "gpurun_out", "pmc_r05")
     passes = [("fetch", "FETCH_SIZE", args.depth), ("write", "WRITE_SIZE", args.depth),
               ("mops", "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE", 1),
+              ("mopsbf", "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA", 1),
               ("lds", "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY", 1)]
     vals = {}
     for name, counters, depth in passes:
@@ -182,6 +190,8 @@ def collect_pmc(args):
         out["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     if "SQ_INSTS_VALU_MFMA_MOPS_F32" in vals:
         out["executed_gflop_per_launch"] = vals["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0 / 1e9
+    if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in vals:
+        out["executed_bf16_gflop_per_launch"] = vals["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0 / 1e9
     if "SQ_LDS_BANK_CONFLICT" in vals and vals.get("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_frac"] = vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and vals.get("GRBM_GUI_ACTIVE"):
@@ -224,9 +234,10 @@ def real_data_rate(depth, device=0):
     rpipe.sync()
     v_dt = (time.perf_counter() - t1) / nrep
     v_flops = synth.algorithmic_flops(np.diff(v_off), int(vl[0][0].last_stats()[0]))
+    v_peak, _ = synth.mixed_pipe_peak(np.diff(v_off), int(vl[0][0].last_stats()[0]))
     rpipe.close()
     print(json.dumps({"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
-                      "algorithmic_gflop_per_batch": v_flops / 1e9, "frac": v_flops / v_dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                      "algorithmic_gflop_per_batch": v_flops / 1e9, "frac": v_flops / v_dt / 1e12 / v_peak, "peak": v_peak,
                       "workload": f"the reference's {len(mols)}-system validation split of `mixed` (3..38 atoms, {int(v_off[-1])} atoms), "
                                   f"N = 41, device-resident, {len(vl)} batches in flight, in a process of its own"}))
 
@@ -384,6 +395,7 @@ def main():
     assert np.abs(sums - Q).max() < 1e-4, np.abs(sums - Q).max()
     ns = np.diff(offsets)
     flops = synth.algorithmic_flops(ns, int(stats[0]))
+    peak, bf_share = synth.mixed_pipe_peak(ns, int(stats[0]))
 
     def timed_steps():
         """W warm-up steps, barrier, K timed steps, barrier -> seconds of the timed region on this rank"""
@@ -519,7 +531,7 @@ def main():
         extras["single_launch"] = {"molecules": B * rep, "launches": nbig, "kernel_ms_avg": big_ms,
                                    "algorithmic_gflop_per_launch": flops * rep / 1e9,
                                    "achieved": flops * rep / (big_ms * 1e-3) / 1e12,
-                                   "frac": flops * rep / (big_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                   "frac": flops * rep / (big_ms * 1e-3) / 1e12 / peak,
                                    "atoms_per_s": A * rep / (big_ms * 1e-3)}
     q_after = d_q.download((A,))
     assert np.array_equal(q_after, q)                       # the timed steps produced the charges that were checked
@@ -611,20 +623,30 @@ def main():
         pmc = committed_pmc(workload)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         executed = pmc.get("executed_gflop_per_launch") if pmc else None
-        roof = {"bound": "mfma", "kernel": KNAME, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "frac_basis": "algorithmic flops (SURVEY section 8d); the matrix pipe's own utilisation (executed MFMA flops, PMC) is pipe_frac",
+        executed_bf = pmc.get("executed_bf16_gflop_per_launch") if pmc else None
+        # time the two matrix pipes need for what the kernel executes on them (PMC), per launch
+        pipe_s = (executed * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + executed_bf * 1e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12)) if executed is not None and executed_bf is not None else None
+        roof = {"bound": "mfma", "kernel": KNAME, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "peak_basis": f"both matrix pipes: f32 MFMA {FP32_MFMA_PEAK_TFLOPS} TFLOP/s for {1 - bf_share:.3f} of the algorithmic flops, the pair MLPs' second Dense "
+                              f"({bf_share:.3f}) as six bf16 MFMAs per f32-grade product at {BF16_MFMA_PEAK_TFLOPS:.0f} / 6 = {BF16_MFMA_PEAK_TFLOPS / 6:.1f}; "
+                              "peak = total / (f32 part / 157.3 + second-Dense part / 416.7)",
+                "frac_vs_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "frac_basis": "algorithmic flops (SURVEY section 8d); the matrix pipes' own utilisation (executed MFMA flops of either kind, PMC) is pipe_frac",
                 "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                 "traffic_source": (pmc["command"] + f"; kernel source {pmc['kernel_source_sha']}; profiles/r05_pmc_bench.json") if pmc else None,
                 "algorithmic_gflop_per_launch": flops / 1e9,
                 "executed_gflop_per_launch": executed,
-                "pipe_frac": (executed * 1e9 / (k_ms / in_flight * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if executed else None,
+                "executed_bf16_gflop_per_launch": executed_bf,
+                "pipe_frac": (pipe_s / (k_ms / in_flight * 1e-3)) if pipe_s else None,
                 "kernel_ms_avg": k_ms, "launches_in_flight": in_flight,
-                "frac_of_one_launch_sharing_the_gpu": flops / (k_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "frac_of_one_launch_sharing_the_gpu": flops / (k_ms * 1e-3) / 1e12 / peak,
                 "note": "frac = algorithmic flops per launch / (kernel_ms_avg / launches_in_flight) / peak = flops x launches / "
                         "wall time of the timed region: `launches_in_flight` launches of this kernel share the GPU, so flops / "
                         "kernel_ms_avg alone (frac_of_one_launch_sharing_the_gpu, what a rocprofv3 --stats average of THIS command "
                         "gives) is one launch's share of the machine; single_launch is the same kernel with the GPU to itself; "
-                        "pipe_frac counts the MFMA flops the kernel executes (PMC) instead of the algorithmic ones",
+                        "pipe_frac = the time the two matrix pipes need for the MFMA flops the kernel executes (PMC: f32 / 157.3 + "
+                        "bf16 / 2500) over the time it takes",
                 "device_ms_per_forward_avg": float(stage[:, 3].mean())}
         if "single_launch" in extras:
             roof["single_launch"] = extras["single_launch"]

@@ -28,7 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 // Offsets (in floats) into the packed weight buffer.
 struct PairMlpPack {      // one message_fns[t] / pass_fns[t]
     int wiF;              // [KA][64]  Wi[2s+hh][c]      (A operand of P^T = Wi^T a^T)

@@ -120,6 +120,25 @@ def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=Fal
     n1, n2 = ns.sum(), (ns * ns).sum()
     gnn = n1 * 2 * F * H + nnz * E * H + n2 * H * H + n1 * H * H + n1 * H * H + n1 * (80 * H + H * H + H * 48)
     epn = n1 * 2 * F * H + (nnz / 2) * (E * H + 2 * H * H + 2 * H)
+    if parts == "pipes":
+        # (f32-MFMA flops, flops of the pair MLPs' second Dense: the kernels run that K = 32 product on the bf16 matrix pipe as six
+        #  bf16 products of exact three-piece splits, f32-grade -- DESIGN.md section 4)
+        dense2 = 2.0 * T * (n2 * H * H + (nnz / 2) * 2 * H * H)
+        return 2.0 * T * (gnn + epn) - dense2, dense2
     if parts:
         return 2.0 * T * gnn, 2.0 * T * epn
     return 2.0 * T * (gnn + epn)
+
+
+# Dense matrix-pipe peaks of MI355X (MI355X_MICROARCH.md): v_mfma_f32_16x16x4_f32 / 32x32x2; v_mfma_f32_16x16x32_bf16 / 32x32x16
+FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0     # an f32-grade product = six bf16 products
+
+
+def mixed_pipe_peak(ns, near_unordered_pairs, nx=9, T=5):
+    """The matrix pipes' bound on the forward, in ALGORITHMIC TFLOP/s: the flops that run as f32 MFMAs at 157.3 TFLOP/s, the pair
+    MLPs' second Dense at 2500 / 6 (six bf16 MFMAs per f32-grade product): peak = total / (f32 / 157.3 + dense2 / 416.7).
+    Returns (peak, share of the algorithmic flops on the bf16 pipe)."""
+    f32, d2 = algorithmic_flops(ns, near_unordered_pairs, nx=nx, T=T, parts="pipes")
+    return (f32 + d2) / (f32 / FP32_MFMA_PEAK_TFLOPS + d2 / BF16X6_PEAK_TFLOPS), d2 / (f32 + d2)

@@ -84,9 +84,10 @@ def main():
     stats = eng.last_stats()
     q = dq.download((A,))
     flops = synth.algorithmic_flops([A], int(stats[0]))
+    peak, bf_share = synth.mixed_pipe_peak([A], int(stats[0]))
     if rank == 0:
       print((f"[{world} processes, rows of atoms partitioned, exchange {how}] " if world > 1 else "") + f"{what}: {A} atoms, {stats[0]} near pairs; {dt_plain*1e3:.3f} ms/forward wall without stage events, {dt*1e3:.3f} with; device stages front/fused/tiled/total ms = {np.round(st,3)}; "
-          f"{A/dt:.3e} atoms/s; algorithmic {flops/1e9:.1f} Gflop -> {flops/(st[3]*1e-3)/1e12:.1f} TFLOP/s; sum q = {q.sum(dtype=np.float64):.6f}", flush=True)
+          f"{A/dt:.3e} atoms/s; algorithmic {flops/1e9:.1f} Gflop -> {flops/(st[3]*1e-3)/1e12:.1f} TFLOP/s = {flops/(st[3]*1e-3)/1e12/peak:.3f} of the two matrix pipes' bound {peak:.1f} ({bf_share:.3f} of the flops on the bf16 pipe at 2500/6); sum q = {q.sum(dtype=np.float64):.6f}", flush=True)
       import json
       # the same facts as ONE JSON line in bench.py's vocabulary (last line of the output)
       print(json.dumps({"metric": "atoms/sec (inference), one large system", "value": A / dt, "unit": "atoms/s", "n_gpus": world,
@@ -94,7 +95,9 @@ def main():
                         "config": {"workload": what, "atoms": A, "pairs_under_cutoff": int(stats[0]), "N": int(N), "weights": "decay_model_weights",
                                    "parallelism": f"rows of atoms partitioned x{world} ({how})" if world > 1 else "one GPU"},
                         "roofline": {"bound": "mfma", "kernel": "k_lg_sweep (all-pairs sum of charge_gn.py:70) + per-step tails", "achieved": flops / (st[3] * 1e-3) / 1e12,
-                                     "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (st[3] * 1e-3) / 1e12 / 157.3, "traffic": None,
+                                     "peak": peak, "unit": "TFLOP/s", "frac": flops / (st[3] * 1e-3) / 1e12 / peak, "traffic": None,
+                                     "peak_basis": f"f32 MFMA 157.3 TFLOP/s for {1 - bf_share:.3f} of the algorithmic flops, the all-pairs Dense ({bf_share:.3f}) as six bf16 MFMAs per f32-grade product at 2500 / 6",
+                                     "frac_vs_f32_mfma_peak": flops / (st[3] * 1e-3) / 1e12 / 157.3,
                                      "algorithmic_gflop_per_forward": flops / 1e9, "device_ms_per_forward": float(st[3]),
                                      "note": "whole forward (hipEvents on the handle's stream), not the sweep kernel alone"}}), flush=True)
     eng.close()

@@ -48,7 +48,8 @@ __global__ void k_check(const float *W, const float *Z, float *C6, float *C32) {
     for (int r = 0; r < 4; ++r) C32[(4 * q + r) * 16 + m] = a32[r];
 }
 // timing: `tiles` dependent-free tiles per wave; MODE 0 = f32 MFMA (16 per tile: 2 row blocks x 8), 1 = bf16x6 incl. the split of z
-template <int MODE>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MODE, int EXTRA = 0>
 __global__ __launch_bounds__(64, 2) void k_time(const float *src, float *dst, int tiles) {
     const int lane = threadIdx.x;
     float z[8], w32[2][8];
@@ -60,6 +61,36 @@ __global__ __launch_bounds__(64, 2) void k_time(const float *src, float *dst, in
         float zz[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) zz[s] = fmaxf(z[s] + S[s >> 2][s & 3] * 1e-9f, 0.f);     // (a dependence on the last tile, like S += relu(acc))
+        if (EXTRA == 1) {
+#pragma unroll
+            for (int s = 0; s < 8; s += 2) {
+                f32x2 a = {zz[s], zz[s + 1]}, b = {z[s], z[s + 1]}, c;
+                asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(c) : "v"(a), "v"(b));
+                asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a) : "v"(c), "v"(b));
+                zz[s] = a[0]; zz[s + 1] = a[1];
+            }
+        } else if (EXTRA == 2) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float c;
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(c) : "v"(zz[s]), "v"(z[s]));
+                asm volatile("v_add_f32 %0, %1, %2" : "=v"(zz[s]) : "v"(c), "v"(z[s]));
+            }
+        } else if (EXTRA == 3) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float c;
+                asm volatile("v_max_f32 %0, %1, %2" : "=v"(c) : "v"(zz[s]), "v"(z[s]));
+                asm volatile("v_max_f32 %0, %1, %2" : "=v"(zz[s]) : "v"(c), "v"(z[s]));
+            }
+        } else if (EXTRA == 4) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float c;
+                asm volatile("v_and_b32 %0, %1, %2" : "=v"(c) : "v"(zz[s]), "v"(z[s]));
+                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(zz[s]) : "v"(c), "v"(zz[s]), "v"(0x07060302u));
+            }
+        }
         f32x4 d[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if (MODE == 0) {
 #pragma unroll
@@ -104,15 +135,20 @@ int main() {
     for (auto &v : s) v = rand() / (float)RAND_MAX - 0.3f;
     hipMemcpy(src, s.data(), 1536 * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode) {
+    const char *names[7] = {"f32 MFMA     ", "bf16x6 + split", "  + 8 v_pk_add_f32 (16 adds)", "  + 16 v_add_f32", "  + 16 v_max_f32", "  + 8 v_and_b32 + 8 v_perm_b32", ""};
+    for (int mode = 0; mode < 6; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k_time<0>, dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
-            else hipLaunchKernelGGL(k_time<1>, dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
+            else if (mode == 1) hipLaunchKernelGGL(k_time<1>, dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
+            else if (mode == 2) hipLaunchKernelGGL((k_time<1, 1>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
+            else if (mode == 3) hipLaunchKernelGGL((k_time<1, 2>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
+            else if (mode == 4) hipLaunchKernelGGL((k_time<1, 3>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
+            else hipLaunchKernelGGL((k_time<1, 4>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             // 2048 wavefronts = 2 per SIMD: cycles per tile and SIMD = ms * clock / (tiles * 2)
-            if (rep) printf("%s: %.3f ms, %.0f cycles per tile and wavefront pair at 2.4 GHz (%.0f per wavefront)\n", mode ? "bf16x6 + split" : "f32 MFMA     ", ms, ms * 1e-3 * 2.4e9 / tiles, ms * 1e-3 * 2.4e9 / tiles / 2);
+            if (rep) printf("%s: %.3f ms, %.0f cycles per tile and wavefront pair at 2.4 GHz (%.0f per wavefront)\n", names[mode], ms, ms * 1e-3 * 2.4e9 / tiles, ms * 1e-3 * 2.4e9 / tiles / 2);
         }
     }
     return 0;

@@ -10,7 +10,7 @@ DEV = os.path.join(ROOT, "tools", "_dev", "libepnn_clocks.so")
 if "--build" in sys.argv or not os.path.exists(DEV):
     os.makedirs(os.path.dirname(DEV), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-mllvm",
-                    "-amdgpu-mfma-vgpr-form", "-DEPNN_TF_CLOCKS", "-shared", "-fPIC", "-o", DEV, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"),
+                    "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DEPNN_TF_CLOCKS", "-shared", "-fPIC", "-o", DEV, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"),
                     "-L/opt/rocm/lib", "-lrccl"], check=True)
     if "--build" in sys.argv: sys.exit(0)
 from epnn_amd import _lib

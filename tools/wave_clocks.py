@@ -20,7 +20,7 @@ if "--lib" in args:
 elif "--build" in args or not os.path.exists(DEV):
     os.makedirs(os.path.dirname(DEV), exist_ok=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffinite-math-only", "-fno-signed-zeros", "-mllvm",
-                    "-amdgpu-mfma-vgpr-form", "-DEPNN_STAMPS"] + (["-DEPNN_STAMPS_INIT"] if INIT else []) + ["-shared", "-fPIC", "-o", DEV, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"),
+                    "-amdgpu-mfma-vgpr-form", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DEPNN_STAMPS"] + (["-DEPNN_STAMPS_INIT"] if INIT else []) + ["-shared", "-fPIC", "-o", DEV, os.path.join(ROOT, "epnn_amd/csrc/epnn_api.hip"),
                     "-L/opt/rocm/lib", "-lrccl"], check=True)
     if "--build" in args:
         sys.exit(0)
