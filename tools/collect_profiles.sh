@@ -77,7 +77,7 @@ python3 $R/tools/pmc_wave.py --molecules 8192 --out $OUT/r05_pmc_wave_8192.json 
 rm -rf $R/gpurun_out/pmc_wave
 python3 $R/tools/large_clocks.py --forwards 5 --detail 2>/dev/null | grep -A6 "k_lg_sweep" > $OUT/r05_protein_sweep_clocks.txt
 python3 $R/tools/large_clocks.py --forwards 200 --detail 2>/dev/null | grep -A6 "k_lg_sweep" >> $OUT/r05_protein_sweep_clocks.txt
-(cd $R/tools/micro && ./clamp_relu > $OUT/r05_micro_clamp_relu.txt 2>&1; ./clock_cal > $OUT/r05_micro_clock_cal.txt 2>&1; ./issue_mix > $OUT/r05_micro_issue_mix.txt 2>&1)
+(cd $R/tools/micro && ./clamp_relu > $OUT/r05_micro_clamp_relu.txt 2>&1; ./clock_cal > $OUT/r05_micro_clock_cal.txt 2>&1; ./issue_mix > $OUT/r05_micro_issue_mix.txt 2>&1; ./bf16x6 > $OUT/r05_micro_bf16x6.txt 2>&1)
 python3 $R/tools/bench_mixed.py > $OUT/r05_mixed_val.txt 2>/dev/null
 fi
 rm -rf $OUT/big $OUT/bench $OUT/bench20 $OUT/prot $OUT/protpmc $OUT/train
