@@ -68,8 +68,8 @@ int epnn_device_count(void);
  * kernels DESIGN.md describes, and so does every `layers` of one or two hidden layers of at most 32 units: the library runs it as a
  * [32, 32] model on a zero-padded copy of its weights (units with zero weights and bias feed nothing; a missing second layer is the
  * identity on the first layer's non-negative outputs) -- exact, not an approximation.  One or two hidden layers of at most 64
- * units run molecules of up to 32 atoms on a 64-unit build of the fused kernel (the same embedding into [64, 64]; 168 M atoms/s on
- * the bench batch against 233 M for [32, 32]) and larger ones through the tiled kernels with one launch per stage and a generic
+ * units run molecules of up to 32 atoms on a 64-unit build of the fused kernel (the same embedding into [64, 64]; 181 M atoms/s on
+ * the bench batch against 274 M for [32, 32]) and larger ones through the tiled kernels with one launch per stage and a generic
  * (f32 FMA) Dense stack as the update stage; any other `layers` (a width above 64, three or more hidden layers) runs every molecule
  * that way (28 M atoms/s on the bench batch: tools/bench_layers.py).  The training step of any `layers` but [32, 32] runs one launch per Dense layer ("train_fused" = 0's kernels)
  * on the model's own shapes -- the same results to float32 rounding, several times slower per small molecule. */
