@@ -409,13 +409,14 @@ static int pack_weights(epnn_handle *h) {
         auto accf = [](int s, int q) { return 16 * (s >> 2) + 4 * q + (s & 3); };       // "acc" K order
         // a K = 32 kernel as three bf16 pieces per weight (epnn_wave.hip.h, w16_split3: truncation, exact), [2][3][64 lanes][4 dwords]:
         // lane (q, m) of row block rb: K slots s = 0..7 = input feature accf(s, q), output feature 16 rb + m; dword j = slots 2j | 2j+1 << 16
-        auto frag_bf3 = [&](auto &&fn) {
+        // frag_bf3s: the K slot (lane group q, slot s) -> value mapping is the caller's (fn(q, s, out)); frag_bf3: acc order
+        auto frag_bf3s = [&](auto &&fn) {
             const int off = alloc((size_t)2 * 3 * 64 * 4);
             for (int rb = 0; rb < 2; ++rb)
                 for (int l = 0; l < 64; ++l) {
                     uint32_t pc[3][8];
                     for (int s = 0; s < 8; ++s) {
-                        float v = (float)fn(accf(s, l >> 4), 16 * rb + (l & 15));
+                        float v = (float)fn(l >> 4, s, 16 * rb + (l & 15));
                         for (int k = 0; k < 3; ++k) {
                             uint32_t bits;
                             memcpy(&bits, &v, 4);
@@ -434,6 +435,7 @@ static int pack_weights(epnn_handle *h) {
                 }
             return off;
         };
+        auto frag_bf3 = [&](auto &&fn) { return frag_bf3s([&](int q, int s, int out) { return fn(accf(s, q), out); }); };
         auto xq_row = [&](const float *W1, const float *b1, int r0, int phi, int m, double nmrow) -> double {
             if (phi == 0) return nmrow;
             if (phi <= nx) return W1[(size_t)(r0 + phi - 1) * 32 + m];
@@ -447,7 +449,8 @@ static int pack_weights(epnn_handle *h) {
                 return W1[(size_t)(r0 + nx + accf(s - EPNN_XS, q)) * 32 + m];
             });
         };
-        auto folded = [&](const float *W1, const float *b1, int r0) {        // KU acc steps (Wu3 M_h), then the xq steps
+        struct FoldedOff { int f32, hb, xb; };
+        auto folded = [&](const float *W1, const float *b1, int r0) -> FoldedOff {        // KU acc steps (Wu3 M_h), then the xq steps
             std::vector<double> prod((size_t)HU * 32), cb(32);
             for (int k = 0; k < HU; ++k)
                 for (int m = 0; m < 32; ++m) {
@@ -460,10 +463,19 @@ static int pack_weights(epnn_handle *h) {
                 for (int f = 0; f < EPNN_EDIM; ++f) a += (double)bu3[f] * (double)W1[(size_t)(r0 + nx + f) * 32 + m];
                 cb[m] = a;
             }
-            return frag(2, KU + EPNN_XS, [&](int s, int q, int m) -> double {
+            FoldedOff o{0, 0, 0};
+            o.f32 = frag(2, KU + EPNN_XS, [&](int s, int q, int m) -> double {
                 if (s < KU) return prod[accf(s, q) * 32 + m];
                 return xq_row(W1, b1, r0, 4 * (s - KU) + q, m, cb[m]);
             });
+            if (HU == 32) {      // the same two blocks as bf16 pieces (the per-atom chains on the bf16 pipe; 32-unit update MLPs)
+                o.hb = frag_bf3([&](int in, int out) { return prod[(size_t)in * 32 + out]; });
+                o.xb = frag_bf3s([&](int q, int s, int out) -> double {
+                    const int phi = wave_xq_slot(q, s, nx);
+                    return phi < 0 ? 0.0 : xq_row(W1, b1, r0, phi, out, cb[out]);
+                });
+            }
+            return o;
         };
         const bool have_basis = (int)h->edge_B.size() == EPNN_EDIM * EPNN_ER;
         auto pair_common = [&](HostDense (&mm)[3], int &we, int &we16, int &w2, int &b2) {
@@ -493,6 +505,8 @@ static int pack_weights(epnn_handle *h) {
         const int off_pu1 = frag(NRU, KU, [&](int s, int q, int m) { return pu1[(size_t)accf(s, q) * HU + m]; });
         const int off_cu3 = vec(HU, [&](int k) { return cu3[k]; });
         const int off_u2 = frag(NRU, KU, [&](int s, int q, int m) { return (double)Wu2[(size_t)accf(s, q) * HU + m]; });
+        const int off_u2b = HU == 32 ? frag_bf3([&](int in, int out) { return (double)Wu2[(size_t)in * HU + out]; }) : 0;
+        const int off_pu1b = HU == 32 ? frag_bf3([&](int in, int out) { return pu1[(size_t)in * HU + out]; }) : 0;
         const int off_bu1 = vec(HU, [&](int k) { return (double)bu1[k]; });
         const int off_bu2 = vec(HU, [&](int k) { return (double)bu2[k]; });
         for (int t = 0; t < T; ++t) {
@@ -516,6 +530,12 @@ static int pack_weights(epnn_handle *h) {
                 cb3[m] = a;
             }
             G.u1s = frag(NRU, 8, [&](int s, int q, int m) { return fold[(size_t)accf(s, q) * HU + m]; });
+            G.u1sb = G.u2b = G.pu1b = G.pwihb = G.pwixb = G.pwjhb = G.pwjxb = 0;
+            if (HU == 32) {
+                G.u1sb = frag_bf3([&](int in, int out) { return fold[(size_t)in * HU + out]; });
+                G.u2b = off_u2b;
+                G.pu1b = off_pu1b;
+            }
             G.cb3 = vec(HU, [&](int k) { return cb3[k]; });
             G.bu1 = off_bu1;
             G.u2 = off_u2;
@@ -524,8 +544,9 @@ static int pack_weights(epnn_handle *h) {
             G.cu3 = off_cu3;
             if (t + 1 < T) {
                 const float *N1 = h->msg[t + 1][0].W.data(), *nb1 = h->msg[t + 1][0].b.data();
-                G.pwi = folded(N1, nb1, 0);
-                G.pwj = folded(N1, nullptr, F);
+                const FoldedOff fi = folded(N1, nb1, 0), fj = folded(N1, nullptr, F);
+                G.pwi = fi.f32; G.pwihb = fi.hb; G.pwixb = fi.xb;
+                G.pwj = fj.f32; G.pwjhb = fj.hb; G.pwjxb = fj.xb;
             } else {
                 G.pwi = G.pwj = 0;
             }
@@ -546,8 +567,9 @@ static int pack_weights(epnn_handle *h) {
             E.w3 = vec(32, [&](int k) { return (double)h->pas[t][2].W[k]; });
             E.wi = unfolded(W1, b1, 0);
             E.wj = unfolded(W1, nullptr, F);
-            E.wif = folded(W1, b1, 0);
-            E.wjf = folded(W1, nullptr, F);
+            const FoldedOff fi = folded(W1, b1, 0), fj = folded(W1, nullptr, F);
+            E.wif = fi.f32; E.wifhb = fi.hb; E.wifxb = fi.xb;
+            E.wjf = fj.f32; E.wjfhb = fj.hb; E.wjfxb = fj.xb;
         }
     }
     std::vector<float> gbuf;

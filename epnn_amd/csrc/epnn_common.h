@@ -84,13 +84,26 @@ struct WaveGnnPack {           // GNN step t
     int pwi, pwj;         // [2][8+XS][64]  acc rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]   (M = Wi / Wj of step t+1)
     int pu1;              // [2][8][64]   acc order     Wu3 Wu1_H
     int cu3;              // [32]         Wu1_H^T bu3
+    // the same kernels as three bf16 pieces per weight, [2][3][64][4] dwords each (w2b's layout; 32-unit update MLPs only): the
+    // per-atom chains on the bf16 matrix pipe.  `..hb` = the K = 32 block that multiplies nm u2 (acc order), `..xb` = the xq block in
+    // the slot order of wave_xq_slot (mask / charge as three pieces, x and the bias in one)
+    int u1sb, u2b, pu1b, pwihb, pwixb, pwjhb, pwjxb;
 };
+// K slot (lane group q, slot s of the lane) of the xq block's bf16 operand -> index into xq (0 node mask, 1..nx x, nx + 1 q, nx + 2 one),
+// -1 = empty.  Lane group 0: mask pieces, one, charge pieces; 1: x[0..7]; 2: x[8..9]
+__host__ __device__ static inline int wave_xq_slot(int q, int s, int nx) {
+    if (q == 0) return s < 3 ? 0 : (s == 3 ? nx + 2 : (s < 7 ? nx + 1 : -1));
+    if (q == 1) return s < nx ? 1 + s : -1;
+    if (q == 2) return 8 + s < nx ? 9 + s : -1;
+    return -1;
+}
 struct WaveEpnPack {           // EPN step t
     int we, w2, b2, w3;   // w3: [32]
     int w2b;              // [2][3][64][4] dwords: W2_t as three bf16 pieces per weight (see WaveGnnPack)
     int we16;             // [2][4][64]   B^T We_t
     int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features): h given by the caller
     int wif, wjf;         // [2][8+XS][64]   acc rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]: h = nm (Wu3^T u2 + bu3) of the GNN stack
+    int wifhb, wifxb, wjfhb, wjfxb;      // wif / wjf as bf16 pieces (see WaveGnnPack)
 };
 struct WaveIndex {
     WaveGnnPack g[EPNN_MAXT];

@@ -188,6 +188,16 @@ __device__ __forceinline__ void w16_mm_bf(const u32x4 (&w)[2][3], u32x4 z1, u32x
         d[rb] = w16_mfma_bf(w[rb][0], z1, d[rb]);
     }
 }
+// the same for an operand whose K slots hold values that ARE bf16 numbers (the xq block: mask / charge already as pieces, x and the
+// bias exact): the kernel's three pieces against the one operand
+__device__ __forceinline__ void w16_mm_bfx(const u32x4 (&w)[2][3], u32x4 x, f32x4 (&d)[2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        d[rb] = w16_mfma_bf(w[rb][2], x, d[rb]);
+        d[rb] = w16_mfma_bf(w[rb][1], x, d[rb]);
+        d[rb] = w16_mfma_bf(w[rb][0], x, d[rb]);
+    }
+}
 // the three-piece kernel of a product: [2 row blocks][3 pieces][64 lanes][4 dwords], one 16-byte load each
 #define W16_LDB(dst, off)                                                                                       \
     _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                         \
@@ -537,6 +547,57 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         }
     }
 
+    // The per-atom chains (update MLP, the next step's P / R / u1pre, the EPN stack's P / R) on the bf16 matrix pipe as well (32-unit
+    // update MLPs; -DEPNN_CHAIN_F32: f32 MFMAs as before): the K = 32 inputs S, u1 and nm u2 are split like the sweep's activations,
+    // the xq block (mask, x, charge, one) is an operand of bf16 numbers in the slot order of wave_xq_slot -- mask and charge as three
+    // pieces in three slots, x (small integers) and the one exact in a slot each -- against the kernel's three pieces.
+#ifdef EPNN_CHAIN_F32
+    constexpr bool CHB = false;
+#else
+    constexpr bool CHB = NRU == 2 && GNN;
+#endif
+    u32x4 Bp0[3], Bp1[3];                                  // nm u2 of the last step as pieces (CHB)
+    u32x4 xqb0 = {0u, 0u, 0u, 0u}, xqb1 = {0u, 0u, 0u, 0u};
+    float qc0 = cat0 ? qa0 : 0.f, qc1 = cat1 ? qa1 : 0.f;  // the columns' charges, in every lane (CHB: lane group 0 rebuilds its slots from them)
+    auto xq_charge = [&]() {                               // slots 4..6 of lane group 0: the charge's three pieces
+        if (q != 0) return;
+        const float a0_ = __uint_as_float(__float_as_uint(qc0) & 0xffff0000u), r0_ = qc0 - a0_;
+        const float b0_ = __uint_as_float(__float_as_uint(r0_) & 0xffff0000u), c0_ = r0_ - b0_;
+        const float a1_ = __uint_as_float(__float_as_uint(qc1) & 0xffff0000u), r1_ = qc1 - a1_;
+        const float b1_ = __uint_as_float(__float_as_uint(r1_) & 0xffff0000u), c1_ = r1_ - b1_;
+        xqb0[2] = __builtin_amdgcn_perm(__float_as_uint(b0_), __float_as_uint(a0_), 0x07060302u);
+        xqb0[3] = __float_as_uint(c0_) >> 16;
+        xqb1[2] = __builtin_amdgcn_perm(__float_as_uint(b1_), __float_as_uint(a1_), 0x07060302u);
+        xqb1[3] = __float_as_uint(c1_) >> 16;
+    };
+    if constexpr (CHB) {
+        if (q == 0) {
+            auto mask_one = [&](float nmv, bool cat, u32x4 &o) {
+                const float a_ = __uint_as_float(__float_as_uint(nmv) & 0xffff0000u), r_ = nmv - a_;
+                const float b_ = __uint_as_float(__float_as_uint(r_) & 0xffff0000u), c_ = r_ - b_;
+                o[0] = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u);
+                o[1] = (__float_as_uint(c_) >> 16) | (cat ? 0x3f800000u : 0u);        // third piece | 1.0 as a bf16
+            };
+            mask_one(nm0, cat0, xqb0);
+            mask_one(nm1, cat1, xqb1);
+        } else if (q < 3) {
+            // x of the two columns' atoms: slots s = 0..7 of this lane group hold x[8 (q - 1) + s] (small integers: exact in a bf16)
+            float x0_[8], x1_[8];
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) {
+                const int k = 8 * (q - 1) + s_, kc = min(k, nx - 1);
+                const float u0 = A.xin[(size_t)ia0 * A.nx + kc], u1 = A.xin[(size_t)ia1 * A.nx + kc];
+                x0_[s_] = cat0 && k < nx ? u0 : 0.f;
+                x1_[s_] = cat1 && k < nx ? u1 : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xqb0[j] = __builtin_amdgcn_perm(__float_as_uint(x0_[2 * j + 1]), __float_as_uint(x0_[2 * j]), 0x07060302u);
+                xqb1[j] = __builtin_amdgcn_perm(__float_as_uint(x1_[2 * j + 1]), __float_as_uint(x1_[2 * j]), 0x07060302u);
+            }
+        }
+        xq_charge();
+    }
     WAVE_STAMP();   // init done
     const float Nf = (float)A.N, padw = (float)(A.N - n);
     const int Tg = GNN ? A.T : 0, Te = EPN ? A.T : 0;
@@ -788,7 +849,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                             WAVE_FENCE();
                             tile(Pc, Sc, ob, dp);
                         }
-                        if (!b1) { W16_LD(u1s, M.u1s, NRU, 8); }   // first operand of the update MLP
+                        if constexpr (!CHB) { if (!b1) { W16_LD(u1s, M.u1s, NRU, 8); } }   // first operand of the update MLP
                         if (ntr - k == 2) {                       // real tiles k, k + 1, then the last tile
                             load_rg(ob, ra, en);
                             WAVE_FENCE();
@@ -836,6 +897,45 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             }
             if (t < 2) WAVE_STAMP();   // pair tiles
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
+            if constexpr (CHB) {
+                u32x4 w1[2][3], w2b[2][3];
+                f32x4 cv[2], bv[2];
+                W16_LDB(w1, M.u1sb);
+                W16_LDB(w2b, M.u2b);
+                vecu(M.cb3, cv);
+                vecu(M.bu1, bv);
+                WAVE_FENCE();
+                f32x4 d0[2] = {U0[0], U0[1]}, d1[2] = {U1[0], U1[1]};
+                float in0[8], in1[8];
+                u32x4 s1, s2, s3;
+                w16_feed<2>(S0, in0);
+                w16_split3(in0, s1, s2, s3);
+                w16_mm_bf(w1, s1, s2, s3, d0);
+                if (two) { w16_feed<2>(S1, in1); w16_split3(in1, s1, s2, s3); w16_mm_bf(w1, s1, s2, s3, d1); }
+                f32x4 a0_[2], a1_[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    a0_[rb] = w16_relu(nm0 * (d0[rb] + Nf * cv[rb]) + bv[rb]);
+                    a1_[rb] = w16_relu(nm1 * (d1[rb] + Nf * cv[rb]) + bv[rb]);
+                }
+                vecu(M.bu2, bv);
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
+                else if (Te > 0) { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
+                WAVE_FENCE();
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { d0[rb] = bv[rb]; d1[rb] = bv[rb]; }
+                w16_feed<2>(a0_, in0);
+                w16_split3(in0, s1, s2, s3);
+                w16_mm_bf(w2b, s1, s2, s3, d0);
+                if (two) { w16_feed<2>(a1_, in1); w16_split3(in1, s1, s2, s3); w16_mm_bf(w2b, s1, s2, s3, d1); }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { B0[rb] = nm0 * w16_relu(d0[rb]); B1[rb] = nm1 * w16_relu(d1[rb]); }
+                // nm u2 as pieces: the three projections below and, after the last step, the EPN stack's take them
+                w16_feed<2>(B0, in0);
+                w16_split3(in0, Bp0[0], Bp0[1], Bp0[2]);
+                w16_feed<2>(B1, in1);
+                w16_split3(in1, Bp1[0], Bp1[1], Bp1[2]);
+            } else
             {
                 float w2[NRU][KU], in0[8], in1[8];
                 f32x4 cv[NRU], bv[NRU];
@@ -872,6 +972,45 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 for (int rb = 0; rb < NRU; ++rb) { B0[rb] = nm0 * w16_relu(d0[rb]); B1[rb] = nm1 * w16_relu(d1[rb]); }
             }
             if (t < 2) WAVE_STAMP();   // U1, U2
+            if constexpr (CHB) {
+              if (!lastg) {
+                // next step: G rows, then P / R / u1pre from (nm u2 pieces | xq operand) through the folded matrices' pieces
+                u32x4 wh[2][3], wx[2][3];
+                W16_LDB(wh, M.pwihb);
+                W16_LDB(wx, M.pwixb);
+                WAVE_FENCE();
+                gtiles();
+                if (t < 2) WAVE_STAMP();   // G tiles
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); }
+                w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], P0);
+                w16_mm_bfx(wx, xqb0, P0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], P1); w16_mm_bfx(wx, xqb1, P1); }
+                W16_LDB(wh, M.pwjhb);
+                W16_LDB(wx, M.pwjxb);
+                f32x4 cu[2];
+                vecu(M.cu3, cu);
+                f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], r0);
+                w16_mm_bfx(wx, xqb0, r0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], r1); w16_mm_bfx(wx, xqb1, r1); }
+                if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
+                if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
+                W16_LDB(wh, M.pu1b);
+#ifdef EPNN_SWEEP_F32
+                W16_LD(pb, X.g[t + 1].w2, 2, 8);
+#else
+                W16_LDB(pb, X.g[t + 1].w2b);
+#endif
+                vec2(X.g[t + 1].b2, b2v);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { U0[rb] = nm0 * cu[rb]; U1[rb] = nm1 * cu[rb]; }
+                w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], U0);
+                if (two) w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], U1);
+                wave_sync_all();
+                if (t < 2) WAVE_STAMP();   // projections
+              }
+            } else
             if (!lastg) {
                 // next step: G rows, then P / R / u1pre from (nm*u2 | xq) through the folded matrices
                 float wa[2][KU + EPNN_XS], wb[2][KU + EPNN_XS], in0[KU + EPNN_XS], in1[KU + EPNN_XS];
@@ -962,7 +1101,27 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
 #pragma unroll 1
         for (int t = 0; t < Te; ++t) {
             const WaveEpnPack &M = X.e[t];
-            {
+            if constexpr (CHB && FOLD) {
+                // P / R of this step from (nm u2 pieces | xq operand): the bf16 pipe (see CHB)
+                u32x4 wh[2][3], wx[2][3];
+                W16_LDB(wh, M.wifhb);
+                W16_LDB(wx, M.wifxb);
+                WAVE_FENCE();
+                f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)}, d1[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], d0);
+                w16_mm_bfx(wx, xqb0, d0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], d1); w16_mm_bfx(wx, xqb1, d1); }
+                W16_LDB(wh, M.wjfhb);
+                W16_LDB(wx, M.wjfxb);
+                if (cat0) { w16_st(Pl + n16 * EPNN_PST + fo, d0[0]); w16_st(Pl + n16 * EPNN_PST + 16 + fo, d0[1]); }
+                if (own1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
+                d0[0] = w16_splat(0.f); d0[1] = w16_splat(0.f); d1[0] = w16_splat(0.f); d1[1] = w16_splat(0.f);
+                w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], d0);
+                w16_mm_bfx(wx, xqb0, d0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], d1); w16_mm_bfx(wx, xqb1, d1); }
+                if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
+                if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
+            } else {
                 constexpr int KS = FOLD ? KU + EPNN_XS : EPNN_XS + 12;
                 constexpr int SK = FOLD ? KU - 1 + EPNN_XS : EPNN_XS - 1;    // the last xq step
                 float wa[2][KS], wb[2][KS], in0[KS], in1[KS];
@@ -1116,6 +1275,11 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
 #pragma unroll
                 for (int s = 0; s < EPNN_XS; ++s)
                     if (s == qs && q == ql) { xq0[s] += cat0 ? dq0 : 0.f; xq1[s] += cat1 ? dq1 : 0.f; }
+                if constexpr (CHB && FOLD) {               // the same sums in every lane: lane group 0 re-makes the charge's slots
+                    qc0 += cat0 ? dq0 : 0.f;
+                    qc1 += cat1 ? dq1 : 0.f;
+                    xq_charge();
+                }
             }
             wave_sync_lds();
             if (t < 2) WAVE_STAMP();   // charge update
