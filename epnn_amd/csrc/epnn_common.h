@@ -86,15 +86,15 @@ struct WaveGnnPack {           // GNN step t
     int cu3;              // [32]         Wu1_H^T bu3
     // the same kernels as three bf16 pieces per weight, [2][3][64][4] dwords each (w2b's layout; 32-unit update MLPs only): the
     // per-atom chains on the bf16 matrix pipe.  `..hb` = the K = 32 block that multiplies nm u2 (acc order), `..xb` = the xq block in
-    // the slot order of wave_xq_slot (mask / charge as three pieces, x and the bias in one)
+    // the slot order of wave_xq_slot
     int u1sb, u2b, pu1b, pwihb, pwixb, pwjhb, pwjxb;
 };
-// K slot (lane group q, slot s of the lane) of the xq block's bf16 operand -> index into xq (0 node mask, 1..nx x, nx + 1 q, nx + 2 one),
-// -1 = empty.  Lane group 0: mask pieces, one, charge pieces; 1: x[0..7]; 2: x[8..9]
+// K slot (lane group q, slot s of the lane) of the xq block's operand -> index into xq (0 node mask, 1..nx x, nx + 1 q, nx + 2 one),
+// -1 = empty.  Lane group 0: mask, one, charge, x[0..4]; lane group 1: x[5..9].  (Every value is a float32 -- x is whatever the
+// caller's feature columns hold -- and is split into three pieces like any other operand.)
 __host__ __device__ static inline int wave_xq_slot(int q, int s, int nx) {
-    if (q == 0) return s < 3 ? 0 : (s == 3 ? nx + 2 : (s < 7 ? nx + 1 : -1));
-    if (q == 1) return s < nx ? 1 + s : -1;
-    if (q == 2) return 8 + s < nx ? 9 + s : -1;
+    if (q == 0) return s == 0 ? 0 : (s == 1 ? nx + 2 : (s == 2 ? nx + 1 : (s - 3 < nx ? s - 2 : -1)));
+    if (q == 1) return 5 + s < nx ? 6 + s : -1;
     return -1;
 }
 struct WaveEpnPack {           // EPN step t

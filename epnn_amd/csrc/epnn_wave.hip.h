@@ -188,16 +188,6 @@ __device__ __forceinline__ void w16_mm_bf(const u32x4 (&w)[2][3], u32x4 z1, u32x
         d[rb] = w16_mfma_bf(w[rb][0], z1, d[rb]);
     }
 }
-// the same for an operand whose K slots hold values that ARE bf16 numbers (the xq block: mask / charge already as pieces, x and the
-// bias exact): the kernel's three pieces against the one operand
-__device__ __forceinline__ void w16_mm_bfx(const u32x4 (&w)[2][3], u32x4 x, f32x4 (&d)[2]) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        d[rb] = w16_mfma_bf(w[rb][2], x, d[rb]);
-        d[rb] = w16_mfma_bf(w[rb][1], x, d[rb]);
-        d[rb] = w16_mfma_bf(w[rb][0], x, d[rb]);
-    }
-}
 // the three-piece kernel of a product: [2 row blocks][3 pieces][64 lanes][4 dwords], one 16-byte load each
 #define W16_LDB(dst, off)                                                                                       \
     _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                         \
@@ -549,54 +539,34 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
 
     // The per-atom chains (update MLP, the next step's P / R / u1pre, the EPN stack's P / R) on the bf16 matrix pipe as well (32-unit
     // update MLPs; -DEPNN_CHAIN_F32: f32 MFMAs as before): the K = 32 inputs S, u1 and nm u2 are split like the sweep's activations,
-    // the xq block (mask, x, charge, one) is an operand of bf16 numbers in the slot order of wave_xq_slot -- mask and charge as three
-    // pieces in three slots, x (small integers) and the one exact in a slot each -- against the kernel's three pieces.
+    // the xq block (mask, one, charge, x) is one more operand of up to 13 values in the slot order of wave_xq_slot.
 #ifdef EPNN_CHAIN_F32
     constexpr bool CHB = false;
 #else
     constexpr bool CHB = NRU == 2 && GNN;
 #endif
     u32x4 Bp0[3], Bp1[3];                                  // nm u2 of the last step as pieces (CHB)
-    u32x4 xqb0 = {0u, 0u, 0u, 0u}, xqb1 = {0u, 0u, 0u, 0u};
-    float qc0 = cat0 ? qa0 : 0.f, qc1 = cat1 ? qa1 : 0.f;  // the columns' charges, in every lane (CHB: lane group 0 rebuilds its slots from them)
-    auto xq_charge = [&]() {                               // slots 4..6 of lane group 0: the charge's three pieces
-        if (q != 0) return;
-        const float a0_ = __uint_as_float(__float_as_uint(qc0) & 0xffff0000u), r0_ = qc0 - a0_;
-        const float b0_ = __uint_as_float(__float_as_uint(r0_) & 0xffff0000u), c0_ = r0_ - b0_;
-        const float a1_ = __uint_as_float(__float_as_uint(qc1) & 0xffff0000u), r1_ = qc1 - a1_;
-        const float b1_ = __uint_as_float(__float_as_uint(r1_) & 0xffff0000u), c1_ = r1_ - b1_;
-        xqb0[2] = __builtin_amdgcn_perm(__float_as_uint(b0_), __float_as_uint(a0_), 0x07060302u);
-        xqb0[3] = __float_as_uint(c0_) >> 16;
-        xqb1[2] = __builtin_amdgcn_perm(__float_as_uint(b1_), __float_as_uint(a1_), 0x07060302u);
-        xqb1[3] = __float_as_uint(c1_) >> 16;
+    u32x4 xqb0[3], xqb1[3];                                // the xq operand's pieces (CHB)
+    float xs0[8], xs1[8];                                  // its slots as float32: wave_xq_slot (lane group 0: mask, one, charge, x[0..4]; 1: x[5..9])
+    auto xq_split = [&]() {
+        w16_split3(xs0, xqb0[0], xqb0[1], xqb0[2]);
+        w16_split3(xs1, xqb1[0], xqb1[1], xqb1[2]);
     };
     if constexpr (CHB) {
-        if (q == 0) {
-            auto mask_one = [&](float nmv, bool cat, u32x4 &o) {
-                const float a_ = __uint_as_float(__float_as_uint(nmv) & 0xffff0000u), r_ = nmv - a_;
-                const float b_ = __uint_as_float(__float_as_uint(r_) & 0xffff0000u), c_ = r_ - b_;
-                o[0] = __builtin_amdgcn_perm(__float_as_uint(b_), __float_as_uint(a_), 0x07060302u);
-                o[1] = (__float_as_uint(c_) >> 16) | (cat ? 0x3f800000u : 0u);        // third piece | 1.0 as a bf16
-            };
-            mask_one(nm0, cat0, xqb0);
-            mask_one(nm1, cat1, xqb1);
-        } else if (q < 3) {
-            // x of the two columns' atoms: slots s = 0..7 of this lane group hold x[8 (q - 1) + s] (small integers: exact in a bf16)
-            float x0_[8], x1_[8];
 #pragma unroll
-            for (int s_ = 0; s_ < 8; ++s_) {
-                const int k = 8 * (q - 1) + s_, kc = min(k, nx - 1);
-                const float u0 = A.xin[(size_t)ia0 * A.nx + kc], u1 = A.xin[(size_t)ia1 * A.nx + kc];
-                x0_[s_] = cat0 && k < nx ? u0 : 0.f;
-                x1_[s_] = cat1 && k < nx ? u1 : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                xqb0[j] = __builtin_amdgcn_perm(__float_as_uint(x0_[2 * j + 1]), __float_as_uint(x0_[2 * j]), 0x07060302u);
-                xqb1[j] = __builtin_amdgcn_perm(__float_as_uint(x1_[2 * j + 1]), __float_as_uint(x1_[2 * j]), 0x07060302u);
-            }
+        for (int s_ = 0; s_ < 8; ++s_) {
+            // (unconditional loads of clamped columns, selects afterwards)
+            const int k = q == 0 ? s_ - 3 : 5 + s_, kc = min(max(k, 0), nx - 1);
+            const float u0 = A.xin[(size_t)ia0 * A.nx + kc], u1 = A.xin[(size_t)ia1 * A.nx + kc];
+            const bool isx = q < 2 && k >= 0 && k < nx;
+            float v0 = isx && cat0 ? u0 : 0.f, v1 = isx && cat1 ? u1 : 0.f;
+            if (q == 0 && s_ == 0) { v0 = nm0; v1 = nm1; }
+            if (q == 0 && s_ == 1) { v0 = cat0 ? 1.f : 0.f; v1 = cat1 ? 1.f : 0.f; }
+            if (q == 0 && s_ == 2) { v0 = cat0 ? qa0 : 0.f; v1 = cat1 ? qa1 : 0.f; }
+            xs0[s_] = v0;
+            xs1[s_] = v1;
         }
-        xq_charge();
+        xq_split();
     }
     WAVE_STAMP();   // init done
     const float Nf = (float)A.N, padw = (float)(A.N - n);
@@ -984,16 +954,16 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) { P0[rb] = w16_splat(0.f); P1[rb] = w16_splat(0.f); }
                 w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], P0);
-                w16_mm_bfx(wx, xqb0, P0);
-                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], P1); w16_mm_bfx(wx, xqb1, P1); }
+                w16_mm_bf(wx, xqb0[0], xqb0[1], xqb0[2], P0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], P1); w16_mm_bf(wx, xqb1[0], xqb1[1], xqb1[2], P1); }
                 W16_LDB(wh, M.pwjhb);
                 W16_LDB(wx, M.pwjxb);
                 f32x4 cu[2];
                 vecu(M.cu3, cu);
                 f32x4 r0[2] = {w16_splat(0.f), w16_splat(0.f)}, r1[2] = {w16_splat(0.f), w16_splat(0.f)};
                 w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], r0);
-                w16_mm_bfx(wx, xqb0, r0);
-                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], r1); w16_mm_bfx(wx, xqb1, r1); }
+                w16_mm_bf(wx, xqb0[0], xqb0[1], xqb0[2], r0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], r1); w16_mm_bf(wx, xqb1[0], xqb1[1], xqb1[2], r1); }
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, r0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, r0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, r1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, r1[1]); }
                 W16_LDB(wh, M.pu1b);
@@ -1109,16 +1079,16 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 WAVE_FENCE();
                 f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)}, d1[2] = {w16_splat(0.f), w16_splat(0.f)};
                 w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], d0);
-                w16_mm_bfx(wx, xqb0, d0);
-                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], d1); w16_mm_bfx(wx, xqb1, d1); }
+                w16_mm_bf(wx, xqb0[0], xqb0[1], xqb0[2], d0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], d1); w16_mm_bf(wx, xqb1[0], xqb1[1], xqb1[2], d1); }
                 W16_LDB(wh, M.wjfhb);
                 W16_LDB(wx, M.wjfxb);
                 if (cat0) { w16_st(Pl + n16 * EPNN_PST + fo, d0[0]); w16_st(Pl + n16 * EPNN_PST + 16 + fo, d0[1]); }
                 if (own1) { w16_st(Pl + col1 * EPNN_PST + fo, d1[0]); w16_st(Pl + col1 * EPNN_PST + 16 + fo, d1[1]); }
                 d0[0] = w16_splat(0.f); d0[1] = w16_splat(0.f); d1[0] = w16_splat(0.f); d1[1] = w16_splat(0.f);
                 w16_mm_bf(wh, Bp0[0], Bp0[1], Bp0[2], d0);
-                w16_mm_bfx(wx, xqb0, d0);
-                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], d1); w16_mm_bfx(wx, xqb1, d1); }
+                w16_mm_bf(wx, xqb0[0], xqb0[1], xqb0[2], d0);
+                if (two) { w16_mm_bf(wh, Bp1[0], Bp1[1], Bp1[2], d1); w16_mm_bf(wx, xqb1[0], xqb1[1], xqb1[2], d1); }
                 if (cat0) { w16_st(Rl + n16 * EPNN_PST + fo, d0[0]); w16_st(Rl + n16 * EPNN_PST + 16 + fo, d0[1]); }
                 if (own1) { w16_st(Rl + col1 * EPNN_PST + fo, d1[0]); w16_st(Rl + col1 * EPNN_PST + 16 + fo, d1[1]); }
             } else {
@@ -1275,10 +1245,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
 #pragma unroll
                 for (int s = 0; s < EPNN_XS; ++s)
                     if (s == qs && q == ql) { xq0[s] += cat0 ? dq0 : 0.f; xq1[s] += cat1 ? dq1 : 0.f; }
-                if constexpr (CHB && FOLD) {               // the same sums in every lane: lane group 0 re-makes the charge's slots
-                    qc0 += cat0 ? dq0 : 0.f;
-                    qc1 += cat1 ? dq1 : 0.f;
-                    xq_charge();
+                if constexpr (CHB && FOLD) {               // (the same sums in every lane: lane group 0 holds the charge's slot)
+                    if (q == 0) { xs0[2] += cat0 ? dq0 : 0.f; xs1[2] += cat1 ? dq1 : 0.f; }
+                    xq_split();
                 }
             }
             wave_sync_lds();

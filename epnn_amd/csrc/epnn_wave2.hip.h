@@ -131,6 +131,27 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
             xq[s] = v;
         }
     }
+    // the per-atom chains on the bf16 matrix pipe, exactly as in k_wave_forward (its CHB: same operands, same order of the products)
+#ifdef EPNN_CHAIN_F32
+    constexpr bool CHB = false;
+#else
+    constexpr bool CHB = true;
+#endif
+    u32x4 Bp[3], xqb[3];
+    float xs_[8];                                           // the xq operand's slots (wave_xq_slot)
+    if constexpr (CHB) {
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const int k = q == 0 ? s_ - 3 : 5 + s_, kc = min(max(k, 0), nx - 1);
+            const float u = A.xin[(size_t)ia * nx + kc];
+            float v = q < 2 && k >= 0 && k < nx && cat ? u : 0.f;
+            if (q == 0 && s_ == 0) v = nm;
+            if (q == 0 && s_ == 1) v = cat ? 1.f : 0.f;
+            if (q == 0 && s_ == 2) v = cat ? qa : 0.f;
+            xs_[s_] = v;
+        }
+        w16_split3(xs_, xqb[0], xqb[1], xqb[2]);
+    }
     const bool have_h = !FRONT && A.h_in != nullptr;        // h given by the caller (make_model's h_inp); zeros with the compact entry
     f32x4 hk[3] = {w16_splat(0.f), w16_splat(0.f), w16_splat(0.f)};
     if (have_h && cat) {
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                             WAVE_FENCE();
                             tile(ob);
                         }
-                        if (last_phase) { W16_LD(u1s, M.u1s, 2, 8); }         // first operand of the update MLP
+                        if constexpr (!CHB) { if (last_phase) { W16_LD(u1s, M.u1s, 2, 8); } }         // first operand of the update MLP
                         if (tt + 1 < ntile) {
                             load_ops(tt + 1, ob);
                             WAVE_FENCE();
@@ -443,6 +464,36 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                 }
             }
             // ---- update MLP (charge_gn.py:71-74); the last message Dense is folded into u1s
+            if constexpr (CHB) {
+                u32x4 w1[2][3], w2b[2][3];
+                f32x4 cv[2], bv[2];
+                W16_LDB(w1, M.u1sb);
+                W16_LDB(w2b, M.u2b);
+                vec2(M.cb3, cv);
+                vec2(M.bu1, bv);
+                WAVE_FENCE();
+                f32x4 d[2] = {U[0], U[1]};
+                float in[8];
+                u32x4 s1, s2, s3;
+                w16_feed(S, in);
+                w16_split3(in, s1, s2, s3);
+                w16_mm_bf(w1, s1, s2, s3, d);
+                f32x4 a_[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) a_[rb] = w16_relu(nm * (d[rb] + Nf * cv[rb]) + bv[rb]);
+                vec2(M.bu2, bv);
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
+                else { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
+                WAVE_FENCE();
+                d[0] = bv[0]; d[1] = bv[1];
+                w16_feed(a_, in);
+                w16_split3(in, s1, s2, s3);
+                w16_mm_bf(w2b, s1, s2, s3, d);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) Bv[rb] = nm * w16_relu(d[rb]);
+                w16_feed(Bv, in);
+                w16_split3(in, Bp[0], Bp[1], Bp[2]);
+            } else
             {
                 float w2[2][8], in[8];
                 f32x4 cv[2], bv[2];
@@ -466,6 +517,39 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) Bv[rb] = nm * w16_relu(d[rb]);
             }
+            if constexpr (CHB) {
+              if (!lastg) {
+                u32x4 wh[2][3], wx[2][3];
+                W16_LDB(wh, M.pwihb);
+                W16_LDB(wx, M.pwixb);
+                WAVE_FENCE();
+                gtiles();
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) P[rb] = w16_splat(0.f);
+                w16_mm_bf(wh, Bp[0], Bp[1], Bp[2], P);
+                w16_mm_bf(wx, xqb[0], xqb[1], xqb[2], P);
+                W16_LDB(wh, M.pwjhb);
+                W16_LDB(wx, M.pwjxb);
+                f32x4 cu[2];
+                vec2(M.cu3, cu);
+                f32x4 r[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm_bf(wh, Bp[0], Bp[1], Bp[2], r);
+                w16_mm_bf(wx, xqb[0], xqb[1], xqb[2], r);
+                if (own) { w16_st(Rl + col * EPNN_PST + fo, r[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, r[1]); }
+                if (nxt > 0 && !blk1) { w16_st(P0t + col * EPNN_PST + fo, P[0]); w16_st(P0t + col * EPNN_PST + 16 + fo, P[1]); }
+                W16_LDB(wh, M.pu1b);
+#ifdef EPNN_SWEEP_F32
+                W16_LD(pb, X.g[t + 1].w2, 2, 8);
+#else
+                W16_LDB(pb, X.g[t + 1].w2b);
+#endif
+                vec2(X.g[t + 1].b2, b2v);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) U[rb] = nm * cu[rb];
+                w16_mm_bf(wh, Bp[0], Bp[1], Bp[2], U);
+                sync();
+              }
+            } else
             if (!lastg) {
                 float wa[2][8 + EPNN_XS], wbm[2][8 + EPNN_XS], in[8 + EPNN_XS];
                 W16_LD(wa, M.pwi, 2, 8 + EPNN_XS);
@@ -513,7 +597,22 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
 #pragma unroll 1
         for (int t = 0; t < Te; ++t) {
             const WaveEpnPack &M = X.e[t];
-            {
+            if constexpr (CHB) {
+                u32x4 wh[2][3], wx[2][3];
+                W16_LDB(wh, M.wifhb);
+                W16_LDB(wx, M.wifxb);
+                WAVE_FENCE();
+                f32x4 d[2] = {w16_splat(0.f), w16_splat(0.f)};
+                w16_mm_bf(wh, Bp[0], Bp[1], Bp[2], d);
+                w16_mm_bf(wx, xqb[0], xqb[1], xqb[2], d);
+                W16_LDB(wh, M.wjfhb);
+                W16_LDB(wx, M.wjfxb);
+                if (own) { w16_st(Pl + col * EPNN_PST + fo, d[0]); w16_st(Pl + col * EPNN_PST + 16 + fo, d[1]); }
+                d[0] = w16_splat(0.f); d[1] = w16_splat(0.f);
+                w16_mm_bf(wh, Bp[0], Bp[1], Bp[2], d);
+                w16_mm_bf(wx, xqb[0], xqb[1], xqb[2], d);
+                if (own) { w16_st(Rl + col * EPNN_PST + fo, d[0]); w16_st(Rl + col * EPNN_PST + 16 + fo, d[1]); }
+            } else {
                 constexpr int KS = 8 + EPNN_XS, SK = 7 + EPNN_XS;
                 float wa[2][KS], wbm[2][KS], in[KS];
 #pragma unroll
@@ -637,6 +736,10 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
 #pragma unroll
                 for (int s = 0; s < EPNN_XS; ++s)
                     if (s == qs && q == ql) xq[s] += cat ? dq : 0.f;
+                if constexpr (CHB) {
+                    if (q == 0) xs_[2] += cat ? dq : 0.f;
+                    w16_split3(xs_, xqb[0], xqb[1], xqb[2]);
+                }
             }
         }
 #pragma unroll
