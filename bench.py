@@ -28,8 +28,8 @@ warm-up steps (--no-extras) they read 182-185 M atoms/s instead of 194-197 M (`o
 
 Prints ONE JSON line on rank 0.  Besides the contract's fields:
   roofline.*          dominant kernel k_wave_forward; `frac` is ALGORITHMIC flops of the launches per second of
-                      the timed region / `peak`, the bound of the two matrix pipes the kernel uses (f32 MFMA 157.3 TFLOP/s; the pair
-                      MLPs' second Dense as six bf16 MFMAs per f32-grade product, 2500 / 6: `peak_basis`); `pipe_frac` = the pipes'
+                      the timed region / `peak`, the bound of the two matrix pipes the kernel uses (f32 MFMA 157.3 TFLOP/s for the
+                      edge products; every Dense layer as six bf16 MFMAs per f32-grade product, 2500 / 6: `peak_basis`); `pipe_frac` = the pipes'
                       time for the MFMA flops the kernel really executes (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 / _BF16 x 512) over the
                       time taken; `frac_vs_f32_mfma_peak` = against 157.3 alone; `single_launch` = a launch with the GPU to itself
                       (65536 molecules, depth 1: flops / hipEvent duration IS its fraction, reproducible from
@@ -57,10 +57,11 @@ if ROOT not in sys.path:
 # (GPU_MAX_HW_QUEUES is decided in main(), before anything initialises HIP in this process: one hardware queue per batch in
 # flight, fewer when ranks share a device)
 
-# Matrix-pipe peaks (MI355X_MICROARCH.md, dense): f32 MFMA 157.3 TFLOP/s, bf16 MFMA 2500.  The kernels run the pair MLPs' second
-# Dense -- 41 % of the bench batch's algorithmic flops -- on the bf16 pipe as SIX bf16 products of exact three-piece splits
-# (f32-grade): an f32-grade flop there is priced at 2500 / 6 = 416.7 TFLOP/s, and `roofline.peak` is the bound
-# of the two pipes together, total flops / (f32 flops / 157.3 + second-Dense flops / 416.7) (synth.mixed_pipe_peak).
+# Matrix-pipe peaks (MI355X_MICROARCH.md, dense): f32 MFMA 157.3 TFLOP/s, bf16 MFMA 2500.  The fused kernels run every Dense layer
+# -- the pair MLPs' second Dense, the first Dense's atom blocks, the update MLP: 69 % of the bench batch's algorithmic flops -- on the
+# bf16 pipe as SIX bf16 products of exact three-piece splits (f32-grade): an f32-grade flop there is priced at
+# 2500 / 6 = 416.7 TFLOP/s, the edge products (G = We^T e) stay f32 MFMAs, and `roofline.peak` is the bound of the two pipes
+# together, total flops / (f32 flops / 157.3 + bf16-pipe flops / 416.7) (synth.mixed_pipe_peak).
 FP32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 KNAME = "k_wave_forward<true,true,true>"
@@ -234,7 +235,7 @@ def real_data_rate(depth, device=0):
     rpipe.sync()
     v_dt = (time.perf_counter() - t1) / nrep
     v_flops = synth.algorithmic_flops(np.diff(v_off), int(vl[0][0].last_stats()[0]))
-    v_peak, _ = synth.mixed_pipe_peak(np.diff(v_off), int(vl[0][0].last_stats()[0]))
+    v_peak, _ = synth.mixed_pipe_peak(np.diff(v_off), int(vl[0][0].last_stats()[0]), chains_bf16=True)
     rpipe.close()
     print(json.dumps({"value": float(v_off[-1]) / v_dt, "unit": "atoms/s", "ms_per_batch": v_dt * 1e3,
                       "algorithmic_gflop_per_batch": v_flops / 1e9, "frac": v_flops / v_dt / 1e12 / v_peak, "peak": v_peak,
@@ -395,7 +396,7 @@ def main():
     assert np.abs(sums - Q).max() < 1e-4, np.abs(sums - Q).max()
     ns = np.diff(offsets)
     flops = synth.algorithmic_flops(ns, int(stats[0]))
-    peak, bf_share = synth.mixed_pipe_peak(ns, int(stats[0]))
+    peak, bf_share = synth.mixed_pipe_peak(ns, int(stats[0]), chains_bf16=True)
 
     def timed_steps():
         """W warm-up steps, barrier, K timed steps, barrier -> seconds of the timed region on this rank"""
@@ -628,9 +629,9 @@ def main():
         pipe_s = (executed * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + executed_bf * 1e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12)) if executed is not None and executed_bf is not None else None
         roof = {"bound": "mfma", "kernel": KNAME, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "peak_basis": f"both matrix pipes: f32 MFMA {FP32_MFMA_PEAK_TFLOPS} TFLOP/s for {1 - bf_share:.3f} of the algorithmic flops, the pair MLPs' second Dense "
+                "peak_basis": f"both matrix pipes: f32 MFMA {FP32_MFMA_PEAK_TFLOPS} TFLOP/s for {1 - bf_share:.3f} of the algorithmic flops (the edge products), the Dense layers "
                               f"({bf_share:.3f}) as six bf16 MFMAs per f32-grade product at {BF16_MFMA_PEAK_TFLOPS:.0f} / 6 = {BF16_MFMA_PEAK_TFLOPS / 6:.1f}; "
-                              "peak = total / (f32 part / 157.3 + second-Dense part / 416.7)",
+                              "peak = total / (f32 part / 157.3 + bf16-pipe part / 416.7)",
                 "frac_vs_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                 "frac_basis": "algorithmic flops (SURVEY section 8d); the matrix pipes' own utilisation (executed MFMA flops of either kind, PMC) is pipe_frac",
                 "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",

@@ -110,7 +110,7 @@ def box_system(n_atoms=100_000, seed=0, density=0.1, min_sep=0.9):
     return offsets, pts.astype(np.float32), features(symbols), np.zeros(1, dtype=np.float32), n_atoms
 
 
-def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=False):
+def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=False, chains_bf16=False):
     """Forward flop count of the factorised exact algorithm (flop = 2*MAC).
 
     ns: atom count per molecule; near_unordered_pairs: total number of unordered pairs with D < cutoff."""
@@ -121,10 +121,14 @@ def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=Fal
     gnn = n1 * 2 * F * H + nnz * E * H + n2 * H * H + n1 * H * H + n1 * H * H + n1 * (80 * H + H * H + H * 48)
     epn = n1 * 2 * F * H + (nnz / 2) * (E * H + 2 * H * H + 2 * H)
     if parts == "pipes":
-        # (f32-MFMA flops, flops of the pair MLPs' second Dense: the kernels run that K = 32 product on the bf16 matrix pipe as six
-        #  bf16 products of exact three-piece splits, f32-grade -- DESIGN.md section 4)
-        dense2 = 2.0 * T * (n2 * H * H + (nnz / 2) * 2 * H * H)
-        return 2.0 * T * (gnn + epn) - dense2, dense2
+        # (f32-MFMA flops, flops on the bf16 matrix pipe as six bf16 products of exact three-piece splits per f32-grade product --
+        #  DESIGN.md section 4): the pair MLPs' second Dense always; with chains_bf16 (the fused kernels) also the per-atom chains --
+        #  the first Dense's atom blocks, the update MLP --, which leaves the edge products G = We^T e (and the EPN read-out) on the
+        #  f32 pipe; the tiled kernels keep their per-atom chains there
+        bf = n2 * H * H + (nnz / 2) * 2 * H * H
+        if chains_bf16:
+            bf += 2 * (n1 * 2 * F * H) + n1 * H * H + n1 * H * H + n1 * (80 * H + H * H + H * 48)
+        return 2.0 * T * (gnn + epn - bf), 2.0 * T * bf
     if parts:
         return 2.0 * T * gnn, 2.0 * T * epn
     return 2.0 * T * (gnn + epn)
@@ -136,9 +140,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0     # an f32-grade product = six bf16 products
 
 
-def mixed_pipe_peak(ns, near_unordered_pairs, nx=9, T=5):
-    """The matrix pipes' bound on the forward, in ALGORITHMIC TFLOP/s: the flops that run as f32 MFMAs at 157.3 TFLOP/s, the pair
-    MLPs' second Dense at 2500 / 6 (six bf16 MFMAs per f32-grade product): peak = total / (f32 / 157.3 + dense2 / 416.7).
+def mixed_pipe_peak(ns, near_unordered_pairs, nx=9, T=5, chains_bf16=False):
+    """The matrix pipes' bound on the forward, in ALGORITHMIC TFLOP/s: the flops that run as f32 MFMAs at 157.3 TFLOP/s, those on
+    the bf16 pipe at 2500 / 6 (six bf16 MFMAs per f32-grade product): peak = total / (f32 part / 157.3 + bf16 part / 416.7).
+    chains_bf16: the fused kernels (per-atom chains on the bf16 pipe too); False: the tiled kernels (the all-pairs Dense only).
     Returns (peak, share of the algorithmic flops on the bf16 pipe)."""
-    f32, d2 = algorithmic_flops(ns, near_unordered_pairs, nx=nx, T=T, parts="pipes")
+    f32, d2 = algorithmic_flops(ns, near_unordered_pairs, nx=nx, T=T, parts="pipes", chains_bf16=chains_bf16)
     return (f32 + d2) / (f32 / FP32_MFMA_PEAK_TFLOPS + d2 / BF16X6_PEAK_TFLOPS), d2 / (f32 + d2)
