@@ -107,6 +107,25 @@ def test_algorithmic_flops_matches_survey_figure():
     assert abs(fl / 1e6 - 10.8) < 0.1, fl
 
 
+def test_roofline_of_the_two_matrix_pipes():
+    """bench.py prices the forward against the bound of the two matrix pipes it runs on (synth.mixed_pipe_peak): the split of the
+    algorithmic flops adds up to the total, the peak lies between the f32 MFMA peak and 2500 / 6, a system whose flops are all
+    all-pairs Dense reaches the bf16 form's bound, and the bench batch's figures are the ones DESIGN.md section 5 quotes."""
+    import numpy as np
+    from epnn_amd import synth
+    for ns, pairs in (([18], 72), ([2220], 12810), ([100000], 532253)):
+        total = synth.algorithmic_flops(ns, pairs)
+        for chains in (False, True):
+            f32, bf = synth.algorithmic_flops(ns, pairs, parts="pipes", chains_bf16=chains)
+            assert f32 > 0 and bf > 0 and abs(f32 + bf - total) <= 1e-9 * total
+            peak, share = synth.mixed_pipe_peak(ns, pairs, chains_bf16=chains)
+            assert synth.FP32_MFMA_PEAK_TFLOPS < peak < synth.BF16X6_PEAK_TFLOPS and abs(share - bf / total) < 1e-12
+    assert synth.mixed_pipe_peak([100000], 532253)[0] > 0.999 * synth.BF16X6_PEAK_TFLOPS
+    off = synth.qm9_like_batch(1024, 0, 29)[0]
+    peak, share = synth.mixed_pipe_peak(np.diff(off), 72439, chains_bf16=True)
+    assert abs(peak - 277.2) < 0.5 and abs(share - 0.695) < 0.005
+
+
 _DP_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
