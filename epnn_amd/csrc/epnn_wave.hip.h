@@ -547,12 +547,26 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
 #endif
     u32x4 Bp0[3], Bp1[3];                                  // nm u2 of the last step as pieces (CHB)
     u32x4 xqb0[3], xqb1[3];                                // the xq operand's pieces (CHB)
-    float xs0[8], xs1[8];                                  // its slots as float32: wave_xq_slot (lane group 0: mask, one, charge, x[0..4]; 1: x[5..9])
-    auto xq_split = [&]() {
-        w16_split3(xs0, xqb0[0], xqb0[1], xqb0[2]);
-        w16_split3(xs1, xqb1[0], xqb1[1], xqb1[2]);
+    // (slots: wave_xq_slot -- lane group 0: mask, one, charge, x[0..4]; 1: x[5..9].  Only the charge changes, between EPN steps:
+    //  its three pieces go into the low half of dword 1 of the three operand pieces of lane group 0; nothing else is kept)
+    float qc0 = 0.f, qc1 = 0.f;                            // the columns' charges, the same bits in every lane
+    auto xq_charge = [&]() {
+        if (q != 0) return;
+        const float a0_ = __uint_as_float(__float_as_uint(qc0) & 0xffff0000u), r0_ = qc0 - a0_;
+        const float b0_ = __uint_as_float(__float_as_uint(r0_) & 0xffff0000u), c0_ = r0_ - b0_;
+        const float a1_ = __uint_as_float(__float_as_uint(qc1) & 0xffff0000u), r1_ = qc1 - a1_;
+        const float b1_ = __uint_as_float(__float_as_uint(r1_) & 0xffff0000u), c1_ = r1_ - b1_;
+        const float pc0[3] = {a0_, b0_, c0_}, pc1[3] = {a1_, b1_, c1_};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xqb0[k][1] = (xqb0[k][1] & 0xffff0000u) | (__float_as_uint(pc0[k]) >> 16);
+            xqb1[k][1] = (xqb1[k][1] & 0xffff0000u) | (__float_as_uint(pc1[k]) >> 16);
+        }
     };
     if constexpr (CHB) {
+        float xs0[8], xs1[8];
+        qc0 = cat0 ? qa0 : 0.f;
+        qc1 = cat1 ? qa1 : 0.f;
 #pragma unroll
         for (int s_ = 0; s_ < 8; ++s_) {
             // (unconditional loads of clamped columns, selects afterwards)
@@ -566,7 +580,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
             xs0[s_] = v0;
             xs1[s_] = v1;
         }
-        xq_split();
+        w16_split3(xs0, xqb0[0], xqb0[1], xqb0[2]);
+        w16_split3(xs1, xqb1[0], xqb1[1], xqb1[2]);
     }
     WAVE_STAMP();   // init done
     const float Nf = (float)A.N, padw = (float)(A.N - n);
@@ -1246,8 +1261,9 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 for (int s = 0; s < EPNN_XS; ++s)
                     if (s == qs && q == ql) { xq0[s] += cat0 ? dq0 : 0.f; xq1[s] += cat1 ? dq1 : 0.f; }
                 if constexpr (CHB && FOLD) {               // (the same sums in every lane: lane group 0 holds the charge's slot)
-                    if (q == 0) { xs0[2] += cat0 ? dq0 : 0.f; xs1[2] += cat1 ? dq1 : 0.f; }
-                    xq_split();
+                    qc0 += cat0 ? dq0 : 0.f;
+                    qc1 += cat1 ? dq1 : 0.f;
+                    xq_charge();
                 }
             }
             wave_sync_lds();

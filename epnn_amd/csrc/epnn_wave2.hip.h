@@ -138,8 +138,17 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     constexpr bool CHB = true;
 #endif
     u32x4 Bp[3], xqb[3];
-    float xs_[8];                                           // the xq operand's slots (wave_xq_slot)
+    float qc = cat ? qa : 0.f;                              // the column's charge, the same bits in every lane
+    auto xq_charge = [&]() {                                // (k_wave_forward: the charge's pieces into the low half of dword 1)
+        if (q != 0) return;
+        const float a_ = __uint_as_float(__float_as_uint(qc) & 0xffff0000u), r_ = qc - a_;
+        const float b_ = __uint_as_float(__float_as_uint(r_) & 0xffff0000u), c_ = r_ - b_;
+        const float pc[3] = {a_, b_, c_};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xqb[k][1] = (xqb[k][1] & 0xffff0000u) | (__float_as_uint(pc[k]) >> 16);
+    };
     if constexpr (CHB) {
+        float xs_[8];
 #pragma unroll
         for (int s_ = 0; s_ < 8; ++s_) {
             const int k = q == 0 ? s_ - 3 : 5 + s_, kc = min(max(k, 0), nx - 1);
@@ -737,8 +746,8 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                 for (int s = 0; s < EPNN_XS; ++s)
                     if (s == qs && q == ql) xq[s] += cat ? dq : 0.f;
                 if constexpr (CHB) {
-                    if (q == 0) xs_[2] += cat ? dq : 0.f;
-                    w16_split3(xs_, xqb[0], xqb[1], xqb[2]);
+                    qc += cat ? dq : 0.f;
+                    xq_charge();
                 }
             }
         }
