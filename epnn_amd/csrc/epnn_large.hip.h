@@ -497,6 +497,10 @@ typedef u32x4 LgW2[2][3];
 template <bool TWO>
 __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const LgW2 (&pb),
                                               const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
+#ifndef EPNN_SWEEP_F32
+    u32x4 idA[2];
+    w16_ident(idA);
+#endif
     auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
     auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
         nn[0] = w16_ld(Ns + j * 32 + po);
@@ -511,12 +515,16 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
     // SIMD's issue time (protein 0.570 -> 0.545 ms, 10 000-atom box 8.12 -> 7.60 ms).
     f32x4 dp0[2] = {w16_splat(0.f), w16_splat(0.f)}, dp1[2] = {w16_splat(0.f), w16_splat(0.f)};      // nothing pending: relu(0) adds nothing
     auto partner_b = [&](const f32x4 (&nn)[2], const f32x4 (&yy)[2]) {
+#ifndef EPNN_SWEEP_F32
+        const f32x4 dq0[2] = {dp0[0], dp0[1]}, dq1[2] = {dp1[0], dp1[1]};
+#else
         S0[0] += w16_relu(dp0[0]);
         S0[1] += w16_relu(dp0[1]);
         if (TWO) {
             S1[0] += w16_relu(dp1[0]);
             S1[1] += w16_relu(dp1[1]);
         }
+#endif
         const f32x4 za = vmax(P0[0], nn[0]), zb = vmax(P0[1], nn[1]);
         const float z0[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
         const f32x4 zc = vmax(P1[0], nn[0]), zd = vmax(P1[1], nn[1]);
@@ -535,9 +543,31 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
             }
         }
 #else
+        // The split's remainders on the matrix pipe (w16_ident / w16_pack_hi, epnn_wave.hip.h): x - piece as D = C - I B, two MFMAs
+        // per 8 values and level instead of 8 v_and + 8 v_sub -- exact, the same pieces as w16_split3's (tools/micro/bf16x6.hip).  The
+        // ReLU + sum of the partner before this one sits behind the first remainders' MFMAs.  88 -> 24 vector instructions per
+        // partner for 8 more MFMAs: protein 0.382 -> 0.372 ms, 100 000-atom box 427 -> 417 ms (the first level alone: no change).
         u32x4 a1, a2, a3, b1, b2, b3;
-        w16_split3(z0, a1, a2, a3);
-        if (TWO) w16_split3(z1, b1, b2, b3);
+        f32x4 ra0 = za, ra1 = zb, rb0 = zc, rb1 = zd;
+        a1 = w16_pack_hi(ra0, ra1);
+        if (TWO) b1 = w16_pack_hi(rb0, rb1);
+        ra0 = w16_mfma_bf(idA[0], a1, ra0); ra1 = w16_mfma_bf(idA[1], a1, ra1);
+        if (TWO) { rb0 = w16_mfma_bf(idA[0], b1, rb0); rb1 = w16_mfma_bf(idA[1], b1, rb1); }
+        __builtin_amdgcn_sched_barrier(0);
+        S0[0] += w16_relu(dq0[0]);
+        S0[1] += w16_relu(dq0[1]);
+        if (TWO) {
+            S1[0] += w16_relu(dq1[0]);
+            S1[1] += w16_relu(dq1[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a2 = w16_pack_hi(ra0, ra1);
+        if (TWO) b2 = w16_pack_hi(rb0, rb1);
+        ra0 = w16_mfma_bf(idA[0], a2, ra0); ra1 = w16_mfma_bf(idA[1], a2, ra1);
+        if (TWO) { rb0 = w16_mfma_bf(idA[0], b2, rb0); rb1 = w16_mfma_bf(idA[1], b2, rb1); }
+        __builtin_amdgcn_sched_barrier(0);
+        a3 = w16_pack_hi(ra0, ra1);
+        if (TWO) b3 = w16_pack_hi(rb0, rb1);
         __builtin_amdgcn_sched_barrier(0);
         w16_mm_bf(pb, a1, a2, a3, dp0);
         if (TWO) w16_mm_bf(pb, b1, b2, b3, dp1);

@@ -162,6 +162,40 @@ typedef __bf16 w16_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 w16_mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w16_bf16x8, a), __builtin_bit_cast(w16_bf16x8, b), c, 0, 0, 0);
 }
+// The remainders of a split on the MATRIX pipe (tools/micro/bf16x6.hip: exact, the pipe adds C unrounded).  With a piece packed as a B
+// operand (lane 16 q + m: column m, K slots 8 q + s = its values v[s]) and the values as the accumulators (row 4 q + r of row block rb
+// = v[4 rb + r]), D = C + A B with A[i][k] = -1 at k = 8 (i / 4) + 4 rb + i % 4 is "x - piece" in place: 2 MFMAs per 8 values and
+// level instead of 8 v_and + 8 v_sub -- 12 vector instructions per split instead of 44, the SAME pieces bit for bit (round 5: bench
+// 321 -> 327 M atoms/s; protein 0.382 -> 0.372 ms with the tiled sweep's own arrangement, epnn_large.hip.h).
+__device__ __forceinline__ void w16_ident(u32x4 (&A)[2]) {
+    const int lane = threadIdx.x & 63, qa = lane >> 4, ma = lane & 15;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            A[rb][d] = (qa == (ma >> 2) && d == 2 * rb + ((ma & 3) >> 1)) ? (0xbf80u << (16 * (ma & 1))) : 0u;
+}
+__device__ __forceinline__ u32x4 w16_pack_hi(const f32x4 &lo, const f32x4 &hi) {      // v_perm_b32: the upper halves of two floats side by side
+    u32x4 p;
+    p[0] = __builtin_amdgcn_perm(__float_as_uint(lo[1]), __float_as_uint(lo[0]), 0x07060302u);
+    p[1] = __builtin_amdgcn_perm(__float_as_uint(lo[3]), __float_as_uint(lo[2]), 0x07060302u);
+    p[2] = __builtin_amdgcn_perm(__float_as_uint(hi[1]), __float_as_uint(hi[0]), 0x07060302u);
+    p[3] = __builtin_amdgcn_perm(__float_as_uint(hi[3]), __float_as_uint(hi[2]), 0x07060302u);
+    return p;
+}
+#ifndef EPNN_SPLIT_VALU
+__device__ __forceinline__ void w16_split3(const float (&v)[8], u32x4 &p1, u32x4 &p2, u32x4 &p3) {
+    u32x4 A[2];
+    w16_ident(A);                          // (a function of the lane alone: the compiler keeps or rebuilds it as registers allow)
+    f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+    p1 = w16_pack_hi(x0, x1);
+    x0 = w16_mfma_bf(A[0], p1, x0); x1 = w16_mfma_bf(A[1], p1, x1);
+    p2 = w16_pack_hi(x0, x1);
+    x0 = w16_mfma_bf(A[0], p2, x0); x1 = w16_mfma_bf(A[1], p2, x1);
+    p3 = w16_pack_hi(x0, x1);
+}
+#else
+// (development builds, for comparison: the remainders as v_and_b32 + v_sub_f32, 44 vector instructions per split)
 __device__ __forceinline__ void w16_split3(const float (&v)[8], u32x4 &p1, u32x4 &p2, u32x4 &p3) {
     float r1[8], r2[8];
 #pragma unroll
@@ -170,12 +204,13 @@ __device__ __forceinline__ void w16_split3(const float (&v)[8], u32x4 &p1, u32x4
         r2[s] = r1[s] - __uint_as_float(__float_as_uint(r1[s]) & 0xffff0000u);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {      // v_perm_b32: the upper halves of two floats side by side
+    for (int j = 0; j < 4; ++j) {
         p1[j] = __builtin_amdgcn_perm(__float_as_uint(v[2 * j + 1]), __float_as_uint(v[2 * j]), 0x07060302u);
         p2[j] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * j + 1]), __float_as_uint(r1[2 * j]), 0x07060302u);
         p3[j] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * j + 1]), __float_as_uint(r2[2 * j]), 0x07060302u);
     }
 }
+#endif
 // D[rb] += W[rb] z for one column block: w = the kernel's three pieces per row block, z1..z3 the activations' (smallest terms first)
 __device__ __forceinline__ void w16_mm_bf(const u32x4 (&w)[2][3], u32x4 z1, u32x4 z2, u32x4 z3, f32x4 (&d)[2]) {
 #pragma unroll
