@@ -494,13 +494,10 @@ typedef float LgW2[2][8];
 typedef u32x4 LgW2[2][3];
 #define LG_LDW2(dst, off) W16_LDB(dst, off)
 #endif
+#ifdef EPNN_SWEEP_F32
 template <bool TWO>
 __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const LgW2 (&pb),
                                               const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
-#ifndef EPNN_SWEEP_F32
-    u32x4 idA[2];
-    w16_ident(idA);
-#endif
     auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
     auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
         nn[0] = w16_ld(Ns + j * 32 + po);
@@ -515,23 +512,18 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
     // SIMD's issue time (protein 0.570 -> 0.545 ms, 10 000-atom box 8.12 -> 7.60 ms).
     f32x4 dp0[2] = {w16_splat(0.f), w16_splat(0.f)}, dp1[2] = {w16_splat(0.f), w16_splat(0.f)};      // nothing pending: relu(0) adds nothing
     auto partner_b = [&](const f32x4 (&nn)[2], const f32x4 (&yy)[2]) {
-#ifndef EPNN_SWEEP_F32
-        const f32x4 dq0[2] = {dp0[0], dp0[1]}, dq1[2] = {dp1[0], dp1[1]};
-#else
         S0[0] += w16_relu(dp0[0]);
         S0[1] += w16_relu(dp0[1]);
         if (TWO) {
             S1[0] += w16_relu(dp1[0]);
             S1[1] += w16_relu(dp1[1]);
         }
-#endif
         const f32x4 za = vmax(P0[0], nn[0]), zb = vmax(P0[1], nn[1]);
         const float z0[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
         const f32x4 zc = vmax(P1[0], nn[0]), zd = vmax(P1[1], nn[1]);
         const float z1[8] = {zc[0], zc[1], zc[2], zc[3], zd[0], zd[1], zd[2], zd[3]};
         dp0[0] = yy[0]; dp0[1] = yy[1];
         dp1[0] = yy[0]; dp1[1] = yy[1];
-#ifdef EPNN_SWEEP_F32
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -542,36 +534,6 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
                 dp1[1] = w16_mfma(pb[1][k], z1[k], dp1[1]);
             }
         }
-#else
-        // The split's remainders on the matrix pipe (w16_ident / w16_pack_hi, epnn_wave.hip.h): x - piece as D = C - I B, two MFMAs
-        // per 8 values and level instead of 8 v_and + 8 v_sub -- exact, the same pieces as w16_split3's (tools/micro/bf16x6.hip).  The
-        // ReLU + sum of the partner before this one sits behind the first remainders' MFMAs.  88 -> 24 vector instructions per
-        // partner for 8 more MFMAs: protein 0.382 -> 0.372 ms, 100 000-atom box 427 -> 417 ms (the first level alone: no change).
-        u32x4 a1, a2, a3, b1, b2, b3;
-        f32x4 ra0 = za, ra1 = zb, rb0 = zc, rb1 = zd;
-        a1 = w16_pack_hi(ra0, ra1);
-        if (TWO) b1 = w16_pack_hi(rb0, rb1);
-        ra0 = w16_mfma_bf(idA[0], a1, ra0); ra1 = w16_mfma_bf(idA[1], a1, ra1);
-        if (TWO) { rb0 = w16_mfma_bf(idA[0], b1, rb0); rb1 = w16_mfma_bf(idA[1], b1, rb1); }
-        __builtin_amdgcn_sched_barrier(0);
-        S0[0] += w16_relu(dq0[0]);
-        S0[1] += w16_relu(dq0[1]);
-        if (TWO) {
-            S1[0] += w16_relu(dq1[0]);
-            S1[1] += w16_relu(dq1[1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        a2 = w16_pack_hi(ra0, ra1);
-        if (TWO) b2 = w16_pack_hi(rb0, rb1);
-        ra0 = w16_mfma_bf(idA[0], a2, ra0); ra1 = w16_mfma_bf(idA[1], a2, ra1);
-        if (TWO) { rb0 = w16_mfma_bf(idA[0], b2, rb0); rb1 = w16_mfma_bf(idA[1], b2, rb1); }
-        __builtin_amdgcn_sched_barrier(0);
-        a3 = w16_pack_hi(ra0, ra1);
-        if (TWO) b3 = w16_pack_hi(rb0, rb1);
-        __builtin_amdgcn_sched_barrier(0);
-        w16_mm_bf(pb, a1, a2, a3, dp0);
-        if (TWO) w16_mm_bf(pb, b1, b2, b3, dp1);
-#endif
     };
     f32x4 na[2], ya[2], nb[2], yb[2];
     fetch(0, na, ya);
@@ -592,6 +554,99 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
         S1[1] += w16_relu(dp1[1]);
     }
 }
+#else
+// The bf16 form (round 5).  Per partner and 32 atoms: 16 v_max (first layer), the three-piece split of the 16 activations per lane with
+// its remainders on the matrix pipe (w16_ident / w16_pack_hi, epnn_wave.hip.h: x - piece as D = C - I B, 2 MFMAs per 8 values and
+// level instead of 8 v_and + 8 v_sub, the same pieces bit for bit; 24 v_perm + 8 MFMAs), 24 MFMAs of the Dense itself, and the
+// ReLU + sum of the partner BEFORE this one (16 v_max + 16 v_add) woven into those 24 MFMAs' gaps: a v_mfma_f32_16x16x32_bf16 holds
+// the SIMD's vector issue for 8 of its 16 cycles, so one or two independent vector instructions per gap cost nothing
+// (MI355X_MICROARCH.md, cycle constants).  The accumulators of two consecutive partners are two register sets (the loop is two
+// partners deep anyway), so the pending sums never wait for the running MFMAs.
+template <bool TWO>
+__device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const LgW2 (&pb),
+                                              const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
+    u32x4 idA[2];
+    w16_ident(idA);
+    auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
+    auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
+        nn[0] = w16_ld(Ns + j * 32 + po);
+        nn[1] = w16_ld(Ns + j * 32 + po + 8);
+        yy[0] = w16_ld(Ys + j * 32 + fo);
+        yy[1] = w16_ld(Ys + j * 32 + 16 + fo);
+    };
+    // c0 / c1: this partner's accumulators (column blocks 0 / 1); p0 / p1: the partner's before it, whose ReLU + sum is pending
+    auto partner_b = [&](const f32x4 (&nn)[2], const f32x4 (&yy)[2], f32x4 (&c0)[2], f32x4 (&c1)[2], const f32x4 (&p0)[2], const f32x4 (&p1)[2]) {
+        f32x4 ra0 = vmax(P0[0], nn[0]), ra1 = vmax(P0[1], nn[1]), rb0 = vmax(P1[0], nn[0]), rb1 = vmax(P1[1], nn[1]);
+        u32x4 a1, a2, a3, b1, b2, b3;
+        a1 = w16_pack_hi(ra0, ra1);
+        if (TWO) b1 = w16_pack_hi(rb0, rb1);
+        ra0 = w16_mfma_bf(idA[0], a1, ra0); ra1 = w16_mfma_bf(idA[1], a1, ra1);
+        if (TWO) { rb0 = w16_mfma_bf(idA[0], b1, rb0); rb1 = w16_mfma_bf(idA[1], b1, rb1); }
+        __builtin_amdgcn_sched_barrier(0);
+        a2 = w16_pack_hi(ra0, ra1);
+        if (TWO) b2 = w16_pack_hi(rb0, rb1);
+        ra0 = w16_mfma_bf(idA[0], a2, ra0); ra1 = w16_mfma_bf(idA[1], a2, ra1);
+        if (TWO) { rb0 = w16_mfma_bf(idA[0], b2, rb0); rb1 = w16_mfma_bf(idA[1], b2, rb1); }
+        __builtin_amdgcn_sched_barrier(0);
+        a3 = w16_pack_hi(ra0, ra1);
+        if (TWO) b3 = w16_pack_hi(rb0, rb1);
+        c0[0] = yy[0]; c0[1] = yy[1];
+        c1[0] = yy[0]; c1[1] = yy[1];
+        __builtin_amdgcn_sched_barrier(0);
+        w16_mm_bf(pb, a1, a2, a3, c0);
+        if (TWO) w16_mm_bf(pb, b1, b2, b3, c1);
+        S0[0] += w16_relu(p0[0]);
+        S0[1] += w16_relu(p0[1]);
+        if (TWO) {
+            S1[0] += w16_relu(p1[0]);
+            S1[1] += w16_relu(p1[1]);
+        }
+#ifndef EPNN_LG_NOWEAVE
+        // 24 (12) MFMAs, 32 (16) vector instructions: two behind each of the first 8 (4) MFMAs, one behind each of the others
+#pragma unroll
+        for (int i = 0; i < (TWO ? 8 : 4); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < (TWO ? 16 : 8); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x4 dA0[2] = {w16_splat(0.f), w16_splat(0.f)}, dA1[2] = {w16_splat(0.f), w16_splat(0.f)};      // nothing pending: relu(0) adds nothing
+    f32x4 dB0[2] = {w16_splat(0.f), w16_splat(0.f)}, dB1[2] = {w16_splat(0.f), w16_splat(0.f)};
+    f32x4 na[2], ya[2], nb[2], yb[2];
+    fetch(0, na, ya);
+    int j = 0;
+    for (; j + 2 <= nj; j += 2) {
+        fetch(j + 1, nb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        partner_b(na, ya, dA0, dA1, dB0, dB1);
+        fetch(min(j + 2, nj - 1), na, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        partner_b(nb, yb, dB0, dB1, dA0, dA1);
+    }
+    if (j < nj) {
+        partner_b(na, ya, dA0, dA1, dB0, dB1);
+        S0[0] += w16_relu(dA0[0]);
+        S0[1] += w16_relu(dA0[1]);
+        if (TWO) {
+            S1[0] += w16_relu(dA1[0]);
+            S1[1] += w16_relu(dA1[1]);
+        }
+    } else {
+        S0[0] += w16_relu(dB0[0]);
+        S0[1] += w16_relu(dB0[1]);
+        if (TWO) {
+            S1[0] += w16_relu(dB1[0]);
+            S1[1] += w16_relu(dB1[1]);
+        }
+    }
+}
+#endif
 #ifdef EPNN_SWEEP_F32
 static inline int lg_w2_off(const epnn_handle *h, int t) { return h->wvidx.g[t].w2; }
 #else
