@@ -565,8 +565,7 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
 template <bool TWO>
 __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, int nj, int po, int fo, const LgW2 (&pb),
                                               const f32x4 (&P0)[2], const f32x4 (&P1)[2], f32x4 (&S0)[2], f32x4 (&S1)[2]) {
-    u32x4 idA[2];
-    w16_ident(idA);
+    const w16_u32x2 idI = w16_ident();
     auto vmax = [](const f32x4 &a, const f32x4 &b) { return f32x4{fmaxf(a[0], b[0]), fmaxf(a[1], b[1]), fmaxf(a[2], b[2]), fmaxf(a[3], b[3])}; };
     auto fetch = [&](int j, f32x4 (&nn)[2], f32x4 (&yy)[2]) {
         nn[0] = w16_ld(Ns + j * 32 + po);
@@ -580,13 +579,13 @@ __device__ __forceinline__ void lg_sweep_rows(const float *Ns, const float *Ys, 
         u32x4 a1, a2, a3, b1, b2, b3;
         a1 = w16_pack_hi(ra0, ra1);
         if (TWO) b1 = w16_pack_hi(rb0, rb1);
-        ra0 = w16_mfma_bf(idA[0], a1, ra0); ra1 = w16_mfma_bf(idA[1], a1, ra1);
-        if (TWO) { rb0 = w16_mfma_bf(idA[0], b1, rb0); rb1 = w16_mfma_bf(idA[1], b1, rb1); }
+        ra0 = w16_rem(idI, a1[0], a1[1], ra0); ra1 = w16_rem(idI, a1[2], a1[3], ra1);
+        if (TWO) { rb0 = w16_rem(idI, b1[0], b1[1], rb0); rb1 = w16_rem(idI, b1[2], b1[3], rb1); }
         __builtin_amdgcn_sched_barrier(0);
         a2 = w16_pack_hi(ra0, ra1);
         if (TWO) b2 = w16_pack_hi(rb0, rb1);
-        ra0 = w16_mfma_bf(idA[0], a2, ra0); ra1 = w16_mfma_bf(idA[1], a2, ra1);
-        if (TWO) { rb0 = w16_mfma_bf(idA[0], b2, rb0); rb1 = w16_mfma_bf(idA[1], b2, rb1); }
+        ra0 = w16_rem(idI, a2[0], a2[1], ra0); ra1 = w16_rem(idI, a2[2], a2[3], ra1);
+        if (TWO) { rb0 = w16_rem(idI, b2[0], b2[1], rb0); rb1 = w16_rem(idI, b2[2], b2[3], rb1); }
         __builtin_amdgcn_sched_barrier(0);
         a3 = w16_pack_hi(ra0, ra1);
         if (TWO) b3 = w16_pack_hi(rb0, rb1);

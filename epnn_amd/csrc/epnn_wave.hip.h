@@ -162,18 +162,25 @@ typedef __bf16 w16_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 w16_mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w16_bf16x8, a), __builtin_bit_cast(w16_bf16x8, b), c, 0, 0, 0);
 }
-// The remainders of a split on the MATRIX pipe (tools/micro/bf16x6.hip: exact, the pipe adds C unrounded).  With a piece packed as a B
-// operand (lane 16 q + m: column m, K slots 8 q + s = its values v[s]) and the values as the accumulators (row 4 q + r of row block rb
-// = v[4 rb + r]), D = C + A B with A[i][k] = -1 at k = 8 (i / 4) + 4 rb + i % 4 is "x - piece" in place: 2 MFMAs per 8 values and
-// level instead of 8 v_and + 8 v_sub -- 12 vector instructions per split instead of 44, the SAME pieces bit for bit (round 5: bench
-// 321 -> 327 M atoms/s; protein 0.382 -> 0.372 ms with the tiled sweep's own arrangement, epnn_large.hip.h).
-__device__ __forceinline__ void w16_ident(u32x4 (&A)[2]) {
+// The remainders of a split on the MATRIX pipe (tools/micro/bf16x6.hip: exact, the pipe adds C unrounded).  With four values packed
+// as the B operand of v_mfma_f32_16x16x16_bf16 (lane 16 q + m: column m, K slots 4 q + s = its values v[s]) and the values themselves
+// as the accumulator (rows 4 q + r = v[r]), D = C + A B with A = -I (lane 16 qa + ma holds -1 in slot ma % 4 when qa = ma / 4) is
+// "x - piece" in place: 2 MFMAs per 8 values and level instead of 8 v_and + 8 v_sub -- 12 vector instructions per split instead
+// of 44, the SAME pieces bit for bit (round 5: bench 321 -> 327 M atoms/s; protein 0.382 -> 0.372 ms with the tiled sweep's own
+// arrangement, epnn_large.hip.h).  The K = 16 instruction takes half the pipe time of the K = 32 one (a row block's four values
+// are two dwords of the packed piece) and its operand is two registers, the same for both row blocks.
+typedef short w16_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned w16_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ w16_u32x2 w16_ident() {
     const int lane = threadIdx.x & 63, qa = lane >> 4, ma = lane & 15;
+    w16_u32x2 I;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-            A[rb][d] = (qa == (ma >> 2) && d == 2 * rb + ((ma & 3) >> 1)) ? (0xbf80u << (16 * (ma & 1))) : 0u;
+    for (int d = 0; d < 2; ++d) I[d] = (qa == (ma >> 2) && d == ((ma & 3) >> 1)) ? (0xbf80u << (16 * (ma & 1))) : 0u;
+    return I;
+}
+// x - piece for one row block: p_lo | p_hi = the two dwords of the packed piece that hold the block's four values
+__device__ __forceinline__ f32x4 w16_rem(w16_u32x2 I, unsigned p_lo, unsigned p_hi, f32x4 x) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(w16_s16x4, I), __builtin_bit_cast(w16_s16x4, w16_u32x2{p_lo, p_hi}), x, 0, 0, 0);
 }
 __device__ __forceinline__ u32x4 w16_pack_hi(const f32x4 &lo, const f32x4 &hi) {      // v_perm_b32: the upper halves of two floats side by side
     u32x4 p;
@@ -185,13 +192,12 @@ __device__ __forceinline__ u32x4 w16_pack_hi(const f32x4 &lo, const f32x4 &hi) {
 }
 #ifndef EPNN_SPLIT_VALU
 __device__ __forceinline__ void w16_split3(const float (&v)[8], u32x4 &p1, u32x4 &p2, u32x4 &p3) {
-    u32x4 A[2];
-    w16_ident(A);                          // (a function of the lane alone: the compiler keeps or rebuilds it as registers allow)
+    const w16_u32x2 I = w16_ident();       // (a function of the lane alone: the compiler keeps or rebuilds it as registers allow)
     f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
     p1 = w16_pack_hi(x0, x1);
-    x0 = w16_mfma_bf(A[0], p1, x0); x1 = w16_mfma_bf(A[1], p1, x1);
+    x0 = w16_rem(I, p1[0], p1[1], x0); x1 = w16_rem(I, p1[2], p1[3], x1);
     p2 = w16_pack_hi(x0, x1);
-    x0 = w16_mfma_bf(A[0], p2, x0); x1 = w16_mfma_bf(A[1], p2, x1);
+    x0 = w16_rem(I, p2[0], p2[1], x0); x1 = w16_rem(I, p2[2], p2[3], x1);
     p3 = w16_pack_hi(x0, x1);
 }
 #else

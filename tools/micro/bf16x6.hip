@@ -78,8 +78,26 @@ __device__ __forceinline__ void split3m(const float (&v)[8], const u32x4 (&A)[2]
     x0 = mm(A[0], p2, x0); x1 = mm(A[1], p2, x1);
     p3 = pack_hi(x0, x1);
 }
+// Fourth form: the same remainders with v_mfma_f32_16x16x16_bf16 (K = 16: lane 16 q + m holds K slots 4 q .. 4 q + 3; a row block's
+// four values are two dwords of the packed piece, the -I operand is the same for both row blocks)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mm16(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split3k(const float (&v)[8], u32x4 &p1, u32x4 &p2, u32x4 &p3) {
+    const int lane = threadIdx.x & 63, qa = lane >> 4, ma = lane & 15;
+    u32x2 I;
+    for (int d = 0; d < 2; ++d) I[d] = (qa == (ma >> 2) && d == ((ma & 3) >> 1)) ? (0xbf80u << (16 * (ma & 1))) : 0u;
+    f32x4 x0 = {v[0], v[1], v[2], v[3]}, x1 = {v[4], v[5], v[6], v[7]};
+    p1 = pack_hi(x0, x1);
+    x0 = mm16(I, u32x2{p1[0], p1[1]}, x0); x1 = mm16(I, u32x2{p1[2], p1[3]}, x1);
+    p2 = pack_hi(x0, x1);
+    x0 = mm16(I, u32x2{p2[0], p2[1]}, x0); x1 = mm16(I, u32x2{p2[2], p2[3]}, x1);
+    p3 = pack_hi(x0, x1);
+}
 template <int SPLIT> __device__ __forceinline__ void split_any(const float (&v)[8], const u32x4 (&A)[2], u32x4 &p1, u32x4 &p2, u32x4 &p3) {
-    if (SPLIT == 2) split3m(v, A, p1, p2, p3); else if (SPLIT) split3r(v, p1, p2, p3); else split3(v, p1, p2, p3);
+    if (SPLIT == 3) split3k(v, p1, p2, p3); else if (SPLIT == 2) split3m(v, A, p1, p2, p3); else if (SPLIT) split3r(v, p1, p2, p3); else split3(v, p1, p2, p3);
 }
 // exactness of a split: every lane splits 8 values, the host adds the pieces in float64
 template <int SPLIT> __global__ void k_exact(const float *x, unsigned *pieces) {
@@ -218,8 +236,9 @@ int main() {
         hipMalloc(&dx, (size_t)nv * 4); hipMalloc(&dp, (size_t)nv / 8 * 12 * 4);
         hipMemcpy(dx, xv.data(), (size_t)nv * 4, hipMemcpyHostToDevice);
         std::vector<unsigned> pc((size_t)nv / 8 * 12), pc0;
-        for (int sp = 0; sp < 3; ++sp) {
-            if (sp == 2) hipLaunchKernelGGL(k_exact<2>, dim3(nv / 512), dim3(64), 0, 0, dx, dp);
+        for (int sp = 0; sp < 4; ++sp) {
+            if (sp == 3) hipLaunchKernelGGL(k_exact<3>, dim3(nv / 512), dim3(64), 0, 0, dx, dp);
+            else if (sp == 2) hipLaunchKernelGGL(k_exact<2>, dim3(nv / 512), dim3(64), 0, 0, dx, dp);
             else if (sp) hipLaunchKernelGGL(k_exact<1>, dim3(nv / 512), dim3(64), 0, 0, dx, dp);
             else hipLaunchKernelGGL(k_exact<0>, dim3(nv / 512), dim3(64), 0, 0, dx, dp);
             hipMemcpy(pc.data(), dp, pc.size() * 4, hipMemcpyDeviceToHost);
@@ -240,12 +259,12 @@ int main() {
                     }
                 }
             if (sp == 0) pc0 = pc;
-            if (sp == 2) {
+            if (sp >= 2) {
                 long diff = 0;
                 for (size_t i = 0; i < pc.size(); ++i) diff += pc[i] != pc0[i];
-                printf("truncated / MFMA remainders: %ld of %zu piece words differ from the v_and / v_sub form's\n", diff, pc.size());
+                printf("truncated / MFMA remainders (K = %d): %ld of %zu piece words differ from the v_and / v_sub form's\n", sp == 2 ? 32 : 16, diff, pc.size());
             }
-            printf("%s pieces: %ld of %d values not reproduced exactly by x1 + x2 + x3 (worst relative %.3g)\n", sp == 2 ? "truncated / MFMA remainders" : sp ? "nearest / dot2c" : "truncated", bad, nv, worst);
+            printf("%s pieces: %ld of %d values not reproduced exactly by x1 + x2 + x3 (worst relative %.3g)\n", sp == 3 ? "truncated / MFMA remainders, K = 16" : sp == 2 ? "truncated / MFMA remainders" : sp ? "nearest / dot2c" : "truncated", bad, nv, worst);
         }
     }
     const int blocks = 2048, tiles = 4000;
@@ -255,8 +274,8 @@ int main() {
     for (auto &v : s) v = rand() / (float)RAND_MAX - 0.3f;
     hipMemcpy(src, s.data(), 1536 * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char *names[9] = {"f32 MFMA     ", "bf16x6 + split", "  + 8 v_pk_add_f32 (16 adds)", "  + 16 v_add_f32", "  + 16 v_max_f32", "  + 8 v_and_b32 + 8 v_perm_b32", "bf16x6 + split by v_cvt_pk_bf16_f32 / v_dot2c_f32_bf16", "bf16x6 + split with the remainders by MFMA (16 per tile)", ""};
-    for (int mode = 0; mode < 8; ++mode) {
+    const char *names[10] = {"f32 MFMA     ", "bf16x6 + split", "  + 8 v_pk_add_f32 (16 adds)", "  + 16 v_add_f32", "  + 16 v_max_f32", "  + 8 v_and_b32 + 8 v_perm_b32", "bf16x6 + split by v_cvt_pk_bf16_f32 / v_dot2c_f32_bf16", "bf16x6 + split with the remainders by MFMA (16 per tile)", "bf16x6 + split with the remainders by v_mfma_f32_16x16x16_bf16", ""};
+    for (int mode = 0; mode < 9; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k_time<0>, dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
@@ -266,7 +285,8 @@ int main() {
             else if (mode == 4) hipLaunchKernelGGL((k_time<1, 3>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
             else if (mode == 5) hipLaunchKernelGGL((k_time<1, 4>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
             else if (mode == 6) hipLaunchKernelGGL((k_time<1, 0, 1>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
-            else hipLaunchKernelGGL((k_time<1, 0, 2>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
+            else if (mode == 7) hipLaunchKernelGGL((k_time<1, 0, 2>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
+            else hipLaunchKernelGGL((k_time<1, 0, 3>), dim3(blocks), dim3(64), 0, 0, src, dst, tiles);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             // 2048 wavefronts = 2 per SIMD: cycles per tile and SIMD = ms * clock / (tiles * 2)
