@@ -1200,3 +1200,26 @@ def test_more_atom_types_than_the_table_holds_falls_back_to_the_sweep(gpu_engine
     qa = eng2.forward_xyz(o2, mols[1][0], mols[1][1], Q[1:], N=96)
     assert eng2.last_stats()[3] == 0
     assert np.abs(qa - q[off[1]:off[2]]).max() <= max(TOL, 3 * noise)
+
+
+def test_bf16_split_forms_on_the_device():
+    """The arithmetic the Dense layers rest on, checked on the device itself (tools/micro/bf16x6, built by __graft_entry__.build):
+    the three-piece bf16 split with its remainders taken on the matrix pipe (x - piece as D = C - I B, both the K = 32 and the
+    shipped K = 16 instruction) gives bit for bit the pieces of the v_and / v_sub form on 4 M float32 values of every kind, and the
+    six-product sum of such pieces is at least as close to float64 as the f32 MFMA's own result."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "micro", "bf16x6")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe), "bf16x6"], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300).stdout
+    for k in (32, 16):
+        m = re.search(r"MFMA remainders \(K = %d\): (\d+) of (\d+) piece words differ" % k, out)
+        assert m, out[-2000:]
+        assert int(m.group(1)) == 0 and int(m.group(2)) >= 6_000_000, m.group(0)
+    bad = {name: int(n) for name, n in re.findall(r"^(truncated|truncated / MFMA remainders|truncated / MFMA remainders, K = 16) pieces: (\d+) of", out, re.M)}
+    assert len(bad) == 3 and len(set(bad.values())) == 1, bad            # (only values whose pieces leave the normal float32 range)
+    assert bad["truncated"] < 0.01 * 4194304, bad
+    m = re.search(r"remainders by MFMA pieces\) ([0-9.e+-]+), f32 MFMA ([0-9.e+-]+)", out)
+    assert m and float(m.group(1)) <= float(m.group(2)), out[:600]
