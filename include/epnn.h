@@ -16,8 +16,8 @@
  *     flat atom arrays; N is the padded atom count the reference would have used (gen_padded_init_state pads
  *     every molecule to the directory maximum, charge_gn.py:340-364).  N enters the arithmetic: the reference
  *     sums messages over all N partners including the padded ones (charge_gn.py:70).
- *   - arithmetic: float32-grade throughout, like the reference's (TensorFlow float32).  The inference kernels run the pair MLPs'
- *     second Dense on the bf16 matrix pipe as six bf16 products of EXACT three-piece splits of both operands per product (what is
+ *   - arithmetic: float32-grade throughout, like the reference's (TensorFlow float32).  The inference kernels run the Dense layers
+ *     of the pair and update MLPs on the bf16 matrix pipe as six bf16 products of EXACT three-piece splits of both operands per product (what is
  *     left out is below 2^-24 of a product, the rounding of an f32 multiply-add); results agree with a
  *     float64 evaluation of the reference's algorithm to float32 rounding noise (1e-7 .. 1e-6 on the charges).  Every sum has a
  *     fixed order: results are bit-reproducible and independent of batch composition and of sharding.
