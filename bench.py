@@ -666,6 +666,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": ("float32 inputs, outputs and accumulation; every Dense product float32-grade: both operands split EXACTLY into "
+                           "three bf16 pieces, the six largest partial products summed in f32 on the bf16 matrix pipe (what is left out is "
+                           "below 2^-24 of a product; error against float64 below the f32 MFMA's own, profiles/r05_micro_bf16x6.txt); "
+                           "the edge products as f32 MFMAs; `parity` below is measured with this arithmetic"),
             "data": "synthetic",
             "config": {"workload": workload, "molecules_per_gpu": B, "atoms_per_gpu": A, "N": N,
                        "pairs_under_cutoff_per_gpu": int(stats[0]), "entry": "epnn_forward_xyz_dev (coordinates in HBM)",
