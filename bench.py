@@ -28,8 +28,9 @@ warm-up steps (--no-extras) they read 182-185 M atoms/s instead of 194-197 M (`o
 
 Prints ONE JSON line on rank 0.  Besides the contract's fields:
   roofline.*          dominant kernel k_wave_forward; `frac` is ALGORITHMIC flops of the launches per second of
-                      the timed region / `peak`, the bound of the two matrix pipes the kernel uses (f32 MFMA 157.3 TFLOP/s for the
-                      edge products; every Dense layer as six bf16 MFMAs per f32-grade product, 2500 / 6: `peak_basis`); `pipe_frac` = the pipes'
+                      the timed region / `peak`, the bound of the matrix pipe the kernel's products run on (every Dense layer AND the edge
+                      products as six bf16 MFMAs per f32-grade product, 2500 / 6 = 416.7 TFLOP/s: `peak_basis`; until the edge products
+                      moved there too the line priced them at the f32 MFMA's 157.3: `frac_with_edge_products_at_f32_peak`); `pipe_frac` = the pipes'
                       time for the MFMA flops the kernel really executes (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 / _BF16 x 512) over the
                       time taken; `frac_vs_f32_mfma_peak` = against 157.3 alone; `single_launch` = a launch with the GPU to itself
                       (65536 molecules, depth 1: flops / hipEvent duration IS its fraction, reproducible from
@@ -58,10 +59,10 @@ if ROOT not in sys.path:
 # flight, fewer when ranks share a device)
 
 # Matrix-pipe peaks (MI355X_MICROARCH.md, dense): f32 MFMA 157.3 TFLOP/s, bf16 MFMA 2500.  The fused kernels run every Dense layer
-# -- the pair MLPs' second Dense, the first Dense's atom blocks, the update MLP: 69 % of the bench batch's algorithmic flops -- on the
-# bf16 pipe as SIX bf16 products of exact three-piece splits (f32-grade): an f32-grade flop there is priced at
-# 2500 / 6 = 416.7 TFLOP/s, the edge products (G = We^T e) stay f32 MFMAs, and `roofline.peak` is the bound of the two pipes
-# together, total flops / (f32 flops / 157.3 + bf16-pipe flops / 416.7) (synth.mixed_pipe_peak).
+# -- the pair MLPs' second Dense, the first Dense's atom blocks, the update MLP: 69 % of the bench batch's algorithmic flops -- and the
+# edge products G = We^T e (31 %) on the bf16 pipe as SIX bf16 products of exact three-piece splits (f32-grade, DESIGN.md section
+# 4): an f32-grade flop there is priced at 2500 / 6 = 416.7 TFLOP/s, and `roofline.peak` is the bound of the two pipes together,
+# total flops / (f32 flops / 157.3 + bf16-pipe flops / 416.7) (synth.mixed_pipe_peak; only the EPN read-out is left in the f32 part).
 FP32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0
 KNAME = "k_wave_forward<true,true,true>"
@@ -397,6 +398,7 @@ def main():
     ns = np.diff(offsets)
     flops = synth.algorithmic_flops(ns, int(stats[0]))
     peak, bf_share = synth.mixed_pipe_peak(ns, int(stats[0]), chains_bf16=True)
+    peak_edges_f32 = synth.mixed_pipe_peak(ns, int(stats[0]), chains_bf16=True, edges_bf16=False)[0]     # (the pricing of this line until the edge products moved: 277.2)
 
     def timed_steps():
         """W warm-up steps, barrier, K timed steps, barrier -> seconds of the timed region on this rank"""
@@ -629,10 +631,11 @@ def main():
         pipe_s = (executed * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) + executed_bf * 1e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12)) if executed is not None and executed_bf is not None else None
         roof = {"bound": "mfma", "kernel": KNAME, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "peak_basis": f"both matrix pipes: f32 MFMA {FP32_MFMA_PEAK_TFLOPS} TFLOP/s for {1 - bf_share:.3f} of the algorithmic flops (the edge products), the Dense layers "
-                              f"({bf_share:.3f}) as six bf16 MFMAs per f32-grade product at {BF16_MFMA_PEAK_TFLOPS:.0f} / 6 = {BF16_MFMA_PEAK_TFLOPS / 6:.1f}; "
-                              "peak = total / (f32 part / 157.3 + bf16-pipe part / 416.7)",
+                "peak_basis": f"the bf16 matrix pipe for {bf_share:.3f} of the algorithmic flops -- every Dense layer and the edge products as six bf16 MFMAs "
+                              f"per f32-grade product, {BF16_MFMA_PEAK_TFLOPS:.0f} / 6 = {BF16_MFMA_PEAK_TFLOPS / 6:.1f} TFLOP/s --, f32 MFMA {FP32_MFMA_PEAK_TFLOPS} for the rest "
+                              "(the EPN read-out); peak = total / (f32 part / 157.3 + bf16-pipe part / 416.7)",
                 "frac_vs_f32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "frac_with_edge_products_at_f32_peak": achieved / peak_edges_f32,
                 "frac_basis": "algorithmic flops (SURVEY section 8d); the matrix pipes' own utilisation (executed MFMA flops of either kind, PMC) is pipe_frac",
                 "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                 "traffic_source": (pmc["command"] + f"; kernel source {pmc['kernel_source_sha']}; profiles/r05_pmc_bench.json") if pmc else None,

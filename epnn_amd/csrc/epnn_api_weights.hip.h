@@ -478,10 +478,43 @@ static int pack_weights(epnn_handle *h) {
             return o;
         };
         const bool have_basis = (int)h->edge_B.size() == EPNN_EDIM * EPNN_ER;
-        auto pair_common = [&](HostDense (&mm)[3], int &we, int &we16, int &w2, int &b2) {
+        // a K = 16 kernel as three bf16 pieces per weight for v_mfma_f32_16x16x16_bf16, [2][3][64 lanes][2 dwords]: lane (q, m) of row
+        // block rb: K slots s = 0..3 = fn(q, s, 16 rb + m); dword j = slots 2j | 2j+1 << 16
+        auto frag_bf3k16 = [&](auto &&fn) {
+            const int off = alloc((size_t)2 * 3 * 64 * 2);
+            for (int rb = 0; rb < 2; ++rb)
+                for (int l = 0; l < 64; ++l) {
+                    uint32_t pc[3][4];
+                    for (int s = 0; s < 4; ++s) {
+                        float v = (float)fn(l >> 4, s, 16 * rb + (l & 15));
+                        for (int k = 0; k < 3; ++k) {
+                            uint32_t bits;
+                            memcpy(&bits, &v, 4);
+                            bits &= 0xffff0000u;
+                            float top;
+                            memcpy(&top, &bits, 4);
+                            pc[k][s] = bits >> 16;
+                            v = v - top;
+                        }
+                    }
+                    for (int k = 0; k < 3; ++k)
+                        for (int j = 0; j < 2; ++j) {
+                            const uint32_t word = pc[k][2 * j] | pc[k][2 * j + 1] << 16;
+                            memcpy(&buf[off + ((rb * 3 + k) * 64 + l) * 2 + j], &word, 4);
+                        }
+                }
+            return off;
+        };
+        auto pair_common = [&](HostDense (&mm)[3], int &we, int &we16, int &we16b, int &w2, int &b2) {
             const float *W1 = mm[0].W.data(), *W2 = mm[1].W.data(), *bb2 = mm[1].b.data();
             we = frag(2, 12, [&](int s, int q, int m) { return (double)W1[(size_t)(2 * F + 12 * q + s) * 32 + m]; });
             we16 = frag(2, EPNN_ER / 4, [&](int s, int q, int m) -> double {      // (B^T We)[4q + s][m]
+                if (!have_basis) return 0.0;
+                double a = 0;
+                for (int ch = 0; ch < EPNN_EDIM; ++ch) a += h->edge_B[(size_t)ch * EPNN_ER + 4 * q + s] * (double)W1[(size_t)(2 * F + ch) * 32 + m];
+                return a;
+            });
+            we16b = frag_bf3k16([&](int q, int s, int m) -> double {                // the same, K slot s of lane group q = coefficient 4q + s
                 if (!have_basis) return 0.0;
                 double a = 0;
                 for (int ch = 0; ch < EPNN_EDIM; ++ch) a += h->edge_B[(size_t)ch * EPNN_ER + 4 * q + s] * (double)W1[(size_t)(2 * F + ch) * 32 + m];
@@ -511,7 +544,7 @@ static int pack_weights(epnn_handle *h) {
         const int off_bu2 = vec(HU, [&](int k) { return (double)bu2[k]; });
         for (int t = 0; t < T; ++t) {
             WaveGnnPack &G = X.g[t];
-            pair_common(h->msg[t], G.we, G.we16, G.w2, G.b2);
+            pair_common(h->msg[t], G.we, G.we16, G.we16b, G.w2, G.b2);
             {
                 const float *W2m = h->msg[t][1].W.data();
                 G.w2b = frag_bf3([&](int in, int out) { return (double)W2m[(size_t)in * 32 + out]; });
@@ -558,7 +591,7 @@ static int pack_weights(epnn_handle *h) {
         X.bu3 = vec(48, [&](int k) { return (double)bu3[k]; });
         for (int t = 0; t < T; ++t) {
             WaveEpnPack &E = X.e[t];
-            pair_common(h->pas[t], E.we, E.we16, E.w2, E.b2);
+            pair_common(h->pas[t], E.we, E.we16, E.we16b, E.w2, E.b2);
             {
                 const float *W2p = h->pas[t][1].W.data();
                 E.w2b = frag_bf3([&](int in, int out) { return (double)W2p[(size_t)in * 32 + out]; });

@@ -74,6 +74,7 @@ struct WeightIndex {
 struct WaveGnnPack {           // GNN step t
     int we;               // [2][12][64]  e order       We_t
     int we16;             // [2][4][64]   k = 4q + s    B^T We_t   (edge features in the 16-dimensional basis)
+    int we16b;            // [2][3][64][2] dwords       the same as three bf16 pieces per weight (v_mfma_f32_16x16x16_bf16: K slot s of lane q = coefficient 4q + s)
     int w2;               // [2][8][64]   acc order     W2_t
     int w2b;              // [2][3][64][4] dwords       W2_t as three bf16 pieces per weight (w16_split3 / pack_bf16x3), K slot s of lane q = acc order
     int b2;               // [32]
@@ -101,6 +102,7 @@ struct WaveEpnPack {           // EPN step t
     int we, w2, b2, w3;   // w3: [32]
     int w2b;              // [2][3][64][4] dwords: W2_t as three bf16 pieces per weight (see WaveGnnPack)
     int we16;             // [2][4][64]   B^T We_t
+    int we16b;            // [2][3][64][2] dwords: B^T We_t as three bf16 pieces per weight (see WaveGnnPack)
     int wi, wj;           // [2][XS+12][64]  xq rows, then h rows (acc order over 48 features): h given by the caller
     int wif, wjf;         // [2][8+XS][64]   acc rows: Wu3 M_h;  xq rows: [M_h^T bu3, M_x, M_q, b1]: h = nm (Wu3^T u2 + bu3) of the GNN stack
     int wifhb, wifxb, wjfhb, wjfxb;      // wif / wjf as bf16 pieces (see WaveGnnPack)

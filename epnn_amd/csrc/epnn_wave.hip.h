@@ -190,6 +190,12 @@ __device__ __forceinline__ u32x4 w16_pack_hi(const f32x4 &lo, const f32x4 &hi) {
     p[3] = __builtin_amdgcn_perm(__float_as_uint(hi[3]), __float_as_uint(hi[2]), 0x07060302u);
     return p;
 }
+__device__ __forceinline__ w16_u32x2 w16_pack_hi2(const f32x4 &v) {                    // the same for four values
+    w16_u32x2 p;
+    p[0] = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+    p[1] = __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u);
+    return p;
+}
 #ifndef EPNN_SPLIT_VALU
 __device__ __forceinline__ void w16_split3(const float (&v)[8], u32x4 &p1, u32x4 &p2, u32x4 &p3) {
     const w16_u32x2 I = w16_ident();       // (a function of the lane alone: the compiler keeps or rebuilds it as registers allow)
@@ -310,6 +316,50 @@ __device__ __forceinline__ void w16_feed(const f32x4 (&a)[NRB], float (&in)[4 * 
 // NRU: row blocks (16 units each) of the update MLP's two hidden layers -- 2 for the reference's [32, 32] (and anything embedded
 // in it), 4 for make_model(layers) of up to [64, 64] (charge_gn.py:369-371; epnn_set_update_layers pads to 64 units).  The state
 // between steps is nm * u2 (4 NRU K steps), the pair sweep and the EPN stack are the same for every NRU.
+// ---- the edge products G = We^T pt of the in-kernel front-end (K = 16 coordinates per pair, §2 of DESIGN.md) on the bf16 pipe as well:
+// pt split into three pieces (remainders on the matrix pipe, like every activation), We as three bf16 pieces from the host
+// (WaveGnnPack::we16b), six v_mfma_f32_16x16x16_bf16 per row block (48 cycles against 4 x 32 of v_mfma_f32_16x16x4_f32): bench
+// 331.6 -> 337.8 M atoms/s.  Pair lists from outside (K = 48, !FRONT) keep the f32 MFMAs; -DEPNN_G_F32 builds them everywhere.
+// Both macros are used inside the kernels (k_wave_forward, k_wave_forward2), where FRONT, KE, gw, wp, lane exist.
+#ifdef EPNN_G_F32
+#define W16_G_BF 0
+#else
+#define W16_G_BF 1
+#endif
+#define W16_G_DECL                                                                                                        \
+    constexpr bool GB = FRONT && W16_G_BF;                                                                                \
+    w16_u32x2 gwb[2][3];                                                                                                  \
+    auto g_mm = [&](const float (&e)[KE], f32x4 (&d)[2]) {      /* d[rb] += We[rb] e for 16 pairs (columns) */            \
+        if constexpr (GB) {                                                                                               \
+            const w16_u32x2 I = w16_ident();                                                                              \
+            f32x4 x = {e[0], e[1], e[2], e[3]};                                                                           \
+            w16_u32x2 z1, z2, z3;                                                                                         \
+            z1 = w16_pack_hi2(x);                                                                                         \
+            x = w16_rem(I, z1[0], z1[1], x);                                                                              \
+            z2 = w16_pack_hi2(x);                                                                                         \
+            x = w16_rem(I, z2[0], z2[1], x);                                                                              \
+            z3 = w16_pack_hi2(x);                                                                                         \
+            _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) {                                                            \
+                d[rb] = w16_rem(gwb[rb][0], z3[0], z3[1], d[rb]);                                                         \
+                d[rb] = w16_rem(gwb[rb][1], z2[0], z2[1], d[rb]);                                                         \
+                d[rb] = w16_rem(gwb[rb][2], z1[0], z1[1], d[rb]);                                                         \
+                d[rb] = w16_rem(gwb[rb][0], z2[0], z2[1], d[rb]);                                                         \
+                d[rb] = w16_rem(gwb[rb][1], z1[0], z1[1], d[rb]);                                                         \
+                d[rb] = w16_rem(gwb[rb][0], z1[0], z1[1], d[rb]);                                                         \
+            }                                                                                                             \
+        } else {                                                                                                          \
+            w16_mm<2, KE>(gw, e, d);                                                                                      \
+        }                                                                                                                 \
+    }
+// the kernel We of a G product: f32 fragments (offset `off`), or with GB its three bf16 pieces (offset `offb`)
+#define GW_LD(off, offb)                                                                                                  \
+    do {                                                                                                                  \
+        if constexpr (GB) {                                                                                               \
+            _Pragma("unroll") for (int rb_ = 0; rb_ < 2; ++rb_)                                                           \
+                _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_)                                                       \
+                    gwb[rb_][pc_] = reinterpret_cast<const w16_u32x2 *>(wp + (size_t)(unsigned)(offb))[(rb_ * 3 + pc_) * 64 + lane]; \
+        } else { W16_LD(gw, off, 2, KE); }                                                                                \
+    } while (0)
 template <bool GNN, bool EPN, bool FRONT, int NRU = 2>
 __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveArgs A, WaveIndex X) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -458,7 +508,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     };
     // first G tiles: We and the first e rows are on their way while the LDS tables are built
     float gw[2][KE], ge0[KE], ge1[KE];
-    W16_LD(gw, FRONT ? X.g[0].we16 : (GNN ? X.g[0].we : X.e[0].we), 2, KE);
+    W16_G_DECL;
+    GW_LD(FRONT ? X.g[0].we16 : (GNN ? X.g[0].we : X.e[0].we), X.g[0].we16b);
     if (GNN && !FRONT && ngt > 0) load_e(0, ge0, ge1);
     WAVE_FENCE();
 
@@ -633,7 +684,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
     auto gtile = [&](int gt, const float (&e0)[KE], const float (&e1)[KE]) {
         const int s0 = gt * 32 + n16, s1 = s0 + 16;
         f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
-        w16_mm<2, KE>(gw, e0, d0);
+        g_mm(e0, d0);
         // two separate predicated stores per target (LDS / HBM): merged into one pointer they become flat stores
         if (s0 < min(np, glds)) { w16_st(Gl + (s0 + 1) * EPNN_PST + fo, d0[0]); w16_st(Gl + (s0 + 1) * EPNN_PST + 16 + fo, d0[1]); }
         if (gover) {
@@ -642,7 +693,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         }
         if (gt * 32 + 16 < np) {                            // the second 16 pairs of the tile exist
             f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
-            w16_mm<2, KE>(gw, e1, d1);
+            g_mm(e1, d1);
             if (s1 < min(np, glds)) { w16_st(Gl + (s1 + 1) * EPNN_PST + fo, d1[0]); w16_st(Gl + (s1 + 1) * EPNN_PST + 16 + fo, d1[1]); }
             if (gover) {
                 asm volatile("" ::: "memory");
@@ -664,8 +715,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
         }
         if (gt < ngt) gtile(gt, ge0, ge1);
     };
-    auto gprefetch = [&](int weoff) {
-        W16_LD(gw, weoff, 2, KE);
+    auto gprefetch = [&](int weoff, int weoffb) {
+        GW_LD(weoff, weoffb);
         if (ngt > 0) load_e(0, ge0, ge1);
     };
     // 32-vector in natural feature order -> this lane's two groups of four
@@ -945,8 +996,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     a1_[rb] = w16_relu(nm1 * (d1[rb] + Nf * cv[rb]) + bv[rb]);
                 }
                 vecu(M.bu2, bv);
-                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
-                else if (Te > 0) { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we, X.g[t + 1].we16b);
+                else if (Te > 0) { GW_LD(FRONT ? X.e[0].we16 : X.e[0].we, X.e[0].we16b); }
                 WAVE_FENCE();
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) { d0[rb] = bv[rb]; d1[rb] = bv[rb]; }
@@ -985,8 +1036,8 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 }
                 if constexpr (NRU != 2) { W16_LD(w2, M.u2, NRU, KU); }
                 vecu(M.bu2, bv);
-                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
-                else if (Te > 0) { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we, X.g[t + 1].we16b);
+                else if (Te > 0) { GW_LD(FRONT ? X.e[0].we16 : X.e[0].we, X.e[0].we16b); }
                 WAVE_FENCE();
                 float ain0[KU], ain1[KU];
 #pragma unroll
@@ -1221,7 +1272,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                     const bool valid = blk * 16 + n16 < np;
                     const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
                     f32x4 g[2] = {w16_splat(0.f), w16_splat(0.f)};       // G = We^T e of the 16 pairs (charge_gn.py:105, e block)
-                    w16_mm<2, KE>(gw, w_.e, g);
+                    g_mm(w_.e, g);
                     const f32x4 ua = w16_relu((g[0] + w_.pi_[0]) + w_.rj_[0]), ub = w16_relu((g[1] + w_.pi_[1]) + w_.rj_[1]);
                     const f32x4 va = w16_relu((g[0] + w_.pj_[0]) + w_.ri_[0]), vb = w16_relu((g[1] + w_.pj_[1]) + w_.ri_[1]);
                     const float zu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
@@ -1280,7 +1331,7 @@ __global__ __launch_bounds__(64, EPNN_WAVES_PER_SIMD) void k_wave_forward(WaveAr
                 }
             }
             wave_sync_lds();
-            if (t + 1 < Te) { W16_LD(gw, FRONT ? X.e[t + 1].we16 : X.e[t + 1].we, 2, KE); }     // on its way during the charge update
+            if (t + 1 < Te) { GW_LD(FRONT ? X.e[t + 1].we16 : X.e[t + 1].we, X.e[t + 1].we16b); }     // on its way during the charge update
             WAVE_FENCE();
             if (t < 2) WAVE_STAMP();   // EPN pair tiles
             // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of the rows of its two atoms

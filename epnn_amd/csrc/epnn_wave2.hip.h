@@ -189,7 +189,8 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
         load_e1(gt * 32 + 16 + n16, e1);
     };
     float gw[2][KE], ge0[KE], ge1[KE];
-    W16_LD(gw, FRONT ? X.g[0].we16 : X.g[0].we, 2, KE);
+    W16_G_DECL;
+    GW_LD(FRONT ? X.g[0].we16 : X.g[0].we, X.g[0].we16b);
     WAVE_FENCE();
 
     for (int i = tid; i < n * (PMS / 2); i += nthr) reinterpret_cast<unsigned *>(pm)[i] = 0xFFFFFFFFu;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
     auto gtile = [&](int gt, const float (&e0)[KE], const float (&e1)[KE]) {
         const int s0 = gt * 32 + n16, s1 = s0 + 16;
         f32x4 d0[2] = {w16_splat(0.f), w16_splat(0.f)};
-        w16_mm<2, KE>(gw, e0, d0);
+        g_mm(e0, d0);
         if (s0 < min(np, glds)) { w16_st(Gl + s0 * EPNN_PST + fo, d0[0]); w16_st(Gl + s0 * EPNN_PST + 16 + fo, d0[1]); }
         if (gover) {
             asm volatile("" ::: "memory");
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
         }
         if (gt * 32 + 16 < np) {
             f32x4 d1[2] = {w16_splat(0.f), w16_splat(0.f)};
-            w16_mm<2, KE>(gw, e1, d1);
+            g_mm(e1, d1);
             if (s1 < min(np, glds)) { w16_st(Gl + s1 * EPNN_PST + fo, d1[0]); w16_st(Gl + s1 * EPNN_PST + 16 + fo, d1[1]); }
             if (gover) {
                 asm volatile("" ::: "memory");
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
         }
         if (gt < ngt) gtile(gt, ge0, ge1);
     };
-    auto gprefetch = [&](int weoff) {
-        W16_LD(gw, weoff, 2, KE);
+    auto gprefetch = [&](int weoff, int weoffb) {
+        GW_LD(weoff, weoffb);
         if (FRONT && ngt > 0) load_e(doff, ge0, ge1);
     };
     auto vec2 = [&](int off, f32x4 (&v)[2]) {
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) a_[rb] = w16_relu(nm * (d[rb] + Nf * cv[rb]) + bv[rb]);
                 vec2(M.bu2, bv);
-                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
-                else { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we, X.g[t + 1].we16b);
+                else { GW_LD(FRONT ? X.e[0].we16 : X.e[0].we, X.e[0].we16b); }
                 WAVE_FENCE();
                 d[0] = bv[0]; d[1] = bv[1];
                 w16_feed(a_, in);
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) a_[rb] = w16_relu(nm * (d[rb] + Nf * cv[rb]) + bv[rb]);
                 vec2(M.bu2, bv);
-                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we);
-                else { W16_LD(gw, FRONT ? X.e[0].we16 : X.e[0].we, 2, KE); }
+                if (!lastg) gprefetch(FRONT ? X.g[t + 1].we16 : X.g[t + 1].we, X.g[t + 1].we16b);
+                else { GW_LD(FRONT ? X.e[0].we16 : X.e[0].we, X.e[0].we16b); }
                 WAVE_FENCE();
                 d[0] = bv[0]; d[1] = bv[1];
                 w16_feed(a_, in);
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                     const bool valid = blk * 16 + n16 < np;
                     const int li = r_.ij & 0xFF, lj = r_.ij >> 8;
                     f32x4 g[2] = {w16_splat(0.f), w16_splat(0.f)};
-                    w16_mm<2, KE>(gw, w_.e, g);
+                    g_mm(w_.e, g);
                     const f32x4 ua = w16_relu((g[0] + w_.pi_[0]) + w_.rj_[0]), ub = w16_relu((g[1] + w_.pi_[1]) + w_.rj_[1]);
                     const f32x4 va = w16_relu((g[0] + w_.pj_[0]) + w_.ri_[0]), vb = w16_relu((g[1] + w_.pj_[1]) + w_.ri_[1]);
                     const float zu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(64 * NW, EPNN_WAVES_PER_SIMD) void k_wave_forward2(
                 }
             }
             sync();                                         // every transfer of this step is in the matrix
-            if (t + 1 < Te) { W16_LD(gw, FRONT ? X.e[t + 1].we16 : X.e[t + 1].we, 2, KE); }
+            if (t + 1 < Te) { GW_LD(FRONT ? X.e[t + 1].we16 : X.e[t + 1].we, X.e[t + 1].we16b); }
             WAVE_FENCE();
             // q_i += sum_j antisym_ij (charge_gn.py:118): lane (q, n16) adds columns j = q mod 4 of its atom's row.  (The next
             // step writes the matrix only behind its own barrier, which this wavefront reaches after these reads.)

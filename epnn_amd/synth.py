@@ -110,7 +110,7 @@ def box_system(n_atoms=100_000, seed=0, density=0.1, min_sep=0.9):
     return offsets, pts.astype(np.float32), features(symbols), np.zeros(1, dtype=np.float32), n_atoms
 
 
-def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=False, chains_bf16=False):
+def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=False, chains_bf16=False, edges_bf16=True):
     """Forward flop count of the factorised exact algorithm (flop = 2*MAC).
 
     ns: atom count per molecule; near_unordered_pairs: total number of unordered pairs with D < cutoff."""
@@ -123,11 +123,14 @@ def algorithmic_flops(ns, near_unordered_pairs, nx=9, T=5, E=48, H=32, parts=Fal
     if parts == "pipes":
         # (f32-MFMA flops, flops on the bf16 matrix pipe as six bf16 products of exact three-piece splits per f32-grade product --
         #  DESIGN.md section 4): the pair MLPs' second Dense always; with chains_bf16 (the fused kernels) also the per-atom chains --
-        #  the first Dense's atom blocks, the update MLP --, which leaves the edge products G = We^T e (and the EPN read-out) on the
-        #  f32 pipe; the tiled kernels keep their per-atom chains there
+        #  the first Dense's atom blocks, the update MLP -- and, since round 5's last change (edges_bf16), the edge products G = We^T e
+        #  of the in-kernel front-end, which leaves the EPN read-out (32 MACs per pair and direction: vector instructions, priced
+        #  with the f32 part); the tiled kernels keep their per-atom chains and correction tiles on the f32 pipe
         bf = n2 * H * H + (nnz / 2) * 2 * H * H
         if chains_bf16:
             bf += 2 * (n1 * 2 * F * H) + n1 * H * H + n1 * H * H + n1 * (80 * H + H * H + H * 48)
+            if edges_bf16:      # ... and the edge products of both stacks (K = 16 in the kernel's own basis, counted with all E channels)
+                bf += nnz * E * H + (nnz / 2) * E * H
         return 2.0 * T * (gnn + epn - bf), 2.0 * T * bf
     if parts:
         return 2.0 * T * gnn, 2.0 * T * epn
@@ -140,10 +143,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0
 BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0     # an f32-grade product = six bf16 products
 
 
-def mixed_pipe_peak(ns, near_unordered_pairs, nx=9, T=5, chains_bf16=False):
+def mixed_pipe_peak(ns, near_unordered_pairs, nx=9, T=5, chains_bf16=False, edges_bf16=True):
     """The matrix pipes' bound on the forward, in ALGORITHMIC TFLOP/s: the flops that run as f32 MFMAs at 157.3 TFLOP/s, those on
     the bf16 pipe at 2500 / 6 (six bf16 MFMAs per f32-grade product): peak = total / (f32 part / 157.3 + bf16 part / 416.7).
-    chains_bf16: the fused kernels (per-atom chains on the bf16 pipe too); False: the tiled kernels (the all-pairs Dense only).
-    Returns (peak, share of the algorithmic flops on the bf16 pipe)."""
-    f32, d2 = algorithmic_flops(ns, near_unordered_pairs, nx=nx, T=T, parts="pipes", chains_bf16=chains_bf16)
+    chains_bf16: the fused kernels (per-atom chains and, with edges_bf16, the edge products on the bf16 pipe too); False: the tiled
+    kernels (the all-pairs Dense only).  Returns (peak, share of the algorithmic flops on the bf16 pipe)."""
+    f32, d2 = algorithmic_flops(ns, near_unordered_pairs, nx=nx, T=T, parts="pipes", chains_bf16=chains_bf16, edges_bf16=edges_bf16)
     return (f32 + d2) / (f32 / FP32_MFMA_PEAK_TFLOPS + d2 / BF16X6_PEAK_TFLOPS), d2 / (f32 + d2)

@@ -116,13 +116,16 @@ def test_roofline_of_the_two_matrix_pipes():
     for ns, pairs in (([18], 72), ([2220], 12810), ([100000], 532253)):
         total = synth.algorithmic_flops(ns, pairs)
         for chains in (False, True):
-            f32, bf = synth.algorithmic_flops(ns, pairs, parts="pipes", chains_bf16=chains)
-            assert f32 > 0 and bf > 0 and abs(f32 + bf - total) <= 1e-9 * total
-            peak, share = synth.mixed_pipe_peak(ns, pairs, chains_bf16=chains)
-            assert synth.FP32_MFMA_PEAK_TFLOPS < peak < synth.BF16X6_PEAK_TFLOPS and abs(share - bf / total) < 1e-12
+            for edges in (False, True):
+                f32, bf = synth.algorithmic_flops(ns, pairs, parts="pipes", chains_bf16=chains, edges_bf16=edges)
+                assert f32 > 0 and bf > 0 and abs(f32 + bf - total) <= 1e-9 * total
+                peak, share = synth.mixed_pipe_peak(ns, pairs, chains_bf16=chains, edges_bf16=edges)
+                assert synth.FP32_MFMA_PEAK_TFLOPS < peak < synth.BF16X6_PEAK_TFLOPS and abs(share - bf / total) < 1e-12
     assert synth.mixed_pipe_peak([100000], 532253)[0] > 0.999 * synth.BF16X6_PEAK_TFLOPS
     off = synth.qm9_like_batch(1024, 0, 29)[0]
     peak, share = synth.mixed_pipe_peak(np.diff(off), 72439, chains_bf16=True)
+    assert abs(peak - 413.8) < 0.5 and abs(share - 0.996) < 0.002
+    peak, share = synth.mixed_pipe_peak(np.diff(off), 72439, chains_bf16=True, edges_bf16=False)     # (the edge products as f32 MFMAs)
     assert abs(peak - 277.2) < 0.5 and abs(share - 0.695) < 0.005
 
 
